@@ -1,0 +1,178 @@
+"""Generate the golden fixtures in this directory from the REAL reference implementation.
+
+Run in the authoring container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+It imports ``/root/reference/open_flamingo/src/helpers.py`` by file path (with a 1-line
+``einops_exts.rearrange_many`` shim -- that package is not installable offline),
+feeds it seeded weights/inputs, and stores inputs + outputs + autograd gradients as ``.npz``.
+The fixtures are what pins ``oracle/flamingo_oracle.py`` to the reference; nothing on the GPU box
+reads /root/reference.
+
+Files written:
+  small_perceiver.npz        tiny PerceiverResampler (weights stored), fwd + all grads
+  small_perceiver_embs.npz   same with frame_embs / media_time_embs (F=2)
+  small_xattn_<case>.npz     tiny GatedCrossAttentionBlock, one file per mask case (KAT-3)
+  full_perceiver.npz         OF-3B-sized Perceiver (dim 1024, 6 layers): weights rebuilt from
+                             oracle.seeded_state(seed), only output/grad summaries stored
+  full_xattn.npz             OF-3B-sized block (d=2048): same idea
+"""
+
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+from einops import rearrange
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+from oracle.flamingo_oracle import seeded_state  # noqa: E402
+
+shim = types.ModuleType("einops_exts")
+shim.rearrange_many = lambda tensors, pattern, **kw: tuple(rearrange(t, pattern, **kw) for t in tensors)
+sys.modules["einops_exts"] = shim
+spec = importlib.util.spec_from_file_location("ref_helpers", "/root/reference/open_flamingo/src/helpers.py")
+ref = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(ref)
+
+
+def shapes_of(mod):
+    return {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+
+
+def load_seeded(mod, seed, dtype):
+    st = seeded_state(shapes_of(mod), seed, dtype)
+    mod.to(dtype)
+    mod.load_state_dict(st, strict=True)
+    return st
+
+
+def grads_of(mod):
+    return {"grad." + k: v.grad.detach().numpy() for k, v in mod.named_parameters()}
+
+
+def rnd(shape, seed, dtype):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float64).to(dtype)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrs.items()})
+    print(f"{name}: {os.path.getsize(path)/1024:.1f} KiB")
+
+
+def small_perceiver(with_embs):
+    dt = torch.float64
+    kw = dict(dim=32, depth=2, dim_head=8, heads=2, num_latents=4)
+    Fr = 1
+    if with_embs:
+        kw.update(max_num_media=4, max_num_frames=3)
+        Fr = 2
+    m = ref.PerceiverResampler(**kw)
+    st = load_seeded(m, 11, dt)
+    x = rnd((2, 3, Fr, 6, 32), 12, dt).requires_grad_(True)
+    w = rnd((2, 3, 4, 32), 13, dt)
+    y = m(x)
+    (y * w).sum().backward()
+    save("small_perceiver_embs.npz" if with_embs else "small_perceiver.npz",
+         **{"param." + k: v for k, v in st.items()}, x=x, w=w, y=y, **{"grad.x": x.grad}, **grads_of(m),
+         heads=2)
+
+
+XATTN_CASES = {
+    # name: (media_locations rows as 0/1 lists, T_img, only_immediate, use_cached, T_txt override)
+    "basic": ([[1, 0, 0, 0, 1, 0, 0, 1, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0, 0]], 3, True, False, None),
+    "before_first_image": ([[0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0], [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]], 3, True, False, None),
+    "image_last_and_consecutive": ([[1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1], [0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0]], 3, True, False, None),
+    "more_image_tokens_than_images": ([[1, 0, 1, 0, 1, 0, 1, 0, 0, 1, 0, 0], [1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0]], 3, True, False, None),
+    "single_image_laion": ([[1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]], 1, True, False, None),
+    "attend_all_previous": ([[1, 0, 0, 0, 1, 0, 0, 1, 0, 0, 0, 0], [0, 0, 1, 0, 0, 0, 1, 0, 0, 1, 0, 0]], 3, False, False, None),
+    "cached_media_decode": ([[1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]], 3, True, True, 2),
+    "no_media_locations_cached": (None, 3, True, True, 5),
+}
+
+
+def small_xattn(case, gates=None):
+    dt = torch.float64
+    locs, T_img, only_imm, cached, t_txt = XATTN_CASES[case]
+    m = ref.GatedCrossAttentionBlock(dim=32, dim_visual=24, dim_head=8, heads=2,
+                                     only_attend_immediate_media=only_imm)
+    st = load_seeded(m, 21, dt)
+    tag = case
+    if gates is not None:
+        with torch.no_grad():
+            m.attn_gate.fill_(gates)
+            m.ff_gate.fill_(gates)
+        st["attn_gate"] = m.attn_gate.detach().clone()
+        st["ff_gate"] = m.ff_gate.detach().clone()
+        tag = f"{case}_gate{gates:g}"
+    L = 12 if t_txt is None else t_txt
+    x = rnd((2, L, 32), 22, dt).requires_grad_(True)
+    media = rnd((2, T_img, 4, 24), 23, dt).requires_grad_(True)
+    w = rnd((2, L, 32), 24, dt)
+    ml = None if locs is None else torch.tensor(locs, dtype=torch.bool)
+    y = m(x, media, media_locations=ml, use_cached_media=cached)
+    (y * w).sum().backward()
+    save(f"small_xattn_{tag}.npz", **{"param." + k: v for k, v in st.items()}, x=x, media=media, w=w, y=y,
+         media_locations=(np.zeros((0,), dtype=bool) if ml is None else ml.numpy()),
+         has_media_locations=int(ml is not None), only_immediate=int(only_imm), use_cached=int(cached),
+         heads=2, **{"grad.x": x.grad, "grad.media": media.grad}, **grads_of(m))
+
+
+def summarize(t):
+    t = t.detach().double().flatten()
+    idx = torch.linspace(0, t.numel() - 1, 64).long()
+    return np.concatenate([t[idx].numpy(), [t.sum().item(), t.abs().sum().item(), (t * t).sum().item()]])
+
+
+def full_perceiver():
+    dt = torch.float32
+    torch.manual_seed(0)
+    m = ref.PerceiverResampler(dim=1024)
+    load_seeded(m, 31, dt)
+    x = rnd((1, 2, 1, 256, 1024), 32, dt)
+    w = rnd((1, 2, 64, 1024), 33, dt)
+    y = m(x)
+    (y * w).sum().backward()
+    out = {"y.summary": summarize(y), "y.head": y[0, :, :4, :16].detach().numpy()}
+    for k, v in m.named_parameters():
+        out["gradsum." + k] = summarize(v.grad)
+    save("full_perceiver.npz", seed_params=31, seed_x=32, seed_w=33, **out)
+
+
+def full_xattn():
+    dt = torch.float32
+    m = ref.GatedCrossAttentionBlock(dim=2048, dim_visual=1024)
+    load_seeded(m, 41, dt)
+    L = 32
+    x = rnd((1, L, 2048), 42, dt).requires_grad_(True)
+    media = rnd((1, 2, 64, 1024), 43, dt).requires_grad_(True)
+    w = rnd((1, L, 2048), 44, dt)
+    ml = torch.zeros(1, L, dtype=torch.bool)
+    ml[0, 3] = True
+    ml[0, 17] = True
+    y = m(x, media, media_locations=ml)
+    (y * w).sum().backward()
+    out = {"y.summary": summarize(y), "y.head": y[0, :8, :16].detach().numpy(),
+           "gradsum.x": summarize(x.grad), "gradsum.media": summarize(media.grad)}
+    for k, v in m.named_parameters():
+        out["gradsum." + k] = summarize(v.grad)
+    save("full_xattn.npz", seed_params=41, seed_x=42, seed_media=43, seed_w=44,
+         media_positions=np.array([3, 17]), L=L, **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    small_perceiver(False)
+    small_perceiver(True)
+    for c in XATTN_CASES:
+        small_xattn(c)
+    small_xattn("basic", gates=0.0)
+    full_perceiver()
+    full_xattn()
