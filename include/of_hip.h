@@ -1,0 +1,153 @@
+/* libofhip -- C ABI of the MI355X-native OpenFlamingo visual-conditioning path.
+ *
+ * The reference (mlfoundations/open_flamingo) is pure Python and has no FFI layer; its boundary for this
+ * path is the module API in open_flamingo/src/helpers.py.  This header is the native boundary that the
+ * drop-in modules in open_flamingo_amd/src/helpers.py bind through ctypes, and that a reference
+ * maintainer would bind the same way.  Each entry point names the reference code it
+ * replaces (file:line relative to the reference checkout).
+ *
+ * Conventions
+ *  - Plain C: raw device pointers, ints, floats and a hipStream_t passed as void*.  No torch types.
+ *  - The caller owns every buffer (inputs, outputs, saved-for-backward, workspace).  The library allocates
+ *    nothing, keeps no global mutable state, and never synchronises the device: work is enqueued on the
+ *    given stream and the call returns.
+ *  - Return value: 0 ok; negative = argument/shape error (OF_E_*); positive = hipError_t from a launch.
+ *  - bf16 = raw uint16 bfloat16.  "stream dtype" (io_f32 = 1 fp32 / 0 bf16) is the dtype of the residual
+ *    stream tensors the reference keeps in fp32 under amp_bf16 (train_utils.py:34-41): x, y, their grads.
+ *  - All matrices row-major; ld* in elements.
+ */
+#ifndef OF_HIP_H
+#define OF_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OF_ABI_VERSION 1
+#define OF_E_ARG (-1)      /* null pointer / negative size */
+#define OF_E_SHAPE (-2)    /* shape not supported by the kernels (see each function) */
+#define OF_E_ALIGN (-3)    /* pointer or leading dimension not 16-byte aligned */
+#define OF_E_WORKSPACE (-4)/* workspace too small */
+
+int of_abi_version(void);
+/* 1 when built for gfx950, 2 for the host emulator build used by tests (never shipped). */
+int of_build_kind(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * GEMM with fused epilogues: acc[m][n] = sum_k A(m,k) * B(n,k), bf16 operands, fp32 accumulate (MFMA).
+ *   a_trans = 0: A stored [M][K] (lda >= K);  1: A stored [K][M] (lda >= M)
+ *   b_trans = 0: B stored [N][K] (ldb >= K);  1: B stored [K][N] (ldb >= N)
+ * i.e. nn.Linear forward y = x W^T is (a_trans=0,b_trans=0) with B = W; dX = dY W is (0,1) with B = W;
+ * dW = dY^T X is (1,1).  Replaces the aten::mm calls under nn.Linear in helpers.py:19,21,36-38,154-156
+ * and their autograd backward.  Dimensions that are vector-loaded (the contiguous one of each operand)
+ * must be multiples of 8; N must be a multiple of 4.
+ * g = tanh(*gate) if gate != NULL else 1.
+ *   OF_EPI_STORE_BF16  C(bf16)  = g*alpha*acc
+ *   OF_EPI_GELU        C(bf16)  = gelu_erf(acc); if C2: C2(bf16) = acc            (helpers.py:20)
+ *   OF_EPI_GATE_RESID  C(T)     = aux(T) + g*alpha*acc, T = stream dtype          (helpers.py:267-277,130-131)
+ *   OF_EPI_DGELU_DOT   C(bf16)  = g*alpha*acc*gelu'(aux);  *dot_out += (1-g^2)*sum(gelu(aux)*acc)
+ *   OF_EPI_SCALE_DOT   C(bf16)  = g*alpha*acc;             *dot_out += (1-g^2)*sum(aux*acc)
+ *   OF_EPI_ACC_F32     C(f32)   = g*alpha*acc + beta*C
+ * The two *_DOT epilogues produce the tanh-gate gradients of GatedCrossAttentionBlock
+ *  without materialising the un-gated branch output.
+ */
+enum { OF_EPI_STORE_BF16 = 0, OF_EPI_GELU = 1, OF_EPI_GATE_RESID = 2, OF_EPI_DGELU_DOT = 3,
+       OF_EPI_SCALE_DOT = 4, OF_EPI_ACC_F32 = 5 };
+
+typedef struct OfGemmArgs {
+    const uint16_t* A;
+    const uint16_t* B;
+    int M, N, K;
+    int lda, ldb;
+    int a_trans, b_trans;
+    int epi;
+    void* C;
+    int ldc;
+    void* C2;          /* OF_EPI_GELU: optional pre-activation output (bf16, ldc) */
+    const void* aux;   /* residual (stream dtype) or saved bf16 activation, [M][ldaux] */
+    int ldaux;
+    const float* gate; /* device pointer to the raw gate parameter, or NULL */
+    float alpha, beta;
+    float* dot_out;    /* device scalar accumulated atomically, or NULL */
+    int io_f32;        /* OF_EPI_GATE_RESID: 1 = fp32 stream, 0 = bf16 stream */
+    int safe;          /* 1 = use the slow scalar-LDS transposed-fragment path (self-check of tr-read) */
+} OfGemmArgs;
+
+int of_gemm(const OfGemmArgs* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * LayerNorm (eps 1e-5, affine) -- nn.LayerNorm in helpers.py:18,33-34,105,152.
+ * x: rows x dim in stream dtype (x_f32=1 fp32, 0 bf16), row stride ldx; y: bf16, row stride ldy (so the
+ * Perceiver can write media rows and latent rows into one [N][v+n][D] buffer, helpers.py:53);
+ * stats: rows x 2 fp32 (mean, rstd) saved for backward.  dim % 8 == 0, dim <= 8192.
+ * of_layernorm_fwd_out writes the stream dtype instead of bf16 (PerceiverResampler.norm, helpers.py:132).
+ */
+int of_layernorm_fwd(const void* x, int x_f32, long ldx, const float* w, const float* b, uint16_t* y, long ldy,
+                     float* stats, long rows, int dim, void* stream);
+int of_layernorm_fwd_out(const void* x, int x_f32, long ldx, const float* w, const float* b, void* y, int y_f32,
+                         long ldy, float* stats, long rows, int dim, void* stream);
+/* Backward: dy (bf16 if dy_f32==0 else fp32, row stride lddy), x + stats as saved.
+ *   dx_out(T) = (resid ? resid(T) : 0) + LN_bwd(dy)      T = stream dtype (out_f32)
+ *   dx_bf16   = optional bf16 copy of dx_out (feeds the next GEMMs as an operand), may be NULL
+ *   dw, db   += column reductions (fp32, accumulated atomically; caller zero-initialises or accumulates)
+ * dx_out may be NULL when only dw/db are needed (norm_media: the ViT features carry no gradient). */
+int of_layernorm_bwd(const void* dy, int dy_f32, long lddy, const void* x, int x_f32, long ldx, const float* stats,
+                     const float* w, const void* resid, void* dx_out, int out_f32, long lddx, uint16_t* dx_bf16,
+                     float* dw, float* db, long rows, int dim, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Windowed multi-head attention core, head dim 64, flash-style (scores never reach HBM).
+ * One kernel family serves both hot-path attentions:
+ *   - PerceiverAttention core (helpers.py:55-64): text_time == NULL, every query sees all keys.
+ *   - MaskedCrossAttention core (helpers.py:192-231): per-query key window derived from text_time
+ *     (helpers.py:196-218) instead of a materialised (B,1,L,T*n) mask:
+ *        only_immediate=1:  1 <= tt <= T -> keys [(tt-1)*n, tt*n);  tt == 0 -> output 0 (helpers.py:223-229);
+ *                           tt > T -> every key is masked with -finfo.max, softmax is uniform over all T*n keys
+ *        only_immediate=0:  tt >= 1 -> keys [0, min(tt,T)*n);  tt == 0 -> uniform over all keys
+ * Layout: q[(batch*Lq + i)*ldq + h*64 + d], k/v[(batch*Lk + j)*ldk + h*64 + d] (k and v may point into one
+ * fused kv buffer), o like q with ldo.  scale = dim_head^-0.5 is applied to the fp32 scores.
+ * lse (batch,H,Lq) fp32 = row log-sum-exp saved for backward (+inf marks zeroed rows).
+ */
+typedef struct OfAttnArgs {
+    const uint16_t* q; const uint16_t* k; const uint16_t* v;
+    uint16_t* o;
+    float* lse;
+    const int32_t* text_time; /* (batch, Lq) or NULL */
+    int batch, heads, Lq, Lk;
+    long ldq, ldk, ldv, ldo;
+    int n_per_media, T_img, only_immediate;
+    float scale;
+    /* backward only */
+    const uint16_t* dout; long lddo;
+    uint16_t* dq; long lddq;
+    uint16_t* dk; uint16_t* dv; long lddk, lddv;
+    float* delta;             /* (batch,H,Lq) fp32 scratch: rowsum(dO*O), written by the dq pass */
+    int safe;
+} OfAttnArgs;
+
+int of_attn_fwd(const OfAttnArgs* args, void* stream);
+/* Backward = two passes (dq: one workgroup per query tile; dk/dv: one per key block) -- deterministic,
+ * no atomics.  dq/dk/dv are bf16 (they feed the projection-weight GEMMs as operands). */
+int of_attn_bwd(const OfAttnArgs* args, void* stream);
+
+/* text_time (helpers.py:199-208): cumsum of media_locations along the sequence, or (cached decode branch)
+ * the per-sequence count broadcast to Lq new tokens.  media_locations: uint8 (B, Lm). */
+int of_text_time(const uint8_t* media_locations, int32_t* text_time, int B, int Lm, int Lq, int use_cached,
+                 void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Small element-wise helpers of the path. */
+int of_cast_f32_to_bf16(const float* x, uint16_t* y, long n, void* stream);
+int of_cast_bf16_to_f32(const uint16_t* x, float* y, long n, void* stream);
+/* y[r][c] (bf16, ldy) = src[r % src_rows][c] for r < rows: "repeat(latents, 'n d -> b T n d')" helpers.py:128 */
+int of_broadcast_rows(const float* src, int src_rows, void* y, int y_f32, long ldy, long rows, int dim, void* stream);
+/* dst[r % dst_rows][c] += src[r][c]: gradient of the repeat above (sum over b,T). dst fp32. */
+int of_reduce_rows(const void* src, int src_f32, long rows, int dim, float* dst, int dst_rows, void* stream);
+/* out(T) = a(T) + b(T) */
+int of_add(const void* a, const void* b, void* out, int f32, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

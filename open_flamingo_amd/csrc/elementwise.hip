@@ -1,0 +1,139 @@
+// Small HBM-bound helpers of the OpenFlamingo hot path (gfx950): dtype casts of GEMM operands, the
+// latent broadcast "repeat(latents, 'n d -> b T n d')" (open_flamingo/src/helpers.py:128) and its
+// gradient (sum over b,T), and the residual-stream add used when gradients of several consumers meet.
+#include "of_platform.h"
+#include "../../include/of_hip.h"
+
+namespace {
+
+struct EwArgs {
+    const void* a; const void* b; void* out;
+    long n;          // elements (multiple of 8 handled vectorised, tail scalar)
+    int f32;
+    // row-structured variants
+    long rows; int dim; long ld; int src_rows;
+};
+
+constexpr int GRID_CAP = 2048;
+
+OF_GLOBAL void of_cast_f2b_kernel(EwArgs a) {
+    const long nv = a.n >> 3;
+    const long stride = (long)of_gdim_x() * 256;
+    for (long i = (long)of_bid_x() * 256 + of_tid(); i < nv; i += stride) {
+        const f32x4 x0 = *(const f32x4*)((const float*)a.a + i * 8), x1 = *(const f32x4*)((const float*)a.a + i * 8 + 4);
+        u32x4 r = {of_pack_bf16(x0[0], x0[1]), of_pack_bf16(x0[2], x0[3]), of_pack_bf16(x1[0], x1[1]), of_pack_bf16(x1[2], x1[3])};
+        *(u32x4*)((bf16_t*)a.out + i * 8) = r;
+    }
+    if (of_bid_x() == 0) {
+        for (long i = (nv << 3) + of_tid(); i < a.n; i += 256) ((bf16_t*)a.out)[i] = of_f32_to_bf16(((const float*)a.a)[i]);
+    }
+}
+OF_GLOBAL void of_cast_b2f_kernel(EwArgs a) {
+    const long nv = a.n >> 3;
+    const long stride = (long)of_gdim_x() * 256;
+    for (long i = (long)of_bid_x() * 256 + of_tid(); i < nv; i += stride) {
+        const u32x4 r = *(const u32x4*)((const bf16_t*)a.a + i * 8);
+        f32x4 o0, o1;
+        o0[0] = of_bf16_to_f32((bf16_t)(r[0] & 0xffff)); o0[1] = of_bf16_to_f32((bf16_t)(r[0] >> 16));
+        o0[2] = of_bf16_to_f32((bf16_t)(r[1] & 0xffff)); o0[3] = of_bf16_to_f32((bf16_t)(r[1] >> 16));
+        o1[0] = of_bf16_to_f32((bf16_t)(r[2] & 0xffff)); o1[1] = of_bf16_to_f32((bf16_t)(r[2] >> 16));
+        o1[2] = of_bf16_to_f32((bf16_t)(r[3] & 0xffff)); o1[3] = of_bf16_to_f32((bf16_t)(r[3] >> 16));
+        *(f32x4*)((float*)a.out + i * 8) = o0;
+        *(f32x4*)((float*)a.out + i * 8 + 4) = o1;
+    }
+    if (of_bid_x() == 0) {
+        for (long i = (nv << 3) + of_tid(); i < a.n; i += 256) ((float*)a.out)[i] = of_bf16_to_f32(((const bf16_t*)a.a)[i]);
+    }
+}
+OF_GLOBAL void of_add_kernel(EwArgs a) {
+    const long stride = (long)of_gdim_x() * 256;
+    if (a.f32) {
+        const long nv = a.n >> 2;
+        for (long i = (long)of_bid_x() * 256 + of_tid(); i < nv; i += stride) {
+            const f32x4 x = *(const f32x4*)((const float*)a.a + i * 4), y = *(const f32x4*)((const float*)a.b + i * 4);
+            *(f32x4*)((float*)a.out + i * 4) = f32x4{x[0] + y[0], x[1] + y[1], x[2] + y[2], x[3] + y[3]};
+        }
+        if (of_bid_x() == 0)
+            for (long i = (nv << 2) + of_tid(); i < a.n; i += 256) ((float*)a.out)[i] = ((const float*)a.a)[i] + ((const float*)a.b)[i];
+    } else {
+        for (long i = (long)of_bid_x() * 256 + of_tid(); i < a.n; i += stride)
+            ((bf16_t*)a.out)[i] = of_f32_to_bf16(of_bf16_to_f32(((const bf16_t*)a.a)[i]) + of_bf16_to_f32(((const bf16_t*)a.b)[i]));
+    }
+}
+// out[r][c] = src[r % src_rows][c]   (src fp32 parameter, out stream dtype or bf16)
+OF_GLOBAL void of_bcast_rows_kernel(EwArgs a) {
+    const int cpr = a.dim >> 2;  // 4-element chunks per row
+    const long total = a.rows * cpr;
+    const long stride = (long)of_gdim_x() * 256;
+    for (long i = (long)of_bid_x() * 256 + of_tid(); i < total; i += stride) {
+        const long r = i / cpr;
+        const int c = (int)(i - r * cpr) * 4;
+        const f32x4 v = *(const f32x4*)((const float*)a.a + (size_t)(r % a.src_rows) * a.dim + c);
+        if (a.f32) {
+            *(f32x4*)((float*)a.out + (size_t)r * a.ld + c) = v;
+        } else {
+            u32x2 o = {of_pack_bf16(v[0], v[1]), of_pack_bf16(v[2], v[3])};
+            *(u32x2*)((bf16_t*)a.out + (size_t)r * a.ld + c) = o;
+        }
+    }
+}
+// dst[r][c] += sum_{k} src[k*dst_rows + r][c]
+OF_GLOBAL void of_reduce_rows_kernel(EwArgs a) {
+    const long total = (long)a.src_rows * a.dim;  // src_rows = dst_rows here
+    const long i = (long)of_bid_x() * 256 + of_tid();
+    if (i >= total) return;
+    const long r = i / a.dim;
+    const int c = (int)(i - r * a.dim);
+    float s = 0.f;
+    for (long k = r; k < a.rows; k += a.src_rows) {
+        s += a.f32 ? ((const float*)a.a)[(size_t)k * a.dim + c] : of_bf16_to_f32(((const bf16_t*)a.a)[(size_t)k * a.dim + c]);
+    }
+    ((float*)a.out)[i] += s;
+}
+
+unsigned grid_for(long work_items) {
+    long b = (work_items + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > GRID_CAP) b = GRID_CAP;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int of_cast_f32_to_bf16(const float* x, uint16_t* y, long n, void* stream) {
+    if (!x || !y || n <= 0) return OF_E_ARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return OF_E_ALIGN;
+    EwArgs a{};
+    a.a = x; a.out = y; a.n = n;
+    return of_launch(of_cast_f2b_kernel, of_dim3{grid_for(n >> 3), 1, 1}, 256, 0, (of_stream_t)stream, a);
+}
+extern "C" int of_cast_bf16_to_f32(const uint16_t* x, float* y, long n, void* stream) {
+    if (!x || !y || n <= 0) return OF_E_ARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return OF_E_ALIGN;
+    EwArgs a{};
+    a.a = x; a.out = y; a.n = n;
+    return of_launch(of_cast_b2f_kernel, of_dim3{grid_for(n >> 3), 1, 1}, 256, 0, (of_stream_t)stream, a);
+}
+extern "C" int of_add(const void* x, const void* y, void* out, int f32, long n, void* stream) {
+    if (!x || !y || !out || n <= 0) return OF_E_ARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)out & 15)) return OF_E_ALIGN;
+    EwArgs a{};
+    a.a = x; a.b = y; a.out = out; a.n = n; a.f32 = f32;
+    return of_launch(of_add_kernel, of_dim3{grid_for(f32 ? n >> 2 : n), 1, 1}, 256, 0, (of_stream_t)stream, a);
+}
+extern "C" int of_broadcast_rows(const float* src, int src_rows, void* y, int y_f32, long ldy, long rows, int dim,
+                                 void* stream) {
+    if (!src || !y || src_rows <= 0 || rows <= 0 || dim <= 0) return OF_E_ARG;
+    if ((dim & 3) || (ldy & 3)) return OF_E_SHAPE;
+    if (((uintptr_t)src & 15) || ((uintptr_t)y & 7)) return OF_E_ALIGN;
+    EwArgs a{};
+    a.a = src; a.out = y; a.f32 = y_f32; a.ld = ldy; a.rows = rows; a.dim = dim; a.src_rows = src_rows;
+    return of_launch(of_bcast_rows_kernel, of_dim3{grid_for(rows * (dim >> 2)), 1, 1}, 256, 0, (of_stream_t)stream, a);
+}
+extern "C" int of_reduce_rows(const void* src, int src_f32, long rows, int dim, float* dst, int dst_rows, void* stream) {
+    if (!src || !dst || rows <= 0 || dim <= 0 || dst_rows <= 0) return OF_E_ARG;
+    EwArgs a{};
+    a.a = src; a.out = dst; a.f32 = src_f32; a.rows = rows; a.dim = dim; a.src_rows = dst_rows;
+    const long total = (long)dst_rows * dim;
+    return of_launch(of_reduce_rows_kernel, of_dim3{(unsigned)((total + 255) / 256), 1, 1}, 256, 0, (of_stream_t)stream, a);
+}

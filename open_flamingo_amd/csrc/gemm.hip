@@ -1,0 +1,287 @@
+// bf16 MFMA GEMM with fused epilogues for the OpenFlamingo hot path (gfx950).
+//
+// acc[m][n] = sum_k A(m,k) B(n,k); replaces every nn.Linear matmul (forward, dX, dW) of
+// open_flamingo/src/helpers.py:19,21,36-38,154-156.  See include/of_hip.h for the contract.
+//
+// Structure (v1): 128x128x64 tile, 256 threads = 4 waves in 2x2, each wave a 64x64 sub-tile as 4x4
+// v_mfma_f32_16x16x32_bf16 fragments.  Operands are staged global -> VGPR -> LDS (the next K-tile's
+// global loads are issued before the current tile's MFMAs and written to the other LDS buffer after
+// them: one barrier per K-tile).  Two LDS images exist per operand kind:
+//   K-contiguous operand  [128 rows][64 k]  (128 B rows), 16-B slot s of row r stored at slot
+//       s ^ ((r>>1)&7): a ds_read_b128 fragment read (16 rows x 4 k-slots per wave) is conflict-free.
+//   K-strided operand     [64 k][128 cols]  (256 B rows), 32-B chunk c of k-row r stored at chunk
+//       c ^ ((r&3) | ((r>>3)&1)<<2): the ds_read_b64_tr_b16 fragment read (8 k-rows x 32 B per half-wave)
+//       is conflict-free; the transpose itself is done by the LDS transpose-read, so dX = dY W and
+//       dW = dY^T X need no transposed copies of activations or weights in HBM.
+// The MFMA is issued with the operands swapped (D = Bfrag x Afrag) so that a lane ends up with four
+// consecutive n of one output row: epilogue loads/stores are 8-byte (bf16) or 16-byte (fp32) vectors.
+#include "of_platform.h"
+#include "../../include/of_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB for either image
+constexpr int SMEM_BYTES = 4 * TILE_BYTES;
+
+OF_DEV int swz_n(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+OF_DEV int swz_t_f(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
+OF_DEV int swz_t(int krow, int col) {  // byte offset of element (krow, col) in the K-strided image
+    return krow * 256 + ((((col >> 4)) ^ swz_t_f(krow)) << 5) + ((col & 15) << 1);
+}
+
+// ---- global -> registers (4 x 16 B per thread per operand), zero-filled out of range
+template <bool TR>
+OF_DEV void g2r(const bf16_t* __restrict__ base, int ld, int row0, int rows, int k0, int K, int tid, u32x4 (&r)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        int id = c * 256 + tid;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (!TR) {
+            int row = id >> 3, slot = id & 7;
+            int gr = row0 + row, gk = k0 + slot * 8;
+            if (gr < rows && gk < K) v = *(const u32x4*)(base + (size_t)gr * ld + gk);
+        } else {
+            int krow = id >> 4, cs = id & 15;
+            int gk = k0 + krow, gc = row0 + cs * 8;
+            if (gk < K && gc < rows) v = *(const u32x4*)(base + (size_t)gk * ld + gc);
+        }
+        r[c] = v;
+    }
+}
+template <bool TR>
+OF_DEV void r2s(char* tile, int tid, const u32x4 (&r)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        int id = c * 256 + tid;
+        int off;
+        if (!TR) {
+            off = swz_n(id >> 3, id & 7);
+        } else {
+            int krow = id >> 4, cs = id & 15;
+            off = swz_t(krow, cs * 8);
+        }
+        *(u32x4*)(tile + off) = r[c];
+    }
+}
+// ---- LDS -> MFMA fragment for 16 rows (row_base..+15) and the 32-wide k-step kk
+template <bool TR, bool SAFE>
+OF_DEV s16x8 frag(const char* tile, int row_base, int kk, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    if (!TR) {
+        return *(const s16x8*)(tile + swz_n(row_base + i, kk * 4 + g));
+    } else if (!SAFE) {
+        s16x8 f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int krow = kk * 32 + g * 8 + h * 4 + (i >> 2);
+            s16x4 t = of_lds_tr(tile + swz_t(krow, row_base + (i & 3) * 4));
+            f[h * 4 + 0] = t[0];
+            f[h * 4 + 1] = t[1];
+            f[h * 4 + 2] = t[2];
+            f[h * 4 + 3] = t[3];
+        }
+        return f;
+    } else {
+        s16x8 f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = *(const short*)(tile + swz_t(kk * 32 + g * 8 + e, row_base + i));
+        return f;
+    }
+}
+
+OF_DEV void tile_coords(int bid, int nwg, int tiles_m, int tiles_n, int& pm, int& pn) {
+    // XCD-aware (block b runs on XCD b%8: give each XCD a contiguous range of tile ids, bijective for any
+    // nwg), then grouped ordering so neighbouring ids share A panels (8 m-tiles) and walk n.
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int GM = 8;
+    int width = GM * tiles_n;
+    int group = id / width;
+    int first_m = group * GM;
+    int gsz = tiles_m - first_m < GM ? tiles_m - first_m : GM;
+    int in = id - group * width;
+    pm = first_m + in % gsz;
+    pn = in / gsz;
+}
+
+template <bool AT, bool BT, int EPI, bool SAFE>
+OF_GLOBAL void OF_BOUNDS(256, 2) of_gemm_kernel(OfGemmArgs p) {
+    char* smem = of_smem();
+    const int tid = of_tid(), lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i16 = lane & 15;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    int pm, pn;
+    tile_coords(of_bid_x(), of_gdim_x(), tiles_m, tiles_n, pm, pn);
+    const int m0 = pm * BM, n0 = pn * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 ra[4], rb[4];
+    const int nk = (p.K + BK - 1) / BK;
+    g2r<AT>(p.A, p.lda, m0, p.M, 0, p.K, tid, ra);
+    g2r<BT>(p.B, p.ldb, n0, p.N, 0, p.K, tid, rb);
+    r2s<AT>(smem, tid, ra);
+    r2s<BT>(smem + TILE_BYTES, tid, rb);
+    of_sync();
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* ta = smem + (kt & 1) * 2 * TILE_BYTES;
+        const char* tb = ta + TILE_BYTES;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            g2r<AT>(p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, tid, ra);
+            g2r<BT>(p.B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, tid, rb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            s16x8 fa[4], fb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                fa[t] = frag<AT, SAFE>(ta, wr * 64 + t * 16, kk, lane);
+                fb[t] = frag<BT, SAFE>(tb, wc * 64 + t * 16, kk, lane);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = of_mfma(fb[nt], fa[mt], acc[mt][nt]);
+        }
+        if (more) {
+            char* na = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
+            r2s<AT>(na, tid, ra);
+            r2s<BT>(na + TILE_BYTES, tid, rb);
+        }
+        of_sync();
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    float gv = 1.0f;
+    if (p.gate) gv = of_tanh(*p.gate);
+    const float sc = gv * p.alpha;
+    float dot = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + wr * 64 + mt * 16 + i16;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = n0 + wc * 64 + nt * 16 + g * 4;
+            if (m >= p.M || n >= p.N) continue;
+            const f32x4 a = acc[mt][nt];
+            const size_t off = (size_t)m * p.ldc + n;
+            if (EPI == OF_EPI_STORE_BF16) {
+                u32x2 o = {of_pack_bf16(sc * a[0], sc * a[1]), of_pack_bf16(sc * a[2], sc * a[3])};
+                *(u32x2*)((bf16_t*)p.C + off) = o;
+            } else if (EPI == OF_EPI_GELU) {
+                if (p.C2) {
+                    u32x2 o = {of_pack_bf16(a[0], a[1]), of_pack_bf16(a[2], a[3])};
+                    *(u32x2*)((bf16_t*)p.C2 + off) = o;
+                }
+                u32x2 o = {of_pack_bf16(of_gelu(a[0]), of_gelu(a[1])), of_pack_bf16(of_gelu(a[2]), of_gelu(a[3]))};
+                *(u32x2*)((bf16_t*)p.C + off) = o;
+            } else if (EPI == OF_EPI_GATE_RESID) {
+                const size_t aoff = (size_t)m * p.ldaux + n;
+                if (p.io_f32) {
+                    f32x4 r = *(const f32x4*)((const float*)p.aux + aoff);
+                    f32x4 o = {r[0] + sc * a[0], r[1] + sc * a[1], r[2] + sc * a[2], r[3] + sc * a[3]};
+                    *(f32x4*)((float*)p.C + off) = o;
+                } else {
+                    u32x2 r = *(const u32x2*)((const bf16_t*)p.aux + aoff);
+                    float r0 = of_bf16_to_f32((bf16_t)(r[0] & 0xffff)), r1 = of_bf16_to_f32((bf16_t)(r[0] >> 16));
+                    float r2 = of_bf16_to_f32((bf16_t)(r[1] & 0xffff)), r3 = of_bf16_to_f32((bf16_t)(r[1] >> 16));
+                    u32x2 o = {of_pack_bf16(r0 + sc * a[0], r1 + sc * a[1]), of_pack_bf16(r2 + sc * a[2], r3 + sc * a[3])};
+                    *(u32x2*)((bf16_t*)p.C + off) = o;
+                }
+            } else if (EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) {
+                const size_t aoff = (size_t)m * p.ldaux + n;
+                u32x2 r = *(const u32x2*)((const bf16_t*)p.aux + aoff);
+                float x[4] = {of_bf16_to_f32((bf16_t)(r[0] & 0xffff)), of_bf16_to_f32((bf16_t)(r[0] >> 16)),
+                              of_bf16_to_f32((bf16_t)(r[1] & 0xffff)), of_bf16_to_f32((bf16_t)(r[1] >> 16))};
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (EPI == OF_EPI_DGELU_DOT) {
+                        dot += of_gelu(x[e]) * a[e];
+                        o[e] = sc * a[e] * of_dgelu(x[e]);
+                    } else {
+                        dot += x[e] * a[e];
+                        o[e] = sc * a[e];
+                    }
+                }
+                u32x2 ov = {of_pack_bf16(o[0], o[1]), of_pack_bf16(o[2], o[3])};
+                *(u32x2*)((bf16_t*)p.C + off) = ov;
+            } else {  // OF_EPI_ACC_F32
+                float* c = (float*)p.C + off;
+                f32x4 o = {sc * a[0], sc * a[1], sc * a[2], sc * a[3]};
+                if (p.beta != 0.f) {
+                    f32x4 old = *(const f32x4*)c;
+                    o[0] += p.beta * old[0];
+                    o[1] += p.beta * old[1];
+                    o[2] += p.beta * old[2];
+                    o[3] += p.beta * old[3];
+                }
+                *(f32x4*)c = o;
+            }
+        }
+    }
+    if (EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) {
+        if (p.dot_out) {
+            dot = of_wave_sum(dot);
+            if (lane == 0) of_atomic_add(p.dot_out, (1.0f - gv * gv) * dot);
+        }
+    }
+}
+
+template <bool AT, bool BT, int EPI>
+int launch_layout(const OfGemmArgs& a, of_dim3 grid, of_stream_t s) {
+    if (a.safe && (AT || BT)) return of_launch(of_gemm_kernel<AT, BT, EPI, true>, grid, 256, SMEM_BYTES, s, a);
+    return of_launch(of_gemm_kernel<AT, BT, EPI, false>, grid, 256, SMEM_BYTES, s, a);
+}
+// Only the (layout, epilogue) pairs the hot path uses are instantiated (see DESIGN.md kernel table).
+int dispatch(const OfGemmArgs& a, of_dim3 grid, of_stream_t s) {
+    const int layout = a.a_trans * 2 + a.b_trans;
+    if (layout == 0) {  // y = x W^T
+        switch (a.epi) {
+            case OF_EPI_STORE_BF16: return launch_layout<false, false, OF_EPI_STORE_BF16>(a, grid, s);
+            case OF_EPI_GELU: return launch_layout<false, false, OF_EPI_GELU>(a, grid, s);
+            case OF_EPI_GATE_RESID: return launch_layout<false, false, OF_EPI_GATE_RESID>(a, grid, s);
+            case OF_EPI_ACC_F32: return launch_layout<false, false, OF_EPI_ACC_F32>(a, grid, s);
+        }
+    } else if (layout == 1) {  // dX = dY W
+        switch (a.epi) {
+            case OF_EPI_STORE_BF16: return launch_layout<false, true, OF_EPI_STORE_BF16>(a, grid, s);
+            case OF_EPI_DGELU_DOT: return launch_layout<false, true, OF_EPI_DGELU_DOT>(a, grid, s);
+            case OF_EPI_SCALE_DOT: return launch_layout<false, true, OF_EPI_SCALE_DOT>(a, grid, s);
+            case OF_EPI_ACC_F32: return launch_layout<false, true, OF_EPI_ACC_F32>(a, grid, s);
+        }
+    } else if (layout == 3) {  // dW = dY^T X
+        switch (a.epi) {
+            case OF_EPI_STORE_BF16: return launch_layout<true, true, OF_EPI_STORE_BF16>(a, grid, s);
+            case OF_EPI_ACC_F32: return launch_layout<true, true, OF_EPI_ACC_F32>(a, grid, s);
+        }
+    }
+    return OF_E_SHAPE;
+}
+
+}  // namespace
+
+extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
+    if (!args || !args->A || !args->B || !args->C) return OF_E_ARG;
+    const OfGemmArgs& a = *args;
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0) return OF_E_ARG;
+    // vector-loaded (contiguous) extents must be multiples of 8 elements; outputs are written 4 wide
+    const int a_vec = a.a_trans ? a.M : a.K, b_vec = a.b_trans ? a.N : a.K;
+    if ((a_vec & 7) || (b_vec & 7) || (a.N & 3)) return OF_E_SHAPE;
+    if ((a.lda & 7) || (a.ldb & 7) || (a.ldc & 3)) return OF_E_ALIGN;
+    if (((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15) || ((uintptr_t)a.C & 15)) return OF_E_ALIGN;
+    if ((a.epi == OF_EPI_GATE_RESID || a.epi == OF_EPI_DGELU_DOT || a.epi == OF_EPI_SCALE_DOT) &&
+        (!a.aux || (a.ldaux & 3) || ((uintptr_t)a.aux & 15)))
+        return OF_E_ARG;
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+    of_dim3 grid{(unsigned)(tiles_m * tiles_n), 1, 1};
+    of_stream_t s = (of_stream_t)stream;
+    return dispatch(a, grid, s);
+}

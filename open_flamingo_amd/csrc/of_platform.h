@@ -1,0 +1,108 @@
+// Platform layer for the open_flamingo_amd HIP kernels (gfx950 / CDNA4 only).
+//
+// Every kernel in csrc/ is written against the small of_* vocabulary below.  The product build
+// (hipcc --offload-arch=gfx950) maps it 1:1 onto CDNA4 builtins.  Defining OF_HOST_EMU instead
+// (tests/emu/, host clang, TEST INFRASTRUCTURE ONLY) maps it onto a fiber-based SIMT emulator so the
+// index arithmetic of the kernels (tile maps, swizzles, MFMA fragment layouts, masks) can be checked
+// against the oracle on a machine without a GPU.  The product never loads the emulator build.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+struct of_dim3 {
+    unsigned x, y, z;
+};
+
+#ifndef OF_HOST_EMU
+// =============================================================================== gfx950 device build
+#include <hip/hip_runtime.h>
+#define OF_DEV __device__ __forceinline__
+#define OF_HOSTDEV __host__ __device__ __forceinline__
+#define OF_GLOBAL __global__
+#define OF_BOUNDS(threads, waves_per_simd) __launch_bounds__(threads, waves_per_simd)
+typedef hipStream_t of_stream_t;
+typedef __bf16 of_bf16x8n __attribute__((ext_vector_type(8)));
+
+OF_DEV int of_tid() { return threadIdx.x; }
+OF_DEV int of_bid_x() { return blockIdx.x; }
+OF_DEV int of_bid_y() { return blockIdx.y; }
+OF_DEV int of_bid_z() { return blockIdx.z; }
+OF_DEV int of_gdim_x() { return gridDim.x; }
+OF_DEV char* of_smem() {
+    extern __shared__ __attribute__((aligned(16))) char of_smem_[];
+    return of_smem_;
+}
+OF_DEV void of_sync() { __syncthreads(); }
+// D(16x16, f32) += A(16x32 bf16) * B(32x16 bf16).  Lane l supplies A[l&15][8*(l>>4)+0..7] and
+// B[8*(l>>4)+0..7][l&15]; it receives D[4*(l>>4)+r][l&15], r=0..3 (cdna_hip_programming.md section 3).
+OF_DEV f32x4 of_mfma(s16x8 a, s16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(of_bf16x8n, a),
+                                                   __builtin_bit_cast(of_bf16x8n, b), c, 0, 0, 0);
+}
+// ds_read_b64_tr_b16: within each 16-lane group, lane i supplies the LDS address of 4 contiguous bf16
+// (row i>>2, column chunk i&3 of a 4x16 block) and receives column i of that block (4 rows).
+OF_DEV s16x4 of_lds_tr(const void* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+OF_DEV float of_shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
+OF_DEV int of_shfl_xor_i(int v, int m) { return __shfl_xor(v, m, 64); }
+OF_DEV float of_shfl(float v, int src) { return __shfl(v, src, 64); }
+OF_DEV void of_atomic_add(float* p, float v) { atomicAdd(p, v); }
+OF_DEV float of_exp(float x) { return __expf(x); }
+OF_DEV float of_erf(float x) { return erff(x); }
+OF_DEV float of_tanh(float x) { return tanhf(x); }
+OF_DEV float of_rsqrt(float x) { return rsqrtf(x); }
+OF_DEV float of_log(float x) { return __logf(x); }
+
+template <class K, class A>
+static inline int of_launch(K kernel, of_dim3 grid, int block, size_t smem, of_stream_t s, const A& args) {
+    hipLaunchKernelGGL(kernel, dim3(grid.x, grid.y, grid.z), dim3(block), smem, s, args);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+static inline int of_memset_async(void* p, int v, size_t n, of_stream_t s) {
+    hipError_t e = hipMemsetAsync(p, v, n, s);
+    return e == hipSuccess ? 0 : (int)e;
+}
+#else
+// =============================================================================== host SIMT emulator
+#include "of_emu.h"
+#endif
+
+// ------------------------------------------------------------------------------- shared helpers
+#ifndef OF_HOSTDEV
+#define OF_HOSTDEV OF_DEV
+#endif
+
+OF_DEV float of_bf16_to_f32(bf16_t h) {
+    unsigned u = ((unsigned)h) << 16;
+    return __builtin_bit_cast(float, u);
+}
+// round-to-nearest-even; NaN stays NaN (quiet)
+OF_DEV bf16_t of_f32_to_bf16(float f) {
+    unsigned u = __builtin_bit_cast(unsigned, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+OF_DEV unsigned of_pack_bf16(float lo, float hi) {
+    return (unsigned)of_f32_to_bf16(lo) | ((unsigned)of_f32_to_bf16(hi) << 16);
+}
+OF_DEV float of_wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += of_shfl_xor(v, m);
+    return v;
+}
+OF_DEV float of_gelu(float a) { return 0.5f * a * (1.0f + of_erf(a * 0.70710678118654752f)); }
+// d/da gelu(a) = Phi(a) + a * phi(a)
+OF_DEV float of_dgelu(float a) {
+    return 0.5f * (1.0f + of_erf(a * 0.70710678118654752f)) + a * 0.39894228040143268f * of_exp(-0.5f * a * a);
+}

@@ -1,0 +1,230 @@
+// TEST INFRASTRUCTURE ONLY -- host SIMT emulator behind csrc/of_platform.h (OF_HOST_EMU builds).
+//
+// One workgroup = up to 256 ucontext fibers (one per lane) scheduled round-robin on one OS thread;
+// workgroups of a grid are distributed over OS threads.  Barriers and the wave-level collectives
+// (MFMA 16x16x32 bf16, ds_read_b64_tr_b16, shuffles) are implemented with the lane->element maps
+// documented in /opt/skills/guides/cdna_hip_programming.md section 2-3, so a kernel whose tile /
+// swizzle / fragment index math is wrong fails here, on CPU, against the oracle.  What this CANNOT
+// prove is that the documented hardware maps are right -- tests/test_gpu_probes.py does that on a
+// real MI355X.  Nothing under open_flamingo_amd/ links or loads this build.
+#pragma once
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+
+#include <atomic>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#define OF_DEV static inline
+#define OF_GLOBAL
+#define OF_BOUNDS(threads, waves_per_simd)
+typedef void* of_stream_t;
+
+namespace of_emu {
+constexpr int kMaxThreads = 256;
+constexpr size_t kStack = 256 * 1024;
+struct Block {
+    int nthreads = 0;
+    of_dim3 bid{0, 0, 0}, gdim{1, 1, 1};
+    char* smem = nullptr;
+    ucontext_t sched;
+    ucontext_t ctx[kMaxThreads];
+    char* stacks = nullptr;
+    bool done[kMaxThreads];
+    int cur = 0;
+    int blk_count = 0, blk_gen = 0;
+    int wave_count[4] = {0, 0, 0, 0}, wave_gen[4] = {0, 0, 0, 0};
+    alignas(16) char xchg[kMaxThreads][64];
+    std::function<void()> body;
+};
+inline thread_local Block* g_blk = nullptr;
+
+inline void yield() { swapcontext(&g_blk->ctx[g_blk->cur], &g_blk->sched); }
+inline void block_barrier() {
+    Block* b = g_blk;
+    int gen = b->blk_gen;
+    if (++b->blk_count == b->nthreads) {
+        b->blk_count = 0;
+        b->blk_gen++;
+    } else {
+        while (b->blk_gen == gen) yield();
+    }
+}
+inline void wave_barrier() {
+    Block* b = g_blk;
+    int w = b->cur >> 6;
+    int gen = b->wave_gen[w];
+    if (++b->wave_count[w] == 64) {
+        b->wave_count[w] = 0;
+        b->wave_gen[w]++;
+    } else {
+        while (b->wave_gen[w] == gen) yield();
+    }
+}
+inline void trampoline() {
+    Block* b = g_blk;
+    b->body();
+    b->done[b->cur] = true;
+    swapcontext(&b->ctx[b->cur], &b->sched);
+}
+inline void run_block(Block* b) {
+    g_blk = b;
+    for (int t = 0; t < b->nthreads; ++t) {
+        b->done[t] = false;
+        getcontext(&b->ctx[t]);
+        b->ctx[t].uc_stack.ss_sp = b->stacks + (size_t)t * kStack;
+        b->ctx[t].uc_stack.ss_size = kStack;
+        b->ctx[t].uc_link = nullptr;
+        makecontext(&b->ctx[t], (void (*)())trampoline, 0);
+    }
+    b->blk_count = 0;
+    for (int w = 0; w < 4; ++w) b->wave_count[w] = 0;
+    int remaining = b->nthreads;
+    while (remaining > 0) {
+        for (int t = 0; t < b->nthreads; ++t) {
+            if (b->done[t]) continue;
+            b->cur = t;
+            swapcontext(&b->sched, &b->ctx[t]);
+            if (b->done[t]) --remaining;
+        }
+    }
+}
+template <class F>
+inline int launch(of_dim3 grid, int block, size_t smem, F body) {
+    if (block <= 0 || block > kMaxThreads || (block & 63)) return -100;
+    size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+    std::atomic<size_t> next{0};
+    unsigned nworkers = std::thread::hardware_concurrency();
+    if (nworkers == 0) nworkers = 4;
+    if (nworkers > nblocks) nworkers = (unsigned)nblocks;
+    auto worker = [&]() {
+        Block* b = new Block();
+        b->stacks = (char*)malloc(kStack * (size_t)block);
+        b->smem = (char*)aligned_alloc(256, ((smem + 255) / 256 + 1) * 256);
+        b->nthreads = block;
+        b->gdim = grid;
+        b->body = body;
+        for (;;) {
+            size_t i = next.fetch_add(1);
+            if (i >= nblocks) break;
+            b->bid.x = (unsigned)(i % grid.x);
+            b->bid.y = (unsigned)((i / grid.x) % grid.y);
+            b->bid.z = (unsigned)(i / ((size_t)grid.x * grid.y));
+            memset(b->smem, 0xCD, smem);  // poison: reads of unwritten LDS show up as garbage
+            run_block(b);
+        }
+        free(b->smem);
+        free(b->stacks);
+        delete b;
+        g_blk = nullptr;
+    };
+    std::vector<std::thread> ts;
+    for (unsigned i = 0; i < nworkers; ++i) ts.emplace_back(worker);
+    for (auto& t : ts) t.join();
+    return 0;
+}
+}  // namespace of_emu
+
+OF_DEV int of_tid() { return of_emu::g_blk->cur; }
+OF_DEV int of_bid_x() { return (int)of_emu::g_blk->bid.x; }
+OF_DEV int of_bid_y() { return (int)of_emu::g_blk->bid.y; }
+OF_DEV int of_bid_z() { return (int)of_emu::g_blk->bid.z; }
+OF_DEV int of_gdim_x() { return (int)of_emu::g_blk->gdim.x; }
+OF_DEV char* of_smem() { return of_emu::g_blk->smem; }
+OF_DEV void of_sync() { of_emu::block_barrier(); }
+
+OF_DEV float of_emu_bf16f(short h) {
+    unsigned u = ((unsigned)(unsigned short)h) << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+OF_DEV f32x4 of_mfma(s16x8 a, s16x8 b, f32x4 c) {
+    of_emu::Block* blk = of_emu::g_blk;
+    int t = blk->cur, l = t & 63, w0 = t & ~63;
+    memcpy(blk->xchg[t], &a, 16);
+    memcpy(blk->xchg[t] + 16, &b, 16);
+    of_emu::wave_barrier();
+    f32x4 d = c;
+    int col = l & 15, g = l >> 4;
+    for (int r = 0; r < 4; ++r) {
+        int row = g * 4 + r;
+        float acc = 0.f;
+        for (int k = 0; k < 32; ++k) {
+            short av, bv;
+            memcpy(&av, blk->xchg[w0 + row + 16 * (k >> 3)] + 2 * (k & 7), 2);
+            memcpy(&bv, blk->xchg[w0 + col + 16 * (k >> 3)] + 16 + 2 * (k & 7), 2);
+            acc = fmaf(of_emu_bf16f(av), of_emu_bf16f(bv), acc);
+        }
+        d[r] += acc;
+    }
+    of_emu::wave_barrier();
+    return d;
+}
+OF_DEV s16x4 of_lds_tr(const void* p) {
+    of_emu::Block* blk = of_emu::g_blk;
+    int t = blk->cur, i = t & 15, g0 = t & ~15;
+    if (((uintptr_t)p) & 7) {
+        fprintf(stderr, "of_emu: ds_read_b64_tr_b16 address not 8-byte aligned\n");
+        abort();
+    }
+    memcpy(blk->xchg[t], p, 8);
+    of_emu::wave_barrier();
+    s16x4 r;
+    for (int j = 0; j < 4; ++j) {
+        short v;
+        memcpy(&v, blk->xchg[g0 + j * 4 + (i >> 2)] + 2 * (i & 3), 2);
+        r[j] = v;
+    }
+    of_emu::wave_barrier();
+    return r;
+}
+OF_DEV float of_shfl(float v, int src) {
+    of_emu::Block* blk = of_emu::g_blk;
+    int t = blk->cur;
+    memcpy(blk->xchg[t], &v, 4);
+    of_emu::wave_barrier();
+    float r;
+    memcpy(&r, blk->xchg[(t & ~63) | (src & 63)], 4);
+    of_emu::wave_barrier();
+    return r;
+}
+OF_DEV float of_shfl_xor(float v, int m) { return of_shfl(v, (of_emu::g_blk->cur & 63) ^ m); }
+OF_DEV int of_shfl_xor_i(int v, int m) {
+    float f;
+    memcpy(&f, &v, 4);
+    f = of_shfl_xor(f, m);
+    memcpy(&v, &f, 4);
+    return v;
+}
+OF_DEV void of_atomic_add(float* p, float v) {
+    std::atomic<unsigned>* a = (std::atomic<unsigned>*)p;
+    unsigned old = a->load();
+    for (;;) {
+        float f;
+        memcpy(&f, &old, 4);
+        f += v;
+        unsigned nw;
+        memcpy(&nw, &f, 4);
+        if (a->compare_exchange_weak(old, nw)) break;
+    }
+}
+OF_DEV float of_exp(float x) { return expf(x); }
+OF_DEV float of_erf(float x) { return erff(x); }
+OF_DEV float of_tanh(float x) { return tanhf(x); }
+OF_DEV float of_rsqrt(float x) { return 1.0f / sqrtf(x); }
+OF_DEV float of_log(float x) { return logf(x); }
+
+template <class K, class A>
+static inline int of_launch(K kernel, of_dim3 grid, int block, size_t smem, of_stream_t, const A& args) {
+    A copy = args;
+    return of_emu::launch(grid, block, smem, [kernel, copy]() { kernel(copy); });
+}
+static inline int of_memset_async(void* p, int v, size_t n, of_stream_t) {
+    memset(p, v, n);
+    return 0;
+}

@@ -1,0 +1,104 @@
+"""Attention-core kernels on the host SIMT emulator vs the fp64 dense reference (tests/attn_reference.py).
+Covers: Perceiver shape (no mask, Lk not a multiple of 64), every mask case of SURVEY 8c KAT-3 (zero rows,
+image at last position, consecutive images, more <image> tokens than images -> uniform rows, 'ge' variant),
+ragged Lq, fused-kv strided views, tr-read path vs scalar path."""
+import numpy as np
+import pytest
+import torch
+
+from tests.attn_reference import dense_attention
+from tests.emu import harness as H
+
+
+def _r(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16)
+
+
+def _run(q, k, v, heads, tt=None, n=0, T=0, only_imm=1, safe=0, dout=None):
+    B, Lq, _ = q.shape
+    o = torch.full_like(q, float("nan"))
+    lse = torch.full((B, heads, Lq), float("nan"))
+    tt32 = tt.to(torch.int32).contiguous() if tt is not None else None
+    a = H.attn_args(q, k, v, o, lse, tt32, n, T, only_imm, heads=heads, safe=safe)
+    H.attn_fwd(a)
+    res = {"o": o, "lse": lse}
+    if dout is not None:
+        dq = torch.full_like(q, float("nan"))
+        dk = torch.full((B, k.shape[1], heads * 64), float("nan"), dtype=torch.bfloat16)
+        dv = torch.full_like(dk, float("nan"))
+        delta = torch.zeros(B, heads, Lq)
+        a = H.attn_args(q, k, v, o, lse, tt32, n, T, only_imm, heads=heads, safe=safe, dout=dout, dq=dq, dk=dk, dv=dv,
+                        delta=delta)
+        H.attn_bwd(a)
+        res.update(dq=dq, dk=dk, dv=dv)
+    return res
+
+
+def _check(q, k, v, heads, tt=None, n=0, T=0, only_imm=1, safe=0, tol=2e-2):
+    dout = _r(q.shape, 99)
+    res = _run(q, k, v, heads, tt, n, T, only_imm, safe, dout)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    ref = dense_attention(qd, kd, vd, heads, tt, n, T, bool(only_imm))
+    ref.backward(dout.double())
+    for name, got, want in (("o", res["o"], ref.detach()), ("dq", res["dq"], qd.grad), ("dk", res["dk"], kd.grad),
+                            ("dv", res["dv"], vd.grad)):
+        got = got.double()
+        assert torch.isfinite(got).all(), name
+        scale = want.abs().max().item() + 1e-6
+        err = (got - want).abs().max().item()
+        assert err <= tol * scale, f"{name}: err {err:.3e} scale {scale:.3e}"
+    return res
+
+
+@pytest.mark.parametrize("safe", [0, 1])
+def test_perceiver_shape(safe):
+    # 2 media, 2 heads, 64 latent queries, 96 keys (tail block half empty)
+    q, k, v = _r((2, 64, 128), 1), _r((2, 96, 128), 2), _r((2, 96, 128), 3)
+    _check(q, k, v, 2, safe=safe)
+
+
+def test_perceiver_fused_kv_view_and_ragged_queries():
+    kv = _r((1, 80, 256), 4)          # [k | v] fused, 2 heads
+    q = _r((1, 40, 128), 5)           # Lq not a multiple of 16
+    _check(q, kv[..., :128], kv[..., 128:], 2)
+
+
+CASES = {
+    "basic": ([[1, 0, 0, 0, 1, 0, 0, 1, 0, 0, 0, 0] * 6, [1] + [0] * 40 + [1] + [0] * 30], 3, 1),
+    "before_first_image": ([[0, 0, 0, 1] + [0] * 68, [0] * 72], 2, 1),
+    "image_last_and_consecutive": ([[1, 1] + [0] * 69 + [1], [0, 1, 1, 1] + [0] * 68], 3, 1),
+    "more_image_tokens_than_images": ([[1, 0, 1, 0, 1, 0, 1, 0] * 9, [1, 1, 1, 1] + [0] * 68], 3, 1),
+    "single_image": ([[1] + [0] * 71, [1] + [0] * 71], 1, 1),
+    "attend_all_previous": ([[1, 0, 0, 0, 1, 0, 0, 1] * 9, [0, 0, 1] + [0] * 69], 3, 0),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_masked_cases(case):
+    locs, T, only_imm = CASES[case]
+    n = 16
+    ml = torch.tensor(locs, dtype=torch.bool)
+    tt = ml.cumsum(-1)
+    B, L = ml.shape
+    q, k, v = _r((B, L, 128), 6), _r((B, T * n, 128), 7), _r((B, T * n, 128), 8)
+    res = _check(q, k, v, 2, tt, n, T, only_imm)
+    if only_imm:
+        zero_rows = (tt == 0)
+        assert (res["o"][zero_rows] == 0).all()
+        assert torch.isinf(res["lse"].transpose(1, 2)[zero_rows]).all()
+
+
+def test_text_time_kernel():
+    import ctypes as C
+    g = torch.Generator().manual_seed(0)
+    ml = (torch.rand(3, 150, generator=g) < 0.1)
+    tt = torch.zeros(3, 150, dtype=torch.int32)
+    m8 = ml.to(torch.uint8).contiguous()
+    rc = H.lib().of_text_time(H.ptr(m8), H.ptr(tt), 3, 150, 150, 0, None)
+    assert rc == 0
+    assert torch.equal(tt.long(), ml.cumsum(-1))
+    tt2 = torch.zeros(3, 7, dtype=torch.int32)
+    rc = H.lib().of_text_time(H.ptr(m8), H.ptr(tt2), 3, 150, 7, 1, None)
+    assert rc == 0
+    assert torch.equal(tt2.long(), ml.sum(-1, keepdim=True).expand(-1, 7))

@@ -1,0 +1,95 @@
+"""Kernel index-logic checks of the GEMM on the host SIMT emulator (tests/emu) against plain fp64 matmul.
+Bit-level expectations: operands are exactly-representable bf16, accumulation is fp32 fma in k order, so the
+comparison tolerance only covers summation order (1e-5 relative)."""
+import numpy as np
+import pytest
+import torch
+
+from open_flamingo_amd.hip import abi
+from tests.emu import harness as H
+
+
+def _rand(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g).to(torch.bfloat16)
+
+
+def _ref(A, B, at, bt):
+    a = A.double().t() if at else A.double()
+    b = B.double() if bt else B.double().t()
+    return a @ b
+
+
+@pytest.mark.parametrize("at,bt,safe", [(0, 0, 0), (0, 1, 0), (0, 1, 1), (1, 1, 0), (1, 1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 72), (64, 264, 200)])
+def test_gemm_layouts_store(at, bt, safe, M, N, K):
+    if at and (M % 8):
+        M = (M + 7) // 8 * 8
+    A = _rand((K, M) if at else (M, K), 1)
+    B = _rand((K, N) if bt else (N, K), 2)
+    if (not at) and K % 8:
+        pytest.skip("K-contiguous operand needs K % 8 == 0")
+    out = torch.zeros(M, N, dtype=torch.bfloat16)
+    H.gemm(A, B, a_trans=at, b_trans=bt, epi=abi.EPI_ACC_F32 if at else abi.EPI_STORE_BF16,
+           C_out=(torch.zeros(M, N) if at else out), safe=safe)
+    ref = _ref(A, B, at, bt)
+    if at:
+        o32 = torch.zeros(M, N)
+        H.gemm(A, B, a_trans=at, b_trans=bt, epi=abi.EPI_ACC_F32, C_out=o32, safe=safe)
+        np.testing.assert_allclose(o32.double().numpy(), ref.numpy(), rtol=1e-5, atol=1e-4)
+    else:
+        np.testing.assert_allclose(out.double().numpy(), ref.to(torch.bfloat16).double().numpy(), rtol=1e-2, atol=1e-2)
+        err = (out.double() - ref).abs().max() / ref.abs().max()
+        assert err < 5e-3
+
+
+def test_gemm_epilogues():
+    M, N, K = 136, 192, 128
+    A, B = _rand((M, K), 3), _rand((N, K), 4) * 0.1
+    acc = _ref(A, B, 0, 0)
+    gate = torch.tensor([0.37])
+    g = float(torch.tanh(gate))
+    # GELU (+ pre-activation)
+    b_out, a_out = torch.zeros(M, N, dtype=torch.bfloat16), torch.zeros(M, N, dtype=torch.bfloat16)
+    H.gemm(A, B, epi=abi.EPI_GELU, C_out=b_out, C2=a_out)
+    np.testing.assert_allclose(a_out.double().numpy(), acc.numpy(), rtol=1e-2, atol=1e-2)
+    np.testing.assert_allclose(b_out.double().numpy(), torch.nn.functional.gelu(acc).numpy(), rtol=1e-2, atol=1e-2)
+    # gate + residual, fp32 and bf16 stream
+    res = torch.randn(M, N)
+    out = torch.zeros(M, N)
+    H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=out, aux=res, gate=gate, io_f32=1)
+    np.testing.assert_allclose(out.double().numpy(), (res.double() + g * acc).numpy(), rtol=1e-5, atol=1e-4)
+    resb = res.to(torch.bfloat16)
+    outb = torch.zeros(M, N, dtype=torch.bfloat16)
+    H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=outb, aux=resb, gate=gate, io_f32=0)
+    np.testing.assert_allclose(outb.double().numpy(), (resb.double() + g * acc).numpy(), rtol=1e-2, atol=2e-2)
+    # accumulate fp32 with beta
+    c = torch.randn(M, N)
+    c0 = c.clone()
+    H.gemm(A, B, epi=abi.EPI_ACC_F32, C_out=c, alpha=0.5, beta=1.0, gate=gate)
+    np.testing.assert_allclose(c.double().numpy(), (c0.double() + 0.5 * g * acc).numpy(), rtol=1e-5, atol=1e-4)
+
+
+def test_gemm_dot_epilogues():
+    M, N, K = 128, 136, 64
+    A = _rand((M, K), 5)
+    W = _rand((K, N), 6) * 0.2          # dX = dY W : b_trans = 1
+    acc = A.double() @ W.double()
+    aux = _rand((M, N), 7)
+    gate = torch.tensor([-0.8])
+    g = float(torch.tanh(gate))
+    for epi in (abi.EPI_DGELU_DOT, abi.EPI_SCALE_DOT):
+        out = torch.zeros(M, N, dtype=torch.bfloat16)
+        dot = torch.zeros(1)
+        H.gemm(A, W, b_trans=1, epi=epi, C_out=out, aux=aux, gate=gate, dot_out=dot)
+        x = aux.double()
+        if epi == abi.EPI_DGELU_DOT:
+            xx = x.clone().requires_grad_(True)
+            torch.nn.functional.gelu(xx).sum().backward()
+            want = g * acc * xx.grad
+            wdot = (1 - g * g) * (torch.nn.functional.gelu(x) * acc).sum()
+        else:
+            want = g * acc
+            wdot = (1 - g * g) * (x * acc).sum()
+        np.testing.assert_allclose(out.double().numpy(), want.numpy(), rtol=1e-2, atol=2e-2)
+        assert abs(float(dot) - float(wdot)) <= 1e-3 * abs(float(wdot)) + 1e-2

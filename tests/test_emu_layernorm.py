@@ -1,0 +1,82 @@
+"""LayerNorm fwd/bwd + element-wise helpers on the host SIMT emulator vs torch fp64."""
+import numpy as np
+import pytest
+import torch
+
+from tests.emu import harness as H
+
+
+def _ln_ref(x, w, b):
+    return torch.nn.functional.layer_norm(x, (x.shape[-1],), w, b, 1e-5)
+
+
+@pytest.mark.parametrize("x_f32", [1, 0])
+@pytest.mark.parametrize("rows,dim", [(37, 64), (9, 1024)])
+def test_layernorm_fwd_bwd(x_f32, rows, dim):
+    g = torch.Generator().manual_seed(rows * dim)
+    x = torch.randn(rows, dim, generator=g) * 2 + 0.5
+    if not x_f32:
+        x = x.to(torch.bfloat16)
+    w = 1 + 0.1 * torch.randn(dim, generator=g)
+    b = 0.1 * torch.randn(dim, generator=g)
+    y = torch.zeros(rows, dim + 8, dtype=torch.bfloat16)  # strided destination
+    stats = torch.zeros(rows, 2)
+    L = H.lib()
+    rc = L.of_layernorm_fwd(H.ptr(x), x_f32, x.stride(0), H.ptr(w), H.ptr(b), H.ptr(y), y.stride(0), H.ptr(stats),
+                            rows, dim, None)
+    assert rc == 0
+    xd = x.double().requires_grad_(True)
+    wd, bd = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = _ln_ref(xd, wd, bd)
+    np.testing.assert_allclose(y[:, :dim].double().numpy(), ref.detach().numpy(), rtol=1e-2, atol=1e-2)
+    np.testing.assert_allclose(stats[:, 0].double().numpy(), x.double().mean(-1).numpy(), rtol=1e-5, atol=1e-6)
+    # fp32 output variant
+    y32 = torch.zeros(rows, dim)
+    rc = L.of_layernorm_fwd_out(H.ptr(x), x_f32, x.stride(0), H.ptr(w), H.ptr(b), H.ptr(y32), 1, dim, H.ptr(stats),
+                                rows, dim, None)
+    assert rc == 0
+    np.testing.assert_allclose(y32.double().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-5)
+    # backward with residual add, bf16 copy and dw/db accumulation on top of existing values
+    dy = torch.randn(rows, dim, generator=g).to(torch.bfloat16)
+    resid = torch.randn(rows, dim, generator=g)
+    if not x_f32:
+        resid = resid.to(torch.bfloat16)
+    ref.backward(dy.double())
+    dx = torch.zeros_like(resid)
+    dxb = torch.zeros(rows, dim, dtype=torch.bfloat16)
+    dw0, db0 = torch.randn(dim, generator=g), torch.randn(dim, generator=g)
+    dw, db = dw0.clone(), db0.clone()
+    rc = L.of_layernorm_bwd(H.ptr(dy), 0, dim, H.ptr(x), x_f32, x.stride(0), H.ptr(stats), H.ptr(w), H.ptr(resid),
+                            H.ptr(dx), x_f32, dim, H.ptr(dxb), H.ptr(dw), H.ptr(db), rows, dim, None)
+    assert rc == 0
+    want_dx = xd.grad + resid.double()
+    tol = dict(rtol=1e-4, atol=1e-4) if x_f32 else dict(rtol=2e-2, atol=3e-2)
+    np.testing.assert_allclose(dx.double().numpy(), want_dx.numpy(), **tol)
+    np.testing.assert_allclose(dxb.double().numpy(), want_dx.numpy(), rtol=2e-2, atol=3e-2)
+    np.testing.assert_allclose((dw - dw0).double().numpy(), wd.grad.numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose((db - db0).double().numpy(), bd.grad.numpy(), rtol=1e-3, atol=1e-3)
+
+
+def test_elementwise_helpers():
+    L = H.lib()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1003, generator=g)
+    xb = torch.zeros(1003, dtype=torch.bfloat16)
+    assert L.of_cast_f32_to_bf16(H.ptr(x), H.ptr(xb), 1003, None) == 0
+    assert torch.equal(xb, x.to(torch.bfloat16))
+    xf = torch.zeros(1003)
+    assert L.of_cast_bf16_to_f32(H.ptr(xb), H.ptr(xf), 1003, None) == 0
+    assert torch.equal(xf, xb.float())
+    a, b = torch.randn(517, generator=g), torch.randn(517, generator=g)
+    o = torch.zeros(517)
+    assert L.of_add(H.ptr(a), H.ptr(b), H.ptr(o), 1, 517, None) == 0
+    assert torch.equal(o, a + b)
+    lat = torch.randn(4, 16, generator=g)
+    out = torch.zeros(12, 24)
+    assert L.of_broadcast_rows(H.ptr(lat), 4, H.ptr(out), 1, 24, 12, 16, None) == 0
+    assert torch.equal(out[:, :16], lat.repeat(3, 1))
+    dst0 = torch.randn(4, 16, generator=g)
+    dst = dst0.clone()
+    src = torch.randn(12, 16, generator=g)
+    assert L.of_reduce_rows(H.ptr(src), 1, 12, 16, H.ptr(dst), 4, None) == 0
+    np.testing.assert_allclose(dst.numpy(), (dst0 + src.reshape(3, 4, 16).sum(0)).numpy(), rtol=1e-6, atol=1e-6)
