@@ -87,14 +87,23 @@ int of_layernorm_fwd(const void* x, int x_f32, long ldx, const float* w, const f
                      float* stats, long rows, int dim, void* stream);
 int of_layernorm_fwd_out(const void* x, int x_f32, long ldx, const float* w, const float* b, void* y, int y_f32,
                          long ldy, float* stats, long rows, int dim, void* stream);
-/* Backward: dy (bf16 if dy_f32==0 else fp32, row stride lddy), x + stats as saved.
- *   dx_out(T) = (resid ? resid(T) : 0) + LN_bwd(dy)      T = stream dtype (out_f32)
+/* Grouped destination: row r is written at y + (r / grp_rows) * grp_stride + (r % grp_rows) * ldy (elements), so
+ * LN_media(x) and LN_latents(latents) land directly in the [N][v+n][D] key/value input of helpers.py:53 without
+ * a torch.cat copy.  y2 (optional) receives a second contiguous bf16 copy (the to_q operand, helpers.py:52). */
+int of_layernorm_fwd_grouped(const void* x, int x_f32, long ldx, const float* w, const float* b, uint16_t* y, long ldy,
+                             long grp_rows, long grp_stride, uint16_t* y2, float* stats, long rows, int dim,
+                             void* stream);
+/* Backward: dy (bf16 if dy_f32==0 else fp32, row stride lddy, optionally grouped like the forward destination)
+ * plus an optional second upstream gradient dy2 (bf16, contiguous); x + stats as saved.
+ *   dx_out(T) = (resid ? resid(T) : 0) + LN_bwd(dy + dy2)      T = stream dtype (out_f32)
  *   dx_bf16   = optional bf16 copy of dx_out (feeds the next GEMMs as an operand), may be NULL
  *   dw, db   += column reductions (fp32, accumulated atomically; caller zero-initialises or accumulates)
- * dx_out may be NULL when only dw/db are needed (norm_media: the ViT features carry no gradient). */
-int of_layernorm_bwd(const void* dy, int dy_f32, long lddy, const void* x, int x_f32, long ldx, const float* stats,
-                     const float* w, const void* resid, void* dx_out, int out_f32, long lddx, uint16_t* dx_bf16,
-                     float* dw, float* db, long rows, int dim, void* stream);
+ * dx_out and dx_bf16 may both be NULL when only dw/db are needed (norm_media: the ViT features normally carry
+ * no gradient). */
+int of_layernorm_bwd(const void* dy, int dy_f32, long lddy, long dy_grp_rows, long dy_grp_stride, const uint16_t* dy2,
+                     const void* x, int x_f32, long ldx, const float* stats, const float* w, const void* resid,
+                     void* dx_out, int out_f32, long lddx, uint16_t* dx_bf16, float* dw, float* db, long rows, int dim,
+                     void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Windowed multi-head attention core, head dim 64, flash-style (scores never reach HBM).

@@ -13,10 +13,14 @@ struct LnArgs {
     const void* x; int x_f32; long ldx;
     const float* w; const float* b;
     void* y; int y_f32; long ldy;
+    long y_grp_rows, y_grp_stride;   // grp_rows > 0: row r lands at (r / grp_rows) * grp_stride + (r % grp_rows) * ldy
+    bf16_t* y2;                      // optional second, contiguous bf16 copy (row stride dim)
     float* stats;
     long rows; int dim;
     // backward
     const void* dy; int dy_f32; long lddy;
+    long dy_grp_rows, dy_grp_stride;
+    const bf16_t* dy2;               // optional second upstream gradient (bf16, contiguous), added to dy
     const void* resid;
     void* dx; int dx_f32; long lddx;
     bf16_t* dx_bf16;
@@ -77,7 +81,8 @@ OF_GLOBAL void of_ln_fwd_kernel(LnArgs a) {
             a.stats[row * 2] = mean;
             a.stats[row * 2 + 1] = rstd;
         }
-        const size_t yo = (size_t)row * a.ldy;
+        const size_t yo = a.y_grp_rows > 0 ? (size_t)(row / a.y_grp_rows) * a.y_grp_stride + (size_t)(row % a.y_grp_rows) * a.ldy
+                                           : (size_t)row * a.ldy;
         for (int c = lane; c < nchunk; c += 64) {
             float v[8], o[8];
             load8(a.x, a.x_f32, xo + c * 8, v);
@@ -89,6 +94,7 @@ OF_GLOBAL void of_ln_fwd_kernel(LnArgs a) {
                 o[4 + e] = (v[4 + e] - mean) * rstd * w1[e] + b1[e];
             }
             store8(a.y, a.y_f32, yo + c * 8, o);
+            if (a.y2) store8(a.y2, 0, (size_t)row * a.dim + c * 8, o);
         }
     }
 }
@@ -113,12 +119,20 @@ OF_GLOBAL void of_ln_bwd_kernel(LnArgs a) {
         const long row = ((long)of_bid_x() * 4 + wave) * ROWS_PER_WAVE_BWD + rr;
         if (row >= a.rows) break;  // wave-uniform
         const float mean = a.stats[row * 2], rstd = a.stats[row * 2 + 1];
-        const size_t xo = (size_t)row * a.ldx, go = (size_t)row * a.lddy;
+        const size_t xo = (size_t)row * a.ldx;
+        const size_t go = a.dy_grp_rows > 0 ? (size_t)(row / a.dy_grp_rows) * a.dy_grp_stride + (size_t)(row % a.dy_grp_rows) * a.lddy
+                                            : (size_t)row * a.lddy;
         float c1 = 0.f, c2 = 0.f;
         for (int c = lane; c < nchunk; c += 64) {
             float xv[8], gv[8];
             load8(a.x, a.x_f32, xo + c * 8, xv);
             load8(a.dy, a.dy_f32, go + c * 8, gv);
+            if (a.dy2) {
+                float g2[8];
+                load8(a.dy2, 0, (size_t)row * a.dim + c * 8, g2);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gv[e] += g2[e];
+            }
             const f32x4 w0 = *(const f32x4*)(a.w + c * 8), w1 = *(const f32x4*)(a.w + c * 8 + 4);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -135,6 +149,12 @@ OF_GLOBAL void of_ln_bwd_kernel(LnArgs a) {
             float xv[8], gv[8], o[8];
             load8(a.x, a.x_f32, xo + c * 8, xv);
             load8(a.dy, a.dy_f32, go + c * 8, gv);
+            if (a.dy2) {
+                float g2[8];
+                load8(a.dy2, 0, (size_t)row * a.dim + c * 8, g2);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gv[e] += g2[e];
+            }
             const f32x4 w0 = *(const f32x4*)(a.w + c * 8), w1 = *(const f32x4*)(a.w + c * 8 + 4);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -176,36 +196,51 @@ int check_common(const void* x, long ldx, long rows, int dim) {
 
 }  // namespace
 
-extern "C" int of_layernorm_fwd_out(const void* x, int x_f32, long ldx, const float* w, const float* b, void* y,
-                                    int y_f32, long ldy, float* stats, long rows, int dim, void* stream) {
+static int ln_fwd_impl(const void* x, int x_f32, long ldx, const float* w, const float* b, void* y, int y_f32, long ldy,
+                       long grp_rows, long grp_stride, bf16_t* y2, float* stats, long rows, int dim, void* stream) {
     int rc = check_common(x, ldx, rows, dim);
     if (rc) return rc;
     if (!w || !b || !y) return OF_E_ARG;
-    if ((ldy & 7) || ((uintptr_t)y & 15)) return OF_E_ALIGN;
+    if ((ldy & 7) || (grp_stride & 7) || ((uintptr_t)y & 15) || ((uintptr_t)y2 & 15)) return OF_E_ALIGN;
     LnArgs a{};
     a.x = x; a.x_f32 = x_f32; a.ldx = ldx; a.w = w; a.b = b; a.y = y; a.y_f32 = y_f32; a.ldy = ldy;
+    a.y_grp_rows = grp_rows; a.y_grp_stride = grp_stride; a.y2 = y2;
     a.stats = stats; a.rows = rows; a.dim = dim;
     const long rows_per_block = 4 * ROWS_PER_WAVE_FWD;
     of_dim3 grid{(unsigned)((rows + rows_per_block - 1) / rows_per_block), 1, 1};
     return of_launch(of_ln_fwd_kernel, grid, 256, 0, (of_stream_t)stream, a);
 }
 
-extern "C" int of_layernorm_fwd(const void* x, int x_f32, long ldx, const float* w, const float* b, uint16_t* y,
-                                long ldy, float* stats, long rows, int dim, void* stream) {
-    return of_layernorm_fwd_out(x, x_f32, ldx, w, b, y, 0, ldy, stats, rows, dim, stream);
+extern "C" int of_layernorm_fwd_out(const void* x, int x_f32, long ldx, const float* w, const float* b, void* y,
+                                    int y_f32, long ldy, float* stats, long rows, int dim, void* stream) {
+    return ln_fwd_impl(x, x_f32, ldx, w, b, y, y_f32, ldy, 0, 0, nullptr, stats, rows, dim, stream);
 }
 
-extern "C" int of_layernorm_bwd(const void* dy, int dy_f32, long lddy, const void* x, int x_f32, long ldx,
-                                const float* stats, const float* w, const void* resid, void* dx_out, int out_f32,
-                                long lddx, uint16_t* dx_bf16, float* dw, float* db, long rows, int dim, void* stream) {
+extern "C" int of_layernorm_fwd(const void* x, int x_f32, long ldx, const float* w, const float* b, uint16_t* y,
+                                long ldy, float* stats, long rows, int dim, void* stream) {
+    return ln_fwd_impl(x, x_f32, ldx, w, b, y, 0, ldy, 0, 0, nullptr, stats, rows, dim, stream);
+}
+
+extern "C" int of_layernorm_fwd_grouped(const void* x, int x_f32, long ldx, const float* w, const float* b, uint16_t* y,
+                                        long ldy, long grp_rows, long grp_stride, uint16_t* y2, float* stats, long rows,
+                                        int dim, void* stream) {
+    if (grp_rows <= 0) return OF_E_ARG;
+    return ln_fwd_impl(x, x_f32, ldx, w, b, y, 0, ldy, grp_rows, grp_stride, y2, stats, rows, dim, stream);
+}
+
+extern "C" int of_layernorm_bwd(const void* dy, int dy_f32, long lddy, long dy_grp_rows, long dy_grp_stride,
+                                const uint16_t* dy2, const void* x, int x_f32, long ldx, const float* stats,
+                                const float* w, const void* resid, void* dx_out, int out_f32, long lddx,
+                                uint16_t* dx_bf16, float* dw, float* db, long rows, int dim, void* stream) {
     int rc = check_common(x, ldx, rows, dim);
     if (rc) return rc;
     if (!dy || !stats || !w) return OF_E_ARG;
     if ((dw == nullptr) != (db == nullptr)) return OF_E_ARG;
-    if ((lddy & 7) || (lddx & 7) || ((uintptr_t)dy & 15)) return OF_E_ALIGN;
+    if ((lddy & 7) || (lddx & 7) || (dy_grp_stride & 7) || ((uintptr_t)dy & 15) || ((uintptr_t)dy2 & 15)) return OF_E_ALIGN;
     LnArgs a{};
     a.x = x; a.x_f32 = x_f32; a.ldx = ldx; a.w = w; a.stats = const_cast<float*>(stats); a.rows = rows; a.dim = dim;
-    a.dy = dy; a.dy_f32 = dy_f32; a.lddy = lddy; a.resid = resid; a.dx = dx_out; a.dx_f32 = out_f32; a.lddx = lddx;
+    a.dy = dy; a.dy_f32 = dy_f32; a.lddy = lddy; a.dy_grp_rows = dy_grp_rows; a.dy_grp_stride = dy_grp_stride;
+    a.dy2 = dy2; a.resid = resid; a.dx = dx_out; a.dx_f32 = out_f32; a.lddx = lddx;
     a.dx_bf16 = dx_bf16; a.dw = dw; a.db = db;
     const long rows_per_block = 4 * ROWS_PER_WAVE_BWD;
     of_dim3 grid{(unsigned)((rows + rows_per_block - 1) / rows_per_block), 1, 1};

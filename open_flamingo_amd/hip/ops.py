@@ -1,0 +1,191 @@
+"""Thin marshalling of torch tensors onto the C ABI of include/of_hip.h.
+
+``Ops`` only turns tensors into (pointer, stride, size) arguments and checks return codes; it holds a library
+handle and a way to obtain the current stream.  The product instance (``Ops.default()``) is bound to
+``libofhip.so`` + the current HIP stream and is the only one ``open_flamingo_amd.src`` ever uses.
+"""
+import ctypes as C
+
+import torch
+
+from . import abi
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+_ERR = {-1: "OF_E_ARG", -2: "OF_E_SHAPE", -3: "OF_E_ALIGN", -4: "OF_E_WORKSPACE"}
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _is_f32(t):
+    if t.dtype == F32:
+        return 1
+    if t.dtype == BF16:
+        return 0
+    raise TypeError(f"stream tensors must be float32 or bfloat16, got {t.dtype}")
+
+
+class Ops:
+    def __init__(self, lib, stream_fn):
+        self.lib = lib
+        self._stream_fn = stream_fn
+
+    _default = None
+
+    @classmethod
+    def default(cls):
+        """The product instance: libofhip.so (gfx950) on the current HIP stream.  No fallback."""
+        if cls._default is None:
+            from . import lib as _lib
+            handle = _lib.load()
+            cls._default = cls(handle, lambda: torch.cuda.current_stream().cuda_stream)
+        return cls._default
+
+    def _stream(self):
+        s = self._stream_fn()
+        return None if s is None else C.c_void_p(s)
+
+    @staticmethod
+    def _chk(rc, what):
+        if rc != 0:
+            raise RuntimeError(f"libofhip {what} failed: {_ERR.get(rc, 'hipError ' + str(rc))} ({rc})")
+
+    # ------------------------------------------------------------------ GEMM
+    def gemm(self, A, B, out, *, ta=False, tb=False, epi=abi.EPI_STORE_BF16, out2=None, aux=None, gate=None,
+             alpha=1.0, beta=0.0, dot=None, safe=0):
+        """acc[m][n] = sum_k A(m,k) B(n,k); A is (M,K) or, with ta, (K,M); B is (N,K) or, with tb, (K,N)."""
+        assert A.dim() == 2 and B.dim() == 2 and out.dim() == 2
+        assert A.dtype == BF16 and B.dtype == BF16 and A.stride(1) == 1 and B.stride(1) == 1 and out.stride(1) == 1
+        M, K = (A.shape[1], A.shape[0]) if ta else (A.shape[0], A.shape[1])
+        N, Kb = (B.shape[1], B.shape[0]) if tb else (B.shape[0], B.shape[1])
+        assert K == Kb, f"K mismatch {K} vs {Kb}"
+        assert out.shape[0] == M and out.shape[1] == N, f"out {tuple(out.shape)} != ({M},{N})"
+        a = abi.OfGemmArgs()
+        a.A, a.B = A.data_ptr(), B.data_ptr()
+        a.M, a.N, a.K = M, N, K
+        a.lda, a.ldb = A.stride(0), B.stride(0)
+        a.a_trans, a.b_trans, a.epi = int(ta), int(tb), epi
+        a.C, a.ldc = out.data_ptr(), out.stride(0)
+        a.C2 = _p(out2)
+        if out2 is not None:
+            assert out2.stride(0) == out.stride(0) and out2.dtype == BF16
+        a.aux = _p(aux)
+        a.ldaux = aux.stride(0) if aux is not None else 0
+        a.gate = _p(gate)
+        a.alpha, a.beta = float(alpha), float(beta)
+        a.dot_out = _p(dot)
+        a.io_f32 = _is_f32(out) if epi == abi.EPI_GATE_RESID else 0
+        if epi == abi.EPI_GATE_RESID:
+            assert aux is not None and aux.dtype == out.dtype
+        elif epi == abi.EPI_ACC_F32:
+            assert out.dtype == F32
+        else:
+            assert out.dtype == BF16
+        a.safe = safe
+        self._chk(self.lib.of_gemm(C.byref(a), self._stream()), "of_gemm")
+        return out
+
+    # ------------------------------------------------------------------ LayerNorm
+    def ln_fwd(self, x, w, b, y, stats):
+        rows, dim = x.shape
+        self._chk(self.lib.of_layernorm_fwd(x.data_ptr(), _is_f32(x), x.stride(0), w.data_ptr(), b.data_ptr(),
+                                            y.data_ptr(), y.stride(0), _p(stats), rows, dim, self._stream()),
+                  "of_layernorm_fwd")
+
+    def ln_fwd_out(self, x, w, b, y, stats):
+        rows, dim = x.shape
+        self._chk(self.lib.of_layernorm_fwd_out(x.data_ptr(), _is_f32(x), x.stride(0), w.data_ptr(), b.data_ptr(),
+                                                y.data_ptr(), _is_f32(y), y.stride(0), _p(stats), rows, dim,
+                                                self._stream()), "of_layernorm_fwd_out")
+
+    def ln_fwd_grouped(self, x, w, b, y_base, ldy, grp_rows, grp_stride, y2, stats):
+        """y_base: bf16 tensor whose data_ptr is the first destination row."""
+        rows, dim = x.shape
+        self._chk(self.lib.of_layernorm_fwd_grouped(x.data_ptr(), _is_f32(x), x.stride(0), w.data_ptr(), b.data_ptr(),
+                                                    y_base.data_ptr(), ldy, grp_rows, grp_stride, _p(y2), _p(stats),
+                                                    rows, dim, self._stream()), "of_layernorm_fwd_grouped")
+
+    def ln_bwd(self, dy, x, stats, w, *, lddy=None, dy_grp_rows=0, dy_grp_stride=0, dy2=None, resid=None, dx=None,
+               dx_bf16=None, dw=None, db=None):
+        rows, dim = x.shape
+        lddy = dy.stride(0) if lddy is None else lddy
+        out_f32 = _is_f32(dx) if dx is not None else (_is_f32(resid) if resid is not None else 1)
+        lddx = dx.stride(0) if dx is not None else dim
+        if dx_bf16 is not None:
+            assert dx_bf16.stride(0) == lddx
+        if resid is not None:
+            assert resid.stride(0) == lddx
+        self._chk(self.lib.of_layernorm_bwd(dy.data_ptr(), _is_f32(dy), lddy, dy_grp_rows, dy_grp_stride, _p(dy2),
+                                            x.data_ptr(), _is_f32(x), x.stride(0), stats.data_ptr(), w.data_ptr(),
+                                            _p(resid), _p(dx), out_f32, lddx, _p(dx_bf16), _p(dw), _p(db), rows, dim,
+                                            self._stream()), "of_layernorm_bwd")
+
+    # ------------------------------------------------------------------ attention core
+    def _attn_args(self, q, k, v, o, lse, batch, Lq, Lk, heads, text_time, n_per_media, T_img, only_immediate, scale,
+                   safe):
+        a = abi.OfAttnArgs()
+        a.q, a.k, a.v, a.o, a.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr()
+        a.text_time = _p(text_time)
+        a.batch, a.heads, a.Lq, a.Lk = batch, heads, Lq, Lk
+        a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
+        a.n_per_media, a.T_img, a.only_immediate = n_per_media, T_img, int(only_immediate)
+        a.scale = scale
+        a.safe = safe
+        return a
+
+    def attn_fwd(self, q, k, v, o, lse, *, batch, Lq, Lk, heads, text_time=None, n_per_media=0, T_img=0,
+                 only_immediate=True, scale=0.125, safe=0):
+        """q,o: (batch*Lq, >=heads*64) rows; k,v: (batch*Lk, ...) rows (views into a fused kv buffer are fine)."""
+        a = self._attn_args(q, k, v, o, lse, batch, Lq, Lk, heads, text_time, n_per_media, T_img, only_immediate,
+                            scale, safe)
+        self._chk(self.lib.of_attn_fwd(C.byref(a), self._stream()), "of_attn_fwd")
+
+    def attn_bwd(self, q, k, v, o, lse, dout, dq, dk, dv, delta, *, batch, Lq, Lk, heads, text_time=None,
+                 n_per_media=0, T_img=0, only_immediate=True, scale=0.125, safe=0):
+        a = self._attn_args(q, k, v, o, lse, batch, Lq, Lk, heads, text_time, n_per_media, T_img, only_immediate,
+                            scale, safe)
+        a.dout, a.lddo = dout.data_ptr(), dout.stride(0)
+        a.dq, a.lddq = dq.data_ptr(), dq.stride(0)
+        a.dk, a.dv, a.lddk, a.lddv = dk.data_ptr(), dv.data_ptr(), dk.stride(0), dv.stride(0)
+        a.delta = delta.data_ptr()
+        self._chk(self.lib.of_attn_bwd(C.byref(a), self._stream()), "of_attn_bwd")
+
+    def text_time(self, media_locations_u8, out_i32, Lq, use_cached):
+        B, Lm = media_locations_u8.shape
+        self._chk(self.lib.of_text_time(media_locations_u8.data_ptr(), out_i32.data_ptr(), B, Lm, Lq, int(use_cached),
+                                        self._stream()), "of_text_time")
+
+    # ------------------------------------------------------------------ element-wise
+    def to_bf16(self, x, out=None):
+        """Contiguous fp32 -> bf16 copy (GEMM operand); bf16 input is returned unchanged."""
+        if x.dtype == BF16:
+            return x
+        assert x.dtype == F32 and x.is_contiguous()
+        out = torch.empty(x.shape, dtype=BF16, device=x.device) if out is None else out
+        self._chk(self.lib.of_cast_f32_to_bf16(x.data_ptr(), out.data_ptr(), x.numel(), self._stream()),
+                  "of_cast_f32_to_bf16")
+        return out
+
+    def to_f32(self, x):
+        assert x.dtype == BF16 and x.is_contiguous()
+        out = torch.empty(x.shape, dtype=F32, device=x.device)
+        self._chk(self.lib.of_cast_bf16_to_f32(x.data_ptr(), out.data_ptr(), x.numel(), self._stream()),
+                  "of_cast_bf16_to_f32")
+        return out
+
+    def broadcast_rows(self, src, out, rows):
+        self._chk(self.lib.of_broadcast_rows(src.data_ptr(), src.shape[0], out.data_ptr(), _is_f32(out), out.stride(0),
+                                             rows, src.shape[1], self._stream()), "of_broadcast_rows")
+
+    def reduce_rows(self, src, dst):
+        self._chk(self.lib.of_reduce_rows(src.data_ptr(), _is_f32(src), src.shape[0], src.shape[1], dst.data_ptr(),
+                                          dst.shape[0], self._stream()), "of_reduce_rows")
+
+    def add(self, a, b, out):
+        assert a.dtype == b.dtype == out.dtype and a.is_contiguous() and b.is_contiguous() and out.is_contiguous()
+        self._chk(self.lib.of_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), _is_f32(a), a.numel(), self._stream()),
+                  "of_add")
+        return out

@@ -1,0 +1,237 @@
+"""Kernel schedules of the hot path: which libofhip kernels run, in which order, on which buffers.
+
+Pure orchestration over ``Ops`` (no arithmetic happens in Python/PyTorch here): forward and hand-derived
+backward of ``GatedCrossAttentionBlock`` (reference helpers.py:236-279) and ``PerceiverResampler``
+(helpers.py:68-132).  The backward formulas are SURVEY.md appendix A; each GEMM names its role.
+
+Conventions: P = fp32 master parameters by their reference state-dict names; W = bf16 copies of the weight
+matrices (GEMM operands); "stream dtype" tensors (x, y, their grads) are fp32 or bf16 as the caller provides.
+All matrices are 2-D row-major views: token rows x features.
+"""
+import torch
+
+from .abi import (EPI_ACC_F32, EPI_DGELU_DOT, EPI_GATE_RESID, EPI_GELU, EPI_SCALE_DOT, EPI_STORE_BF16)
+from .ops import BF16, F32
+
+
+def _e(shape, dtype, dev):
+    return torch.empty(shape, dtype=dtype, device=dev)
+
+
+def _z(shape, dev):
+    return torch.zeros(shape, dtype=F32, device=dev)
+
+
+# =================================================================================================
+# GatedCrossAttentionBlock
+# =================================================================================================
+def xattn_block_fwd(ops, P, W, x, media_bf, tt, *, B, L, T, n, heads, only_immediate, safe=0):
+    """x (B*L, d) stream dtype; media_bf (B*T*n, Dv) bf16; tt (B, L) int32 or None.  Returns (y, saved)."""
+    dev = x.device
+    rows, d = x.shape
+    inner = heads * 64
+    hid = W["ff.1.weight"].shape[0]
+    # --- masked cross attention (helpers.py:160-233)
+    xn = _e((rows, d), BF16, dev)
+    st1 = _e((rows, 2), F32, dev)
+    ops.ln_fwd(x, P["attn.norm.weight"], P["attn.norm.bias"], xn, st1)
+    q = _e((rows, inner), BF16, dev)
+    ops.gemm(xn, W["attn.to_q.weight"], q)                                   # to_q
+    kv = _e((B * T * n, 2 * inner), BF16, dev)
+    ops.gemm(media_bf, W["attn.to_kv.weight"], kv)                           # to_kv (k | v fused)
+    o = _e((rows, inner), BF16, dev)
+    lse = _e((B, heads, L), F32, dev)
+    ops.attn_fwd(q, kv[:, :inner], kv[:, inner:], o, lse, batch=B, Lq=L, Lk=T * n, heads=heads, text_time=tt,
+                 n_per_media=n, T_img=T, only_immediate=only_immediate, safe=safe)
+    y1 = torch.empty_like(x)
+    ops.gemm(o, W["attn.to_out.weight"], y1, epi=EPI_GATE_RESID, aux=x, gate=P["attn_gate"])   # to_out, *tanh(gate), +x
+    # --- gated feed forward (helpers.py:15-22, 277)
+    u = _e((rows, d), BF16, dev)
+    st2 = _e((rows, 2), F32, dev)
+    ops.ln_fwd(y1, P["ff.0.weight"], P["ff.0.bias"], u, st2)
+    a = _e((rows, hid), BF16, dev)
+    b = _e((rows, hid), BF16, dev)
+    ops.gemm(u, W["ff.1.weight"], b, epi=EPI_GELU, out2=a)                   # up-projection + erf GELU
+    y2 = torch.empty_like(x)
+    ops.gemm(b, W["ff.3.weight"], y2, epi=EPI_GATE_RESID, aux=y1, gate=P["ff_gate"])  # down, *tanh(gate), +y1
+    saved = dict(x=x, xn=xn, st1=st1, q=q, kv=kv, o=o, lse=lse, y1=y1, u=u, st2=st2, a=a, b=b)
+    return y2, saved
+
+
+def xattn_block_bwd(ops, P, W, S, media_bf, tt, dy, *, B, L, T, n, heads, only_immediate, need_dmedia=True, safe=0):
+    """Returns (dx, dmedia fp32 (B*T*n, Dv) or None, grads dict keyed like P)."""
+    dev = dy.device
+    rows, d = S["x"].shape
+    inner = heads * 64
+    hid = W["ff.1.weight"].shape[0]
+    Dv = media_bf.shape[1]
+    g = {}
+    dy = dy.contiguous()
+    dyb = ops.to_bf16(dy)
+    # ---- feed forward branch: y2 = y1 + tanh(gf) * F(y1)
+    g["ff_gate"] = _z((1,), dev)
+    da = _e((rows, hid), BF16, dev)
+    ops.gemm(dyb, W["ff.3.weight"], da, tb=True, epi=EPI_DGELU_DOT, aux=S["a"], gate=P["ff_gate"], dot=g["ff_gate"])
+    g["ff.3.weight"] = _e((d, hid), F32, dev)
+    ops.gemm(dyb, S["b"], g["ff.3.weight"], ta=True, tb=True, epi=EPI_ACC_F32, gate=P["ff_gate"])     # dW2
+    du = _e((rows, d), BF16, dev)
+    ops.gemm(da, W["ff.1.weight"], du, tb=True)
+    g["ff.1.weight"] = _e((hid, d), F32, dev)
+    ops.gemm(da, S["u"], g["ff.1.weight"], ta=True, tb=True, epi=EPI_ACC_F32)                        # dW1
+    g["ff.0.weight"], g["ff.0.bias"] = _z((d,), dev), _z((d,), dev)
+    dy1 = torch.empty_like(dy)
+    dy1b = _e((rows, d), BF16, dev) if dy.dtype == F32 else None
+    ops.ln_bwd(du, S["y1"], S["st2"], P["ff.0.weight"], resid=dy, dx=dy1, dx_bf16=dy1b, dw=g["ff.0.weight"],
+               db=g["ff.0.bias"])
+    if dy1b is None:
+        dy1b = dy1
+    # ---- attention branch: y1 = x + tanh(ga) * A(x, media)
+    g["attn_gate"] = _z((1,), dev)
+    dO = _e((rows, inner), BF16, dev)
+    ops.gemm(dy1b, W["attn.to_out.weight"], dO, tb=True, epi=EPI_SCALE_DOT, aux=S["o"], gate=P["attn_gate"],
+             dot=g["attn_gate"])
+    g["attn.to_out.weight"] = _e((d, inner), F32, dev)
+    ops.gemm(dy1b, S["o"], g["attn.to_out.weight"], ta=True, tb=True, epi=EPI_ACC_F32, gate=P["attn_gate"])
+    dq = _e((rows, inner), BF16, dev)
+    dkv = _e((B * T * n, 2 * inner), BF16, dev)
+    delta = _e((B, heads, L), F32, dev)
+    kv = S["kv"]
+    ops.attn_bwd(S["q"], kv[:, :inner], kv[:, inner:], S["o"], S["lse"], dO, dq, dkv[:, :inner], dkv[:, inner:], delta,
+                 batch=B, Lq=L, Lk=T * n, heads=heads, text_time=tt, n_per_media=n, T_img=T,
+                 only_immediate=only_immediate, safe=safe)
+    dxn = _e((rows, d), BF16, dev)
+    ops.gemm(dq, W["attn.to_q.weight"], dxn, tb=True)
+    g["attn.to_q.weight"] = _e((inner, d), F32, dev)
+    ops.gemm(dq, S["xn"], g["attn.to_q.weight"], ta=True, tb=True, epi=EPI_ACC_F32)
+    g["attn.norm.weight"], g["attn.norm.bias"] = _z((d,), dev), _z((d,), dev)
+    dx = torch.empty_like(dy)
+    ops.ln_bwd(dxn, S["x"], S["st1"], P["attn.norm.weight"], resid=dy1, dx=dx, dw=g["attn.norm.weight"],
+               db=g["attn.norm.bias"])
+    g["attn.to_kv.weight"] = _e((2 * inner, Dv), F32, dev)
+    ops.gemm(dkv, media_bf, g["attn.to_kv.weight"], ta=True, tb=True, epi=EPI_ACC_F32)
+    dmedia = None
+    if need_dmedia:
+        dmedia = _e((B * T * n, Dv), F32, dev)
+        ops.gemm(dkv, W["attn.to_kv.weight"], dmedia, tb=True, epi=EPI_ACC_F32)
+    return dx, dmedia, g
+
+
+# =================================================================================================
+# PerceiverResampler
+# =================================================================================================
+def perceiver_fwd(ops, P, W, x, *, N, Fv, n, heads, depth, safe=0):
+    """x (N*Fv, D) stream dtype (already flattened 'b T (F v) d' rows); returns (out (N*n, D) stream, saved)."""
+    dev = x.device
+    D = x.shape[1]
+    inner = heads * 64
+    S_ = Fv + n
+    hid = W["layers.0.1.1.weight"].shape[0]
+    lat = _e((N * n, D), x.dtype, dev)
+    ops.broadcast_rows(P["latents"], lat, N * n)                              # repeat(latents, 'n d -> b T n d')
+    layers = []
+    for i in range(depth):
+        pa, pf = f"layers.{i}.0.", f"layers.{i}.1."
+        kvin = _e((N * S_, D), BF16, dev)          # [LN_media(x) rows | LN_latents(latents) rows] per media item
+        st_m = _e((N * Fv, 2), F32, dev)
+        st_l = _e((N * n, 2), F32, dev)
+        ltn = _e((N * n, D), BF16, dev)
+        ops.ln_fwd_grouped(x, P[pa + "norm_media.weight"], P[pa + "norm_media.bias"], kvin, D, Fv, S_ * D, None, st_m)
+        ops.ln_fwd_grouped(lat, P[pa + "norm_latents.weight"], P[pa + "norm_latents.bias"], kvin[Fv:], D, n, S_ * D,
+                           ltn, st_l)
+        q = _e((N * n, inner), BF16, dev)
+        ops.gemm(ltn, W[pa + "to_q.weight"], q)
+        kv = _e((N * S_, 2 * inner), BF16, dev)
+        ops.gemm(kvin, W[pa + "to_kv.weight"], kv)
+        o = _e((N * n, inner), BF16, dev)
+        lse = _e((N, heads, n), F32, dev)
+        ops.attn_fwd(q, kv[:, :inner], kv[:, inner:], o, lse, batch=N, Lq=n, Lk=S_, heads=heads, safe=safe)
+        lat1 = torch.empty_like(lat)
+        ops.gemm(o, W[pa + "to_out.weight"], lat1, epi=EPI_GATE_RESID, aux=lat)              # attn(x, latents) + latents
+        u = _e((N * n, D), BF16, dev)
+        st_f = _e((N * n, 2), F32, dev)
+        ops.ln_fwd(lat1, P[pf + "0.weight"], P[pf + "0.bias"], u, st_f)
+        a = _e((N * n, hid), BF16, dev)
+        b = _e((N * n, hid), BF16, dev)
+        ops.gemm(u, W[pf + "1.weight"], b, epi=EPI_GELU, out2=a)
+        lat2 = torch.empty_like(lat)
+        ops.gemm(b, W[pf + "3.weight"], lat2, epi=EPI_GATE_RESID, aux=lat1)                 # ff(latents) + latents
+        layers.append(dict(lat=lat, kvin=kvin, st_m=st_m, st_l=st_l, ltn=ltn, q=q, kv=kv, o=o, lse=lse, lat1=lat1, u=u,
+                           st_f=st_f, a=a, b=b))
+        lat = lat2
+    out = torch.empty_like(lat)
+    st_o = _e((N * n, 2), F32, dev)
+    ops.ln_fwd_out(lat, P["norm.weight"], P["norm.bias"], out, st_o)
+    return out, dict(layers=layers, lat_last=lat, st_o=st_o, x=x)
+
+
+def perceiver_bwd(ops, P, W, S, dout, *, N, Fv, n, heads, depth, need_dx=False, safe=0):
+    """Returns (dx (N*Fv, D) stream dtype or None, grads dict keyed like P)."""
+    dev = dout.device
+    x = S["x"]
+    D = x.shape[1]
+    inner = heads * 64
+    S_ = Fv + n
+    hid = W["layers.0.1.1.weight"].shape[0]
+    g = {}
+    dout = dout.contiguous()
+    g["norm.weight"], g["norm.bias"] = _z((D,), dev), _z((D,), dev)
+    dlat = torch.empty_like(dout)
+    ops.ln_bwd(dout, S["lat_last"], S["st_o"], P["norm.weight"], dx=dlat, dw=g["norm.weight"], db=g["norm.bias"])
+    dx = None
+    for i in reversed(range(depth)):
+        pa, pf = f"layers.{i}.0.", f"layers.{i}.1."
+        Lr = S["layers"][i]
+        # ---- ff(latents) + latents
+        dlb = ops.to_bf16(dlat)
+        da = _e((N * n, hid), BF16, dev)
+        ops.gemm(dlb, W[pf + "3.weight"], da, tb=True, epi=EPI_DGELU_DOT, aux=Lr["a"])
+        g[pf + "3.weight"] = _e((D, hid), F32, dev)
+        ops.gemm(dlb, Lr["b"], g[pf + "3.weight"], ta=True, tb=True, epi=EPI_ACC_F32)
+        du = _e((N * n, D), BF16, dev)
+        ops.gemm(da, W[pf + "1.weight"], du, tb=True)
+        g[pf + "1.weight"] = _e((hid, D), F32, dev)
+        ops.gemm(da, Lr["u"], g[pf + "1.weight"], ta=True, tb=True, epi=EPI_ACC_F32)
+        g[pf + "0.weight"], g[pf + "0.bias"] = _z((D,), dev), _z((D,), dev)
+        dlat1 = torch.empty_like(dlat)
+        dlat1b = _e((N * n, D), BF16, dev) if dlat.dtype == F32 else None
+        ops.ln_bwd(du, Lr["lat1"], Lr["st_f"], P[pf + "0.weight"], resid=dlat, dx=dlat1, dx_bf16=dlat1b,
+                   dw=g[pf + "0.weight"], db=g[pf + "0.bias"])
+        if dlat1b is None:
+            dlat1b = dlat1
+        # ---- attn(x, latents) + latents
+        dO = _e((N * n, inner), BF16, dev)
+        ops.gemm(dlat1b, W[pa + "to_out.weight"], dO, tb=True)
+        g[pa + "to_out.weight"] = _e((D, inner), F32, dev)
+        ops.gemm(dlat1b, Lr["o"], g[pa + "to_out.weight"], ta=True, tb=True, epi=EPI_ACC_F32)
+        dq = _e((N * n, inner), BF16, dev)
+        dkv = _e((N * S_, 2 * inner), BF16, dev)
+        delta = _e((N, heads, n), F32, dev)
+        kv = Lr["kv"]
+        ops.attn_bwd(Lr["q"], kv[:, :inner], kv[:, inner:], Lr["o"], Lr["lse"], dO, dq, dkv[:, :inner], dkv[:, inner:],
+                     delta, batch=N, Lq=n, Lk=S_, heads=heads, safe=safe)
+        dltn = _e((N * n, D), BF16, dev)
+        ops.gemm(dq, W[pa + "to_q.weight"], dltn, tb=True)                      # through to_q
+        g[pa + "to_q.weight"] = _e((inner, D), F32, dev)
+        ops.gemm(dq, Lr["ltn"], g[pa + "to_q.weight"], ta=True, tb=True, epi=EPI_ACC_F32)
+        dkvin = _e((N * S_, D), BF16, dev)
+        ops.gemm(dkv, W[pa + "to_kv.weight"], dkvin, tb=True)                    # through to_kv (media + latent rows)
+        g[pa + "to_kv.weight"] = _e((2 * inner, D), F32, dev)
+        ops.gemm(dkv, Lr["kvin"], g[pa + "to_kv.weight"], ta=True, tb=True, epi=EPI_ACC_F32)
+        # norm_media: parameter grads always; dx only if the vision features require grad (they do not in Flamingo,
+        # flamingo.py:194-195 runs the ViT under no_grad)
+        g[pa + "norm_media.weight"], g[pa + "norm_media.bias"] = _z((D,), dev), _z((D,), dev)
+        dx_new = torch.empty_like(x) if need_dx else None
+        ops.ln_bwd(dkvin, x, Lr["st_m"], P[pa + "norm_media.weight"], lddy=D, dy_grp_rows=Fv, dy_grp_stride=S_ * D,
+                   resid=dx if need_dx else None, dx=dx_new, dw=g[pa + "norm_media.weight"],
+                   db=g[pa + "norm_media.bias"])
+        dx = dx_new
+        # norm_latents: two upstream gradients (k/v rows of kv_input and the to_q input) + the residual
+        g[pa + "norm_latents.weight"], g[pa + "norm_latents.bias"] = _z((D,), dev), _z((D,), dev)
+        dlat_prev = torch.empty_like(dlat)
+        ops.ln_bwd(dkvin[Fv:], Lr["lat"], Lr["st_l"], P[pa + "norm_latents.weight"], lddy=D, dy_grp_rows=n,
+                   dy_grp_stride=S_ * D, dy2=dltn, resid=dlat1, dx=dlat_prev, dw=g[pa + "norm_latents.weight"],
+                   db=g[pa + "norm_latents.bias"])
+        dlat = dlat_prev
+    g["latents"] = _z(tuple(P["latents"].shape), dev)
+    ops.reduce_rows(dlat, g["latents"])                                          # sum over (b, T) of the repeat
+    return dx, g

@@ -84,3 +84,9 @@ def attn_fwd(a):
 def attn_bwd(a):
     rc = lib().of_attn_bwd(C.byref(a), None)
     assert rc == 0, f"of_attn_bwd rc={rc}"
+
+
+def emu_ops():
+    """Ops bound to the emulator library (CPU tensors, no stream).  Tests only."""
+    from open_flamingo_amd.hip.ops import Ops
+    return Ops(lib(), lambda: None)

@@ -1,0 +1,33 @@
+"""Composed forward/backward of the hot path (open_flamingo_amd.hip.path) on the host SIMT emulator vs the
+oracle: checks the kernel schedule, buffer wiring and every hand-derived gradient on CPU."""
+import pytest
+import torch
+
+from tests import path_checks as PC
+from tests.emu import harness as H
+
+
+@pytest.mark.parametrize("stream_dtype", [torch.float32, torch.bfloat16])
+def test_xattn_block_path(stream_dtype):
+    errs = PC.check_xattn(H.emu_ops(), "cpu", stream_dtype=stream_dtype)
+    print(errs)
+
+
+def test_xattn_block_path_quirk_rows_and_ge():
+    L = 40
+    ml = torch.zeros(2, L, dtype=torch.bool)
+    ml[0, [1, 5, 9, 30]] = True      # 4 <image> tokens but only T=2 images -> uniform rows
+    ml[1, [7]] = True                 # rows before the first image -> zero rows
+    PC.check_xattn(H.emu_ops(), "cpu", media_locs=ml, seed=1)
+    PC.check_xattn(H.emu_ops(), "cpu", media_locs=ml, only_immediate=False, seed=2)
+
+
+def test_xattn_zero_gates_identity():
+    errs = PC.check_xattn(H.emu_ops(), "cpu", gates=(0.0, 0.0), seed=3, fwd_tol=1e-6)
+    assert errs["y"] == 0.0
+
+
+@pytest.mark.parametrize("stream_dtype", [torch.float32, torch.bfloat16])
+def test_perceiver_path(stream_dtype):
+    errs = PC.check_perceiver(H.emu_ops(), "cpu", stream_dtype=stream_dtype)
+    print(errs)
