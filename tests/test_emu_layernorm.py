@@ -46,9 +46,7 @@ def test_layernorm_fwd_bwd(x_f32, rows, dim):
     dxb = torch.zeros(rows, dim, dtype=torch.bfloat16)
     dw0, db0 = torch.randn(dim, generator=g), torch.randn(dim, generator=g)
     dw, db = dw0.clone(), db0.clone()
-    rc = L.of_layernorm_bwd(H.ptr(dy), 0, dim, H.ptr(x), x_f32, x.stride(0), H.ptr(stats), H.ptr(w), H.ptr(resid),
-                            H.ptr(dx), x_f32, dim, H.ptr(dxb), H.ptr(dw), H.ptr(db), rows, dim, None)
-    assert rc == 0
+    H.emu_ops().ln_bwd(dy, x, stats, w, resid=resid, dx=dx, dx_bf16=dxb, dw=dw, db=db)
     want_dx = xd.grad + resid.double()
     tol = dict(rtol=1e-4, atol=1e-4) if x_f32 else dict(rtol=2e-2, atol=3e-2)
     np.testing.assert_allclose(dx.double().numpy(), want_dx.numpy(), **tol)
@@ -80,3 +78,32 @@ def test_elementwise_helpers():
     src = torch.randn(12, 16, generator=g)
     assert L.of_reduce_rows(H.ptr(src), 1, 12, 16, H.ptr(dst), 4, None) == 0
     np.testing.assert_allclose(dst.numpy(), (dst0 + src.reshape(3, 4, 16).sum(0)).numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_layernorm_grouped_rows_and_second_gradient():
+    """Perceiver addressing: LN output rows land inside a [N][v+n][D] buffer; backward reads dy from the same
+    grouped rows and adds a second contiguous gradient (kv_input = cat(LN_m(x), LN_l(latents)))."""
+    ops = H.emu_ops()
+    g = torch.Generator().manual_seed(9)
+    N, v, n, D = 3, 5, 4, 32
+    lat = torch.randn(N * n, D, generator=g)
+    w, b = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    buf = torch.zeros(N * (v + n), D, dtype=torch.bfloat16)
+    y2 = torch.zeros(N * n, D, dtype=torch.bfloat16)
+    st = torch.zeros(N * n, 2)
+    ops.ln_fwd_grouped(lat, w, b, buf[v:], D, n, (v + n) * D, y2, st)
+    ref = _ln_ref(lat.double(), w.double(), b.double()).reshape(N, n, D)
+    got = buf.reshape(N, v + n, D)
+    np.testing.assert_allclose(got[:, v:].double().numpy(), ref.numpy(), rtol=1e-2, atol=1e-2)
+    assert (got[:, :v] == 0).all()
+    assert torch.equal(y2.reshape(N, n, D), got[:, v:])
+    dybuf = torch.randn(N * (v + n), D, generator=g).to(torch.bfloat16)
+    dy2 = torch.randn(N * n, D, generator=g).to(torch.bfloat16)
+    dx = torch.zeros(N * n, D)
+    dw, db = torch.zeros(D), torch.zeros(D)
+    ops.ln_bwd(dybuf[v:], lat, st, w, lddy=D, dy_grp_rows=n, dy_grp_stride=(v + n) * D, dy2=dy2, dx=dx, dw=dw, db=db)
+    xd, wd, bd = lat.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    dyt = dybuf.reshape(N, v + n, D)[:, v:].reshape(N * n, D).double() + dy2.double()
+    _ln_ref(xd, wd, bd).backward(dyt)
+    np.testing.assert_allclose(dx.double().numpy(), xd.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(dw.double().numpy(), wd.grad.numpy(), rtol=1e-3, atol=1e-3)

@@ -1,0 +1,117 @@
+"""Micro-benchmark of the libofhip kernels at OF-3B cfg-2 shapes on one MI355X (HIP events).  Prints one JSON
+line per kernel; torch.matmul (hipBLASLt/rocBLAS) is timed beside each GEMM for orientation only."""
+import json
+import sys
+
+import torch
+
+from open_flamingo_amd.hip import abi
+from open_flamingo_amd.hip.ops import Ops
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def main():
+    ops = Ops.default()
+    dev = "cuda"
+    out = []
+    shapes = [  # (name, M, N, K, ta, tb, epi)
+        ("ffn_up   y=xW1^T +gelu", 8192, 8192, 2048, False, False, abi.EPI_GELU),
+        ("ffn_down y=bW2^T +gate+res", 8192, 2048, 8192, False, False, abi.EPI_GATE_RESID),
+        ("ffn_dh   da=dyW2 dgelu", 8192, 8192, 2048, False, True, abi.EPI_DGELU_DOT),
+        ("ffn_du   du=daW1", 8192, 2048, 8192, False, True, abi.EPI_STORE_BF16),
+        ("ffn_dW2  dy^T b", 2048, 8192, 8192, True, True, abi.EPI_ACC_F32),
+        ("ffn_dW1  da^T u", 8192, 2048, 8192, True, True, abi.EPI_ACC_F32),
+        ("to_q", 8192, 512, 2048, False, False, abi.EPI_STORE_BF16),
+        ("to_out +gate+res", 8192, 2048, 512, False, False, abi.EPI_GATE_RESID),
+        ("to_kv media", 4096, 1024, 1024, False, False, abi.EPI_STORE_BF16),
+        ("perceiver to_kv", 20480, 1024, 1024, False, False, abi.EPI_STORE_BF16),
+    ]
+    for name, M, N, K, ta, tb, epi in shapes:
+        A = torch.randn((K, M) if ta else (M, K), device=dev).to(torch.bfloat16)
+        B = torch.randn((K, N) if tb else (N, K), device=dev).to(torch.bfloat16)
+        kw = {}
+        if epi == abi.EPI_GATE_RESID:
+            C = torch.empty(M, N, device=dev)
+            kw = dict(aux=torch.randn(M, N, device=dev), gate=torch.tensor([0.5], device=dev))
+        elif epi == abi.EPI_ACC_F32:
+            C = torch.empty(M, N, device=dev)
+        elif epi == abi.EPI_GELU:
+            C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            kw = dict(out2=torch.empty(M, N, device=dev, dtype=torch.bfloat16))
+        elif epi == abi.EPI_DGELU_DOT:
+            C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            kw = dict(aux=torch.randn(M, N, device=dev).to(torch.bfloat16), gate=torch.tensor([0.5], device=dev),
+                      dot=torch.zeros(1, device=dev))
+        else:
+            C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        ms = timeit(lambda: ops.gemm(A, B, C, ta=ta, tb=tb, epi=epi, **kw))
+        At = A.t() if ta else A
+        Bt = B if tb else B.t()
+        ms_t = timeit(lambda: torch.matmul(At, Bt))
+        fl = 2.0 * M * N * K
+        out.append(dict(kernel="gemm", name=name, M=M, N=N, K=K, ms=round(ms, 4), tflops=round(fl / ms / 1e9, 1),
+                        torch_ms=round(ms_t, 4), torch_tflops=round(fl / ms_t / 1e9, 1)))
+        print(json.dumps(out[-1]), flush=True)
+    # LayerNorm (HBM bound)
+    x = torch.randn(8192, 2048, device=dev)
+    w, b = torch.ones(2048, device=dev), torch.zeros(2048, device=dev)
+    y = torch.empty(8192, 2048, device=dev, dtype=torch.bfloat16)
+    st = torch.empty(8192, 2, device=dev)
+    ms = timeit(lambda: ops.ln_fwd(x, w, b, y, st))
+    by = 8192 * 2048 * (4 + 2)
+    print(json.dumps(dict(kernel="ln_fwd", rows=8192, dim=2048, ms=round(ms, 4), GBps=round(by / ms / 1e6, 1))), flush=True)
+    dy = torch.randn(8192, 2048, device=dev).to(torch.bfloat16)
+    dx = torch.empty_like(x)
+    dxb = torch.empty_like(y)
+    dw, db = torch.zeros(2048, device=dev), torch.zeros(2048, device=dev)
+    ms = timeit(lambda: ops.ln_bwd(dy, x, st, w, resid=x, dx=dx, dx_bf16=dxb, dw=dw, db=db))
+    by = 8192 * 2048 * (2 + 4 + 4 + 4 + 2)
+    print(json.dumps(dict(kernel="ln_bwd", rows=8192, dim=2048, ms=round(ms, 4), GBps=round(by / ms / 1e6, 1))), flush=True)
+    # attention cores
+    B_, L, T, n, H = 32, 256, 2, 64, 8
+    q = torch.randn(B_ * L, H * 64, device=dev).to(torch.bfloat16)
+    kv = torch.randn(B_ * T * n, 2 * H * 64, device=dev).to(torch.bfloat16)
+    o = torch.empty_like(q)
+    lse = torch.empty(B_, H, L, device=dev)
+    ml = torch.zeros(B_, L, dtype=torch.uint8, device=dev)
+    ml[:, 0] = 1
+    ml[:, L // 2] = 1
+    tt = torch.empty(B_, L, dtype=torch.int32, device=dev)
+    ops.text_time(ml, tt, L, False)
+    kw = dict(batch=B_, Lq=L, Lk=T * n, heads=H, text_time=tt, n_per_media=n, T_img=T)
+    ms = timeit(lambda: ops.attn_fwd(q, kv[:, :512], kv[:, 512:], o, lse, **kw))
+    print(json.dumps(dict(kernel="xattn_core_fwd", ms=round(ms, 4), gflop_restricted=round(4 * B_ * H * L * 64 * 64 / 1e9, 2))), flush=True)
+    do = torch.randn_like(q)
+    dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+    delta = torch.empty(B_, H, L, device=dev)
+    ms = timeit(lambda: ops.attn_bwd(q, kv[:, :512], kv[:, 512:], o, lse, do, dq, dkv[:, :512], dkv[:, 512:], delta, **kw))
+    print(json.dumps(dict(kernel="xattn_core_bwd", ms=round(ms, 4))), flush=True)
+    N = 64
+    q = torch.randn(N * 64, 512, device=dev).to(torch.bfloat16)
+    kv = torch.randn(N * 320, 1024, device=dev).to(torch.bfloat16)
+    o = torch.empty_like(q)
+    lse = torch.empty(N, H, 64, device=dev)
+    kw = dict(batch=N, Lq=64, Lk=320, heads=H)
+    ms = timeit(lambda: ops.attn_fwd(q, kv[:, :512], kv[:, 512:], o, lse, **kw))
+    print(json.dumps(dict(kernel="perceiver_core_fwd", ms=round(ms, 4), gflop=round(4 * N * H * 64 * 320 * 64 / 1e9, 2))), flush=True)
+    do = torch.randn_like(q)
+    dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+    delta = torch.empty(N, H, 64, device=dev)
+    ms = timeit(lambda: ops.attn_bwd(q, kv[:, :512], kv[:, 512:], o, lse, do, dq, dkv[:, :512], dkv[:, 512:], delta, **kw))
+    print(json.dumps(dict(kernel="perceiver_core_bwd", ms=round(ms, 4))), flush=True)
+
+
+if __name__ == "__main__":
+    main()
