@@ -1,0 +1,187 @@
+"""bench.py -- OpenFlamingo training-step throughput on MI355X (BASELINE.json metric: train images/sec + step ms,
+OF-3B = ViT-L/14 + MPT-1B, xattn every layer, amp_bf16, synthetic MMC4-style batch B=32 T=2 F=1 L=256 per GPU).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full optimizer step on one synthetic batch: frozen ViT forward (no_grad), PerceiverResampler
+fwd+bwd (libofhip), 24 x [GatedCrossAttentionBlock (libofhip) + frozen MPT block] fwd + bwd, LM head + loss, masked
+embedding gradient, gradient exchange (RCCL, overlapped), global-norm clip, AdamW.  Inputs are resident in HBM before
+the timed region.  Weights are random-init of the named architecture (no network), data synthetic.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus:
+  roofline      -- the dominant libofhip kernel family (the bf16 MFMA GEMM) measured live with HIP events on the
+                   compute stream inside the timed region: algorithmic FLOPs / summed launch time vs 2.5 PFLOP/s.
+  cpu_baseline  -- the oracle (CPU port of the reference arithmetic) timed on the host cores for a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+EPI_NAMES = {0: "store_bf16", 1: "gelu", 2: "gate_resid", 3: "dgelu_dot", 4: "scale_dot", 5: "acc_f32"}
+LAYOUT_NAMES = {(0, 0): "NT(y=xW^T)", (0, 1): "NN(dX=dY W)", (1, 1): "TN(dW=dY^T X)"}
+MFMA_PEAK_TFLOPS = 2500.0   # bf16 dense, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(family_info, threads):
+    """Oracle (CPU restatement of reference helpers.py) fwd+bwd of the hot path at BASELINE config #1 shapes
+    (B=1, T=2, L=32), fp32, all host cores; Perceiver in full + 4 of the xattn blocks, scaled to all blocks."""
+    from oracle import flamingo_oracle as O
+    torch.set_num_threads(threads)
+    d, nblk = family_info["d"], family_info["layers"] // family_info["every"]
+    B, T, L = 1, 2, 32
+    g = torch.Generator().manual_seed(0)
+    per = O.OraclePerceiverResampler(dim=1024)
+    sample_blocks = min(4, nblk)
+    blocks = [O.OracleGatedCrossAttentionBlock(dim=d, dim_visual=1024) for _ in range(sample_blocks)]
+    for b in blocks:
+        with torch.no_grad():
+            b.attn_gate.fill_(0.5)
+            b.ff_gate.fill_(0.5)
+    feats = torch.randn(B, T, 1, 256, 1024, generator=g)
+    x0 = torch.randn(B, L, d, generator=g)
+    ml = torch.zeros(B, L, dtype=torch.bool)
+    ml[:, 0] = True
+    ml[:, L // 2] = True
+
+    def one():
+        t0 = time.perf_counter()
+        vis = per(feats)
+        t1 = time.perf_counter()
+        x = x0.clone().requires_grad_(True)
+        y = x
+        for b in blocks:
+            y = b(y, vis, media_locations=ml)
+        t2 = time.perf_counter()
+        y.square().mean().backward()
+        t3 = time.perf_counter()
+        for m in [per] + blocks:
+            m.zero_grad(set_to_none=True)
+        return t1 - t0, t2 - t1, t3 - t2
+
+    one()
+    ts = [one() for _ in range(3)]
+    t_per = min(t[0] for t in ts)
+    t_blk_f = min(t[1] for t in ts)
+    t_bwd = min(t[2] for t in ts)
+    # backward covers perceiver + sample blocks; scale the block share (fwd-proportional) to all blocks
+    share = t_blk_f / (t_blk_f + t_per)
+    total = t_per + t_blk_f * nblk / sample_blocks + t_bwd * (share * nblk / sample_blocks + (1 - share))
+    return {"value": round(B * T / total, 3), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"hot path only (PerceiverResampler + {nblk} gated xattn blocks, fwd+bwd), fp32 oracle, B=1 T=2 "
+                      f"L=32 (BASELINE config 1); timed Perceiver + {sample_blocks} blocks x3, scaled to {nblk} blocks; "
+                      f"{total * 1e3:.0f} ms/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--family", default="OF-3B")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--T", type=int, default=2)
+    ap.add_argument("--L", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--wire-bf16", action="store_true", help="all-reduce gradients in bf16 on the wire")
+    args = ap.parse_args()
+
+    from open_flamingo_amd.hip.ops import Ops
+    from open_flamingo_amd.train import distributed, step, synthetic, towers
+    from open_flamingo_amd.train.reducer import GradReducer
+
+    device = distributed.init_distributed_device()
+    assert device.type == "cuda", "bench.py needs an AMD GPU"
+    local_rank, rank, world = distributed.world_info_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    model, info = towers.build_flamingo(args.family, device=device, seed=0, gates=0.5)
+    model.train()
+    reducer = GradReducer(model, wire_dtype=torch.bfloat16 if args.wire_bf16 else torch.float32,
+                          embedding_rows=[info["media_token_id"], info["eoc_token_id"]])
+    reducer.broadcast_parameters()
+    opt = step.build_optimizer(model)
+    batch = synthetic.make_batch(args.batch, args.T, args.L, info, device, seed=1 + rank)
+    ops = Ops.default()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step.train_step(model, reducer, opt, batch, info)
+    sync()
+    if not args.no_roofline:
+        ops.gemm_timing = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step.train_step(model, reducer, opt, batch, info)
+    sync()
+    elapsed = time.perf_counter() - t0
+    timing, ops.gemm_timing = ops.gemm_timing, None
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    images = args.batch * args.T * world
+    value = images * args.steps / elapsed
+
+    roofline = None
+    if timing:
+        groups = {}
+        for key, flops, shape, e0, e1 in timing:
+            gsum = groups.setdefault(key, [0.0, 0.0, 0])
+            gsum[0] += flops
+            gsum[1] += e0.elapsed_time(e1)
+            gsum[2] += 1
+        key = max(groups, key=lambda k: groups[k][1])
+        fl, ms, n = groups[key]
+        all_fl = sum(v[0] for v in groups.values())
+        all_ms = sum(v[1] for v in groups.values())
+        ach = fl / ms / 1e9
+        roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "kernel": f"of_gemm_kernel<{LAYOUT_NAMES[key[:2]]},{EPI_NAMES[key[2]]}>",
+                    "launches_per_step": n // args.steps, "avg_launch_ms": round(ms / n, 4),
+                    "gflop_per_launch": round(fl / n / 1e9, 2),
+                    "all_gemm_tflops": round(all_fl / all_ms / 1e9, 1),
+                    "all_gemm_ms_per_step": round(all_ms / args.steps, 2)}
+
+    if rank == 0:
+        out = {"metric": "train images/sec (+ step ms) OF-3B ViT-L/14+MPT-1B, 1/2/4/8 MI355X", "value": round(value, 2),
+               "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": f"{args.family} (ViT-L/14 + {'MPT-1B' if args.family == 'OF-3B' else args.family}, "
+                                      f"xattn_every={info['every']}) full train step, amp_bf16, per-GPU B={args.batch} "
+                                      f"T={args.T} F=1 L={args.L} synthetic MMC4-style batch, random-init weights",
+                          "global_batch": args.batch * world, "images_per_step": images, "seq_len": args.L,
+                          "parallelism": f"dp{world}", "grad_wire_dtype": "bf16" if args.wire_bf16 else "fp32"},
+               "loss": None if loss is None else round(float(loss), 4)}
+        if roofline is not None:
+            out["roofline"] = roofline
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(info, os.cpu_count() or 1)
+            except Exception as exc:  # the baseline is a reported number, never the thing measured
+                out["cpu_baseline"] = {"error": repr(exc)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -6,6 +6,10 @@ loudly.  Build it with ``python -m open_flamingo_amd.csrc.build`` (or ``__graft_
 import ctypes
 import os
 
+import torch  # noqa: F401  -- MUST precede the dlopen below: libofhip.so needs libamdhip64.so.7 and has to bind to
+# the HIP runtime instance torch has already loaded (torch bundles its own copy under the same SONAME); loading
+# libofhip first would pull a second runtime from /opt/rocm and every launch would fail with hipErrorNoDevice.
+
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -32,6 +32,7 @@ class Ops:
     def __init__(self, lib, stream_fn):
         self.lib = lib
         self._stream_fn = stream_fn
+        self.gemm_timing = None   # bench.py sets this to a list to collect (key, flops, start_evt, end_evt) per launch
 
     _default = None
 
@@ -85,6 +86,13 @@ class Ops:
         else:
             assert out.dtype == BF16
         a.safe = safe
+        if self.gemm_timing is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._chk(self.lib.of_gemm(C.byref(a), self._stream()), "of_gemm")
+            e1.record()
+            self.gemm_timing.append(((int(ta), int(tb), epi), 2.0 * M * N * K, (M, N, K), e0, e1))
+            return out
         self._chk(self.lib.of_gemm(C.byref(a), self._stream()), "of_gemm")
         return out
 

@@ -1,0 +1,268 @@
+"""Drop-in modules of the visual-conditioning hot path, computed by libofhip (gfx950) -- no PyTorch math.
+
+Mirrors the public surface of the reference ``open_flamingo/src/helpers.py``: the same class names, constructor
+signatures, parameter names/shapes (so reference checkpoints load with ``strict=True``) and forward signatures:
+
+  PerceiverResampler(*, dim, depth=6, dim_head=64, heads=8, num_latents=64, max_num_media=None,
+                     max_num_frames=None, ff_mult=4)              reference helpers.py:68-132
+  GatedCrossAttentionBlock(*, dim, dim_visual, dim_head=64, heads=8, ff_mult=4,
+                           only_attend_immediate_media=True)       reference helpers.py:236-279
+  MaskedCrossAttention / PerceiverAttention / FeedForward          parameter containers with the reference names
+
+The nn.Modules only own fp32 master parameters.  ``forward`` hands raw device pointers to the C ABI
+(include/of_hip.h) through ``torch.autograd.Function``s whose backward is the hand-derived kernel schedule in
+``open_flamingo_amd/hip/path.py``.  There is no CPU or eager fallback: CPU tensors raise, a missing
+``libofhip.so`` raises at first use.
+"""
+import torch
+from torch import nn
+
+from ..hip import path as _path
+from ..hip.ops import BF16, F32, Ops
+
+
+def exists(val):
+    return val is not None
+
+
+def _require_hip(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what}: the open_flamingo_amd hot path only runs on an AMD GPU through libofhip.so "
+            f"(got a {t.device} tensor); there is no CPU/PyTorch fallback.")
+    if t.dtype not in (F32, BF16):
+        raise TypeError(f"{what}: activations must be float32 or bfloat16 (got {t.dtype})")
+
+
+# per-forward artefacts shared by all blocks that see the same media / media_locations tensors (the reference
+# recomputes them in each of the 24 blocks: helpers.py:187-189, 199-208)
+class _SharedCache:
+    def __init__(self, cap=8):
+        self.cap, self.items = cap, []
+
+    def get(self, key_tensor, tag, make):
+        key = (key_tensor.data_ptr(), key_tensor._version, tuple(key_tensor.shape), key_tensor.dtype, tag)
+        for k, src, val in self.items:
+            if k == key and src is key_tensor:
+                return val
+        val = make()
+        self.items.append((key, key_tensor, val))
+        if len(self.items) > self.cap:
+            self.items.pop(0)
+        return val
+
+
+_shared = _SharedCache()
+
+
+class _HipParamModule(nn.Module):
+    """Common: bf16 operand copies of the weight matrices, refreshed when a parameter's version changes."""
+
+    def _weights_bf16(self, ops, named):
+        cache = self.__dict__.setdefault("_w_bf16_cache", {})
+        out = {}
+        for name, p in named:
+            if p.dim() != 2 or name.endswith("latents") or "embs" in name:
+                continue
+            if p.dtype == BF16:
+                out[name] = p.detach()
+                continue
+            ent = cache.get(name)
+            if ent is None or ent[0] != p._version or ent[1] != p.data_ptr():
+                ent = (p._version, p.data_ptr(), ops.to_bf16(p.detach().contiguous()))
+                cache[name] = ent
+            out[name] = ent[2]
+        return out
+
+    def invalidate_weight_cache(self):
+        """Call after mutating parameters through ``.data`` (which does not bump the version counter)."""
+        self.__dict__.pop("_w_bf16_cache", None)
+
+    @staticmethod
+    def _masters(named):
+        return {k: (p.detach() if p.dtype == F32 else p.detach().float()).contiguous() for k, p in named}
+
+
+class FeedForward(nn.Sequential):
+    """Parameter container with the reference's Sequential layout (0: LayerNorm, 1: Linear, 2: GELU, 3: Linear;
+    helpers.py:15-22).  It is executed fused inside its parent block; calling it directly is not supported."""
+
+    def __init__(self, dim, mult=4):
+        inner_dim = int(dim * mult)
+        super().__init__(nn.LayerNorm(dim), nn.Linear(dim, inner_dim, bias=False), nn.GELU(),
+                         nn.Linear(inner_dim, dim, bias=False))
+
+    def forward(self, x):
+        raise NotImplementedError("FeedForward runs fused inside PerceiverResampler / GatedCrossAttentionBlock "
+                                  "(libofhip); call the parent module.")
+
+
+class PerceiverAttention(nn.Module):
+    """Parameters of helpers.py:25-38; the arithmetic of helpers.py:39-65 runs in PerceiverResampler.forward."""
+
+    def __init__(self, *, dim, dim_head=64, heads=8):
+        super().__init__()
+        self.scale = dim_head ** -0.5
+        self.heads = heads
+        inner_dim = dim_head * heads
+        self.norm_media = nn.LayerNorm(dim)
+        self.norm_latents = nn.LayerNorm(dim)
+        self.to_q = nn.Linear(dim, inner_dim, bias=False)
+        self.to_kv = nn.Linear(dim, inner_dim * 2, bias=False)
+        self.to_out = nn.Linear(inner_dim, dim, bias=False)
+
+    def forward(self, x, latents):
+        raise NotImplementedError("PerceiverAttention runs fused inside PerceiverResampler (libofhip).")
+
+
+class _PerceiverFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, names, x, *params):
+        ops = Ops.default()
+        b, T, Fr, v, D = x.shape
+        named = list(zip(names, params))
+        P = mod._masters(named)
+        W = mod._weights_bf16(ops, named)
+        xr = x.detach().reshape(b * T * Fr * v, D)
+        if not xr.is_contiguous():
+            xr = xr.contiguous()
+        dims = dict(N=b * T, Fv=Fr * v, n=P["latents"].shape[0], heads=mod.heads, depth=mod.depth)
+        out, S = _path.perceiver_fwd(ops, P, W, xr, **dims)
+        ctx.mod, ctx.names, ctx.dims, ctx.S, ctx.P, ctx.W = mod, names, dims, S, P, W
+        ctx.xshape = tuple(x.shape)
+        ctx.param_dtypes = tuple(p.dtype for p in params)
+        return out.view(b, T, dims["n"], D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        ops = Ops.default()
+        dims = ctx.dims
+        D = ctx.xshape[-1]
+        need_dx = ctx.needs_input_grad[2]
+        dx, g = _path.perceiver_bwd(ops, ctx.P, ctx.W, ctx.S, dout.reshape(-1, D), need_dx=need_dx, **dims)
+        ctx.S = None
+        grads = tuple(g[k].to(p_dtype) if g[k].dtype != p_dtype else g[k]
+                      for k, p_dtype in zip(ctx.names, ctx.param_dtypes))
+        return (None, None, dx.view(ctx.xshape) if need_dx else None) + grads
+
+
+class PerceiverResampler(_HipParamModule):
+    def __init__(self, *, dim, depth=6, dim_head=64, heads=8, num_latents=64, max_num_media=None,
+                 max_num_frames=None, ff_mult=4):
+        super().__init__()
+        if dim_head != 64:
+            raise NotImplementedError("libofhip attention kernels are built for dim_head=64 (every released "
+                                      "OpenFlamingo model); got dim_head=%d" % dim_head)
+        # creation order == reference (helpers.py:82-105) so torch.manual_seed(s) gives identical initial weights
+        self.latents = nn.Parameter(torch.randn(num_latents, dim))
+        self.frame_embs = nn.Parameter(torch.randn(max_num_frames, dim)) if exists(max_num_frames) else None
+        self.media_time_embs = nn.Parameter(torch.randn(max_num_media, 1, dim)) if exists(max_num_media) else None
+        self.layers = nn.ModuleList([])
+        for _ in range(depth):
+            self.layers.append(nn.ModuleList([PerceiverAttention(dim=dim, dim_head=dim_head, heads=heads),
+                                              FeedForward(dim=dim, mult=ff_mult)]))
+        self.norm = nn.LayerNorm(dim)
+        self.heads, self.depth, self.dim = heads, depth, dim
+
+    def forward(self, x):
+        """x (b, T, F, v, D) -> (b, T, num_latents, D)   [reference helpers.py:107-132]"""
+        _require_hip(x, "PerceiverResampler")
+        assert x.dim() == 5 and x.shape[-1] == self.dim, f"expected (b,T,F,v,{self.dim}), got {tuple(x.shape)}"
+        if exists(self.frame_embs) or exists(self.media_time_embs):
+            # not used by any OpenFlamingo model (flamingo.py:48 passes neither); TODO(round 2): tiny add kernel
+            raise NotImplementedError("frame_embs / media_time_embs are not implemented in the HIP path yet")
+        named = list(self.named_parameters())
+        names = tuple(k for k, _ in named)
+        return _PerceiverFn.apply(self, names, x, *[p for _, p in named])
+
+
+class MaskedCrossAttention(nn.Module):
+    """Parameters of helpers.py:137-158; the arithmetic of helpers.py:160-233 runs in GatedCrossAttentionBlock."""
+
+    def __init__(self, *, dim, dim_visual, dim_head=64, heads=8, only_attend_immediate_media=True):
+        super().__init__()
+        self.scale = dim_head ** -0.5
+        self.heads = heads
+        inner_dim = dim_head * heads
+        self.norm = nn.LayerNorm(dim)
+        self.to_q = nn.Linear(dim, inner_dim, bias=False)
+        self.to_kv = nn.Linear(dim_visual, inner_dim * 2, bias=False)
+        self.to_out = nn.Linear(inner_dim, dim, bias=False)
+        self.only_attend_immediate_media = only_attend_immediate_media
+
+    def forward(self, x, media, media_locations=None, use_cached_media=False):
+        raise NotImplementedError("MaskedCrossAttention runs fused inside GatedCrossAttentionBlock (libofhip).")
+
+
+_XATTN_NAMES = ("attn_gate", "ff_gate", "attn.norm.weight", "attn.norm.bias", "attn.to_q.weight", "attn.to_kv.weight",
+                "attn.to_out.weight", "ff.0.weight", "ff.0.bias", "ff.1.weight", "ff.3.weight")
+
+
+class _GatedXAttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, x, media, media_locations, use_cached_media, *params):
+        ops = Ops.default()
+        B, L, d = x.shape
+        _, T, n, Dv = media.shape
+        named = list(zip(_XATTN_NAMES, params))
+        P = mod._masters(named)
+        W = mod._weights_bf16(ops, named)
+        xr = x.detach().reshape(B * L, d)
+        if not xr.is_contiguous():
+            xr = xr.contiguous()
+        med = media.detach()
+        media_bf = _shared.get(media, "bf16", lambda: ops.to_bf16(med.reshape(B * T * n, Dv).contiguous())
+                               if med.dtype == F32 else med.reshape(B * T * n, Dv).contiguous())
+        tt = None
+        if media_locations is not None:
+            def _tt():
+                out = torch.empty(B, L, dtype=torch.int32, device=x.device)
+                ml = media_locations.to(torch.uint8).contiguous()
+                ops.text_time(ml, out, L, bool(use_cached_media))
+                return out
+            tt = _shared.get(media_locations, ("tt", L, bool(use_cached_media)), _tt)
+        dims = dict(B=B, L=L, T=T, n=n, heads=mod.attn.heads, only_immediate=mod.attn.only_attend_immediate_media)
+        y, S = _path.xattn_block_fwd(ops, P, W, xr, media_bf, tt, **dims)
+        ctx.mod, ctx.dims, ctx.S, ctx.P, ctx.W, ctx.media_bf, ctx.tt = mod, dims, S, P, W, media_bf, tt
+        ctx.xshape, ctx.mshape, ctx.mdtype = tuple(x.shape), tuple(media.shape), media.dtype
+        ctx.param_dtypes = tuple(p.dtype for p in params)
+        return y.view(B, L, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ops = Ops.default()
+        d = ctx.xshape[-1]
+        need_dmedia = ctx.needs_input_grad[2]
+        dx, dmedia, g = _path.xattn_block_bwd(ops, ctx.P, ctx.W, ctx.S, ctx.media_bf, ctx.tt, dy.reshape(-1, d),
+                                              need_dmedia=need_dmedia, **ctx.dims)
+        ctx.S = None
+        if dmedia is not None:
+            dmedia = (dmedia if ctx.mdtype == F32 else ops.to_bf16(dmedia)).view(ctx.mshape)
+        grads = tuple(g[k] if g[k].dtype == dt else g[k].to(dt) for k, dt in zip(_XATTN_NAMES, ctx.param_dtypes))
+        return (None, dx.view(ctx.xshape), dmedia, None, None) + grads
+
+
+class GatedCrossAttentionBlock(_HipParamModule):
+    def __init__(self, *, dim, dim_visual, dim_head=64, heads=8, ff_mult=4, only_attend_immediate_media=True):
+        super().__init__()
+        if dim_head != 64:
+            raise NotImplementedError("libofhip attention kernels are built for dim_head=64; got %d" % dim_head)
+        self.attn = MaskedCrossAttention(dim=dim, dim_visual=dim_visual, dim_head=dim_head, heads=heads,
+                                         only_attend_immediate_media=only_attend_immediate_media)
+        self.attn_gate = nn.Parameter(torch.tensor([0.0]))
+        self.ff = FeedForward(dim, mult=ff_mult)
+        self.ff_gate = nn.Parameter(torch.tensor([0.0]))
+
+    def forward(self, x, media, media_locations=None, use_cached_media=False):
+        """x (B, T_txt, D_txt), media (B, T_img, n, D_img), media_locations (B, T_txt) bool
+        [reference helpers.py:260-279 + 160-233]"""
+        _require_hip(x, "GatedCrossAttentionBlock")
+        _require_hip(media, "GatedCrossAttentionBlock(media)")
+        if not use_cached_media:
+            if media_locations is None:
+                raise ValueError("media_locations is required unless use_cached_media=True")
+            assert media_locations.shape[1] == x.shape[1], (
+                f"media_location.shape is {media_locations.shape} but x.shape is {x.shape}")
+        params = dict(self.named_parameters())
+        return _GatedXAttnFn.apply(self, x, media, media_locations, use_cached_media,
+                                   *[params[k] for k in _XATTN_NAMES])

@@ -1,0 +1,157 @@
+"""Data-parallel gradient exchange for the trainable part of Flamingo (Perceiver + gated cross-attention blocks +
+the two new embedding rows), RCCL over xGMI.
+
+Replaces ``DistributedDataParallel(model)`` of the reference (open_flamingo/train/train.py:364-366), whose default
+reducer all-reduces every trainable gradient inside EACH ``backward()`` -- twice per optimizer step
+(train_utils.py:118,172) -- including the dense (vocab x d) embedding gradient that is then masked down to two rows
+(train_utils.py:174-196).  Gradients are linear, so:
+
+  * one exchange per optimizer step: hooks only fire the collectives during the LAST backward of the step
+    (``with reducer.no_sync():`` around the earlier ones, same contract as DDP.no_sync);
+  * buckets follow backward order: one bucket per gated cross-attention block (last block first), then the
+    Perceiver, so each all-reduce overlaps the frozen LM block backward that follows it.  The collectives run on
+    a dedicated side stream; the compute stream only waits in ``finish()`` (before clipping / the optimizer);
+  * parameter ``.grad``s are views into the flat fp32 bucket buffers: no flatten/unflatten copies;
+  * only the ``<image>`` / ``<|endofchunk|>`` rows of the input-embedding gradient travel (2 x d floats instead of
+    vocab x d), and the rest of that gradient is zeroed here -- exactly the reference's post-all-reduce mask.
+
+xGMI is point to point (7 links x ~153 GB/s per GPU): with ~147 MB fp32 per block bucket the collective is
+bandwidth-, not latency-bound, and RCCL is free to use all links; ``wire_dtype=torch.bfloat16`` halves the bytes.
+"""
+import contextlib
+
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, model, process_group=None, wire_dtype=torch.float32, embedding_rows=None):
+        """model: a Flamingo (or any module exposing .perceiver and .lang_encoder.gated_cross_attn_layers);
+        embedding_rows: token ids whose input-embedding gradient rows are kept (media + endofchunk)."""
+        self.module = model                      # DDP-style handle (train_utils.py:181 reaches through .module)
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.wire_dtype = wire_dtype
+        self.embedding_rows = list(embedding_rows) if embedding_rows is not None else None
+        self._sync = True
+        self._pending = []
+        self._stream = None
+        lm = model.lang_encoder
+        groups = []
+        for blk in reversed([b for b in lm.gated_cross_attn_layers if b is not None]):
+            groups.append([p for p in blk.parameters() if p.requires_grad])
+        per = [p for p in model.perceiver.parameters() if p.requires_grad]
+        if per:
+            groups.append(per)
+        self.embedding = None
+        emb = lm.get_input_embeddings().weight
+        if emb.requires_grad:
+            self.embedding = emb
+        self.buckets = []
+        for params in groups:
+            if not params:
+                continue
+            n = sum(p.numel() for p in params)
+            flat = torch.zeros(n, dtype=torch.float32, device=params[0].device)
+            off = 0
+            for p in params:
+                p.grad = flat[off:off + p.numel()].view_as(p)      # gradient-as-bucket-view
+                off += p.numel()
+            self.buckets.append(dict(flat=flat, params=params, ready=0))
+        self._param_bucket = {}
+        for bi, b in enumerate(self.buckets):
+            for p in b["params"]:
+                self._param_bucket[p] = bi
+                p.register_post_accumulate_grad_hook(self._hook)
+        if self.embedding is not None:
+            self.embedding.register_post_accumulate_grad_hook(self._emb_hook)
+
+    # ------------------------------------------------------------------
+    def _side_stream(self, device):
+        if device.type != "cuda":
+            return None
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=device)
+        return self._stream
+
+    def _launch(self, flat):
+        """all-reduce(avg) of one flat buffer on the side stream (or inline on CPU/gloo)."""
+        if self.world == 1:
+            return
+        side = self._side_stream(flat.device)
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(flat.device))
+            ctx = torch.cuda.stream(side)
+        else:
+            ctx = contextlib.nullcontext()
+        with ctx:
+            if self.wire_dtype != flat.dtype:
+                wire = flat.to(self.wire_dtype)
+                if side is not None:
+                    wire.record_stream(torch.cuda.current_stream(flat.device))   # consumed on the compute stream later
+                work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._pending.append((work, flat, wire))
+            else:
+                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._pending.append((work, flat, None))
+
+    def _hook(self, p):
+        if not self._sync:
+            return
+        b = self.buckets[self._param_bucket[p]]
+        b["ready"] += 1
+        if b["ready"] == len(b["params"]):
+            b["ready"] = 0
+            self._launch(b["flat"])
+
+    def _emb_hook(self, p):
+        if not self._sync or self.embedding_rows is None:
+            return
+        rows = torch.as_tensor(self.embedding_rows, device=p.grad.device)
+        kept = p.grad.index_select(0, rows).contiguous()
+        p.grad.zero_()                                   # train_utils.py:184-196: every other row is masked to 0
+        self._emb_rows = (rows, kept)
+        self._launch(kept)
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Skip the exchange for backward passes that are not the last of the optimizer step."""
+        old, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = old
+
+    def finish(self):
+        """Make the compute stream wait for all collectives of this step, apply 1/world (avg), write back."""
+        for work, flat, wire in self._pending:
+            work.wait()
+            if wire is not None:
+                flat.copy_(wire)
+            if self.world > 1:
+                flat.div_(self.world)
+        self._pending.clear()
+        if self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
+        if getattr(self, "_emb_rows", None) is not None:
+            rows, kept = self._emb_rows
+            self.embedding.grad.index_copy_(0, rows, kept)
+            self._emb_rows = None
+
+    def zero_grad(self):
+        """Zero in place (the .grad views must stay attached to the buckets)."""
+        for b in self.buckets:
+            b["flat"].zero_()
+            b["ready"] = 0
+        if self.embedding is not None and self.embedding.grad is not None:
+            self.embedding.grad = None
+
+    def broadcast_parameters(self, src=0):
+        """DDP-constructor equivalent (train.py:366): make every rank start from rank ``src``'s trainable weights."""
+        if self.world == 1:
+            return
+        for b in self.buckets:
+            for p in b["params"]:
+                dist.broadcast(p.data, src=src, group=self.group)
+        if self.embedding is not None:
+            dist.broadcast(self.embedding.data, src=src, group=self.group)

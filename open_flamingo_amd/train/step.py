@@ -1,0 +1,64 @@
+"""One optimizer step with the reference's semantics (open_flamingo/train/train_utils.py:94-216, train.py:392-408):
+(optional LAION pass) + MMC4-style pass under amp_bf16, labels masked as in :127-150, embedding-gradient rows masked
+to <image>/<|endofchunk|> (:174-196), global-norm clip 1.0 (:199-208), AdamW with weight decay only on the
+gated cross-attention parameters (train.py:392-408).  Differences, all result-preserving:
+one gradient exchange per step through GradReducer instead of one per backward; label masking vectorised on device.
+"""
+import contextlib
+
+import torch
+
+from . import synthetic
+
+
+def build_optimizer(model, lr=1e-4, weight_decay=0.1):
+    """train.py:384-408: wd only on params whose name contains 'gated_cross_attn'."""
+    with_wd, without_wd = [], []
+    for n, p in model.named_parameters():
+        if not p.requires_grad or getattr(p, "exclude_from_optimizer", False):
+            continue
+        (with_wd if "gated_cross_attn" in n else without_wd).append(p)
+    groups = [{"params": with_wd, "weight_decay": weight_decay}, {"params": without_wd, "weight_decay": 0.0}]
+    fused = all(p.is_cuda for p in with_wd + without_wd)
+    return torch.optim.AdamW(groups, lr=lr, fused=fused)
+
+
+def _autocast(device_type, enabled=True):
+    return torch.autocast(device_type=device_type, dtype=torch.bfloat16, enabled=enabled)
+
+
+def forward_loss(model, batch, info, amp=True):
+    ids = batch["lang_x"]
+    labels = synthetic.make_labels(ids, info["media_token_id"], info["eoc_token_id"], info["pad_token_id"])
+    with _autocast(ids.device.type, amp):
+        out = model(vision_x=batch["vision_x"], lang_x=ids, attention_mask=batch["attention_mask"], labels=labels)
+    return out[0]
+
+
+def train_step(model, reducer, optimizer, batch_mmc4, info, batch_laion=None, loss_multiplier_laion=1.0,
+               loss_multiplier_mmc4=1.0, clip_norm=1.0, amp=True, nan_check=True, lr_scheduler=None):
+    """Returns the (detached) MMC4 loss tensor, or None if the step was skipped because the loss was NaN."""
+    params = [p for g in optimizer.param_groups for p in g["params"]]
+    if batch_laion is not None:
+        with reducer.no_sync() if reducer is not None else contextlib.nullcontext():
+            loss_l = forward_loss(model, batch_laion, info, amp)
+            (loss_l * loss_multiplier_laion).backward()
+    loss = forward_loss(model, batch_mmc4, info, amp)
+    if nan_check and torch.isnan(loss):          # train_utils.py:161-169 (host sync, as in the reference)
+        if reducer is not None:
+            reducer.zero_grad()
+        else:
+            optimizer.zero_grad(set_to_none=True)
+        return None
+    (loss * loss_multiplier_mmc4).backward()
+    if reducer is not None:
+        reducer.finish()                          # waits for the overlapped RCCL all-reduces, masks the embedding grad
+    torch.nn.utils.clip_grad_norm_(params, clip_norm)
+    optimizer.step()
+    if lr_scheduler is not None:
+        lr_scheduler.step()
+    if reducer is not None:
+        reducer.zero_grad()
+    else:
+        optimizer.zero_grad(set_to_none=True)
+    return loss.detach()

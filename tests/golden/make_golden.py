@@ -167,7 +167,62 @@ def full_xattn():
          media_positions=np.array([3, 17]), L=L, **out)
 
 
+def tiny_flamingo():
+    """End-to-end pin of the boundary: the REAL reference Flamingo/FlamingoLMMixin/
+    FlamingoLayer (open_clip stubbed at import time, HF tiny MPT + CLIP stand-in towers) loaded with the state_dict
+    of our model (strict=True, so every key name matches), then loss, gradients and greedy generate()."""
+    sys.modules.setdefault("open_clip", types.ModuleType("open_clip"))
+    sys.path.insert(0, "/root/reference")
+    from open_flamingo.src.flamingo import Flamingo as RefFlamingo
+    from open_flamingo.src.flamingo_lm import FlamingoLMMixin as RefMixin
+    from open_flamingo.src.utils import extend_instance as ref_extend
+    from open_flamingo_amd.train import step, synthetic, towers
+    from tests.cpu_model import tiny_cpu_flamingo
+
+    mine, info = tiny_cpu_flamingo(seed=0)
+    torch.manual_seed(123)
+    vision = towers.VisionStandIn(width=64, layers=2, heads=2, patch=14, image=224)
+    lm, attr = towers.build_lang_encoder("OF-tiny")
+    ref_extend(lm, RefMixin)
+    lm.set_decoder_layers_attr_name(attr)
+    ref = RefFlamingo(vision, lm, info["eoc_token_id"], info["media_token_id"], vis_dim=64,
+                      cross_attn_every_n_layers=info["every"])
+    missing = ref.load_state_dict(mine.state_dict(), strict=True)
+    print("strict load ok:", missing)
+    ref.requires_grad_(False)
+    ref.perceiver.requires_grad_(True)
+    ref.lang_encoder.gated_cross_attn_layers.requires_grad_(True)
+    ref.lang_encoder.get_input_embeddings().requires_grad_(True)
+    batch = synthetic.make_batch(2, 2, 24, info, "cpu", seed=5)
+    labels = synthetic.make_labels(batch["lang_x"], info["media_token_id"], info["eoc_token_id"], info["pad_token_id"])
+    ref.train()
+    out = ref(vision_x=batch["vision_x"], lang_x=batch["lang_x"], attention_mask=batch["attention_mask"], labels=labels)
+    out[0].backward()
+    grads = {k: p.grad.detach().clone() for k, p in ref.state_dict(keep_vars=True).items()
+             if getattr(p, "grad", None) is not None and "old_decoder_blocks" not in k and ".transformer.blocks." not in k}
+    keep = ["perceiver.latents", "perceiver.layers.0.0.to_kv.weight", "perceiver.norm.weight",
+            "lang_encoder.gated_cross_attn_layers.1.attn_gate", "lang_encoder.gated_cross_attn_layers.1.ff_gate",
+            "lang_encoder.gated_cross_attn_layers.3.attn.to_q.weight", "lang_encoder.gated_cross_attn_layers.3.ff.3.weight",
+            "lang_encoder.gated_cross_attn_layers.1.attn.norm.bias"]
+    ref.eval()
+    with torch.no_grad():
+        gen = ref.generate(batch["vision_x"][:1], batch["lang_x"][:1, :8], attention_mask=batch["attention_mask"][:1, :8],
+                           max_new_tokens=6, do_sample=False)
+        # cached-media scoring flow (eval/models/open_flamingo.py:155-313)
+        ref.cache_media(input_ids=batch["lang_x"][:, :12], vision_x=batch["vision_x"])
+        cached_logits = ref(vision_x=None, lang_x=batch["lang_x"][:, 12:16], attention_mask=batch["attention_mask"][:, 12:16],
+                            clear_conditioned_layers=False).logits
+        ref.uncache_media()
+    save("tiny_flamingo.npz", loss=out[0].detach(), logits_head=out.logits[:, :4, :32].detach(), generated=gen,
+         cached_logits_head=cached_logits[:, :, :32],
+         state_dict_keys=np.array(sorted(ref.state_dict().keys())),
+         **{"grad." + k: grads[k] for k in keep},
+         **{"gradnorm." + k: v.norm() for k, v in grads.items() if "wte" not in k})
+
+
 if __name__ == "__main__":
+    tiny_flamingo()
+    sys.exit(0) if "--only-flamingo" in sys.argv else None
     torch.set_num_threads(8)
     small_perceiver(False)
     small_perceiver(True)

@@ -1,0 +1,106 @@
+"""Host-side logic of the boundary (no GPU, no kernels): label masking, synthetic batches, state-dict names,
+interleave rule, conditioning control flow of Flamingo/FlamingoLMMixin, factory freezing, loud failure on CPU
+tensors, C-ABI symbol table."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from open_flamingo_amd.hip import abi
+from open_flamingo_amd.train import synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _labels_loop(input_ids, media, eoc, pad):
+    """Literal restatement of the reference loops, train_utils.py:127-150."""
+    labels = input_ids.clone()
+    labels[labels == pad] = -100
+    for i in range(labels.shape[0]):
+        j = 0
+        while j < labels.shape[1] and labels[i][j] != media:
+            labels[i][j] = -100
+            j += 1
+        for e in torch.where(labels[i] == eoc)[0]:
+            t = e + 1
+            while t < labels.shape[1] and labels[i][t] != media:
+                labels[i][t] = -100
+                t += 1
+    labels[labels == media] = -100
+    return labels
+
+
+def test_label_masking_matches_reference_loops():
+    g = torch.Generator().manual_seed(0)
+    for trial in range(20):
+        ids = torch.randint(0, 12, (4, 40), generator=g)     # small vocab -> many specials; 9=media 10=eoc 11=pad
+        got = synthetic.make_labels(ids, 9, 10, 11)
+        assert torch.equal(got, _labels_loop(ids, 9, 10, 11)), trial
+
+
+def test_synthetic_batch_contract():
+    info = dict(vocab=1000, media_token_id=1001, eoc_token_id=1000, pad_token_id=1002)
+    b = synthetic.make_batch(3, 2, 32, info, "cpu")
+    assert b["vision_x"].shape == (3, 2, 1, 3, 224, 224) and b["lang_x"].shape == (3, 32)
+    assert (b["lang_x"][:, 0] == 1001).all() and (b["lang_x"][:, 16] == 1001).all() and (b["lang_x"][:, 15] == 1000).all()
+    assert ((b["lang_x"] == 1001).sum(-1) == 2).all()
+
+
+def test_header_and_ctypes_prototypes_agree():
+    """Every function declared in include/of_hip.h has a ctypes prototype and vice versa."""
+    src = open(os.path.join(ROOT, "include", "of_hip.h")).read()
+    declared = set(re.findall(r"\bint\s+(of_[a-z0-9_]+)\s*\(", src))
+    assert declared == set(abi.PROTOTYPES), declared ^ set(abi.PROTOTYPES)
+
+
+def test_library_exports_every_symbol():
+    """The gfx950 library loads (no GPU needed for dlopen) and exports the whole ABI; built by build()."""
+    from open_flamingo_amd.csrc import build
+    path = build.build(emu=False)
+    lib = ctypes.CDLL(path)
+    assert abi.declare(lib, require_all=True) == []
+    assert lib.of_abi_version() == abi.OF_ABI_VERSION and lib.of_build_kind() == 1
+
+
+def test_struct_layouts_match_header():
+    """sizeof the two argument structs as the C compiler sees them == ctypes layout."""
+    import subprocess
+    import tempfile
+    code = '#include "of_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu\\n", sizeof(OfGemmArgs), sizeof(OfAttnArgs));return 0;}'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(code)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
+        out = subprocess.check_output([os.path.join(d, "s")]).split()
+    assert int(out[0]) == ctypes.sizeof(abi.OfGemmArgs) and int(out[1]) == ctypes.sizeof(abi.OfAttnArgs)
+
+
+def test_modules_have_reference_state_dict_and_fail_loudly_on_cpu():
+    from open_flamingo_amd.src.helpers import GatedCrossAttentionBlock, PerceiverResampler
+    from oracle.flamingo_oracle import OracleGatedCrossAttentionBlock, OraclePerceiverResampler
+    p, po = PerceiverResampler(dim=64, depth=2, heads=2), OraclePerceiverResampler(dim=64, depth=2, heads=2)
+    assert {k: tuple(v.shape) for k, v in p.state_dict().items()} == {k: tuple(v.shape) for k, v in po.state_dict().items()}
+    po.load_state_dict(p.state_dict(), strict=True)
+    b, bo = GatedCrossAttentionBlock(dim=128, dim_visual=64, heads=2), OracleGatedCrossAttentionBlock(dim=128, dim_visual=64, heads=2)
+    b.load_state_dict(bo.state_dict(), strict=True)
+    assert list(b.state_dict()) == list(bo.state_dict())
+    with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
+        b(torch.zeros(1, 4, 128), torch.zeros(1, 1, 64, 64), torch.zeros(1, 4, dtype=torch.bool))
+    with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
+        p(torch.zeros(1, 1, 1, 8, 64))
+    with pytest.raises(NotImplementedError):
+        GatedCrossAttentionBlock(dim=128, dim_visual=64, dim_head=32)
+
+
+def test_golden_state_dict_names():
+    """Key names of the reference modules (captured in the golden fixtures) == ours (checkpoint compatibility)."""
+    import numpy as np
+    from open_flamingo_amd.src.helpers import GatedCrossAttentionBlock, PerceiverResampler
+    z = np.load(os.path.join(ROOT, "tests", "golden", "small_xattn_basic.npz"))
+    ref_keys = sorted(k[len("param."):] for k in z.files if k.startswith("param."))
+    assert ref_keys == sorted(GatedCrossAttentionBlock(dim=64, dim_visual=64).state_dict())
+    z = np.load(os.path.join(ROOT, "tests", "golden", "small_perceiver_embs.npz"))
+    ref_keys = sorted(k[len("param."):] for k in z.files if k.startswith("param."))
+    ours = PerceiverResampler(dim=64, depth=2, heads=2, num_latents=4, max_num_media=4, max_num_frames=3)
+    assert ref_keys == sorted(ours.state_dict())

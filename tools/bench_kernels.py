@@ -1,7 +1,10 @@
 """Micro-benchmark of the libofhip kernels at OF-3B cfg-2 shapes on one MI355X (HIP events).  Prints one JSON
 line per kernel; torch.matmul (hipBLASLt/rocBLAS) is timed beside each GEMM for orientation only."""
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import torch
 
