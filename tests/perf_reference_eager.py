@@ -1,0 +1,45 @@
+"""Reference-equivalent EAGER step time on the MI355X itself (BASELINE.md section 3 "Also": this is the number the
+>=5x target refers to).  /root/reference does not exist on the GPU box, so the hot-path modules are the oracle's
+nn.Modules -- a line-for-line PyTorch restatement of reference helpers.py, pinned to it by tests/test_oracle_golden.py
+-- plugged into the same Flamingo + the same frozen towers, run as the reference runs them: eager ATen ops under
+torch.autocast(bfloat16), gradients exchanged by nothing (1 GPU), AdamW.  Not part of the product."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from open_flamingo_amd.train import step, synthetic, towers
+from tests.cpu_model import swap_in_oracle
+
+
+def main():
+    family = sys.argv[1] if len(sys.argv) > 1 else "OF-3B"
+    B, T, L = (int(x) for x in (sys.argv[2:5] if len(sys.argv) > 4 else (32, 2, 256)))
+    steps, warm = 4, 2
+    model, info = towers.build_flamingo(family, device="cuda", seed=0, gates=0.5)
+    swap_in_oracle(model)
+    model.cuda().train()
+    opt = step.build_optimizer(model)
+    batch = synthetic.make_batch(B, T, L, info, "cuda", seed=1)
+
+    def one():
+        return step.train_step(model, None, opt, batch, info)
+
+    for _ in range(warm):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = one()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    print(json.dumps({"what": "reference-equivalent eager step (oracle modules, autocast bf16) on MI355X", "family": family,
+                      "B": B, "T": T, "L": L, "ms_per_step": round(ms, 2), "images_per_s": round(B * T / ms * 1e3, 2),
+                      "loss": float(loss), "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1)}))
+
+
+if __name__ == "__main__":
+    main()
