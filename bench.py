@@ -175,7 +175,7 @@ def main():
             out["roofline"] = roofline
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(info, os.cpu_count() or 1)
+                out["cpu_baseline"] = cpu_baseline(info, min(os.cpu_count() or 1, 32))
             except Exception as exc:  # the baseline is a reported number, never the thing measured
                 out["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)
