@@ -71,7 +71,9 @@ typedef struct OfGemmArgs {
     float alpha, beta;
     float* dot_out;    /* device scalar accumulated atomically, or NULL */
     int io_f32;        /* OF_EPI_GATE_RESID: 1 = fp32 stream, 0 = bf16 stream */
-    int safe;          /* 1 = use the slow scalar-LDS transposed-fragment path (self-check of tr-read) */
+    int safe;          /* kernel selection for self-checks: 0 = auto (256x256 LDS-DMA kernel when the shape is tile
+                          aligned, else the general 128x128 kernel); 1 = general kernel with the slow scalar-LDS
+                          transposed-fragment path; 2 = general kernel (tr-read path) */
 } OfGemmArgs;
 
 int of_gemm(const OfGemmArgs* args, void* stream);

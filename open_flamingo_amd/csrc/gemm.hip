@@ -15,8 +15,7 @@
 //       dW = dY^T X need no transposed copies of activations or weights in HBM.
 // The MFMA is issued with the operands swapped (D = Bfrag x Afrag) so that a lane ends up with four
 // consecutive n of one output row: epilogue loads/stores are 8-byte (bf16) or 16-byte (fp32) vectors.
-#include "of_platform.h"
-#include "../../include/of_hip.h"
+#include "gemm_common.h"
 
 namespace {
 
@@ -90,21 +89,6 @@ OF_DEV s16x8 frag(const char* tile, int row_base, int kk, int lane) {
     }
 }
 
-OF_DEV void tile_coords(int bid, int nwg, int tiles_m, int tiles_n, int& pm, int& pn) {
-    // XCD-aware (block b runs on XCD b%8: give each XCD a contiguous range of tile ids, bijective for any
-    // nwg), then grouped ordering so neighbouring ids share A panels (8 m-tiles) and walk n.
-    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int GM = 8;
-    int width = GM * tiles_n;
-    int group = id / width;
-    int first_m = group * GM;
-    int gsz = tiles_m - first_m < GM ? tiles_m - first_m : GM;
-    int in = id - group * width;
-    pm = first_m + in % gsz;
-    pn = in / gsz;
-}
-
 template <bool AT, bool BT, int EPI, bool SAFE>
 OF_GLOBAL void OF_BOUNDS(256, 2) of_gemm_kernel(OfGemmArgs p) {
     char* smem = of_smem();
@@ -113,7 +97,7 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_gemm_kernel(OfGemmArgs p) {
     const int wr = wave >> 1, wc = wave & 1;
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     int pm, pn;
-    tile_coords(of_bid_x(), of_gdim_x(), tiles_m, tiles_n, pm, pn);
+    ofg::tile_coords(of_bid_x(), of_gdim_x(), tiles_m, tiles_n, pm, pn);
     const int m0 = pm * BM, n0 = pn * BN;
 
     f32x4 acc[4][4];
@@ -164,80 +148,16 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_gemm_kernel(OfGemmArgs p) {
     const float sc = gv * p.alpha;
     float dot = 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + wr * 64 + mt * 16 + i16;
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n = n0 + wc * 64 + nt * 16 + g * 4;
-            if (m >= p.M || n >= p.N) continue;
-            const f32x4 a = acc[mt][nt];
-            const size_t off = (size_t)m * p.ldc + n;
-            if (EPI == OF_EPI_STORE_BF16) {
-                u32x2 o = {of_pack_bf16(sc * a[0], sc * a[1]), of_pack_bf16(sc * a[2], sc * a[3])};
-                *(u32x2*)((bf16_t*)p.C + off) = o;
-            } else if (EPI == OF_EPI_GELU) {
-                if (p.C2) {
-                    u32x2 o = {of_pack_bf16(a[0], a[1]), of_pack_bf16(a[2], a[3])};
-                    *(u32x2*)((bf16_t*)p.C2 + off) = o;
-                }
-                u32x2 o = {of_pack_bf16(of_gelu(a[0]), of_gelu(a[1])), of_pack_bf16(of_gelu(a[2]), of_gelu(a[3]))};
-                *(u32x2*)((bf16_t*)p.C + off) = o;
-            } else if (EPI == OF_EPI_GATE_RESID) {
-                const size_t aoff = (size_t)m * p.ldaux + n;
-                if (p.io_f32) {
-                    f32x4 r = *(const f32x4*)((const float*)p.aux + aoff);
-                    f32x4 o = {r[0] + sc * a[0], r[1] + sc * a[1], r[2] + sc * a[2], r[3] + sc * a[3]};
-                    *(f32x4*)((float*)p.C + off) = o;
-                } else {
-                    u32x2 r = *(const u32x2*)((const bf16_t*)p.aux + aoff);
-                    float r0 = of_bf16_to_f32((bf16_t)(r[0] & 0xffff)), r1 = of_bf16_to_f32((bf16_t)(r[0] >> 16));
-                    float r2 = of_bf16_to_f32((bf16_t)(r[1] & 0xffff)), r3 = of_bf16_to_f32((bf16_t)(r[1] >> 16));
-                    u32x2 o = {of_pack_bf16(r0 + sc * a[0], r1 + sc * a[1]), of_pack_bf16(r2 + sc * a[2], r3 + sc * a[3])};
-                    *(u32x2*)((bf16_t*)p.C + off) = o;
-                }
-            } else if (EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) {
-                const size_t aoff = (size_t)m * p.ldaux + n;
-                u32x2 r = *(const u32x2*)((const bf16_t*)p.aux + aoff);
-                float x[4] = {of_bf16_to_f32((bf16_t)(r[0] & 0xffff)), of_bf16_to_f32((bf16_t)(r[0] >> 16)),
-                              of_bf16_to_f32((bf16_t)(r[1] & 0xffff)), of_bf16_to_f32((bf16_t)(r[1] >> 16))};
-                float o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (EPI == OF_EPI_DGELU_DOT) {
-                        dot += of_gelu(x[e]) * a[e];
-                        o[e] = sc * a[e] * of_dgelu(x[e]);
-                    } else {
-                        dot += x[e] * a[e];
-                        o[e] = sc * a[e];
-                    }
-                }
-                u32x2 ov = {of_pack_bf16(o[0], o[1]), of_pack_bf16(o[2], o[3])};
-                *(u32x2*)((bf16_t*)p.C + off) = ov;
-            } else {  // OF_EPI_ACC_F32
-                float* c = (float*)p.C + off;
-                f32x4 o = {sc * a[0], sc * a[1], sc * a[2], sc * a[3]};
-                if (p.beta != 0.f) {
-                    f32x4 old = *(const f32x4*)c;
-                    o[0] += p.beta * old[0];
-                    o[1] += p.beta * old[1];
-                    o[2] += p.beta * old[2];
-                    o[3] += p.beta * old[3];
-                }
-                *(f32x4*)c = o;
-            }
-        }
-    }
-    if (EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) {
-        if (p.dot_out) {
-            dot = of_wave_sum(dot);
-            if (lane == 0) of_atomic_add(p.dot_out, (1.0f - gv * gv) * dot);
-        }
-    }
+        for (int nt = 0; nt < 4; ++nt)
+            ofg::epilogue_frag<EPI>(p, acc[mt][nt], m0 + wr * 64 + mt * 16 + i16, n0 + wc * 64 + nt * 16 + g * 4, gv, sc, dot);
+    ofg::epilogue_finish<EPI>(p, gv, dot, lane);
 }
 
 template <bool AT, bool BT, int EPI>
 int launch_layout(const OfGemmArgs& a, of_dim3 grid, of_stream_t s) {
-    if (a.safe && (AT || BT)) return of_launch(of_gemm_kernel<AT, BT, EPI, true>, grid, 256, SMEM_BYTES, s, a);
+    if (a.safe == 1 && (AT || BT)) return of_launch(of_gemm_kernel<AT, BT, EPI, true>, grid, 256, SMEM_BYTES, s, a);
     return of_launch(of_gemm_kernel<AT, BT, EPI, false>, grid, 256, SMEM_BYTES, s, a);
 }
 // Only the (layout, epilogue) pairs the hot path uses are instantiated (see DESIGN.md kernel table).
@@ -283,5 +203,9 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     of_dim3 grid{(unsigned)(tiles_m * tiles_n), 1, 1};
     of_stream_t s = (of_stream_t)stream;
+    if (!a.safe) {
+        const int rc = of_gemm256_try(a, s);   // 256x256 LDS-DMA pipelined kernel for tile-aligned shapes
+        if (rc != OF_E_SHAPE) return rc;
+    }
     return dispatch(a, grid, s);
 }

@@ -1,0 +1,101 @@
+// Shared pieces of the two GEMM kernels (gemm.hip: general 128x128 register-staged tile; gemm256.hip: 256x256
+// LDS-DMA pipelined tile): block->tile map and the fused epilogues of include/of_hip.h.
+#pragma once
+#include "of_platform.h"
+#include "../../include/of_hip.h"
+
+namespace ofg {
+
+// XCD-aware tile order: block b runs on XCD b%8, so give each XCD a contiguous run of tile ids (bijective for any
+// nwg), then walk tiles in groups of GM m-tiles so neighbouring ids share A panels and sweep n.
+OF_DEV void tile_coords(int bid, int nwg, int tiles_m, int tiles_n, int& pm, int& pn) {
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int GM = 8;
+    int width = GM * tiles_n;
+    int group = id / width;
+    int first_m = group * GM;
+    int gsz = tiles_m - first_m < GM ? tiles_m - first_m : GM;
+    int in = id - group * width;
+    pm = first_m + in % gsz;
+    pn = in / gsz;
+}
+
+OF_DEV void unpack4(u32x2 r, float (&x)[4]) {
+    x[0] = of_bf16_to_f32((bf16_t)(r[0] & 0xffff));
+    x[1] = of_bf16_to_f32((bf16_t)(r[0] >> 16));
+    x[2] = of_bf16_to_f32((bf16_t)(r[1] & 0xffff));
+    x[3] = of_bf16_to_f32((bf16_t)(r[1] >> 16));
+}
+
+// One accumulator fragment = C[m][n..n+3] (the MFMA is issued operand-swapped so a lane owns 4 consecutive n).
+template <int EPI>
+OF_DEV void epilogue_frag(const OfGemmArgs& p, const f32x4 a, int m, int n, float gv, float sc, float& dot) {
+    if (m >= p.M || n >= p.N) return;
+    const size_t off = (size_t)m * p.ldc + n;
+    if (EPI == OF_EPI_STORE_BF16) {
+        u32x2 o = {of_pack_bf16(sc * a[0], sc * a[1]), of_pack_bf16(sc * a[2], sc * a[3])};
+        *(u32x2*)((bf16_t*)p.C + off) = o;
+    } else if (EPI == OF_EPI_GELU) {
+        if (p.C2) {
+            u32x2 o = {of_pack_bf16(a[0], a[1]), of_pack_bf16(a[2], a[3])};
+            *(u32x2*)((bf16_t*)p.C2 + off) = o;
+        }
+        u32x2 o = {of_pack_bf16(of_gelu(a[0]), of_gelu(a[1])), of_pack_bf16(of_gelu(a[2]), of_gelu(a[3]))};
+        *(u32x2*)((bf16_t*)p.C + off) = o;
+    } else if (EPI == OF_EPI_GATE_RESID) {
+        const size_t aoff = (size_t)m * p.ldaux + n;
+        if (p.io_f32) {
+            const f32x4 r = *(const f32x4*)((const float*)p.aux + aoff);
+            *(f32x4*)((float*)p.C + off) = f32x4{r[0] + sc * a[0], r[1] + sc * a[1], r[2] + sc * a[2], r[3] + sc * a[3]};
+        } else {
+            float r[4];
+            unpack4(*(const u32x2*)((const bf16_t*)p.aux + aoff), r);
+            u32x2 o = {of_pack_bf16(r[0] + sc * a[0], r[1] + sc * a[1]), of_pack_bf16(r[2] + sc * a[2], r[3] + sc * a[3])};
+            *(u32x2*)((bf16_t*)p.C + off) = o;
+        }
+    } else if (EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) {
+        float x[4], o[4];
+        unpack4(*(const u32x2*)((const bf16_t*)p.aux + (size_t)m * p.ldaux + n), x);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (EPI == OF_EPI_DGELU_DOT) {
+                float ge, dg;
+                of_gelu_both(x[e], ge, dg);
+                dot += ge * a[e];
+                o[e] = sc * a[e] * dg;
+            } else {
+                dot += x[e] * a[e];
+                o[e] = sc * a[e];
+            }
+        }
+        u32x2 ov = {of_pack_bf16(o[0], o[1]), of_pack_bf16(o[2], o[3])};
+        *(u32x2*)((bf16_t*)p.C + off) = ov;
+    } else {  // OF_EPI_ACC_F32
+        float* c = (float*)p.C + off;
+        f32x4 o = {sc * a[0], sc * a[1], sc * a[2], sc * a[3]};
+        if (p.beta != 0.f) {
+            const f32x4 old = *(const f32x4*)c;
+            o[0] += p.beta * old[0];
+            o[1] += p.beta * old[1];
+            o[2] += p.beta * old[2];
+            o[3] += p.beta * old[3];
+        }
+        *(f32x4*)c = o;
+    }
+}
+
+template <int EPI>
+OF_DEV void epilogue_finish(const OfGemmArgs& p, float gv, float dot, int lane) {
+    if (EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) {
+        if (p.dot_out) {
+            dot = of_wave_sum(dot);
+            if (lane == 0) of_atomic_add(p.dot_out, (1.0f - gv * gv) * dot);
+        }
+    }
+}
+
+}  // namespace ofg
+
+// implemented in gemm256.hip; returns OF_E_SHAPE when the shape/layout is not eligible (caller falls back)
+int of_gemm256_try(const OfGemmArgs& a, of_stream_t s);

@@ -52,6 +52,19 @@ OF_DEV f32x4 of_mfma(s16x8 a, s16x8 b, f32x4 c) {
 OF_DEV s16x4 of_lds_tr(const void* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
+// LDS-DMA: 16 bytes per lane from a per-lane global address straight into LDS at (wave-uniform base + lane*16).
+// Asynchronous: completion is tracked only by this wave's vmcnt (of_wait_vm) + a barrier for other waves.
+OF_DEV void of_glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+template <int N>
+OF_DEV void of_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+OF_DEV void of_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// bare s_barrier (no implicit vmcnt(0) drain, unlike __syncthreads with LDS-DMA in flight)
+OF_DEV void of_barrier_raw() { __builtin_amdgcn_s_barrier(); }
 OF_DEV float of_shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 OF_DEV int of_shfl_xor_i(int v, int m) { return __shfl_xor(v, m, 64); }
 OF_DEV float of_shfl(float v, int src) { return __shfl(v, src, 64); }
@@ -101,8 +114,31 @@ OF_DEV float of_wave_sum(float v) {
     for (int m = 32; m >= 1; m >>= 1) v += of_shfl_xor(v, m);
     return v;
 }
-OF_DEV float of_gelu(float a) { return 0.5f * a * (1.0f + of_erf(a * 0.70710678118654752f)); }
+// erf-GELU (nn.GELU() default, reference helpers.py:20) for the GEMM epilogues.  erf by Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7, far below the bf16 rounding of the stored result) so that one exp + one rcp + 6 fma replace
+// the ~40-instruction libm erff; the same exp(-a^2/2) also yields the Gaussian term of the derivative.
+OF_DEV void of_gelu_parts(float a, float& cdf, float& e) {
+    const float x = fabsf(a) * 0.70710678118654752f;
+    const float t = 1.0f / (1.0f + 0.3275911f * x);
+    e = of_exp(-x * x);                                  // = exp(-a^2/2)
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * e;
+    cdf = 0.5f * (1.0f + (a < 0.f ? -erf_abs : erf_abs));
+}
+OF_DEV float of_gelu(float a) {
+    float cdf, e;
+    of_gelu_parts(a, cdf, e);
+    return a * cdf;
+}
 // d/da gelu(a) = Phi(a) + a * phi(a)
 OF_DEV float of_dgelu(float a) {
-    return 0.5f * (1.0f + of_erf(a * 0.70710678118654752f)) + a * 0.39894228040143268f * of_exp(-0.5f * a * a);
+    float cdf, e;
+    of_gelu_parts(a, cdf, e);
+    return cdf + a * 0.39894228040143268f * e;
+}
+OF_DEV void of_gelu_both(float a, float& gelu, float& dgelu) {
+    float cdf, e;
+    of_gelu_parts(a, cdf, e);
+    gelu = a * cdf;
+    dgelu = cdf + a * 0.39894228040143268f * e;
 }

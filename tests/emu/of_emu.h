@@ -25,7 +25,7 @@
 typedef void* of_stream_t;
 
 namespace of_emu {
-constexpr int kMaxThreads = 256;
+constexpr int kMaxThreads = 512;
 constexpr size_t kStack = 256 * 1024;
 struct Block {
     int nthreads = 0;
@@ -37,7 +37,7 @@ struct Block {
     bool done[kMaxThreads];
     int cur = 0;
     int blk_count = 0, blk_gen = 0;
-    int wave_count[4] = {0, 0, 0, 0}, wave_gen[4] = {0, 0, 0, 0};
+    int wave_count[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wave_gen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     alignas(16) char xchg[kMaxThreads][64];
     std::function<void()> body;
 };
@@ -82,7 +82,7 @@ inline void run_block(Block* b) {
         makecontext(&b->ctx[t], (void (*)())trampoline, 0);
     }
     b->blk_count = 0;
-    for (int w = 0; w < 4; ++w) b->wave_count[w] = 0;
+    for (int w = 0; w < 8; ++w) b->wave_count[w] = 0;
     int remaining = b->nthreads;
     while (remaining > 0) {
         for (int t = 0; t < b->nthreads; ++t) {
@@ -183,6 +183,14 @@ OF_DEV s16x4 of_lds_tr(const void* p) {
     of_emu::wave_barrier();
     return r;
 }
+// LDS-DMA executes synchronously here: layout (lane -> LDS address) is emulated, asynchrony is not.
+OF_DEV void of_glds16(const void* gsrc, void* lds_wave_base) {
+    memcpy((char*)lds_wave_base + 16 * (of_emu::g_blk->cur & 63), gsrc, 16);
+}
+template <int N>
+OF_DEV void of_wait_vm() {}
+OF_DEV void of_wait_lgkm0() {}
+OF_DEV void of_barrier_raw() { of_emu::block_barrier(); }
 OF_DEV float of_shfl(float v, int src) {
     of_emu::Block* blk = of_emu::g_blk;
     int t = blk->cur;

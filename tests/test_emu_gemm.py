@@ -93,3 +93,60 @@ def test_gemm_dot_epilogues():
             wdot = (1 - g * g) * (x * acc).sum()
         np.testing.assert_allclose(out.double().numpy(), want.numpy(), rtol=1e-2, atol=2e-2)
         assert abs(float(dot) - float(wdot)) <= 1e-3 * abs(float(wdot)) + 1e-2
+
+
+@pytest.mark.parametrize("at,bt", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (256, 512, 96), (512, 256, 256)])
+def test_gemm256_pipeline_matches_general_kernel(at, bt, M, N, K):
+    """Tile-aligned shapes take the 256x256 LDS-DMA kernel (safe=0); it must agree with the general kernel (safe=2)
+    bit-for-bit in fp32 (same products, same k order within a 32-wide MFMA step) and with fp64 matmul."""
+    A = _rand((K, M) if at else (M, K), 11)
+    B = _rand((K, N) if bt else (N, K), 12)
+    ref = _ref(A, B, at, bt)
+    o_fast, o_gen = torch.zeros(M, N), torch.zeros(M, N)
+    H.gemm(A, B, a_trans=at, b_trans=bt, epi=abi.EPI_ACC_F32, C_out=o_fast, safe=0)
+    H.gemm(A, B, a_trans=at, b_trans=bt, epi=abi.EPI_ACC_F32, C_out=o_gen, safe=2)
+    np.testing.assert_allclose(o_fast.double().numpy(), ref.numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(o_fast.numpy(), o_gen.numpy(), rtol=1e-6, atol=1e-5)
+
+
+def test_gemm256_epilogues():
+    M, N, K = 256, 256, 64
+    A, B = _rand((M, K), 13), _rand((N, K), 14) * 0.1
+    acc = _ref(A, B, 0, 0)
+    gate = torch.tensor([0.37])
+    g = float(torch.tanh(gate))
+    b_out, a_out = torch.zeros(M, N, dtype=torch.bfloat16), torch.zeros(M, N, dtype=torch.bfloat16)
+    H.gemm(A, B, epi=abi.EPI_GELU, C_out=b_out, C2=a_out)
+    np.testing.assert_allclose(b_out.double().numpy(), torch.nn.functional.gelu(acc).numpy(), rtol=1e-2, atol=1e-2)
+    res = torch.randn(M, N)
+    out = torch.zeros(M, N)
+    H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=out, aux=res, gate=gate, io_f32=1)
+    np.testing.assert_allclose(out.double().numpy(), (res.double() + g * acc).numpy(), rtol=1e-5, atol=1e-4)
+    W = _rand((K, N), 15) * 0.2
+    acc2 = A.double() @ W.double()
+    aux = _rand((M, N), 16)
+    out = torch.zeros(M, N, dtype=torch.bfloat16)
+    dot = torch.zeros(1)
+    H.gemm(A, W, b_trans=1, epi=abi.EPI_DGELU_DOT, C_out=out, aux=aux, gate=gate, dot_out=dot)
+    xx = aux.double().clone().requires_grad_(True)
+    torch.nn.functional.gelu(xx).sum().backward()
+    np.testing.assert_allclose(out.double().numpy(), (g * acc2 * xx.grad).numpy(), rtol=1e-2, atol=2e-2)
+    wdot = (1 - g * g) * (torch.nn.functional.gelu(aux.double()) * acc2).sum()
+    assert abs(float(dot) - float(wdot)) <= 1e-3 * abs(float(wdot)) + 1e-2
+
+
+def test_fast_erf_gelu_accuracy():
+    """The epilogue's Abramowitz-Stegun erf: |gelu - exact| and |gelu' - exact| stay below bf16 resolution."""
+    x = torch.linspace(-8, 8, 4001).to(torch.bfloat16)
+    M = 4096
+    A = torch.zeros(M, 32, dtype=torch.bfloat16)
+    A[:4001, 0] = x
+    B = torch.zeros(256, 32, dtype=torch.bfloat16)
+    B[:, 0] = 1
+    out = torch.zeros(M, 256, dtype=torch.bfloat16)
+    H.gemm(A, B, epi=abi.EPI_GELU, C_out=out)
+    want = torch.nn.functional.gelu(x.double())
+    got = out[:4001, 0].double()
+    # one bf16 rounding of the result (2^-8 relative) + the 1.5e-7 absolute error of the erf polynomial (x |a|)
+    assert ((got - want).abs() <= 2.0 ** -8 * want.abs() + 2e-6).all()

@@ -181,3 +181,24 @@ def test_layernorm(ops, x_f32):
     assert _rel(dx, want) < (1e-4 if x_f32 else 2e-2)
     assert _rel(dxb, want) < 2e-2
     assert _rel(dw, wd.grad) < 1e-3 and _rel(db, bd.grad) < 1e-3
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
+def test_gemm256_race_screen(ops, ta, tb):
+    """The 256x256 kernel's LDS-DMA ring is only ordered by counted vmcnt + one barrier per stage; the CPU emulator
+    executes the DMA synchronously and cannot see a race.  Screen on hardware: many shapes (1..64 stages, single and
+    multi wave-of-blocks grids), repeated launches under load, results must be bit-identical to the general kernel
+    (same products, same k order) every time."""
+    torch.manual_seed(0)
+    for (M, N, K) in [(256, 256, 32), (256, 256, 64), (256, 512, 96), (512, 256, 128), (2048, 2048, 2048),
+                      (8192, 2048, 512), (4096, 8192, 1024)]:
+        A = _r((K, M) if ta else (M, K), M + K)
+        B = _r((K, N) if tb else (N, K), N + K)
+        want = torch.zeros(M, N, device="cuda")
+        ops.gemm(A, B, want, ta=ta, tb=tb, epi=abi.EPI_ACC_F32, safe=2)
+        ref = (A.float().t() if ta else A.float()) @ (B.float() if tb else B.float().t())
+        assert _rel(want, ref) < 2e-4
+        for it in range(6):
+            got = torch.full((M, N), float("nan"), device="cuda")
+            ops.gemm(A, B, got, ta=ta, tb=tb, epi=abi.EPI_ACC_F32, safe=0)
+            assert torch.equal(got, want), f"{(M, N, K)} iteration {it}: max diff {(got - want).abs().max().item()}"
