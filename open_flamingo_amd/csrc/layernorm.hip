@@ -25,6 +25,7 @@ struct LnArgs {
     void* dx; int dx_f32; long lddx;
     bf16_t* dx_bf16;
     float* dw; float* db;
+    int rpw;                         // rows per wave (set by the launcher)
 };
 
 OF_DEV void load8(const void* base, int is_f32, size_t off, float (&v)[8]) {
@@ -52,56 +53,76 @@ OF_DEV void store8(void* base, int is_f32, size_t off, const float (&v)[8]) {
     }
 }
 
-constexpr int ROWS_PER_WAVE_FWD = 2;
-
-OF_GLOBAL void of_ln_fwd_kernel(LnArgs a) {
+// Both kernels keep a whole row in registers: one wave per row, lane l owns the 8-column chunks l, l+64, ... (CPL
+// chunks per lane, dim <= CPL*512), so x / dy / resid are read from HBM exactly once, with all of a row's loads in
+// flight together.  RPW rows per wave; the backward accumulates its dw/db column partials in registers across those
+// rows and reduces them once per workgroup (LDS, one add per wave per column) and once per grid (global atomics).
+template <int CPL>
+OF_GLOBAL void OF_BOUNDS(256, 2) of_ln_fwd_kernel(LnArgs a) {
+    const int rpw = a.rpw;
     const int tid = of_tid(), lane = tid & 63, wave = tid >> 6;
     const int nchunk = a.dim >> 3;
-    for (int rr = 0; rr < ROWS_PER_WAVE_FWD; ++rr) {
-        const long row = ((long)of_bid_x() * 4 + wave) * ROWS_PER_WAVE_FWD + rr;
+    const float inv_dim = 1.0f / (float)a.dim;
+    f32x4 wv[CPL][2], bv[CPL][2];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        const int c = lane + j * 64;
+        if (c < nchunk) {
+            wv[j][0] = *(const f32x4*)(a.w + c * 8); wv[j][1] = *(const f32x4*)(a.w + c * 8 + 4);
+            bv[j][0] = *(const f32x4*)(a.b + c * 8); bv[j][1] = *(const f32x4*)(a.b + c * 8 + 4);
+        }
+    }
+    for (int rr = 0; rr < rpw; ++rr) {
+        const long row = ((long)of_bid_x() * 4 + wave) * rpw + rr;
         if (row >= a.rows) return;  // wave-uniform
         const size_t xo = (size_t)row * a.ldx;
+        float v[CPL][8];
         float sum = 0.f;
-        for (int c = lane; c < nchunk; c += 64) {
-            float v[8];
-            load8(a.x, a.x_f32, xo + c * 8, v);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sum += v[e];
+        for (int j = 0; j < CPL; ++j) {
+            const int c = lane + j * 64;
+            if (c < nchunk) {
+                load8(a.x, a.x_f32, xo + c * 8, v[j]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum += v[j][e];
+            }
         }
-        const float mean = of_wave_sum(sum) / (float)a.dim;
+        const float mean = of_wave_sum(sum) * inv_dim;
         float sq = 0.f;
-        for (int c = lane; c < nchunk; c += 64) {
-            float v[8];
-            load8(a.x, a.x_f32, xo + c * 8, v);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sq += (v[e] - mean) * (v[e] - mean);
+        for (int j = 0; j < CPL; ++j) {
+            if (lane + j * 64 < nchunk) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sq += (v[j][e] - mean) * (v[j][e] - mean);
+            }
         }
-        const float rstd = of_rsqrt(of_wave_sum(sq) / (float)a.dim + 1e-5f);
+        const float rstd = of_rsqrt(of_wave_sum(sq) * inv_dim + 1e-5f);
         if (lane == 0 && a.stats) {
             a.stats[row * 2] = mean;
             a.stats[row * 2 + 1] = rstd;
         }
         const size_t yo = a.y_grp_rows > 0 ? (size_t)(row / a.y_grp_rows) * a.y_grp_stride + (size_t)(row % a.y_grp_rows) * a.ldy
                                            : (size_t)row * a.ldy;
-        for (int c = lane; c < nchunk; c += 64) {
-            float v[8], o[8];
-            load8(a.x, a.x_f32, xo + c * 8, v);
-            const f32x4 w0 = *(const f32x4*)(a.w + c * 8), w1 = *(const f32x4*)(a.w + c * 8 + 4);
-            const f32x4 b0 = *(const f32x4*)(a.b + c * 8), b1 = *(const f32x4*)(a.b + c * 8 + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                o[e] = (v[e] - mean) * rstd * w0[e] + b0[e];
-                o[4 + e] = (v[4 + e] - mean) * rstd * w1[e] + b1[e];
+        for (int j = 0; j < CPL; ++j) {
+            const int c = lane + j * 64;
+            if (c < nchunk) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (v[j][e] - mean) * rstd * wv[j][0][e] + bv[j][0][e];
+                    o[4 + e] = (v[j][4 + e] - mean) * rstd * wv[j][1][e] + bv[j][1][e];
+                }
+                store8(a.y, a.y_f32, yo + c * 8, o);
+                if (a.y2) store8(a.y2, 0, (size_t)row * a.dim + c * 8, o);
             }
-            store8(a.y, a.y_f32, yo + c * 8, o);
-            if (a.y2) store8(a.y2, 0, (size_t)row * a.dim + c * 8, o);
         }
     }
 }
 
-constexpr int ROWS_PER_WAVE_BWD = 8;
-
-OF_GLOBAL void of_ln_bwd_kernel(LnArgs a) {
+template <int CPL>
+OF_GLOBAL void OF_BOUNDS(256, (CPL > 5 ? 1 : 2)) of_ln_bwd_kernel(LnArgs a) {
+    const int rpw = a.rpw;
     float* sw = (float*)of_smem();
     float* sb = sw + a.dim;
     const int tid = of_tid(), lane = tid & 63, wave = tid >> 6;
@@ -115,70 +136,87 @@ OF_GLOBAL void of_ln_bwd_kernel(LnArgs a) {
         of_sync();
     }
     const float inv_dim = 1.0f / (float)a.dim;
-    for (int rr = 0; rr < ROWS_PER_WAVE_BWD; ++rr) {
-        const long row = ((long)of_bid_x() * 4 + wave) * ROWS_PER_WAVE_BWD + rr;
+    float aw[CPL][8], ab[CPL][8];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) aw[j][e] = ab[j][e] = 0.f;
+    const bool wr = a.dx || a.dx_bf16;
+    for (int rr = 0; rr < rpw; ++rr) {
+        const long row = ((long)of_bid_x() * 4 + wave) * rpw + rr;
         if (row >= a.rows) break;  // wave-uniform
         const float mean = a.stats[row * 2], rstd = a.stats[row * 2 + 1];
         const size_t xo = (size_t)row * a.ldx;
         const size_t go = a.dy_grp_rows > 0 ? (size_t)(row / a.dy_grp_rows) * a.dy_grp_stride + (size_t)(row % a.dy_grp_rows) * a.lddy
                                             : (size_t)row * a.lddy;
+        const size_t dxo = (size_t)row * a.lddx;
+        float xh[CPL][8], gv[CPL][8];
         float c1 = 0.f, c2 = 0.f;
-        for (int c = lane; c < nchunk; c += 64) {
-            float xv[8], gv[8];
-            load8(a.x, a.x_f32, xo + c * 8, xv);
-            load8(a.dy, a.dy_f32, go + c * 8, gv);
-            if (a.dy2) {
-                float g2[8];
-                load8(a.dy2, 0, (size_t)row * a.dim + c * 8, g2);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) gv[e] += g2[e];
+        for (int j = 0; j < CPL; ++j) {
+            const int c = lane + j * 64;
+            if (c < nchunk) {
+                load8(a.x, a.x_f32, xo + c * 8, xh[j]);
+                load8(a.dy, a.dy_f32, go + c * 8, gv[j]);
+                if (a.dy2) {
+                    float g2[8];
+                    load8(a.dy2, 0, (size_t)row * a.dim + c * 8, g2);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gv[j][e] += g2[e];
+                }
             }
-            const f32x4 w0 = *(const f32x4*)(a.w + c * 8), w1 = *(const f32x4*)(a.w + c * 8 + 4);
+        }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float wv = e < 4 ? w0[e] : w1[e - 4];
-                const float xh = (xv[e] - mean) * rstd;
-                c1 += gv[e] * wv;
-                c2 += gv[e] * wv * xh;
+        for (int j = 0; j < CPL; ++j) {
+            const int c = lane + j * 64;
+            if (c < nchunk) {
+                const f32x4 w0 = *(const f32x4*)(a.w + c * 8), w1 = *(const f32x4*)(a.w + c * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float wgt = e < 4 ? w0[e] : w1[e - 4];
+                    xh[j][e] = (xh[j][e] - mean) * rstd;
+                    aw[j][e] += gv[j][e] * xh[j][e];
+                    ab[j][e] += gv[j][e];
+                    gv[j][e] *= wgt;
+                    c1 += gv[j][e];
+                    c2 += gv[j][e] * xh[j][e];
+                }
             }
         }
         c1 = of_wave_sum(c1) * inv_dim;
         c2 = of_wave_sum(c2) * inv_dim;
-        const size_t dxo = (size_t)row * a.lddx;
-        for (int c = lane; c < nchunk; c += 64) {
-            float xv[8], gv[8], o[8];
-            load8(a.x, a.x_f32, xo + c * 8, xv);
-            load8(a.dy, a.dy_f32, go + c * 8, gv);
-            if (a.dy2) {
-                float g2[8];
-                load8(a.dy2, 0, (size_t)row * a.dim + c * 8, g2);
+        if (wr) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) gv[e] += g2[e];
-            }
-            const f32x4 w0 = *(const f32x4*)(a.w + c * 8), w1 = *(const f32x4*)(a.w + c * 8 + 4);
+            for (int j = 0; j < CPL; ++j) {
+                const int c = lane + j * 64;
+                if (c < nchunk) {
+                    float o[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float wv = e < 4 ? w0[e] : w1[e - 4];
-                const float xh = (xv[e] - mean) * rstd;
-                o[e] = rstd * (gv[e] * wv - c1 - xh * c2);
-                if (red) {
-                    of_atomic_add(sw + c * 8 + e, gv[e] * xh);
-                    of_atomic_add(sb + c * 8 + e, gv[e]);
+                    for (int e = 0; e < 8; ++e) o[e] = rstd * (gv[j][e] - c1 - xh[j][e] * c2);
+                    if (a.resid) {
+                        float rv[8];
+                        load8(a.resid, a.dx_f32, dxo + c * 8, rv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] += rv[e];
+                    }
+                    if (a.dx) store8(a.dx, a.dx_f32, dxo + c * 8, o);
+                    if (a.dx_bf16) store8(a.dx_bf16, 0, dxo + c * 8, o);
                 }
-            }
-            if (a.dx || a.dx_bf16) {
-                if (a.resid) {
-                    float rv[8];
-                    load8(a.resid, a.dx_f32, dxo + c * 8, rv);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] += rv[e];
-                }
-                if (a.dx) store8(a.dx, a.dx_f32, dxo + c * 8, o);
-                if (a.dx_bf16) store8(a.dx_bf16, 0, dxo + c * 8, o);
             }
         }
     }
     if (red) {
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const int c = lane + j * 64;
+            if (c < nchunk) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    of_atomic_add(sw + c * 8 + e, aw[j][e]);
+                    of_atomic_add(sb + c * 8 + e, ab[j][e]);
+                }
+            }
+        }
         of_sync();
         for (int c = tid; c < a.dim; c += 256) {
             of_atomic_add(a.dw + c, sw[c]);
@@ -187,9 +225,41 @@ OF_GLOBAL void of_ln_bwd_kernel(LnArgs a) {
     }
 }
 
+// rows per wave: enough workgroups to give every CU two (8 waves), few enough that the per-workgroup dw/db flush
+// (2*dim global atomics) stays small next to the row traffic
+int pick_rpw(long rows, int cap) {
+    int rpw = 1;
+    while (rpw < cap && rows / (4L * rpw * 2) >= 512) rpw *= 2;
+    return rpw;
+}
+
+#define OF_LN_DISPATCH(KERNEL)                                                                       \
+    if (a.dim <= 512) return of_launch(KERNEL<1>, grid, 256, smem, s, a);                      \
+    if (a.dim <= 1024) return of_launch(KERNEL<2>, grid, 256, smem, s, a);                     \
+    if (a.dim <= 1536) return of_launch(KERNEL<3>, grid, 256, smem, s, a);                     \
+    if (a.dim <= 2048) return of_launch(KERNEL<4>, grid, 256, smem, s, a);                     \
+    if (a.dim <= 2560) return of_launch(KERNEL<5>, grid, 256, smem, s, a);                     \
+    if (a.dim <= 4096) return of_launch(KERNEL<8>, grid, 256, smem, s, a);                     \
+    return OF_E_SHAPE;
+
+int launch_fwd(LnArgs a, of_stream_t s) {
+    const int rpw = a.rpw = pick_rpw(a.rows, 4);
+    const long rows_per_block = 4L * rpw;
+    of_dim3 grid{(unsigned)((a.rows + rows_per_block - 1) / rows_per_block), 1, 1};
+    const size_t smem = 0;
+    OF_LN_DISPATCH(of_ln_fwd_kernel)
+}
+int launch_bwd(LnArgs a, of_stream_t s) {
+    const int rpw = a.rpw = pick_rpw(a.rows, 16);
+    const long rows_per_block = 4L * rpw;
+    of_dim3 grid{(unsigned)((a.rows + rows_per_block - 1) / rows_per_block), 1, 1};
+    const size_t smem = a.dw ? (size_t)a.dim * 2 * sizeof(float) : 0;
+    OF_LN_DISPATCH(of_ln_bwd_kernel)
+}
+
 int check_common(const void* x, long ldx, long rows, int dim) {
     if (!x || rows <= 0 || dim <= 0) return OF_E_ARG;
-    if ((dim & 7) || dim > 8192) return OF_E_SHAPE;
+    if ((dim & 7) || dim > 4096) return OF_E_SHAPE;
     if ((ldx & 7) || ((uintptr_t)x & 15)) return OF_E_ALIGN;
     return 0;
 }
@@ -206,9 +276,7 @@ static int ln_fwd_impl(const void* x, int x_f32, long ldx, const float* w, const
     a.x = x; a.x_f32 = x_f32; a.ldx = ldx; a.w = w; a.b = b; a.y = y; a.y_f32 = y_f32; a.ldy = ldy;
     a.y_grp_rows = grp_rows; a.y_grp_stride = grp_stride; a.y2 = y2;
     a.stats = stats; a.rows = rows; a.dim = dim;
-    const long rows_per_block = 4 * ROWS_PER_WAVE_FWD;
-    of_dim3 grid{(unsigned)((rows + rows_per_block - 1) / rows_per_block), 1, 1};
-    return of_launch(of_ln_fwd_kernel, grid, 256, 0, (of_stream_t)stream, a);
+    return launch_fwd(a, (of_stream_t)stream);
 }
 
 extern "C" int of_layernorm_fwd_out(const void* x, int x_f32, long ldx, const float* w, const float* b, void* y,
@@ -242,8 +310,5 @@ extern "C" int of_layernorm_bwd(const void* dy, int dy_f32, long lddy, long dy_g
     a.dy = dy; a.dy_f32 = dy_f32; a.lddy = lddy; a.dy_grp_rows = dy_grp_rows; a.dy_grp_stride = dy_grp_stride;
     a.dy2 = dy2; a.resid = resid; a.dx = dx_out; a.dx_f32 = out_f32; a.lddx = lddx;
     a.dx_bf16 = dx_bf16; a.dw = dw; a.db = db;
-    const long rows_per_block = 4 * ROWS_PER_WAVE_BWD;
-    of_dim3 grid{(unsigned)((rows + rows_per_block - 1) / rows_per_block), 1, 1};
-    const size_t smem = dw ? (size_t)dim * 2 * sizeof(float) : 0;
-    return of_launch(of_ln_bwd_kernel, grid, 256, smem, (of_stream_t)stream, a);
+    return launch_bwd(a, (of_stream_t)stream);
 }

@@ -54,8 +54,11 @@ def test_cpu_boundary_matches_reference_flamingo():
 @pytest.mark.gpu
 def test_gpu_boundary_matches_reference_flamingo():
     """The product: libofhip-backed modules inside our Flamingo, fp32 residual stream, bf16 MFMA operands.
-    Tolerances: loss 1e-2 relative; gradient tensors 5e-2 of their max-abs; greedy tokens may legitimately differ
-    once logits are within bf16 noise, so only the first generated token and >= 50 % agreement are required."""
+    Tolerances: loss 1e-2 relative; gradient tensors 5e-2 of their max-abs; the (1,)-shaped tanh-gate gradients are
+    whole-tensor reductions sum(dy * branch) that can cancel almost completely (golden: layer-1 ff_gate 1.2e-4 next
+    to layer-3 ff_gate 2.7e-2), so they are held to 5e-2 of the LARGEST gate gradient instead of their own value;
+    greedy tokens may legitimately differ once logits are within bf16 noise, so only the first generated token and
+    >= 50 % agreement are required."""
     from open_flamingo_amd.train import towers
     model, info = towers.build_flamingo("OF-tiny", device="cpu", seed=0, gates=0.5)   # CPU RNG = the golden's weights
     model.cuda()
@@ -64,10 +67,14 @@ def test_gpu_boundary_matches_reference_flamingo():
     assert abs(float(out[0]) - float(z["loss"])) <= 1e-2 * abs(float(z["loss"]))
     got = out.logits[:, :4, :32].detach().float().cpu().numpy()
     assert np.abs(got - z["logits_head"]).max() <= 5e-2 * np.abs(z["logits_head"]).max()
+    gate_scale = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith("grad.") and k.endswith("_gate"))
     for k in z.files:
         if k.startswith("grad."):
             g = sd[k[5:]].grad.float().cpu().numpy()
-            assert np.abs(g - z[k]).max() <= 5e-2 * np.abs(z[k]).max() + 1e-7, k
+            scale = gate_scale if k.endswith("_gate") else np.abs(z[k]).max()
+            assert np.abs(g - z[k]).max() <= 5e-2 * scale + 1e-7, k
+        elif k.startswith("gradnorm.") and k.endswith("_gate"):
+            assert abs(float(sd[k[9:]].grad.norm()) - float(z[k])) <= 5e-2 * gate_scale + 1e-7, k
         elif k.startswith("gradnorm."):
             assert abs(float(sd[k[9:]].grad.norm()) - float(z[k])) <= 5e-2 * float(z[k]) + 1e-7, k
     gen = gen.cpu().numpy()
