@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--wire-bf16", action="store_true", help="all-reduce gradients in bf16 on the wire")
+    ap.add_argument("--gemm-report", default=None, help="write a per-(layout,epilogue,shape) GEMM time table (JSON lines)")
     args = ap.parse_args()
 
     from open_flamingo_amd.hip.ops import Ops
@@ -140,6 +141,18 @@ def main():
     value = images * args.steps / elapsed
 
     roofline = None
+    if timing and args.gemm_report and rank == 0:
+        per = {}
+        for key, flops, shape, e0, e1 in timing:
+            r = per.setdefault((key, shape), [0.0, 0.0, 0])
+            r[0] += flops
+            r[1] += e0.elapsed_time(e1)
+            r[2] += 1
+        with open(args.gemm_report, "w") as f:
+            for (key, shape), (fl, ms, n) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+                f.write(json.dumps({"layout": LAYOUT_NAMES[key[:2]], "epi": EPI_NAMES[key[2]], "MNK": list(shape),
+                                    "launches_per_step": n // args.steps, "ms_per_step": round(ms / args.steps, 3),
+                                    "avg_ms": round(ms / n, 4), "tflops": round(fl / ms / 1e9, 1)}) + "\n")
     if timing:
         groups = {}
         for key, flops, shape, e0, e1 in timing:

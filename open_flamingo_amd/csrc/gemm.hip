@@ -107,9 +107,15 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_gemm_kernel(OfGemmArgs p) {
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     u32x4 ra[4], rb[4];
-    const int nk = (p.K + BK - 1) / BK;
-    g2r<AT>(p.A, p.lda, m0, p.M, 0, p.K, tid, ra);
-    g2r<BT>(p.B, p.ldb, n0, p.N, 0, p.K, tid, rb);
+    // split-K (p.ksplit > 1, OF_EPI_ACC_F32 only): slice of_bid_y() owns k-tiles [kt0, kt0 + nk) and adds its partial
+    // sums into C with fp32 atomics (the launcher has zeroed C when beta == 0)
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int per = (nk_all + p.ksplit - 1) / p.ksplit;
+    const int kt0 = of_bid_y() * per;
+    const int nk = (nk_all - kt0 < per ? nk_all - kt0 : per);
+    if (nk <= 0) return;
+    g2r<AT>(p.A, p.lda, m0, p.M, kt0 * BK, p.K, tid, ra);
+    g2r<BT>(p.B, p.ldb, n0, p.N, kt0 * BK, p.K, tid, rb);
     r2s<AT>(smem, tid, ra);
     r2s<BT>(smem + TILE_BYTES, tid, rb);
     of_sync();
@@ -118,8 +124,8 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_gemm_kernel(OfGemmArgs p) {
         const char* tb = ta + TILE_BYTES;
         const bool more = kt + 1 < nk;
         if (more) {
-            g2r<AT>(p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, tid, ra);
-            g2r<BT>(p.B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, tid, rb);
+            g2r<AT>(p.A, p.lda, m0, p.M, (kt0 + kt + 1) * BK, p.K, tid, ra);
+            g2r<BT>(p.B, p.ldb, n0, p.N, (kt0 + kt + 1) * BK, p.K, tid, rb);
         }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -147,6 +153,20 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_gemm_kernel(OfGemmArgs p) {
     if (p.gate) gv = of_tanh(*p.gate);
     const float sc = gv * p.alpha;
     float dot = 0.f;
+    if (EPI == OF_EPI_ACC_F32 && p.ksplit > 1) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int m = m0 + wr * 64 + mt * 16 + i16, n = n0 + wc * 64 + nt * 16 + g * 4;
+                if (m < p.M && n < p.N) {
+                    float* c = (float*)p.C + (size_t)m * p.ldc + n;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) of_atomic_add(c + e, sc * acc[mt][nt][e]);
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -203,9 +223,35 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     of_dim3 grid{(unsigned)(tiles_m * tiles_n), 1, 1};
     of_stream_t s = (of_stream_t)stream;
-    if (!a.safe) {
-        const int rc = of_gemm256_try(a, s);   // 256x256 LDS-DMA pipelined kernel for tile-aligned shapes
+    OfGemmArgs b = a;
+    b.ksplit = 1;
+    // Kernel selection (safe == 0).  The 256x256 ping-pong kernel needs >= ~3/4 of the 256 CUs' worth of tiles to pay;
+    // below that the 128x128 kernel gives 4x the workgroups, and weight-gradient GEMMs with a small output and a deep
+    // K (K = tokens) are additionally split along K until every CU has work.
+    const long tiles256 = (long)(a.M / 256) * (a.N / 256);
+    const bool pp_ok = !(a.M % 256) && !(a.N % 256) && !(a.K % 64) && tiles256 >= 192;
+    if (a.safe == 0 && !pp_ok && a.epi == OF_EPI_ACC_F32 && (a.beta == 1.f || (a.beta == 0.f && a.ldc == a.N))) {
+        const long t128 = (long)tiles_m * tiles_n;
+        int split = 1;
+        while (split < 16 && t128 * split < 256 && a.K / (split * 2) >= 512) split *= 2;
+        if (split > 1) {
+            if (a.beta == 0.f) {
+                const int rc = of_memset_async(a.C, 0, (size_t)a.M * a.N * sizeof(float), s);
+                if (rc) return rc;
+            }
+            b.ksplit = split;
+            grid.y = (unsigned)split;
+            return dispatch(b, grid, s);
+        }
+    }
+    if ((a.safe == 0 && pp_ok) || a.safe == 4) {   // 4 = force the ping-pong kernel whenever the shape is eligible (tests)
+        const int rc = of_gemm_pp_try(a, s);   // 256x256 ping-pong LDS-DMA kernel for tile-aligned shapes
+        if (rc != OF_E_SHAPE) return rc;
+    } else if (a.safe >= 16) {
+        return of_gemm_pp_ablate(a, a.safe - 16, s);   // timing-only ablations (wrong results by design)
+    } else if (a.safe == 3) {
+        const int rc = of_gemm256_try(a, s);   // previous 256x256 kernel (lock-step waves), kept for A/B timing
         if (rc != OF_E_SHAPE) return rc;
     }
-    return dispatch(a, grid, s);
+    return dispatch(b, grid, s);
 }

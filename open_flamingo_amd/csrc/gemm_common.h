@@ -99,3 +99,6 @@ OF_DEV void epilogue_finish(const OfGemmArgs& p, float gv, float dot, int lane) 
 
 // implemented in gemm256.hip; returns OF_E_SHAPE when the shape/layout is not eligible (caller falls back)
 int of_gemm256_try(const OfGemmArgs& a, of_stream_t s);
+// implemented in gemm_pp.hip; same contract
+int of_gemm_pp_try(const OfGemmArgs& a, of_stream_t s);
+int of_gemm_pp_ablate(const OfGemmArgs& a, int mask, of_stream_t s);

@@ -1,0 +1,311 @@
+// 256x256 bf16 MFMA GEMM tile, ping-pong scheduled (gfx950) -- the fast path of of_gemm for tile-aligned shapes
+// (M % 256 == 0, N % 256 == 0, K % 64 == 0: every large GEMM of the OpenFlamingo model family at the benchmark
+// batch sizes).  Same math, layouts and epilogues as gemm.hip.
+//
+// Structure
+//   * 8 waves = 2 groups (G0 = waves 0-3, G1 = waves 4-7; waves w and w+4 share a SIMD) x 4 N-columns.  A wave owns a
+//     128(M) x 64(N) block of the tile = 4x2 v_mfma_f32_32x32x16_bf16 fragments (128 accumulator VGPRs).
+//   * Operands travel global -> LDS by DMA (global_load_lds_dwordx4, no VGPR round trip) in 64-deep K stages into two
+//     64-KiB slots (A 32 KiB + B 32 KiB each; 128 KiB, one workgroup per CU).
+//   * PING-PONG: a stage is four barrier-delimited segments per wave -- L0 C0 L1 C1: Lh reads the 12 operand fragments
+//     of k-half h LDS -> VGPR and issues 4 DMA pieces, Ch runs the 16 MFMAs of k-half h.  G1 runs exactly one segment
+//     behind G0 (one extra s_barrier up front), so on every SIMD one wave is in an MFMA segment while its partner is
+//     in a load segment.  Wall-clock segments of stage p: T0 = G0.L0|G1.C1(p-1), T1 = G0.C0|G1.L0, T2 = G0.L1|G1.C0,
+//     T3 = G0.C1|G1.L1.
+//   * The measured limiter of this tile on MI355X is the CU's texture path: it accepts one 1-KiB DMA piece per ~38
+//     cycles (~27 B/clk/CU, L2-resident operands) and a wave's global_load_lds stalls at issue until accepted.  So
+//     DMA pieces are issued ONLY from load segments (a stalled MFMA wave would idle the matrix pipe), 16 per wall
+//     segment, one uninterrupted stream with no drain anywhere:
+//         T0(p): G0 -> B rows   0-127 of stage p+1        T1(p): G1 -> B rows 128-255 of stage p+1
+//         T2(p): G0 -> A rows 128-255 of stage p+1        T3(p): G1 -> A rows   0-127 of stage p+2
+//     A rows 0-127 are read only by G0, whose last read of stage p ends with T2(p): that region of the slot is free
+//     one segment before the rest, which is what lets the stream run two stages ahead without a third slot.
+//   * Ordering (there is no other): after its 4 pieces a wave waits s_waitcnt vmcnt(4) -- its PREVIOUS 4 pieces
+//     (issued two segments earlier) have landed -- then lgkmcnt(0) (its fragment reads are done), then the segment's
+//     bare s_barrier publishes both facts.  Checked against every reader/writer pair in the K loop's comment.
+//   * LDS images are lane-linear for the DMA (dest = wave base + lane*16) and swizzled on the SOURCE address.  Each
+//     operand image is two 16-KiB halves (tile rows 0-127 / 128-255), each 16 1-KiB chunks:
+//       K-contiguous operand: chunk = 8 rows x 128 B stored [k-half][8 rows][64 B] (lanes 0-31 fetch the first, lanes
+//           32-63 the second 64 bytes of the same 8 full lines); 16-B slot s of row r lives at slot s ^ f(r),
+//           f = {0,3,2,1}[(r>>2)&3]      -> conflict-free ds_read_b128 reads of 32-row fragments (SQ_LDS_BANK_CONFLICT 0)
+//       K-strided operand:    chunk = 4 k-rows x 256 B (128 columns); 32-B piece c of k-row r lives at c ^ ((r&3)<<1)
+//           -> conflict-free ds_read_b64_tr_b16 (transpose) reads: a half-wave covers 4 k-rows x 2 pieces
+//   * The MFMA is issued operand-swapped (D^T = B^T A^T): a lane owns output row m = lane&31 and 4 consecutive n per
+//     accumulator quad, so epilogue loads/stores are 8-byte (bf16) / 16-byte (fp32) vectors (gemm_common.h).
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int TM = 256, TN = 256;
+constexpr int DK = 64;                          // K depth of one DMA stage (full 128-byte lines of a K-contiguous row)
+constexpr int OPER_BYTES = 256 * DK * 2;        // 32 KiB per operand per stage
+constexpr int STAGE_BYTES = 2 * OPER_BYTES;     // 64 KiB
+constexpr int NSLOT = 2;
+constexpr int SMEM_PP = NSLOT * STAGE_BYTES;    // 128 KiB
+
+OF_DEV int fN(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+OF_DEV int fT(int krow) { return (krow & 3) << 1; }
+
+constexpr int HALF_BYTES = OPER_BYTES / 2;        // 16 KiB: tile rows (or columns) 0-127 / 128-255 of one operand
+
+// per-thread global source of 1-KiB chunk c (0..15) of half hf of one operand at k0 = 0 (advanced by DK [* ld] per stage)
+template <bool TR>
+OF_DEV const bf16_t* chunk_src(const bf16_t* __restrict__ base, long ld, int row0, int hf, int c, int lane) {
+    if (!TR) {
+        const int row = hf * 128 + c * 8 + ((lane >> 2) & 7);
+        const int kh = lane >> 5;
+        const int lslot = (lane & 3) ^ fN(row);
+        return base + (size_t)(row0 + row) * ld + kh * 32 + lslot * 8;
+    } else {
+        const int krow = c * 4 + (lane >> 4);
+        const int pc = (lane & 15) >> 1, half16 = lane & 1;
+        const int col = hf * 128 + ((pc ^ fT(krow)) << 4) + half16 * 8;
+        return base + (size_t)krow * ld + row0 + col;
+    }
+}
+
+// this lane's 16-byte piece of a 32-row operand fragment: k-half h (32 deep) of the stage, k-step ks (16 deep) of the half
+template <bool TR>
+OF_DEV s16x8 frag32(const char* oper, int row_base, int h, int ks, int lane) {
+    if (!TR) {
+        const int row = row_base + (lane & 31);
+        const int slot = ks * 2 + (lane >> 5);
+        return *(const s16x8*)(oper + (row >> 7) * HALF_BYTES + ((row & 127) >> 3) * 1024 + h * 512 + (row & 7) * 64 +
+                               ((slot ^ fN(row)) << 4));
+    } else {
+        const int q = lane >> 4, i = lane & 15;
+        s16x8 f;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int krow = h * 32 + ks * 16 + (q >> 1) * 8 + hh * 4 + (i >> 2);
+            const int col = row_base + (q & 1) * 16 + (i & 3) * 4;
+            const int cw = col & 127;
+            s16x4 t = of_lds_tr(oper + (col >> 7) * HALF_BYTES + krow * 256 + ((((cw >> 4)) ^ fT(krow)) << 5) + ((cw & 15) << 1));
+            f[hh * 4 + 0] = t[0];
+            f[hh * 4 + 1] = t[1];
+            f[hh * 4 + 2] = t[2];
+            f[hh * 4 + 3] = t[3];
+        }
+        return f;
+    }
+}
+
+// ABL: timing-only ablation mask for tools/bench_gemm_ablate.py (results are wrong when != 0):
+//   1 = no DMA inside the K loop, 2 = no fragment reads, 4 = no MFMAs, 16 = no vmcnt waits (racy)
+template <bool AT, bool BT, int EPI, int ABL = 0>
+OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
+    char* smem = of_smem();
+    const int tid = of_tid(), lane = tid & 63;
+    const int wave = of_uniform(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;   // wm doubles as the ping-pong group
+    const int tiles_m = p.M / TM, tiles_n = p.N / TN;
+    int pm, pn;
+    ofg::tile_coords(of_bid_x(), of_gdim_x(), tiles_m, tiles_n, pm, pn);
+    const int m0 = pm * TM, n0 = pn * TN;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    // this wave's DMA duty: 4 chunks of A half (1 - wm) and 4 chunks of B half wm per stage
+    const int hfA = 1 - wm, hfB = wm;
+    const bf16_t* srcA[4];
+    const bf16_t* srcB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        srcA[j] = chunk_src<AT>(p.A, p.lda, m0, hfA, j * 4 + wn, lane);
+        srcB[j] = chunk_src<BT>(p.B, p.ldb, n0, hfB, j * 4 + wn, lane);
+    }
+    const size_t stepA = AT ? (size_t)DK * p.lda : (size_t)DK;
+    const size_t stepB = BT ? (size_t)DK * p.ldb : (size_t)DK;
+    const int nd = p.K / DK;
+    const int offA = hfA * HALF_BYTES + wn * 1024, offB = OPER_BYTES + hfB * HALF_BYTES + wn * 1024;
+
+    auto issueA = [&](char* slot) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            of_glds16(srcA[j], slot + offA + j * 4096);
+            srcA[j] += stepA;
+        }
+    };
+    auto issueB = [&](char* slot) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            of_glds16(srcB[j], slot + offB + j * 4096);
+            srcB[j] += stepB;
+        }
+    };
+    s16x8 fa[4][2], fb[2][2];
+    auto load_frags = [&](const char* stage, int h, int gi) {
+        if (ABL & 2) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) fb[t][ks] = s16x8{(short)gi, 1, 2, 3, 4, 5, 6, (short)lane};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) fa[t][ks] = s16x8{(short)lane, 1, 2, 3, 4, 5, 6, (short)gi};
+            }
+            return;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) fb[t][ks] = frag32<BT>(stage + OPER_BYTES, wn * 64 + t * 32, h, ks, lane);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fa[t][ks] = frag32<AT>(stage, wm * 128 + t * 32, h, ks, lane);
+        }
+    };
+    auto compute = [&]() {
+        of_sched_fence();
+        if (ABL & 4) {
+            acc[0][0][0] += __builtin_bit_cast(float, (int)fa[0][0][0] + fa[1][1][1] + fa[2][0][2] + fa[3][1][3] + fb[0][0][4] + fb[1][1][5]);
+            return;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = of_mfma32(fb[nt][ks], fa[mt][ks], acc[mt][nt]);
+    };
+    // end of a load segment: the 4 pieces issued two segments ago have landed (or everything, if nothing was issued now)
+    auto publish = [&](bool issued) {
+        if (!(ABL & 16)) {
+            if (issued) of_wait_vm<4>();
+            else of_wait_vm<0>();
+        }
+        of_wait_lgkm0();
+        of_sched_fence();
+        of_barrier_raw();
+    };
+
+    // prologue: stage 0 complete for everybody (the 8 waves' duties cover all 64 chunks); G1 starts A rows 0-127 of stage 1
+    issueB(smem);
+    issueA(smem);
+    if (wm == 1 && nd > 1) {
+        issueA(smem + STAGE_BYTES);
+        of_wait_vm<4>();
+    } else {
+        of_wait_vm<0>();
+    }
+    of_barrier_raw();
+    if (wm == 1) of_barrier_raw();   // stagger: G1 runs one segment behind G0
+
+    // Stage p lives in slot p&1.  Reader/writer pairs (T = wall segment, see header):
+    //   B rows 0-127 of p+1   written G0 T0(p), landed+published end of T2(p); first read T0(p+1).
+    //                         overwrites B of p-1, last read G1.L1(p-1) = T3(p-1), published by its barrier.
+    //   B rows 128-255 of p+1 written G1 T1(p), published end of T3(p); first read T0(p+1).   overwrites: same as above.
+    //   A rows 128-255 of p+1 written G0 T2(p), published end of T0(p+1); first read G1.L0(p+1) = T1(p+1).
+    //                         overwrites A 128-255 of p-1, last read G1.L1(p-1) = T3(p-1).
+    //   A rows 0-127 of p+2   written G1 T3(p), published end of T1(p+1); first read G0.L0(p+2) = T0(p+2).
+    //                         overwrites A 0-127 of p (same slot), last read G0.L1(p) = T2(p), published by its barrier.
+    for (int d = 0; d < nd; ++d) {
+        const bool dma = !(ABL & 1);
+        const char* stage = smem + (d & 1) * STAGE_BYTES;
+        char* other = smem + ((d + 1) & 1) * STAGE_BYTES;
+        // ---- L0
+        load_frags(stage, 0, d);
+        const bool i0 = dma && d + 1 < nd;
+        if (i0) issueB(other);
+        publish(i0);
+        // ---- C0
+        compute();
+        of_sched_fence();
+        of_barrier_raw();
+        // ---- L1
+        load_frags(stage, 1, d);
+        const bool i1 = dma && (wm == 0 ? d + 1 < nd : d + 2 < nd);
+        if (i1) issueA(wm == 0 ? other : smem + (d & 1) * STAGE_BYTES);
+        publish(i1);
+        // ---- C1
+        compute();
+        of_sched_fence();
+        of_barrier_raw();
+    }
+    if (wm == 0) of_barrier_raw();   // balances G1's stagger barrier
+
+    float gv = 1.0f;
+    if (p.gate) gv = of_tanh(*p.gate);
+    const float sc = gv * p.alpha;
+    float dot = 0.f;
+    const int mrow = m0 + wm * 128 + (lane & 31);
+    const int ncol = n0 + wn * 64 + 4 * (lane >> 5);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 a4 = {acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+                ofg::epilogue_frag<EPI>(p, a4, mrow + mt * 32, ncol + nt * 32 + q * 8, gv, sc, dot);
+            }
+    ofg::epilogue_finish<EPI>(p, gv, dot, lane);
+}
+
+template <bool AT, bool BT, int EPI>
+int launch_pp(const OfGemmArgs& a, of_stream_t s) {
+    of_dim3 grid{(unsigned)((a.M / TM) * (a.N / TN)), 1, 1};
+    return of_launch(of_gemm_pp_kernel<AT, BT, EPI>, grid, 512, SMEM_PP, s, a);
+}
+
+
+
+template <int ABL>
+int launch_abl(const OfGemmArgs& a, of_stream_t s) {
+    of_dim3 grid{(unsigned)((a.M / TM) * (a.N / TN)), 1, 1};
+    return of_launch(of_gemm_pp_kernel<false, false, OF_EPI_STORE_BF16, ABL>, grid, 512, SMEM_PP, s, a);
+}
+}  // namespace
+
+// timing-only entry (NT layout, bf16 store): mask as documented at the kernel
+int of_gemm_pp_ablate(const OfGemmArgs& a, int mask, of_stream_t s) {
+    if ((a.M % TM) || (a.N % TN) || (a.K % DK) || a.a_trans || a.b_trans || a.epi != OF_EPI_STORE_BF16) return OF_E_SHAPE;
+    switch (mask) {
+        case 0: return launch_abl<0>(a, s);
+        case 1: return launch_abl<1>(a, s);
+        case 2: return launch_abl<2>(a, s);
+        case 3: return launch_abl<3>(a, s);
+        case 4: return launch_abl<4>(a, s);
+        case 5: return launch_abl<5>(a, s);
+        case 6: return launch_abl<6>(a, s);
+        case 16: return launch_abl<16>(a, s);
+        case 22: return launch_abl<22>(a, s);
+        case 38: return launch_abl<38>(a, s);
+        case 54: return launch_abl<54>(a, s);
+        case 18: return launch_abl<18>(a, s);
+    }
+    return OF_E_ARG;
+}
+
+namespace {
+}
+
+int of_gemm_pp_try(const OfGemmArgs& a, of_stream_t s) {
+    if ((a.M % TM) || (a.N % TN) || (a.K % DK)) return OF_E_SHAPE;
+    const int layout = a.a_trans * 2 + a.b_trans;
+    if (layout == 0) {
+        switch (a.epi) {
+            case OF_EPI_STORE_BF16: return launch_pp<false, false, OF_EPI_STORE_BF16>(a, s);
+            case OF_EPI_GELU: return launch_pp<false, false, OF_EPI_GELU>(a, s);
+            case OF_EPI_GATE_RESID: return launch_pp<false, false, OF_EPI_GATE_RESID>(a, s);
+            case OF_EPI_ACC_F32: return launch_pp<false, false, OF_EPI_ACC_F32>(a, s);
+        }
+    } else if (layout == 1) {
+        switch (a.epi) {
+            case OF_EPI_STORE_BF16: return launch_pp<false, true, OF_EPI_STORE_BF16>(a, s);
+            case OF_EPI_DGELU_DOT: return launch_pp<false, true, OF_EPI_DGELU_DOT>(a, s);
+            case OF_EPI_SCALE_DOT: return launch_pp<false, true, OF_EPI_SCALE_DOT>(a, s);
+            case OF_EPI_ACC_F32: return launch_pp<false, true, OF_EPI_ACC_F32>(a, s);
+        }
+    } else if (layout == 3) {
+        switch (a.epi) {
+            case OF_EPI_STORE_BF16: return launch_pp<true, true, OF_EPI_STORE_BF16>(a, s);
+            case OF_EPI_ACC_F32: return launch_pp<true, true, OF_EPI_ACC_F32>(a, s);
+        }
+    }
+    return OF_E_SHAPE;
+}

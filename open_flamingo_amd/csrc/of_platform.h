@@ -14,6 +14,7 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -47,6 +48,17 @@ OF_DEV f32x4 of_mfma(s16x8 a, s16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(of_bf16x8n, a),
                                                    __builtin_bit_cast(of_bf16x8n, b), c, 0, 0, 0);
 }
+// D(32x32, f32) += A(32x16 bf16) * B(16x32 bf16).  Lane l supplies A[l&31][8*(l>>5)+0..7] and B[8*(l>>5)+0..7][l&31];
+// it receives D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31], r=0..15 (cdna_hip_programming.md section 3).
+OF_DEV f32x16 of_mfma32(s16x8 a, s16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(of_bf16x8n, a),
+                                                   __builtin_bit_cast(of_bf16x8n, b), c, 0, 0, 0);
+}
+OF_DEV void of_setprio_hi() { __builtin_amdgcn_s_setprio(1); }
+OF_DEV void of_setprio_lo() { __builtin_amdgcn_s_setprio(0); }
+// pins the instruction scheduler: nothing moves across this point
+OF_DEV void of_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+OF_DEV int of_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // ds_read_b64_tr_b16: within each 16-lane group, lane i supplies the LDS address of 4 contiguous bf16
 // (row i>>2, column chunk i&3 of a 4x16 block) and receives column i of that block (4 rows).
 OF_DEV s16x4 of_lds_tr(const void* p) {

@@ -24,7 +24,7 @@ class OfGemmArgs(C.Structure):
         ("gate", vp),
         ("alpha", C.c_float), ("beta", C.c_float),
         ("dot_out", vp),
-        ("io_f32", C.c_int), ("safe", C.c_int),
+        ("io_f32", C.c_int), ("safe", C.c_int), ("ksplit", C.c_int),
     ]
 
 

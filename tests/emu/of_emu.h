@@ -165,6 +165,32 @@ OF_DEV f32x4 of_mfma(s16x8 a, s16x8 b, f32x4 c) {
     of_emu::wave_barrier();
     return d;
 }
+OF_DEV f32x16 of_mfma32(s16x8 a, s16x8 b, f32x16 c) {
+    of_emu::Block* blk = of_emu::g_blk;
+    int t = blk->cur, l = t & 63, w0 = t & ~63;
+    memcpy(blk->xchg[t], &a, 16);
+    memcpy(blk->xchg[t] + 16, &b, 16);
+    of_emu::wave_barrier();
+    f32x16 d = c;
+    int col = l & 31, h = l >> 5;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        float acc = 0.f;
+        for (int k = 0; k < 16; ++k) {
+            short av, bv;
+            memcpy(&av, blk->xchg[w0 + row + 32 * (k >> 3)] + 2 * (k & 7), 2);
+            memcpy(&bv, blk->xchg[w0 + col + 32 * (k >> 3)] + 16 + 2 * (k & 7), 2);
+            acc = fmaf(of_emu_bf16f(av), of_emu_bf16f(bv), acc);
+        }
+        d[r] += acc;
+    }
+    of_emu::wave_barrier();
+    return d;
+}
+OF_DEV void of_setprio_hi() {}
+OF_DEV void of_setprio_lo() {}
+OF_DEV void of_sched_fence() {}
+OF_DEV int of_uniform(int v) { return v; }
 OF_DEV s16x4 of_lds_tr(const void* p) {
     of_emu::Block* blk = of_emu::g_blk;
     int t = blk->cur, i = t & 15, g0 = t & ~15;

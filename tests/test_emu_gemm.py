@@ -96,39 +96,51 @@ def test_gemm_dot_epilogues():
 
 
 @pytest.mark.parametrize("at,bt", [(0, 0), (0, 1), (1, 1)])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (256, 512, 96), (512, 256, 256)])
-def test_gemm256_pipeline_matches_general_kernel(at, bt, M, N, K):
-    """Tile-aligned shapes take the 256x256 LDS-DMA kernel (safe=0); it must agree with the general kernel (safe=2)
-    bit-for-bit in fp32 (same products, same k order within a 32-wide MFMA step) and with fp64 matmul."""
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 512, 192), (512, 256, 256)])
+def test_gemm_pingpong_matches_general_kernel(at, bt, M, N, K):
+    """The 256x256 ping-pong LDS-DMA kernel (safe=4 forces it) must agree with the general kernel (safe=2) in fp32
+    (same products, fp32 accumulation; only the k order inside a 64-deep stage differs) and with fp64 matmul."""
     A = _rand((K, M) if at else (M, K), 11)
     B = _rand((K, N) if bt else (N, K), 12)
     ref = _ref(A, B, at, bt)
     o_fast, o_gen = torch.zeros(M, N), torch.zeros(M, N)
-    H.gemm(A, B, a_trans=at, b_trans=bt, epi=abi.EPI_ACC_F32, C_out=o_fast, safe=0)
+    H.gemm(A, B, a_trans=at, b_trans=bt, epi=abi.EPI_ACC_F32, C_out=o_fast, safe=4)
     H.gemm(A, B, a_trans=at, b_trans=bt, epi=abi.EPI_ACC_F32, C_out=o_gen, safe=2)
     np.testing.assert_allclose(o_fast.double().numpy(), ref.numpy(), rtol=1e-5, atol=1e-4)
     np.testing.assert_allclose(o_fast.numpy(), o_gen.numpy(), rtol=1e-6, atol=1e-5)
 
 
-def test_gemm256_epilogues():
+def test_gemm_split_k():
+    """Weight-gradient layout with a small output and deep K: of_gemm splits K and accumulates with fp32 atomics."""
+    M, N, K = 128, 256, 2048
+    A, B = _rand((K, M), 21), _rand((K, N), 22)
+    ref = _ref(A, B, 1, 1)
+    for beta in (0.0, 1.0):
+        c0 = torch.randn(M, N)
+        got = c0.clone()
+        H.gemm(A, B, a_trans=1, b_trans=1, epi=abi.EPI_ACC_F32, C_out=got, beta=beta, alpha=0.5)
+        np.testing.assert_allclose(got.double().numpy(), (0.5 * ref + beta * c0.double()).numpy(), rtol=1e-5, atol=2e-4)
+
+
+def test_gemm_pingpong_epilogues():
     M, N, K = 256, 256, 64
     A, B = _rand((M, K), 13), _rand((N, K), 14) * 0.1
     acc = _ref(A, B, 0, 0)
     gate = torch.tensor([0.37])
     g = float(torch.tanh(gate))
     b_out, a_out = torch.zeros(M, N, dtype=torch.bfloat16), torch.zeros(M, N, dtype=torch.bfloat16)
-    H.gemm(A, B, epi=abi.EPI_GELU, C_out=b_out, C2=a_out)
+    H.gemm(A, B, epi=abi.EPI_GELU, C_out=b_out, C2=a_out, safe=4)
     np.testing.assert_allclose(b_out.double().numpy(), torch.nn.functional.gelu(acc).numpy(), rtol=1e-2, atol=1e-2)
     res = torch.randn(M, N)
     out = torch.zeros(M, N)
-    H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=out, aux=res, gate=gate, io_f32=1)
+    H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=out, aux=res, gate=gate, io_f32=1, safe=4)
     np.testing.assert_allclose(out.double().numpy(), (res.double() + g * acc).numpy(), rtol=1e-5, atol=1e-4)
     W = _rand((K, N), 15) * 0.2
     acc2 = A.double() @ W.double()
     aux = _rand((M, N), 16)
     out = torch.zeros(M, N, dtype=torch.bfloat16)
     dot = torch.zeros(1)
-    H.gemm(A, W, b_trans=1, epi=abi.EPI_DGELU_DOT, C_out=out, aux=aux, gate=gate, dot_out=dot)
+    H.gemm(A, W, b_trans=1, epi=abi.EPI_DGELU_DOT, C_out=out, aux=aux, gate=gate, dot_out=dot, safe=4)
     xx = aux.double().clone().requires_grad_(True)
     torch.nn.functional.gelu(xx).sum().backward()
     np.testing.assert_allclose(out.double().numpy(), (g * acc2 * xx.grad).numpy(), rtol=1e-2, atol=2e-2)

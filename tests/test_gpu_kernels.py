@@ -190,7 +190,7 @@ def test_gemm256_race_screen(ops, ta, tb):
     multi wave-of-blocks grids), repeated launches under load, results must be bit-identical to the general kernel
     (same products, same k order) every time."""
     torch.manual_seed(0)
-    for (M, N, K) in [(256, 256, 32), (256, 256, 64), (256, 512, 96), (512, 256, 128), (2048, 2048, 2048),
+    for (M, N, K) in [(256, 256, 64), (256, 256, 128), (256, 512, 192), (512, 256, 128), (2048, 2048, 2048),
                       (8192, 2048, 512), (4096, 8192, 1024)]:
         A = _r((K, M) if ta else (M, K), M + K)
         B = _r((K, N) if tb else (N, K), N + K)
@@ -200,5 +200,21 @@ def test_gemm256_race_screen(ops, ta, tb):
         assert _rel(want, ref) < 2e-4
         for it in range(6):
             got = torch.full((M, N), float("nan"), device="cuda")
-            ops.gemm(A, B, got, ta=ta, tb=tb, epi=abi.EPI_ACC_F32, safe=0)
+            ops.gemm(A, B, got, ta=ta, tb=tb, epi=abi.EPI_ACC_F32, safe=4)
             assert torch.equal(got, want), f"{(M, N, K)} iteration {it}: max diff {(got - want).abs().max().item()}"
+
+
+@pytest.mark.parametrize("beta", [0.0, 1.0])
+def test_gemm_split_k_weight_gradient(ops, beta):
+    """dW = dY^T X with a small output and K = tokens is split along K (fp32 atomics into C): same result as the
+    unsplit general kernel up to fp32 summation order."""
+    M, N, K = 512, 2048, 8192
+    A, B = _r((K, M), 31), _r((K, N), 32)
+    c0 = torch.randn(M, N, device="cuda")
+    want, got = c0.clone(), c0.clone()
+    gate = torch.tensor([0.3], device="cuda")
+    ops.gemm(A, B, want, ta=True, tb=True, epi=abi.EPI_ACC_F32, beta=beta, gate=gate, safe=2)
+    ops.gemm(A, B, got, ta=True, tb=True, epi=abi.EPI_ACC_F32, beta=beta, gate=gate, safe=0)
+    assert _rel(got, want) < 1e-5
+    ref = float(torch.tanh(gate)) * (A.float().t() @ B.float()) + beta * c0
+    assert _rel(got, ref) < 2e-4
