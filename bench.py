@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--wire-bf16", action="store_true", help="all-reduce gradients in bf16 on the wire")
+    ap.add_argument("--frozen-fp32", action="store_true",
+                    help="keep the frozen towers' Linear weights in fp32 (autocast re-casts them every forward, as the "
+                         "reference does) instead of holding their bf16 copies")
     ap.add_argument("--gemm-report", default=None, help="write a per-(layout,epilogue,shape) GEMM time table (JSON lines)")
     args = ap.parse_args()
 
@@ -107,7 +110,7 @@ def main():
     local_rank, rank, world = distributed.world_info_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    model, info = towers.build_flamingo(args.family, device=device, seed=0, gates=0.5)
+    model, info = towers.build_flamingo(args.family, device=device, seed=0, gates=0.5, frozen_bf16=not args.frozen_fp32)
     model.train()
     reducer = GradReducer(model, wire_dtype=torch.bfloat16 if args.wire_bf16 else torch.float32,
                           embedding_rows=[info["media_token_id"], info["eoc_token_id"]])
@@ -182,7 +185,9 @@ def main():
                                       f"xattn_every={info['every']}) full train step, amp_bf16, per-GPU B={args.batch} "
                                       f"T={args.T} F=1 L={args.L} synthetic MMC4-style batch, random-init weights",
                           "global_batch": args.batch * world, "images_per_step": images, "seq_len": args.L,
-                          "parallelism": f"dp{world}", "grad_wire_dtype": "bf16" if args.wire_bf16 else "fp32"},
+                          "parallelism": f"dp{world}",
+                          "frozen_tower_weights": "fp32 (re-cast by autocast)" if args.frozen_fp32 else "bf16 copies held",
+                          "grad_wire_dtype": "bf16" if args.wire_bf16 else "fp32"},
                "loss": None if loss is None else round(float(loss), 4)}
         if roofline is not None:
             out["roofline"] = roofline

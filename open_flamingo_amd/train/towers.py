@@ -24,6 +24,28 @@ FAMILY = {
 }
 
 
+class PatchEmbedAsGemm(nn.Module):
+    """Drop-in for the ViT's non-overlapping ``Conv2d(3, width, kernel=patch, stride=patch, bias=False)`` patch
+    embedding: the same weight tensor, applied as one (N*patches, 3*patch*patch) x (3*patch*patch, width) GEMM.
+    MIOpen has no tuned bf16 kernel for this 14x14/stride-14 convolution on gfx950 and falls back to
+    ``naive_conv_ab_nonpacked_fwd_nchw`` (9.7 ms per call at 64 images -- profiles/r01_*_kernel_stats); the GEMM
+    form takes ~0.1 ms and is arithmetically the same contraction."""
+
+    def __init__(self, conv: nn.Conv2d):
+        super().__init__()
+        assert conv.bias is None and conv.kernel_size == conv.stride and conv.padding == (0, 0)
+        self.weight = conv.weight                     # (width, 3, p, p): same Parameter object -> same state_dict key
+        self.patch = conv.kernel_size[0]
+
+    def forward(self, x):
+        n, c, hh, ww = x.shape
+        p = self.patch
+        gh, gw = hh // p, ww // p
+        cols = x.reshape(n, c, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(n * gh * gw, c * p * p)
+        y = torch.nn.functional.linear(cols, self.weight.reshape(self.weight.shape[0], -1))
+        return y.reshape(n, gh, gw, -1).permute(0, 3, 1, 2)     # conv layout (N, width, gh, gw), as the caller expects
+
+
 class ClipVisualStandIn(nn.Module):
     """``visual(x) -> (pooled, tokens)`` like open_clip's VisionTransformer with output_tokens=True
     (reference factory.py:48, flamingo.py:195): tokens = ln_post(transformer(x))[:, 1:]."""
@@ -34,6 +56,8 @@ class ClipVisualStandIn(nn.Module):
         cfg = CLIPVisionConfig(hidden_size=width, intermediate_size=mlp or 4 * width, num_hidden_layers=layers,
                                num_attention_heads=heads, patch_size=patch, image_size=image)
         self.model = CLIPVisionModel(cfg)
+        emb = getattr(self.model, "vision_model", self.model).embeddings
+        emb.patch_embedding = PatchEmbedAsGemm(emb.patch_embedding)
         self.width = width
 
     def forward(self, x):
@@ -65,8 +89,24 @@ def build_lang_encoder(family: str, extra_tokens: int = 3, max_seq_len: int = 20
     return GPTNeoXForCausalLM(cfg), "gpt_neox.layers"
 
 
+def hold_frozen_linears_in_bf16(model):
+    """amp_bf16 (reference train_utils.py:34-41) re-casts every frozen fp32 nn.Linear weight to bf16 on every forward
+    (autocast only caches casts of leaves that require grad); the frozen towers never change, so keep those weights in
+    bf16 once.  The matmuls see bit-identical operands; LayerNorm/embedding parameters and the residual stream stay
+    fp32.  The tied MPT wte/lm_head matrix stays fp32 (two of its rows are trainable, factory.py:109-113)."""
+    tied = {id(p) for p in model.lang_encoder.get_input_embeddings().parameters()}
+    n = 0
+    for mod in list(model.vision_encoder.modules()) + list(model.lang_encoder.modules()):
+        if isinstance(mod, nn.Linear) and not mod.weight.requires_grad and id(mod.weight) not in tied:
+            mod.weight.data = mod.weight.data.to(torch.bfloat16)
+            if mod.bias is not None:
+                mod.bias.data = mod.bias.data.to(torch.bfloat16)
+            n += 1
+    return n
+
+
 def build_flamingo(family: str = "OF-3B", device="cuda", seed: int = 0, gates: float = 0.5, vision_kw=None,
-                   freeze_lm_embeddings: bool = False, verbose: bool = False):
+                   freeze_lm_embeddings: bool = False, verbose: bool = False, frozen_bf16: bool = False):
     """Random-init Flamingo of the given family, assembled through the factory path, gates set to ``gates``
     (their init value 0 makes the hot path an exact no-op with zero weight gradients -- SURVEY.md section 7)."""
     from ..src.factory import assemble_flamingo
@@ -82,6 +122,8 @@ def build_flamingo(family: str = "OF-3B", device="cuda", seed: int = 0, gates: f
         model = assemble_flamingo(vision, lm, eoc_id, media_id, vis_dim=vis_dim, cross_attn_every_n_layers=f["every"],
                                   decoder_layers_attr_name=attr, freeze_lm_embeddings=freeze_lm_embeddings,
                                   verbose=verbose)
+    if frozen_bf16:
+        hold_frozen_linears_in_bf16(model)
     with torch.no_grad():
         for blk in model.lang_encoder.gated_cross_attn_layers:
             if blk is not None:
