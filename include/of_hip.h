@@ -157,6 +157,14 @@ int of_cast_bf16_to_f32(const uint16_t* x, float* y, long n, void* stream);
 int of_broadcast_rows(const float* src, int src_rows, void* y, int y_f32, long ldy, long rows, int dim, void* stream);
 /* dst[r % dst_rows][c] += src[r][c]: gradient of the repeat above (sum over b,T). dst fp32. */
 int of_reduce_rows(const void* src, int src_f32, long rows, int dim, float* dst, int dst_rows, void* stream);
+/* Perceiver position tables (helpers.py:117-119,123-124): out[r][c] = x[r][c] + e1[(r / inner1) % outer1][c]
+ * + e2[(r / inner2) % outer2][c] (either table may be NULL); x/out stream dtype, tables fp32.  With rows indexed
+ * ((b*T + t)*F + f)*v + i: frame_embs use inner = v, outer = F; media_time_embs inner = F*v, outer = T. */
+int of_add_embs(const void* x, int x_f32, const float* e1, long inner1, int outer1, const float* e2, long inner2,
+                int outer2, void* out, long rows, int dim, void* stream);
+/* Gradient of one table: dst[o][c] += sum over rows r with (r / inner) % outer == o of src[r][c].  dst fp32. */
+int of_reduce_rows_strided(const void* src, int src_f32, long rows, int dim, long inner, int outer, float* dst,
+                           void* stream);
 /* out(T) = a(T) + b(T) */
 int of_add(const void* a, const void* b, void* out, int f32, long n, void* stream);
 

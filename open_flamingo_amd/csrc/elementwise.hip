@@ -91,6 +91,43 @@ OF_GLOBAL void of_reduce_rows_kernel(EwArgs a) {
     ((float*)a.out)[i] += s;
 }
 
+struct EmbArgs {
+    const void* x; int f32; void* out;
+    const float* e1; long inner1; int outer1;
+    const float* e2; long inner2; int outer2;
+    long rows; int dim;
+    // reduction
+    float* dst; long inner; int outer;
+};
+// out[r][c] = x[r][c] + e1[(r / inner1) % outer1][c] + e2[(r / inner2) % outer2][c]   (each table optional)
+OF_GLOBAL void of_add_embs_kernel(EmbArgs a) {
+    const long total = a.rows * a.dim;
+    const long stride = (long)of_gdim_x() * 256;
+    for (long i = (long)of_bid_x() * 256 + of_tid(); i < total; i += stride) {
+        const long r = i / a.dim;
+        const int c = (int)(i - r * a.dim);
+        float v = a.f32 ? ((const float*)a.x)[i] : of_bf16_to_f32(((const bf16_t*)a.x)[i]);
+        if (a.e1) v += a.e1[(size_t)((r / a.inner1) % a.outer1) * a.dim + c];
+        if (a.e2) v += a.e2[(size_t)((r / a.inner2) % a.outer2) * a.dim + c];
+        if (a.f32) ((float*)a.out)[i] = v;
+        else ((bf16_t*)a.out)[i] = of_f32_to_bf16(v);
+    }
+}
+// dst[o][c] += sum over rows r with (r / inner) % outer == o of src[r][c]
+OF_GLOBAL void of_reduce_rows_strided_kernel(EmbArgs a) {
+    const long total = (long)a.outer * a.dim;
+    const long i = (long)of_bid_x() * 256 + of_tid();
+    if (i >= total) return;
+    const long o = i / a.dim;
+    const int c = (int)(i - o * a.dim);
+    const long period = a.inner * a.outer;
+    float s = 0.f;
+    for (long base = o * a.inner; base < a.rows; base += period)
+        for (long r = base; r < base + a.inner && r < a.rows; ++r)
+            s += a.f32 ? ((const float*)a.x)[(size_t)r * a.dim + c] : of_bf16_to_f32(((const bf16_t*)a.x)[(size_t)r * a.dim + c]);
+    a.dst[i] += s;
+}
+
 unsigned grid_for(long work_items) {
     long b = (work_items + 255) / 256;
     if (b < 1) b = 1;
@@ -136,4 +173,23 @@ extern "C" int of_reduce_rows(const void* src, int src_f32, long rows, int dim, 
     a.a = src; a.out = dst; a.f32 = src_f32; a.rows = rows; a.dim = dim; a.src_rows = dst_rows;
     const long total = (long)dst_rows * dim;
     return of_launch(of_reduce_rows_kernel, of_dim3{(unsigned)((total + 255) / 256), 1, 1}, 256, 0, (of_stream_t)stream, a);
+}
+
+extern "C" int of_add_embs(const void* x, int x_f32, const float* e1, long inner1, int outer1, const float* e2, long inner2,
+                           int outer2, void* out, long rows, int dim, void* stream) {
+    if (!x || !out || rows <= 0 || dim <= 0) return OF_E_ARG;
+    if ((e1 && (inner1 <= 0 || outer1 <= 0)) || (e2 && (inner2 <= 0 || outer2 <= 0))) return OF_E_ARG;
+    EmbArgs a{};
+    a.x = x; a.f32 = x_f32; a.out = out; a.e1 = e1; a.inner1 = inner1; a.outer1 = outer1;
+    a.e2 = e2; a.inner2 = inner2; a.outer2 = outer2; a.rows = rows; a.dim = dim;
+    return of_launch(of_add_embs_kernel, of_dim3{grid_for(rows * dim), 1, 1}, 256, 0, (of_stream_t)stream, a);
+}
+extern "C" int of_reduce_rows_strided(const void* src, int src_f32, long rows, int dim, long inner, int outer, float* dst,
+                                      void* stream) {
+    if (!src || !dst || rows <= 0 || dim <= 0 || inner <= 0 || outer <= 0) return OF_E_ARG;
+    EmbArgs a{};
+    a.x = src; a.f32 = src_f32; a.rows = rows; a.dim = dim; a.inner = inner; a.outer = outer; a.dst = dst;
+    const long total = (long)outer * dim;
+    return of_launch(of_reduce_rows_strided_kernel, of_dim3{(unsigned)((total + 255) / 256), 1, 1}, 256, 0,
+                     (of_stream_t)stream, a);
 }

@@ -85,6 +85,76 @@ OF_DEV void epilogue_frag(const OfGemmArgs& p, const f32x4 a, int m, int n, floa
     }
 }
 
+OF_DEV void unpack8(u32x4 r, float (&x)[8]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        x[2 * e] = of_bf16_to_f32((bf16_t)(r[e] & 0xffff));
+        x[2 * e + 1] = of_bf16_to_f32((bf16_t)(r[e] >> 16));
+    }
+}
+OF_DEV u32x4 pack8(const float (&o)[8]) {
+    return u32x4{of_pack_bf16(o[0], o[1]), of_pack_bf16(o[2], o[3]), of_pack_bf16(o[4], o[5]), of_pack_bf16(o[6], o[7])};
+}
+// Eight consecutive n of one output row (tile-aligned shapes only: no bounds checks): 16-byte bf16 / 2 x 16-byte fp32
+// loads and stores, eight lanes cover one full 128-byte (bf16) or 256-byte (fp32) row segment.
+template <int EPI>
+OF_DEV void epilogue_row8(const OfGemmArgs& p, const float (&a)[8], int m, int n, float gv, float sc, float& dot) {
+    const size_t off = (size_t)m * p.ldc + n;
+    float o[8];
+    if (EPI == OF_EPI_STORE_BF16) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = sc * a[e];
+        *(u32x4*)((bf16_t*)p.C + off) = pack8(o);
+    } else if (EPI == OF_EPI_GELU) {
+        if (p.C2) *(u32x4*)((bf16_t*)p.C2 + off) = pack8(a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = of_gelu(a[e]);
+        *(u32x4*)((bf16_t*)p.C + off) = pack8(o);
+    } else if (EPI == OF_EPI_GATE_RESID) {
+        const size_t aoff = (size_t)m * p.ldaux + n;
+        if (p.io_f32) {
+            const f32x4 r0 = *(const f32x4*)((const float*)p.aux + aoff), r1 = *(const f32x4*)((const float*)p.aux + aoff + 4);
+            *(f32x4*)((float*)p.C + off) = f32x4{r0[0] + sc * a[0], r0[1] + sc * a[1], r0[2] + sc * a[2], r0[3] + sc * a[3]};
+            *(f32x4*)((float*)p.C + off + 4) = f32x4{r1[0] + sc * a[4], r1[1] + sc * a[5], r1[2] + sc * a[6], r1[3] + sc * a[7]};
+        } else {
+            float r[8];
+            unpack8(*(const u32x4*)((const bf16_t*)p.aux + aoff), r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = r[e] + sc * a[e];
+            *(u32x4*)((bf16_t*)p.C + off) = pack8(o);
+        }
+    } else if (EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) {
+        float x[8];
+        unpack8(*(const u32x4*)((const bf16_t*)p.aux + (size_t)m * p.ldaux + n), x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (EPI == OF_EPI_DGELU_DOT) {
+                float ge, dg;
+                of_gelu_both(x[e], ge, dg);
+                dot += ge * a[e];
+                o[e] = sc * a[e] * dg;
+            } else {
+                dot += x[e] * a[e];
+                o[e] = sc * a[e];
+            }
+        }
+        *(u32x4*)((bf16_t*)p.C + off) = pack8(o);
+    } else {  // OF_EPI_ACC_F32
+        float* c = (float*)p.C + off;
+        f32x4 o0 = {sc * a[0], sc * a[1], sc * a[2], sc * a[3]}, o1 = {sc * a[4], sc * a[5], sc * a[6], sc * a[7]};
+        if (p.beta != 0.f) {
+            const f32x4 c0 = *(const f32x4*)c, c1 = *(const f32x4*)(c + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o0[e] += p.beta * c0[e];
+                o1[e] += p.beta * c1[e];
+            }
+        }
+        *(f32x4*)c = o0;
+        *(f32x4*)(c + 4) = o1;
+    }
+}
+
 template <int EPI>
 OF_DEV void epilogue_finish(const OfGemmArgs& p, float gv, float dot, int lane) {
     if (EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) {

@@ -228,21 +228,37 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
     }
     if (wm == 0) of_barrier_raw();   // balances G1's stagger barrier
 
+    // ---------------------------------------------------------------- epilogue, staged through LDS
+    // The ring is idle now (every wave's last fragment read and DMA wait are behind its last barrier).  Each wave
+    // transposes its accumulators through a private 32-row x 64-column fp32 patch (row pitch 272 B) so that a lane ends
+    // up with 8 consecutive n of one row: aux loads and output stores are 16-byte, 8 lanes cover a full row segment
+    // (the row-per-lane MFMA layout would store 16-byte fragments of 32 different rows per instruction).
     float gv = 1.0f;
     if (p.gate) gv = of_tanh(*p.gate);
     const float sc = gv * p.alpha;
     float dot = 0.f;
-    const int mrow = m0 + wm * 128 + (lane & 31);
-    const int ncol = n0 + wn * 64 + 4 * (lane >> 5);
+    constexpr int PITCH = 64 * 4 + 16;
+    char* patch = smem + wave * (32 * PITCH);
+    const int wr_off = (lane & 31) * PITCH + (lane >> 5) * 16;
+    const int rd_row = lane >> 3, rd_col = (lane & 7) * 8;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 a4 = {acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
-                ofg::epilogue_frag<EPI>(p, a4, mrow + mt * 32, ncol + nt * 32 + q * 8, gv, sc, dot);
-            }
+            for (int q = 0; q < 4; ++q)
+                *(f32x4*)(patch + wr_off + (nt * 32 + q * 8) * 4) =
+                    f32x4{acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+        of_wave_sync();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int r = it * 8 + rd_row;
+            const f32x4 v0 = *(const f32x4*)(patch + r * PITCH + rd_col * 4), v1 = *(const f32x4*)(patch + r * PITCH + rd_col * 4 + 16);
+            const float a8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            ofg::epilogue_row8<EPI>(p, a8, m0 + wm * 128 + mt * 32 + r, n0 + wn * 64 + rd_col, gv, sc, dot);
+        }
+        of_wave_sync();
+    }
     ofg::epilogue_finish<EPI>(p, gv, dot, lane);
 }
 

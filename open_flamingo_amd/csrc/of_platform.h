@@ -59,6 +59,9 @@ OF_DEV void of_setprio_lo() { __builtin_amdgcn_s_setprio(0); }
 // pins the instruction scheduler: nothing moves across this point
 OF_DEV void of_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 OF_DEV int of_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Point where the lanes of ONE wave exchange data through LDS: hardware executes a wave in lock-step and its LDS
+// operations in program order, so this is only a compiler scheduling fence (the emulator needs a real rendezvous).
+OF_DEV void of_wave_sync() { __builtin_amdgcn_wave_barrier(); }
 // ds_read_b64_tr_b16: within each 16-lane group, lane i supplies the LDS address of 4 contiguous bf16
 // (row i>>2, column chunk i&3 of a 4x16 block) and receives column i of that block (4 rows).
 OF_DEV s16x4 of_lds_tr(const void* p) {

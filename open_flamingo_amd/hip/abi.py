@@ -62,6 +62,8 @@ PROTOTYPES = {
     "of_broadcast_rows": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_long, C.c_long, C.c_int, vp]),
     "of_reduce_rows": (C.c_int, [vp, C.c_int, C.c_long, C.c_int, vp, C.c_int, vp]),
     "of_add": (C.c_int, [vp, vp, vp, C.c_int, C.c_long, vp]),
+    "of_add_embs": (C.c_int, [vp, C.c_int, vp, C.c_long, C.c_int, vp, C.c_long, C.c_int, vp, C.c_long, C.c_int, vp]),
+    "of_reduce_rows_strided": (C.c_int, [vp, C.c_int, C.c_long, C.c_int, C.c_long, C.c_int, vp, vp]),
 }
 
 

@@ -192,6 +192,18 @@ class Ops:
         self._chk(self.lib.of_reduce_rows(src.data_ptr(), _is_f32(src), src.shape[0], src.shape[1], dst.data_ptr(),
                                           dst.shape[0], self._stream()), "of_reduce_rows")
 
+    def add_embs(self, x, e1, inner1, outer1, e2, inner2, outer2, out):
+        rows, dim = x.shape
+        assert x.is_contiguous() and out.is_contiguous() and out.dtype == x.dtype
+        self._chk(self.lib.of_add_embs(x.data_ptr(), _is_f32(x), _p(e1), inner1, outer1, _p(e2), inner2, outer2,
+                                       out.data_ptr(), rows, dim, self._stream()), "of_add_embs")
+        return out
+
+    def reduce_rows_strided(self, src, inner, outer, dst):
+        assert src.is_contiguous() and dst.dtype == F32 and dst.is_contiguous()
+        self._chk(self.lib.of_reduce_rows_strided(src.data_ptr(), _is_f32(src), src.shape[0], src.shape[1], inner, outer,
+                                                  dst.data_ptr(), self._stream()), "of_reduce_rows_strided")
+
     def add(self, a, b, out):
         assert a.dtype == b.dtype == out.dtype and a.is_contiguous() and b.is_contiguous() and out.is_contiguous()
         self._chk(self.lib.of_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), _is_f32(a), a.numel(), self._stream()),

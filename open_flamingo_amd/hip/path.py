@@ -119,10 +119,18 @@ def xattn_block_bwd(ops, P, W, S, media_bf, tt, dy, *, B, L, T, n, heads, only_i
 # =================================================================================================
 # PerceiverResampler
 # =================================================================================================
-def perceiver_fwd(ops, P, W, x, *, N, Fv, n, heads, depth, safe=0):
-    """x (N*Fv, D) stream dtype (already flattened 'b T (F v) d' rows); returns (out (N*n, D) stream, saved)."""
+def perceiver_fwd(ops, P, W, x, *, N, Fv, n, heads, depth, T=1, frames=1, safe=0):
+    """x (N*Fv, D) stream dtype (already flattened 'b T (F v) d' rows, N = b*T, Fv = frames*v); returns
+    (out (N*n, D) stream, saved).  frame_embs / media_time_embs (helpers.py:117-119,123-124) are added when present
+    in P; T and frames give the row structure they index."""
     dev = x.device
     D = x.shape[1]
+    embs = ("frame_embs" in P) or ("media_time_embs" in P)
+    if embs:
+        v = Fv // frames
+        x_in = x
+        x = torch.empty_like(x_in)
+        ops.add_embs(x_in, P.get("frame_embs"), v, frames, P.get("media_time_embs"), Fv, T, x)
     inner = heads * 64
     S_ = Fv + n
     hid = W["layers.0.1.1.weight"].shape[0]
@@ -161,13 +169,15 @@ def perceiver_fwd(ops, P, W, x, *, N, Fv, n, heads, depth, safe=0):
     out = torch.empty_like(lat)
     st_o = _e((N * n, 2), F32, dev)
     ops.ln_fwd_out(lat, P["norm.weight"], P["norm.bias"], out, st_o)
-    return out, dict(layers=layers, lat_last=lat, st_o=st_o, x=x)
+    return out, dict(layers=layers, lat_last=lat, st_o=st_o, x=x, embs=embs, T=T, frames=frames)
 
 
-def perceiver_bwd(ops, P, W, S, dout, *, N, Fv, n, heads, depth, need_dx=False, safe=0):
+def perceiver_bwd(ops, P, W, S, dout, *, N, Fv, n, heads, depth, T=1, frames=1, need_dx=False, safe=0):
     """Returns (dx (N*Fv, D) stream dtype or None, grads dict keyed like P)."""
     dev = dout.device
     x = S["x"]
+    want_dx = need_dx
+    need_dx = need_dx or S.get("embs", False)     # the position tables' gradients are reductions of dx
     D = x.shape[1]
     inner = heads * 64
     S_ = Fv + n
@@ -234,4 +244,12 @@ def perceiver_bwd(ops, P, W, S, dout, *, N, Fv, n, heads, depth, need_dx=False, 
         dlat = dlat_prev
     g["latents"] = _z(tuple(P["latents"].shape), dev)
     ops.reduce_rows(dlat, g["latents"])                                          # sum over (b, T) of the repeat
-    return dx, g
+    if S.get("embs", False):
+        v = Fv // frames
+        if "frame_embs" in P:
+            g["frame_embs"] = _z(tuple(P["frame_embs"].shape), dev)              # rows >= frames keep zero gradient
+            ops.reduce_rows_strided(dx, v, frames, g["frame_embs"])
+        if "media_time_embs" in P:
+            g["media_time_embs"] = _z(tuple(P["media_time_embs"].shape), dev)
+            ops.reduce_rows_strided(dx, Fv, T, g["media_time_embs"])
+    return (dx if want_dx else None), g

@@ -126,7 +126,9 @@ class _PerceiverFn(torch.autograd.Function):
         xr = x.detach().reshape(b * T * Fr * v, D)
         if not xr.is_contiguous():
             xr = xr.contiguous()
-        dims = dict(N=b * T, Fv=Fr * v, n=P["latents"].shape[0], heads=mod.heads, depth=mod.depth)
+        assert ("frame_embs" not in P or Fr <= P["frame_embs"].shape[0]) and \
+            ("media_time_embs" not in P or T <= P["media_time_embs"].shape[0]), "more frames/media than embedding rows"
+        dims = dict(N=b * T, Fv=Fr * v, n=P["latents"].shape[0], heads=mod.heads, depth=mod.depth, T=T, frames=Fr)
         out, S = _path.perceiver_fwd(ops, P, W, xr, **dims)
         ctx.mod, ctx.names, ctx.dims, ctx.S, ctx.P, ctx.W = mod, names, dims, S, P, W
         ctx.xshape = tuple(x.shape)
@@ -168,9 +170,6 @@ class PerceiverResampler(_HipParamModule):
         """x (b, T, F, v, D) -> (b, T, num_latents, D)   [reference helpers.py:107-132]"""
         _require_hip(x, "PerceiverResampler")
         assert x.dim() == 5 and x.shape[-1] == self.dim, f"expected (b,T,F,v,{self.dim}), got {tuple(x.shape)}"
-        if exists(self.frame_embs) or exists(self.media_time_embs):
-            # not used by any OpenFlamingo model (flamingo.py:48 passes neither); TODO(round 2): tiny add kernel
-            raise NotImplementedError("frame_embs / media_time_embs are not implemented in the HIP path yet")
         named = list(self.named_parameters())
         names = tuple(k for k, _ in named)
         return _PerceiverFn.apply(self, names, x, *[p for _, p in named])

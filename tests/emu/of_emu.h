@@ -191,6 +191,7 @@ OF_DEV void of_setprio_hi() {}
 OF_DEV void of_setprio_lo() {}
 OF_DEV void of_sched_fence() {}
 OF_DEV int of_uniform(int v) { return v; }
+OF_DEV void of_wave_sync() { of_emu::wave_barrier(); }
 OF_DEV s16x4 of_lds_tr(const void* p) {
     of_emu::Block* blk = of_emu::g_blk;
     int t = blk->cur, i = t & 15, g0 = t & ~15;

@@ -15,7 +15,7 @@ def rel_err(got, want):
 
 
 def make_bf16_weights(ops, P):
-    return {k: ops.to_bf16(v.contiguous()) for k, v in P.items() if v.dim() == 2 and not k.endswith("latents")}
+    return {k: ops.to_bf16(v.contiguous()) for k, v in P.items() if v.dim() == 2 and not k.endswith("latents") and "embs" not in k}
 
 
 def check_xattn(ops, dev, *, B=2, L=40, T=2, n=16, heads=2, d=64, Dv=48, stream_dtype=torch.float32, media_locs=None,
@@ -64,12 +64,14 @@ def check_xattn(ops, dev, *, B=2, L=40, T=2, n=16, heads=2, d=64, Dv=48, stream_
 
 
 def check_perceiver(ops, dev, *, b=1, T=2, Fv=24, n=16, heads=2, D=64, depth=2, stream_dtype=torch.float32, seed=0,
-                    fwd_tol=1e-2, bwd_tol=3e-2, need_dx=True, safe=0):
-    m = O.OraclePerceiverResampler(dim=D, depth=depth, dim_head=64, heads=heads, num_latents=n)
+                    fwd_tol=1e-2, bwd_tol=3e-2, need_dx=True, safe=0, frames=1, embs=False):
+    m = O.OraclePerceiverResampler(dim=D, depth=depth, dim_head=64, heads=heads, num_latents=n,
+                                   max_num_media=(T + 1 if embs else None), max_num_frames=(frames + 1 if embs else None))
     st = O.seeded_state({k: tuple(v.shape) for k, v in m.state_dict().items()}, 300 + seed)
     m.load_state_dict(st)
     g = torch.Generator().manual_seed(400 + seed)
-    x = torch.randn(b, T, 1, Fv, D, generator=g)
+    assert Fv % frames == 0
+    x = torch.randn(b, T, frames, Fv // frames, D, generator=g)
     w = torch.randn(b, T, n, D, generator=g)
     xo = x.clone().requires_grad_(True)
     yo = m(xo, quant=O.bf16_round)
@@ -78,13 +80,13 @@ def check_perceiver(ops, dev, *, b=1, T=2, Fv=24, n=16, heads=2, D=64, depth=2, 
     W = make_bf16_weights(ops, P)
     N = b * T
     xd = x.to(dev).to(stream_dtype).reshape(N * Fv, D).contiguous()
-    kw = dict(N=N, Fv=Fv, n=n, heads=heads, depth=depth, safe=safe)
+    kw = dict(N=N, Fv=Fv, n=n, heads=heads, depth=depth, safe=safe, T=T, frames=frames)
     y, S = path.perceiver_fwd(ops, P, W, xd, **kw)
     dy = w.to(dev).to(stream_dtype).reshape(N * n, D).contiguous()
     dx, grads = path.perceiver_bwd(ops, P, W, S, dy, need_dx=need_dx, **kw)
     errs = {"y": rel_err(y.reshape(b, T, n, D), yo.detach())}
     if need_dx:
-        errs["dx"] = rel_err(dx.reshape(b, T, 1, Fv, D), xo.grad)
+        errs["dx"] = rel_err(dx.reshape(b, T, frames, Fv // frames, D), xo.grad)
     for k, p in m.named_parameters():
         errs["d" + k] = rel_err(grads[k], p.grad)
     bad = {k: v for k, v in errs.items() if v > (fwd_tol if k == "y" else bwd_tol) * (4 if stream_dtype == torch.bfloat16 else 1)}

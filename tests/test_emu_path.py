@@ -31,3 +31,9 @@ def test_xattn_zero_gates_identity():
 def test_perceiver_path(stream_dtype):
     errs = PC.check_perceiver(H.emu_ops(), "cpu", stream_dtype=stream_dtype)
     print(errs)
+
+
+def test_perceiver_path_with_frame_and_media_time_embs():
+    """helpers.py:117-119,123-124: max_num_frames / max_num_media position tables (F=2 frames)."""
+    errs = PC.check_perceiver(H.emu_ops(), "cpu", T=3, Fv=32, frames=2, embs=True, seed=4)
+    assert "dframe_embs" in errs and "dmedia_time_embs" in errs

@@ -45,3 +45,16 @@ def test_perceiver_small(ops, stream_dtype):
 def test_perceiver_of3b_dims(ops):
     errs = PC.check_perceiver(ops, "cuda", b=1, T=2, Fv=256, n=64, heads=8, D=1024, depth=6, seed=6)
     print({k: f"{v:.1e}" for k, v in errs.items()})
+
+
+def test_perceiver_frame_and_media_time_embs(ops):
+    errs = PC.check_perceiver(ops, "cuda", T=3, Fv=32, frames=2, embs=True, seed=4)
+    assert "dframe_embs" in errs and "dmedia_time_embs" in errs
+
+
+@pytest.mark.parametrize("d,heads_lm", [(2560, 8), (4096, 8)])
+def test_xattn_of4b_of9b_dims(ops, d, heads_lm):
+    """BASELINE configs 4 / 5: RedPajama-3B (d=2560) and MPT-7B (d=4096) hidden sizes (LayerNorm CPL=5 / CPL=8 kernels,
+    GEMM shapes of those families) at a reduced batch."""
+    errs = PC.check_xattn(ops, "cuda", B=2, L=128, T=2, n=64, heads=8, d=d, Dv=1024, seed=9)
+    print({k: f"{v:.1e}" for k, v in errs.items()})
