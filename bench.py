@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--frozen-fp32", action="store_true",
                     help="keep the frozen towers' Linear weights in fp32 (autocast re-casts them every forward, as the "
                          "reference does) instead of holding their bf16 copies")
+    ap.add_argument("--torch-optimizer", action="store_true",
+                    help="clip_grad_norm_ + torch.optim.AdamW(fused) instead of the libofhip step epilogue")
     ap.add_argument("--gemm-report", default=None, help="write a per-(layout,epilogue,shape) GEMM time table (JSON lines)")
     args = ap.parse_args()
 
@@ -115,7 +117,7 @@ def main():
     reducer = GradReducer(model, wire_dtype=torch.bfloat16 if args.wire_bf16 else torch.float32,
                           embedding_rows=[info["media_token_id"], info["eoc_token_id"]])
     reducer.broadcast_parameters()
-    opt = step.build_optimizer(model)
+    opt = step.build_optimizer(model, reducer=None if args.torch_optimizer else reducer)
     batch = synthetic.make_batch(args.batch, args.T, args.L, info, device, seed=1 + rank)
     ops = Ops.default()
 

@@ -1,0 +1,118 @@
+// Step epilogue of the trainable parameters (gfx950, HBM-bound): global-norm gradient clipping + AdamW in two passes
+// over flat fp32 buffers, replacing  torch.nn.utils.clip_grad_norm_(params, 1.0); optimizer.step(); zero_grad()
+// of open_flamingo/train/train_utils.py:199-216 with the AdamW groups of open_flamingo/train/train.py:392-408.
+//   pass 1  of_sumsq:        *acc += sum g^2                                   (4 B/element)
+//   pass 2  of_adamw_clip:   c = min(1, max_norm / (sqrt(*acc) + 1e-6));  g' = c g
+//                            p <- p (1 - lr wd);  m <- b1 m + (1-b1) g';  v <- b2 v + (1-b2) g'^2
+//                            p <- p - (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps)           (torch.optim.AdamW, eps outside
+//                            the bias-corrected sqrt, decoupled decay first); optionally writes the bf16 operand copy of
+//                            p for the next step's GEMMs and zeroes g (16 B read + 12..18 B written per element).
+// The clip coefficient is computed on the device from *acc: no host synchronisation anywhere in the step epilogue.
+#include "of_platform.h"
+#include "../../include/of_hip.h"
+
+namespace {
+
+struct OptArgs {
+    float* p; float* g; float* m; float* v; bf16_t* p_bf16;
+    long n;
+    float* acc;            // sum of squares (device scalar)
+    float max_norm, lr, beta1, beta2, eps, wd, bc1, bc2;
+    int zero_grad;
+};
+
+constexpr int OPT_GRID_CAP = 4096;
+
+OF_GLOBAL void of_sumsq_kernel(OptArgs a) {
+    float* red = (float*)of_smem();
+    const long nv = a.n >> 2;
+    const long stride = (long)of_gdim_x() * 256;
+    float s = 0.f;
+    for (long i = (long)of_bid_x() * 256 + of_tid(); i < nv; i += stride) {
+        const f32x4 g = *(const f32x4*)(a.g + i * 4);
+        s += g[0] * g[0] + g[1] * g[1] + g[2] * g[2] + g[3] * g[3];
+    }
+    if (of_bid_x() == 0)
+        for (long i = (nv << 2) + of_tid(); i < a.n; i += 256) s += a.g[i] * a.g[i];
+    s = of_wave_sum(s);
+    const int tid = of_tid();
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    of_sync();
+    if (tid == 0) of_atomic_add(a.acc, red[0] + red[1] + red[2] + red[3]);
+}
+
+OF_DEV float adamw_one(const OptArgs& a, float coef, float step_size, float inv_sqrt_bc2, float decay, float& p, float g,
+                       float& m, float& v) {
+    g *= coef;
+    p *= decay;
+    m = a.beta1 * m + (1.0f - a.beta1) * g;
+    v = a.beta2 * v + (1.0f - a.beta2) * g * g;
+    const float denom = sqrtf(v) * inv_sqrt_bc2 + a.eps;
+    p -= step_size * (m / denom);
+    return p;
+}
+
+OF_GLOBAL void of_adamw_kernel(OptArgs a) {
+    const float norm = sqrtf(*a.acc);
+    float coef = a.max_norm > 0.f ? a.max_norm / (norm + 1e-6f) : 1.0f;
+    coef = coef < 1.0f ? coef : 1.0f;
+    const float step_size = a.lr / a.bc1, inv_sqrt_bc2 = 1.0f / sqrtf(a.bc2), decay = 1.0f - a.lr * a.wd;
+    const long nv = a.n >> 2;
+    const long stride = (long)of_gdim_x() * 256;
+    for (long i = (long)of_bid_x() * 256 + of_tid(); i < nv; i += stride) {
+        f32x4 p = *(const f32x4*)(a.p + i * 4), m = *(const f32x4*)(a.m + i * 4), v = *(const f32x4*)(a.v + i * 4);
+        const f32x4 g = *(const f32x4*)(a.g + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float pe = p[e], me = m[e], ve = v[e];
+            adamw_one(a, coef, step_size, inv_sqrt_bc2, decay, pe, g[e], me, ve);
+            p[e] = pe; m[e] = me; v[e] = ve;
+        }
+        *(f32x4*)(a.p + i * 4) = p;
+        *(f32x4*)(a.m + i * 4) = m;
+        *(f32x4*)(a.v + i * 4) = v;
+        if (a.p_bf16) *(u32x2*)(a.p_bf16 + i * 4) = u32x2{of_pack_bf16(p[0], p[1]), of_pack_bf16(p[2], p[3])};
+        if (a.zero_grad) *(f32x4*)(a.g + i * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (of_bid_x() == 0) {
+        for (long i = (nv << 2) + of_tid(); i < a.n; i += 256) {
+            float pe = a.p[i], me = a.m[i], ve = a.v[i];
+            adamw_one(a, coef, step_size, inv_sqrt_bc2, decay, pe, a.g[i], me, ve);
+            a.p[i] = pe; a.m[i] = me; a.v[i] = ve;
+            if (a.p_bf16) a.p_bf16[i] = of_f32_to_bf16(pe);
+            if (a.zero_grad) a.g[i] = 0.f;
+        }
+    }
+}
+
+unsigned opt_grid(long n) {
+    long b = ((n >> 2) + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > OPT_GRID_CAP) b = OPT_GRID_CAP;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int of_sumsq(const float* g, long n, float* acc, void* stream) {
+    if (!g || !acc || n <= 0) return OF_E_ARG;
+    if ((uintptr_t)g & 15) return OF_E_ALIGN;
+    OptArgs a{};
+    a.g = const_cast<float*>(g); a.n = n; a.acc = acc;
+    return of_launch(of_sumsq_kernel, of_dim3{opt_grid(n), 1, 1}, 256, 4 * sizeof(float), (of_stream_t)stream, a);
+}
+
+extern "C" int of_adamw_clip(float* p, float* g, float* m, float* v, uint16_t* p_bf16, long n, const float* sumsq,
+                             float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                             int step, int zero_grad, void* stream) {
+    if (!p || !g || !m || !v || !sumsq || n <= 0 || step <= 0) return OF_E_ARG;
+    if (((uintptr_t)p & 15) || ((uintptr_t)g & 15) || ((uintptr_t)m & 15) || ((uintptr_t)v & 15) || ((uintptr_t)p_bf16 & 7))
+        return OF_E_ALIGN;
+    OptArgs a{};
+    a.p = p; a.g = g; a.m = m; a.v = v; a.p_bf16 = p_bf16; a.n = n; a.acc = const_cast<float*>(sumsq);
+    a.max_norm = max_norm; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
+    a.bc1 = 1.0f - powf(beta1, (float)step);
+    a.bc2 = 1.0f - powf(beta2, (float)step);
+    a.zero_grad = zero_grad;
+    return of_launch(of_adamw_kernel, of_dim3{opt_grid(n), 1, 1}, 256, 0, (of_stream_t)stream, a);
+}

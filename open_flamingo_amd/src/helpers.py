@@ -56,10 +56,17 @@ _shared = _SharedCache()
 
 
 class _HipParamModule(nn.Module):
-    """Common: bf16 operand copies of the weight matrices, refreshed when a parameter's version changes."""
+    """Common: bf16 operand copies of the fp32 master weights.
+
+    Freshness: torch optimizers update parameters WITHOUT bumping ``Tensor._version`` (measured: version stays put
+    across ``AdamW.step()``), so a version-keyed cache silently trains on step-0 weights.  Therefore in training mode
+    the copies are re-cast on every forward (one HBM pass over the block's weights) unless the libofhip step epilogue
+    (``train/optim.py``), which rewrites the bf16 copies in its AdamW pass, vouches for them; in eval mode they are
+    cached and re-validated by version/pointer (``load_state_dict`` and other in-place writes do bump the version)."""
 
     def _weights_bf16(self, ops, named):
         cache = self.__dict__.setdefault("_w_bf16_cache", {})
+        provider = self.__dict__.get("_w_bf16_provider")   # train/optim.py keeps bf16 copies current in its AdamW pass
         out = {}
         for name, p in named:
             if p.dim() != 2 or name.endswith("latents") or "embs" in name:
@@ -67,8 +74,13 @@ class _HipParamModule(nn.Module):
             if p.dtype == BF16:
                 out[name] = p.detach()
                 continue
+            if provider is not None:
+                view = provider.bf16_view(p)
+                if view is not None:
+                    out[name] = view
+                    continue
             ent = cache.get(name)
-            if ent is None or ent[0] != p._version or ent[1] != p.data_ptr():
+            if self.training or ent is None or ent[0] != p._version or ent[1] != p.data_ptr():
                 ent = (p._version, p.data_ptr(), ops.to_bf16(p.detach().contiguous()))
                 cache[name] = ent
             out[name] = ent[2]

@@ -1,0 +1,108 @@
+"""Step epilogue on the device: global-norm clip + AdamW over the flat buckets of ``GradReducer``.
+
+Replaces, with the same arithmetic, the reference's
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0); optimizer.step(); optimizer.zero_grad()
+(open_flamingo/train/train_utils.py:199-216) for ``torch.optim.AdamW`` with weight decay only on the gated
+cross-attention parameters (open_flamingo/train/train.py:392-408).  Differences, all result-preserving:
+
+* parameters, gradients and both AdamW moments of a bucket are contiguous fp32 buffers (the ``nn.Parameter``s become
+  views), so one ``of_sumsq`` + one ``of_adamw_clip`` launch per bucket replace ~160 multi-tensor launches; the clip
+  coefficient is computed on the device, gradients are zeroed and the bf16 GEMM-operand copies of the new weights are
+  written in the same pass (the modules pick them up instead of re-casting every step);
+* the input embedding: only the ``<image>`` / ``<|endofchunk|>`` rows ever receive gradient (train_utils.py:174-196) and
+  that group has no weight decay, so AdamW leaves every other row untouched (zero moments): updating just those rows is
+  the dense update.
+"""
+import torch
+
+from ..hip.ops import BF16, F32, Ops
+
+
+class FlatAdamW:
+    def __init__(self, reducer, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1, max_norm=1.0, ops=None):
+        self.reducer, self.ops = reducer, ops
+        self.betas, self.eps, self.max_norm = betas, eps, max_norm
+        self.step_count = 0
+        self.param_groups = [{"lr": lr, "params": [], "weight_decay": weight_decay},
+                             {"lr": lr, "params": [], "weight_decay": 0.0}]      # LR schedulers mutate ["lr"]
+        self._views = {}            # param.data_ptr() -> (bf16 view, parameter version it mirrors, numel)
+        for b in reducer.buckets:
+            flat_g = b["flat"]
+            flat_p = torch.zeros_like(flat_g)
+            flat_b = torch.empty(flat_g.shape, dtype=BF16, device=flat_g.device)
+            for p, off in zip(b["params"], b["offsets"]):
+                n = p.numel()
+                flat_p[off:off + n].copy_(p.data.reshape(-1))
+                p.data = flat_p[off:off + n].view(p.shape)
+            b.update(flat_p=flat_p, flat_bf16=flat_b, m=torch.zeros_like(flat_g), v=torch.zeros_like(flat_g),
+                     wd=weight_decay if b.get("kind") == "xattn" else 0.0)
+            self.param_groups[0 if b["wd"] else 1]["params"].extend(b["params"])
+        self.embedding = reducer.embedding
+        if self.embedding is not None:
+            rows = torch.as_tensor(reducer.embedding_rows, device=self.embedding.device)
+            d = self.embedding.shape[1]
+            self._emb = dict(rows=rows, m=torch.zeros(len(rows), d, device=rows.device),
+                             v=torch.zeros(len(rows), d, device=rows.device))
+            self.param_groups[1]["params"].append(self.embedding)
+        self._sumsq = None
+        self.refresh_bf16()
+        model = reducer.module
+        for mod in [model.perceiver] + [b for b in model.lang_encoder.gated_cross_attn_layers if b is not None]:
+            mod.__dict__["_w_bf16_provider"] = self
+
+    # ------------------------------------------------------------------ bf16 operand copies for the modules
+    def _ops(self):
+        if self.ops is None:
+            self.ops = Ops.default()
+        return self.ops
+
+    def refresh_bf16(self):
+        """(Re)build every bf16 copy from the fp32 masters -- after construction, ``load_state_dict`` or any other
+        out-of-band parameter write."""
+        ops = self._ops()
+        for b in self.reducer.buckets:
+            ops.to_bf16(b["flat_p"], out=b["flat_bf16"])
+            for p, off in zip(b["params"], b["offsets"]):
+                n = p.numel()
+                self._views[p.data_ptr()] = (b["flat_bf16"][off:off + n].view(p.shape), p._version, p.numel())
+
+    def bf16_view(self, p):
+        """bf16 copy of parameter ``p`` kept current by step(), or None if ``p`` was written behind our back."""
+        ent = self._views.get(p.data_ptr())
+        if ent is None or ent[1] != p._version or ent[2] != p.numel():
+            return None
+        return ent[0]
+
+    # ------------------------------------------------------------------ optimizer API subset used by train_step
+    def step(self):
+        ops = self._ops()
+        self.step_count += 1
+        dev = self.reducer.buckets[0]["flat"].device
+        if self._sumsq is None:
+            self._sumsq = torch.zeros(1, dtype=F32, device=dev)
+        self._sumsq.zero_()
+        for b in self.reducer.buckets:
+            ops.sumsq(b["flat"], self._sumsq)
+        g_rows = None
+        if self.embedding is not None and self.embedding.grad is not None:
+            g_rows = self.embedding.grad.index_select(0, self._emb["rows"]).contiguous()
+            ops.sumsq(g_rows, self._sumsq)
+        for b, lr in ((b, self.param_groups[0 if b["wd"] else 1]["lr"]) for b in self.reducer.buckets):
+            ops.adamw_clip(b["flat_p"], b["flat"], b["m"], b["v"], self._sumsq, step=self.step_count, lr=lr,
+                           betas=self.betas, eps=self.eps, weight_decay=b["wd"], max_norm=self.max_norm,
+                           p_bf16=b["flat_bf16"], zero_grad=True)
+        if g_rows is not None:
+            e = self._emb
+            p_rows = self.embedding.data.index_select(0, e["rows"]).contiguous()
+            ops.adamw_clip(p_rows, g_rows, e["m"], e["v"], self._sumsq, step=self.step_count,
+                           lr=self.param_groups[1]["lr"], betas=self.betas, eps=self.eps, weight_decay=0.0,
+                           max_norm=self.max_norm, zero_grad=False)
+            self.embedding.data.index_copy_(0, e["rows"], p_rows)
+            self.embedding.grad = None
+
+    def zero_grad(self, set_to_none=True):
+        self.reducer.zero_grad()
+
+    def grad_norm(self):
+        """Global gradient norm of the last step() (device scalar tensor, pre-clip)."""
+        return self._sumsq.sqrt()

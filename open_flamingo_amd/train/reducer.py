@@ -39,25 +39,28 @@ class GradReducer:
         lm = model.lang_encoder
         groups = []
         for blk in reversed([b for b in lm.gated_cross_attn_layers if b is not None]):
-            groups.append([p for p in blk.parameters() if p.requires_grad])
+            groups.append(("xattn", [p for p in blk.parameters() if p.requires_grad]))
         per = [p for p in model.perceiver.parameters() if p.requires_grad]
         if per:
-            groups.append(per)
+            groups.append(("perceiver", per))
         self.embedding = None
         emb = lm.get_input_embeddings().weight
         if emb.requires_grad:
             self.embedding = emb
         self.buckets = []
-        for params in groups:
+        for kind, params in groups:
             if not params:
                 continue
-            n = sum(p.numel() for p in params)
-            flat = torch.zeros(n, dtype=torch.float32, device=params[0].device)
-            off = 0
+            # every parameter starts on a 256-byte boundary (64 fp32 = 128 bytes of bf16: whole L2 lines for the operand DMA): the fused step epilogue keeps fp32 master / bf16
+            # operand copies at the same offsets and the GEMM kernels need 16-byte aligned operands
+            offsets, n = [], 0
             for p in params:
+                offsets.append(n)
+                n += (p.numel() + 63) // 64 * 64
+            flat = torch.zeros(n, dtype=torch.float32, device=params[0].device)
+            for p, off in zip(params, offsets):
                 p.grad = flat[off:off + p.numel()].view_as(p)      # gradient-as-bucket-view
-                off += p.numel()
-            self.buckets.append(dict(flat=flat, params=params, ready=0))
+            self.buckets.append(dict(flat=flat, params=params, offsets=offsets, ready=0, kind=kind))
         self._param_bucket = {}
         for bi, b in enumerate(self.buckets):
             for p in b["params"]:
@@ -138,10 +141,12 @@ class GradReducer:
             self.embedding.grad.index_copy_(0, rows, kept)
             self._emb_rows = None
 
-    def zero_grad(self):
-        """Zero in place (the .grad views must stay attached to the buckets)."""
+    def zero_grad(self, flat_already_zero=False):
+        """Zero in place (the .grad views must stay attached to the buckets).  ``flat_already_zero``: the fused step
+        epilogue (train/optim.py) cleared the buckets in its AdamW pass."""
         for b in self.buckets:
-            b["flat"].zero_()
+            if not flat_already_zero:
+                b["flat"].zero_()
             b["ready"] = 0
         if self.embedding is not None and self.embedding.grad is not None:
             self.embedding.grad = None

@@ -11,8 +11,13 @@ import torch
 from . import synthetic
 
 
-def build_optimizer(model, lr=1e-4, weight_decay=0.1):
-    """train.py:384-408: wd only on params whose name contains 'gated_cross_attn'."""
+def build_optimizer(model, lr=1e-4, weight_decay=0.1, reducer=None):
+    """train.py:384-408: wd only on params whose name contains 'gated_cross_attn'.  With a GradReducer on a GPU the
+    fused device-side step epilogue (train/optim.py: clip + AdamW over the reducer's flat buckets) is returned; it
+    implements the same update."""
+    if reducer is not None and reducer.buckets and reducer.buckets[0]["flat"].is_cuda:
+        from .optim import FlatAdamW
+        return FlatAdamW(reducer, lr=lr, weight_decay=weight_decay)
     with_wd, without_wd = [], []
     for n, p in model.named_parameters():
         if not p.requires_grad or getattr(p, "exclude_from_optimizer", False):
@@ -38,7 +43,8 @@ def forward_loss(model, batch, info, amp=True):
 def train_step(model, reducer, optimizer, batch_mmc4, info, batch_laion=None, loss_multiplier_laion=1.0,
                loss_multiplier_mmc4=1.0, clip_norm=1.0, amp=True, nan_check=True, lr_scheduler=None):
     """Returns the (detached) MMC4 loss tensor, or None if the step was skipped because the loss was NaN."""
-    params = [p for g in optimizer.param_groups for p in g["params"]]
+    fused = hasattr(optimizer, "reducer")         # FlatAdamW: clip + AdamW + zero_grad in two device passes
+    params = None if fused else [p for g in optimizer.param_groups for p in g["params"]]
     if batch_laion is not None:
         with reducer.no_sync() if reducer is not None else contextlib.nullcontext():
             loss_l = forward_loss(model, batch_laion, info, amp)
@@ -53,12 +59,16 @@ def train_step(model, reducer, optimizer, batch_mmc4, info, batch_laion=None, lo
     (loss * loss_multiplier_mmc4).backward()
     if reducer is not None:
         reducer.finish()                          # waits for the overlapped RCCL all-reduces, masks the embedding grad
-    torch.nn.utils.clip_grad_norm_(params, clip_norm)
-    optimizer.step()
+    if fused:
+        optimizer.max_norm = clip_norm
+        optimizer.step()
+    else:
+        torch.nn.utils.clip_grad_norm_(params, clip_norm)
+        optimizer.step()
     if lr_scheduler is not None:
         lr_scheduler.step()
     if reducer is not None:
-        reducer.zero_grad()
+        reducer.zero_grad(flat_already_zero=fused)
     else:
         optimizer.zero_grad(set_to_none=True)
     return loss.detach()

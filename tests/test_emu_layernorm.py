@@ -107,3 +107,34 @@ def test_layernorm_grouped_rows_and_second_gradient():
     _ln_ref(xd, wd, bd).backward(dyt)
     np.testing.assert_allclose(dx.double().numpy(), xd.grad.numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(dw.double().numpy(), wd.grad.numpy(), rtol=1e-3, atol=1e-3)
+
+
+def test_step_epilogue_matches_torch_adamw_with_clipping():
+    """of_sumsq + of_adamw_clip vs clip_grad_norm_ + torch.optim.AdamW over several steps, two parameter
+    groups (weight decay 0.1 / 0.0) sharing one global norm, odd sizes (vector body + scalar tail)."""
+    ops = H.emu_ops()
+    g = torch.Generator().manual_seed(3)
+    sizes, wds = [1027, 4096], [0.1, 0.0]
+    ps = [torch.randn(n, generator=g) for n in sizes]
+    ref = [torch.nn.Parameter(p.clone()) for p in ps]
+    opt = torch.optim.AdamW([{"params": [ref[0]], "weight_decay": wds[0]}, {"params": [ref[1]], "weight_decay": wds[1]}], lr=1e-2)
+    ms = [torch.zeros(n) for n in sizes]
+    vs = [torch.zeros(n) for n in sizes]
+    for step in range(1, 4):
+        grads = [torch.randn(n, generator=g) * (3.0 if step == 2 else 0.01) for n in sizes]   # step 2 clips, others do not
+        for r, gr in zip(ref, grads):
+            r.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        opt.step()
+        acc = torch.zeros(1)
+        gbuf = [gr.clone() for gr in grads]
+        for gb in gbuf:
+            ops.sumsq(gb, acc)
+        np.testing.assert_allclose(float(acc), sum(float((gr.double() ** 2).sum()) for gr in grads), rtol=1e-5)
+        bf = [torch.zeros(n, dtype=torch.bfloat16) for n in sizes]
+        for p, gb, m, v, wd, b16 in zip(ps, gbuf, ms, vs, wds, bf):
+            ops.adamw_clip(p, gb, m, v, acc, step=step, lr=1e-2, weight_decay=wd, max_norm=1.0, p_bf16=b16, zero_grad=True)
+            assert float(gb.abs().max()) == 0.0
+        for p, r, b16 in zip(ps, ref, bf):
+            np.testing.assert_allclose(p.numpy(), r.detach().numpy(), rtol=2e-5, atol=2e-6)
+            assert torch.equal(b16, p.to(torch.bfloat16))

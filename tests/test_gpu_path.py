@@ -58,3 +58,27 @@ def test_xattn_of4b_of9b_dims(ops, d, heads_lm):
     GEMM shapes of those families) at a reduced batch."""
     errs = PC.check_xattn(ops, "cuda", B=2, L=128, T=2, n=64, heads=8, d=d, Dv=1024, seed=9)
     print({k: f"{v:.1e}" for k, v in errs.items()})
+
+
+def test_fused_step_epilogue_matches_torch_optimizer():
+    """train_step with the libofhip step epilogue (FlatAdamW: clip + AdamW + zero_grad + bf16 weight copies) must track
+    train_step with clip_grad_norm_ + torch.optim.AdamW on the same model/batch for several steps."""
+    from open_flamingo_amd.train import step, synthetic, towers
+    from open_flamingo_amd.train.reducer import GradReducer
+    finals = []
+    for fused in (False, True):
+        model, info = towers.build_flamingo("OF-tiny", device="cuda", seed=0, gates=0.5)
+        model.train()
+        reducer = GradReducer(model, embedding_rows=[info["media_token_id"], info["eoc_token_id"]])
+        opt = step.build_optimizer(model, lr=1e-3, reducer=reducer if fused else None)
+        assert hasattr(opt, "reducer") == fused
+        batch = synthetic.make_batch(2, 2, 24, info, "cuda", seed=5)
+        losses = [float(step.train_step(model, reducer, opt, batch, info)) for _ in range(3)]
+        finals.append((losses, {k: v.detach().float().cpu() for k, v in model.named_parameters() if v.requires_grad}))
+    (l0, p0), (l1, p1) = finals
+    assert all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(l0, l1)), (l0, l1)
+    # Adam moves every element by ~lr per step whatever the gradient's size, so run-to-run noise in tiny gradients
+    # (fp32 atomics order in the dw/db reductions) shows up as a few % of the distance travelled: lr * steps = 3e-3
+    for k in p0:
+        d = (p0[k] - p1[k]).abs().max().item()
+        assert d <= 2e-3 * p0[k].abs().max().item() + 0.05 * 3e-3, (k, d)
