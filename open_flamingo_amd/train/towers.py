@@ -50,14 +50,15 @@ class ClipVisualStandIn(nn.Module):
     """``visual(x) -> (pooled, tokens)`` like open_clip's VisionTransformer with output_tokens=True
     (reference factory.py:48, flamingo.py:195): tokens = ln_post(transformer(x))[:, 1:]."""
 
-    def __init__(self, width=1024, layers=24, heads=16, patch=14, image=224, mlp=None):
+    def __init__(self, width=1024, layers=24, heads=16, patch=14, image=224, mlp=None, patch_embed="gemm"):
         super().__init__()
         from transformers import CLIPVisionConfig, CLIPVisionModel
         cfg = CLIPVisionConfig(hidden_size=width, intermediate_size=mlp or 4 * width, num_hidden_layers=layers,
                                num_attention_heads=heads, patch_size=patch, image_size=image)
         self.model = CLIPVisionModel(cfg)
-        emb = getattr(self.model, "vision_model", self.model).embeddings
-        emb.patch_embedding = PatchEmbedAsGemm(emb.patch_embedding)
+        if patch_embed == "gemm":
+            emb = getattr(self.model, "vision_model", self.model).embeddings
+            emb.patch_embedding = PatchEmbedAsGemm(emb.patch_embedding)
         self.width = width
 
     def forward(self, x):
@@ -75,14 +76,67 @@ class VisionStandIn(nn.Module):
         self.visual = ClipVisualStandIn(**kw)
 
 
-def build_lang_encoder(family: str, extra_tokens: int = 3, max_seq_len: int = 2048):
+_BIAS_CACHE = {}
+
+
+def _alibi_causal_bias(position_bias, attention_mask, q_len, dtype):
+    """Additive (.., H, L, L) attention bias = ALiBi in its relative form slope_h * (j - i) (softmax is shift invariant
+    per row; the relative form keeps the values small enough to survive bf16) with the masked positions of HF's boolean
+    causal/padding mask set to a large negative number (HF fills finfo.min, not -inf: fully masked rows stay finite).
+    Built once per LM forward (all blocks receive the same mask / alibi tensors)."""
+    key = (position_bias.data_ptr(), None if attention_mask is None else (attention_mask.data_ptr(), attention_mask._version),
+           q_len, dtype)
+    hit = _BIAS_CACHE.get("key")
+    if hit == key:
+        return _BIAS_CACHE["val"]
+    pb = position_bias[:, 0, -q_len:].float()                       # (H, L): slope_h * (j - (S - 1))
+    bias = (pb[:, None, :] - pb[:, :, None]).unsqueeze(0)           # (1, H, L, L): slope_h * (j - i)
+    if attention_mask is not None:
+        bias = bias.masked_fill(attention_mask[..., -q_len:, -q_len:], -30000.0)
+    bias = bias.to(dtype).contiguous()
+    _BIAS_CACHE["key"], _BIAS_CACHE["val"] = key, bias
+    return bias
+
+
+def _mpt_attention_fused_forward(self, hidden_states, position_bias, past_key_values=None, attention_mask=None, **kwargs):
+    """MptAttention.forward with the score/softmax/AV chain as ONE fused attention call (torch SDPA) instead of HF's eager
+    chain (matmul, scale, + alibi, masked_fill, fp32 softmax, cast, matmul -- each materialising a (B, H, L, L) tensor).
+    Same arithmetic up to the bf16 rounding of the bias.  Decode with a KV cache, attention dropout and clip_qkv keep the
+    original eager path."""
+    if (past_key_values is not None or position_bias is None or self.clip_qkv
+            or (self.training and self.attn_dropout_p > 0.0)):
+        return self._of_eager_forward(hidden_states, position_bias, past_key_values=past_key_values,
+                                      attention_mask=attention_mask, **kwargs)
+    b, l = hidden_states.shape[:2]
+    q, k, v = self.Wqkv(hidden_states).chunk(3, dim=2)
+    q, k, v = (t.reshape(b, l, self.n_heads, self.head_dim).transpose(1, 2) for t in (q, k, v))
+    bias = _alibi_causal_bias(position_bias, attention_mask, l, q.dtype)
+    ctx = torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=bias, scale=self.softmax_scale)
+    return self.out_proj(ctx.transpose(1, 2).reshape(b, l, -1)), None
+
+
+def use_fused_attention_in_mpt(lm):
+    import types
+    n = 0
+    for mod in lm.modules():
+        if type(mod).__name__ == "MptAttention" and not hasattr(mod, "_of_eager_forward"):
+            mod._of_eager_forward = mod.forward
+            mod.forward = types.MethodType(_mpt_attention_fused_forward, mod)
+            n += 1
+    return n
+
+
+def build_lang_encoder(family: str, extra_tokens: int = 3, max_seq_len: int = 2048, fused_attention: bool = True):
     f = FAMILY[family]
     vocab = f["vocab"] + extra_tokens      # <|endofchunk|>, <image>, <PAD> appended by factory.py:57-63
     if f["lm"] == "mpt":
         from transformers import MptConfig, MptForCausalLM
         cfg = MptConfig(d_model=f["d"], n_heads=f["heads"], n_layers=f["layers"], vocab_size=vocab,
                         max_seq_len=max_seq_len)
-        return MptForCausalLM(cfg), "transformer.blocks"
+        lm = MptForCausalLM(cfg)
+        if fused_attention:
+            use_fused_attention_in_mpt(lm)
+        return lm, "transformer.blocks"
     from transformers import GPTNeoXConfig, GPTNeoXForCausalLM
     cfg = GPTNeoXConfig(hidden_size=f["d"], num_hidden_layers=f["layers"], num_attention_heads=f["heads"],
                         intermediate_size=4 * f["d"], vocab_size=vocab, max_position_embeddings=max_seq_len)
@@ -106,7 +160,8 @@ def hold_frozen_linears_in_bf16(model):
 
 
 def build_flamingo(family: str = "OF-3B", device="cuda", seed: int = 0, gates: float = 0.5, vision_kw=None,
-                   freeze_lm_embeddings: bool = False, verbose: bool = False, frozen_bf16: bool = False):
+                   freeze_lm_embeddings: bool = False, verbose: bool = False, frozen_bf16: bool = False,
+                   fused_lm_attention: bool = True):
     """Random-init Flamingo of the given family, assembled through the factory path, gates set to ``gates``
     (their init value 0 makes the hot path an exact no-op with zero weight gradients -- SURVEY.md section 7)."""
     from ..src.factory import assemble_flamingo
@@ -116,7 +171,7 @@ def build_flamingo(family: str = "OF-3B", device="cuda", seed: int = 0, gates: f
     with torch.device(dev):
         vkw = vision_kw or (dict(width=64, layers=2, heads=2, patch=14, image=224) if family == "OF-tiny" else {})
         vision = VisionStandIn(**vkw)
-        lm, attr = build_lang_encoder(family)
+        lm, attr = build_lang_encoder(family, fused_attention=fused_lm_attention)
         vis_dim = vision.visual.width
         media_id, eoc_id = f["vocab"] + 1, f["vocab"]
         model = assemble_flamingo(vision, lm, eoc_id, media_id, vis_dim=vis_dim, cross_attn_every_n_layers=f["every"],

@@ -16,10 +16,16 @@ from tests.cpu_model import swap_in_oracle
 
 
 def main():
-    family = sys.argv[1] if len(sys.argv) > 1 else "OF-3B"
-    B, T, L = (int(x) for x in (sys.argv[2:5] if len(sys.argv) > 4 else (32, 2, 256)))
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    # --stock-towers: the frozen towers exactly as stock modules run them (MIOpen conv patch embedding, fp32 frozen weights
+    # re-cast by autocast each forward); default: the same two tower-side choices bench.py makes,
+    # so that the difference to bench.py is the hot path + step epilogue only
+    stock = "--stock-towers" in sys.argv
+    family = argv[0] if argv else "OF-3B"
+    B, T, L = (int(x) for x in (argv[1:4] if len(argv) > 3 else (32, 2, 256)))
     steps, warm = 4, 2
-    model, info = towers.build_flamingo(family, device="cuda", seed=0, gates=0.5)
+    model, info = towers.build_flamingo(family, device="cuda", seed=0, gates=0.5, frozen_bf16=not stock, fused_lm_attention=not stock,
+                                        vision_kw=dict(patch_embed="conv") if stock else None)
     swap_in_oracle(model)
     model.cuda().train()
     opt = step.build_optimizer(model)
@@ -36,7 +42,7 @@ def main():
         loss = one()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    print(json.dumps({"what": "reference-equivalent eager step (oracle modules, autocast bf16) on MI355X", "family": family,
+    print(json.dumps({"what": "reference-equivalent eager step (oracle modules, autocast bf16) on MI355X", "family": family, "towers": "stock (conv patch embed, fp32 frozen weights, HF eager MPT attention)" if stock else "as bench.py (GEMM patch embed, bf16-held frozen weights, fused LM attention)",
                       "B": B, "T": T, "L": L, "ms_per_step": round(ms, 2), "images_per_s": round(B * T / ms * 1e3, 2),
                       "loss": float(loss), "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1)}))
 
