@@ -73,8 +73,8 @@ typedef struct OfGemmArgs {
     int io_f32;        /* OF_EPI_GATE_RESID: 1 = fp32 stream, 0 = bf16 stream */
     int safe;          /* kernel selection for self-checks: 0 = auto (256x256 LDS-DMA kernel when the shape is tile
                           aligned, else the general 128x128 kernel); 1 = general kernel with the slow scalar-LDS
-                          transposed-fragment path; 2 = general kernel (tr-read path); 4 = ping-pong kernel whenever eligible; 3 and >= 16: timing aids of
-                          tools/bench_gemm_ablate.py (previous lock-step 256 kernel; ablated ping-pong launches) */
+                          transposed-fragment path; 2 = general kernel (tr-read path); 4 = ping-pong kernel whenever eligible; >= 16: timing aid of
+                          tools/bench_gemm_ablate.py (ablated ping-pong launches, results wrong by design) */
     int ksplit;        /* internal: filled in by of_gemm (number of K slices of a split-K launch); callers pass 0 */
 } OfGemmArgs;
 

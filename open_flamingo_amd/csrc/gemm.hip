@@ -249,9 +249,6 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
         if (rc != OF_E_SHAPE) return rc;
     } else if (a.safe >= 16) {
         return of_gemm_pp_ablate(a, a.safe - 16, s);   // timing-only ablations (wrong results by design)
-    } else if (a.safe == 3) {
-        const int rc = of_gemm256_try(a, s);   // previous 256x256 kernel (lock-step waves), kept for A/B timing
-        if (rc != OF_E_SHAPE) return rc;
     }
     return dispatch(b, grid, s);
 }

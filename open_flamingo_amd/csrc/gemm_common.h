@@ -1,5 +1,5 @@
-// Shared pieces of the two GEMM kernels (gemm.hip: general 128x128 register-staged tile; gemm256.hip: 256x256
-// LDS-DMA pipelined tile): block->tile map and the fused epilogues of include/of_hip.h.
+// Shared pieces of the two GEMM kernels (gemm.hip: general 128x128 register-staged tile; gemm_pp.hip: 256x256
+// ping-pong LDS-DMA tile): block->tile map and the fused epilogues of include/of_hip.h.
 #pragma once
 #include "of_platform.h"
 #include "../../include/of_hip.h"
@@ -167,8 +167,6 @@ OF_DEV void epilogue_finish(const OfGemmArgs& p, float gv, float dot, int lane) 
 
 }  // namespace ofg
 
-// implemented in gemm256.hip; returns OF_E_SHAPE when the shape/layout is not eligible (caller falls back)
-int of_gemm256_try(const OfGemmArgs& a, of_stream_t s);
-// implemented in gemm_pp.hip; same contract
+// implemented in gemm_pp.hip; returns OF_E_SHAPE when the shape/layout is not eligible (caller falls back)
 int of_gemm_pp_try(const OfGemmArgs& a, of_stream_t s);
 int of_gemm_pp_ablate(const OfGemmArgs& a, int mask, of_stream_t s);

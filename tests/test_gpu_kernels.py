@@ -184,8 +184,8 @@ def test_layernorm(ops, x_f32):
 
 
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
-def test_gemm256_race_screen(ops, ta, tb):
-    """The 256x256 kernel's LDS-DMA ring is only ordered by counted vmcnt + one barrier per stage; the CPU emulator
+def test_gemm_pingpong_race_screen(ops, ta, tb):
+    """The 256x256 ping-pong kernel's LDS-DMA slots are only ordered by counted vmcnt + the segment barriers; the CPU emulator
     executes the DMA synchronously and cannot see a race.  Screen on hardware: many shapes (1..64 stages, single and
     multi wave-of-blocks grids), repeated launches under load, results must be bit-identical to the general kernel
     (same products, same k order) every time."""

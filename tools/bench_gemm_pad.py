@@ -15,8 +15,6 @@ for (M, N, K) in [(8192, 2048, 8192), (8192, 8192, 2048)]:
         for mask, nm in ((0, "full"), (6, "dma_only"), (22, "dma_only_nodrain"), (3, "mfma_only")):
             ms = timeit(lambda: ops.gemm(A, B, C, safe=16 + mask))
             r[nm] = round(ms, 4)
-        ms = timeit(lambda: ops.gemm(A, B, C, safe=3))
-        r["lockstep"] = round(ms, 4)
         ms = timeit(lambda: torch.matmul(A, B.t()))
         r["torch"] = round(ms, 4)
         r["full_tflops"] = round(fl / r["full"] / 1e9, 1)
