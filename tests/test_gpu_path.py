@@ -73,12 +73,14 @@ def test_fused_step_epilogue_matches_torch_optimizer():
         opt = step.build_optimizer(model, lr=1e-3, reducer=reducer if fused else None)
         assert hasattr(opt, "reducer") == fused
         batch = synthetic.make_batch(2, 2, 24, info, "cuda", seed=5)
+        init = {k: v.detach().float().cpu().clone() for k, v in model.named_parameters() if v.requires_grad}
         losses = [float(step.train_step(model, reducer, opt, batch, info)) for _ in range(3)]
         finals.append((losses, {k: v.detach().float().cpu() for k, v in model.named_parameters() if v.requires_grad}))
     (l0, p0), (l1, p1) = finals
     assert all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(l0, l1)), (l0, l1)
-    # Adam moves every element by ~lr per step whatever the gradient's size, so run-to-run noise in tiny gradients
-    # (fp32 atomics order in the dw/db reductions) shows up as a few % of the distance travelled: lr * steps = 3e-3
+    # Adam moves every element by ~lr per step whatever the gradient's size, so run-to-run noise in near-zero gradients
+    # (fp32 atomics order in the dw/db reductions) flips individual elements by up to 2*lr per step: compare each tensor's
+    # trajectory in L2, relative to the distance it travelled from its initial value
     for k in p0:
-        d = (p0[k] - p1[k]).abs().max().item()
-        assert d <= 2e-3 * p0[k].abs().max().item() + 0.05 * 3e-3, (k, d)
+        travelled = (p0[k] - init[k]).norm().item()
+        assert (p0[k] - p1[k]).norm().item() <= 0.05 * travelled + 1e-7, (k, (p0[k] - p1[k]).norm().item(), travelled)
