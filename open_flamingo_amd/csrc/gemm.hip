@@ -172,7 +172,7 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_gemm_kernel(OfGemmArgs p) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
             ofg::epilogue_frag<EPI>(p, acc[mt][nt], m0 + wr * 64 + mt * 16 + i16, n0 + wc * 64 + nt * 16 + g * 4, gv, sc, dot);
-    ofg::epilogue_finish<EPI>(p, gv, dot, lane);
+    ofg::epilogue_finish<EPI>(p, gv, dot, lane, wave, 4, (float*)smem);   // the K loop ended with a workgroup barrier
 }
 
 template <bool AT, bool BT, int EPI>

@@ -155,12 +155,21 @@ OF_DEV void epilogue_row8(const OfGemmArgs& p, const float (&a)[8], int m, int n
     }
 }
 
+// Gate-gradient reduction of the *_DOT epilogues: one fp32 atomic per WORKGROUP (wave sums meet in LDS first).  All
+// launches of a step add into the same scalar, and same-address device atomics serialise at ~12 ns each: one per wave
+// cost 0.1 ms on a 1024-tile GEMM.  `red` = nwaves floats of LDS nobody else touches any more; every wave must call.
 template <int EPI>
-OF_DEV void epilogue_finish(const OfGemmArgs& p, float gv, float dot, int lane) {
+OF_DEV void epilogue_finish(const OfGemmArgs& p, float gv, float dot, int lane, int wave, int nwaves, float* red) {
     if (EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) {
         if (p.dot_out) {
             dot = of_wave_sum(dot);
-            if (lane == 0) of_atomic_add(p.dot_out, (1.0f - gv * gv) * dot);
+            if (lane == 0) red[wave] = dot;
+            of_sync();
+            if (wave == 0 && lane == 0) {
+                float s = 0.f;
+                for (int w = 0; w < nwaves; ++w) s += red[w];
+                of_atomic_add(p.dot_out, (1.0f - gv * gv) * s);
+            }
         }
     }
 }

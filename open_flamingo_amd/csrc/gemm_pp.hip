@@ -259,7 +259,7 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
         }
         of_wave_sync();
     }
-    ofg::epilogue_finish<EPI>(p, gv, dot, lane);
+    ofg::epilogue_finish<EPI>(p, gv, dot, lane, wave, 8, (float*)(smem + 8 * 32 * PITCH));
 }
 
 template <bool AT, bool BT, int EPI>

@@ -85,6 +85,14 @@ OF_DEV int of_shfl_xor_i(int v, int m) { return __shfl_xor(v, m, 64); }
 OF_DEV float of_shfl(float v, int src) { return __shfl(v, src, 64); }
 OF_DEV void of_atomic_add(float* p, float v) { atomicAdd(p, v); }
 OF_DEV float of_exp(float x) { return __expf(x); }
+// 1-ulp hardware reciprocal (v_rcp_f32) instead of the ~12-instruction IEEE division sequence
+OF_DEV float of_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+typedef __bf16 of_bf16x2n __attribute__((ext_vector_type(2)));
+// two fp32 -> packed bf16, round-to-nearest-even, in ONE v_cvt_pk_bf16_f32 (gfx950)
+OF_DEV unsigned of_pack_bf16(float lo, float hi) {
+    of_bf16x2n v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
 OF_DEV float of_erf(float x) { return erff(x); }
 OF_DEV float of_tanh(float x) { return tanhf(x); }
 OF_DEV float of_rsqrt(float x) { return rsqrtf(x); }
@@ -121,9 +129,11 @@ OF_DEV bf16_t of_f32_to_bf16(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
 }
+#ifdef OF_HOST_EMU
 OF_DEV unsigned of_pack_bf16(float lo, float hi) {
     return (unsigned)of_f32_to_bf16(lo) | ((unsigned)of_f32_to_bf16(hi) << 16);
 }
+#endif
 OF_DEV float of_wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += of_shfl_xor(v, m);
@@ -134,7 +144,7 @@ OF_DEV float of_wave_sum(float v) {
 // the ~40-instruction libm erff; the same exp(-a^2/2) also yields the Gaussian term of the derivative.
 OF_DEV void of_gelu_parts(float a, float& cdf, float& e) {
     const float x = fabsf(a) * 0.70710678118654752f;
-    const float t = 1.0f / (1.0f + 0.3275911f * x);
+    const float t = of_rcp(1.0f + 0.3275911f * x);
     e = of_exp(-x * x);                                  // = exp(-a^2/2)
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float erf_abs = 1.0f - poly * e;

@@ -249,6 +249,7 @@ OF_DEV void of_atomic_add(float* p, float v) {
     }
 }
 OF_DEV float of_exp(float x) { return expf(x); }
+OF_DEV float of_rcp(float x) { return 1.0f / x; }
 OF_DEV float of_erf(float x) { return erff(x); }
 OF_DEV float of_tanh(float x) { return tanhf(x); }
 OF_DEV float of_rsqrt(float x) { return 1.0f / sqrtf(x); }
