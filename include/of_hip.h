@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OF_ABI_VERSION 1
+#define OF_ABI_VERSION 2
 #define OF_E_ARG (-1)      /* null pointer / negative size */
 #define OF_E_SHAPE (-2)    /* shape not supported by the kernels (see each function) */
 #define OF_E_ALIGN (-3)    /* pointer or leading dimension not 16-byte aligned */
@@ -76,9 +76,15 @@ typedef struct OfGemmArgs {
                           transposed-fragment path; 2 = general kernel (tr-read path); 4 = ping-pong kernel whenever eligible; >= 16: timing aid of
                           tools/bench_gemm_ablate.py (ablated ping-pong launches, results wrong by design) */
     int ksplit;        /* internal: filled in by of_gemm (number of K slices of a split-K launch); callers pass 0 */
+    void* workspace;   /* optional scratch for split-K partial sums (fp32 slabs): with at least
+                          of_gemm_workspace_bytes(args) bytes the K slices are combined by a second pass in a fixed
+                          order (deterministic); without it they are combined with fp32 atomics */
+    size_t workspace_bytes;
 } OfGemmArgs;
 
 int of_gemm(const OfGemmArgs* args, void* stream);
+/* Bytes of workspace of_gemm would use for these arguments (0 when the launch is not split along K). */
+size_t of_gemm_workspace_bytes(const OfGemmArgs* args);
 
 /* ---------------------------------------------------------------------------------------------------
  * LayerNorm (eps 1e-5, affine) -- nn.LayerNorm in helpers.py:18,33-34,105,152.

@@ -154,15 +154,21 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_gemm_kernel(OfGemmArgs p) {
     const float sc = gv * p.alpha;
     float dot = 0.f;
     if (EPI == OF_EPI_ACC_F32 && p.ksplit > 1) {
+        float* slab = p.workspace ? (float*)p.workspace + (size_t)of_bid_y() * p.M * p.N : nullptr;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int m = m0 + wr * 64 + mt * 16 + i16, n = n0 + wc * 64 + nt * 16 + g * 4;
                 if (m < p.M && n < p.N) {
-                    float* c = (float*)p.C + (size_t)m * p.ldc + n;
+                    if (slab) {   // this slice's partial tile, combined by of_splitk_reduce_kernel in slice order
+                        *(f32x4*)(slab + (size_t)m * p.N + n) =
+                            f32x4{sc * acc[mt][nt][0], sc * acc[mt][nt][1], sc * acc[mt][nt][2], sc * acc[mt][nt][3]};
+                    } else {
+                        float* c = (float*)p.C + (size_t)m * p.ldc + n;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) of_atomic_add(c + e, sc * acc[mt][nt][e]);
+                        for (int e = 0; e < 4; ++e) of_atomic_add(c + e, sc * acc[mt][nt][e]);
+                    }
                 }
             }
         return;
@@ -173,6 +179,27 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_gemm_kernel(OfGemmArgs p) {
         for (int nt = 0; nt < 4; ++nt)
             ofg::epilogue_frag<EPI>(p, acc[mt][nt], m0 + wr * 64 + mt * 16 + i16, n0 + wc * 64 + nt * 16 + g * 4, gv, sc, dot);
     ofg::epilogue_finish<EPI>(p, gv, dot, lane, wave, 4, (float*)smem);   // the K loop ended with a workgroup barrier
+}
+
+// C = beta * C + sum over slices of slab[s]  (fixed slice order: deterministic)
+OF_GLOBAL void of_splitk_reduce_kernel(OfGemmArgs p) {
+    const long nv = ((long)p.M * p.N) >> 2;
+    const long stride = (long)of_gdim_x() * 256;
+    const float* ws = (const float*)p.workspace;
+    for (long i = (long)of_bid_x() * 256 + of_tid(); i < nv; i += stride) {
+        const long e = i * 4, m = e / p.N, n = e - m * p.N;
+        f32x4 s = *(const f32x4*)(ws + e);
+        for (int k = 1; k < p.ksplit; ++k) {
+            const f32x4 t = *(const f32x4*)(ws + (size_t)k * p.M * p.N + e);
+            s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+        }
+        float* c = (float*)p.C + (size_t)m * p.ldc + n;
+        if (p.beta != 0.f) {
+            const f32x4 o = *(const f32x4*)c;
+            s[0] += p.beta * o[0]; s[1] += p.beta * o[1]; s[2] += p.beta * o[2]; s[3] += p.beta * o[3];
+        }
+        *(f32x4*)c = s;
+    }
 }
 
 template <bool AT, bool BT, int EPI>
@@ -208,6 +235,31 @@ int dispatch(const OfGemmArgs& a, of_dim3 grid, of_stream_t s) {
 
 }  // namespace
 
+namespace {
+// K slices for a weight-gradient GEMM with a small output and a deep K (see of_gemm); 1 = not split
+int pick_ksplit(const OfGemmArgs& a, bool with_workspace) {
+    const long tiles256 = (long)(a.M / 256) * (a.N / 256);
+    const bool pp_ok = !(a.M % 256) && !(a.N % 256) && !(a.K % 64) && tiles256 >= 192;
+    const bool forced = a.safe >= 8 && a.safe < 16;          // 8 + log2(split): tuning aid (tools/bench_splitk.py)
+    if (!(forced || (a.safe == 0 && !pp_ok)) || a.epi != OF_EPI_ACC_F32) return 1;
+    if (!with_workspace && !(a.beta == 1.f || (a.beta == 0.f && a.ldc == a.N))) return 1;
+    const long t128 = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    int split = 1;
+    // with slabs a slice costs one coalesced fp32 store + read of the tile (cheap): go to two workgroups per CU;
+    // with atomics (~4 M fp32 atomics per 1 M outputs and slice) stop at one
+    const long target = with_workspace ? 512 : 256;
+    while (split < 16 && t128 * split < target && a.K / (split * 2) >= 512) split *= 2;
+    if (forced) split = 1 << (a.safe - 8);
+    return split;
+}
+}  // namespace
+
+extern "C" size_t of_gemm_workspace_bytes(const OfGemmArgs* args) {
+    if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return 0;
+    const int split = pick_ksplit(*args, true);
+    return split > 1 ? (size_t)split * args->M * args->N * sizeof(float) : 0;
+}
+
 extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
     if (!args || !args->A || !args->B || !args->C) return OF_E_ARG;
     const OfGemmArgs& a = *args;
@@ -230,17 +282,26 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
     // K (K = tokens) are additionally split along K until every CU has work.
     const long tiles256 = (long)(a.M / 256) * (a.N / 256);
     const bool pp_ok = !(a.M % 256) && !(a.N % 256) && !(a.K % 64) && tiles256 >= 192;
-    if (a.safe == 0 && !pp_ok && a.epi == OF_EPI_ACC_F32 && (a.beta == 1.f || (a.beta == 0.f && a.ldc == a.N))) {
-        const long t128 = (long)tiles_m * tiles_n;
-        int split = 1;
-        while (split < 16 && t128 * split < 256 && a.K / (split * 2) >= 512) split *= 2;
+    {
+        int split = pick_ksplit(a, true);
+        const bool slabs = split > 1 && a.workspace && a.workspace_bytes >= (size_t)split * a.M * a.N * sizeof(float) &&
+                           !((uintptr_t)a.workspace & 15);
+        if (!slabs) split = pick_ksplit(a, false);
         if (split > 1) {
+            b.ksplit = split;
+            grid.y = (unsigned)split;
+            if (slabs) {
+                int rc = dispatch(b, grid, s);
+                if (rc) return rc;
+                long blocks = (((long)a.M * a.N >> 2) + 255) / 256;
+                if (blocks > 2048) blocks = 2048;
+                return of_launch(of_splitk_reduce_kernel, of_dim3{(unsigned)blocks, 1, 1}, 256, 0, s, b);
+            }
+            b.workspace = nullptr;
             if (a.beta == 0.f) {
                 const int rc = of_memset_async(a.C, 0, (size_t)a.M * a.N * sizeof(float), s);
                 if (rc) return rc;
             }
-            b.ksplit = split;
-            grid.y = (unsigned)split;
             return dispatch(b, grid, s);
         }
     }

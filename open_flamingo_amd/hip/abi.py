@@ -5,7 +5,7 @@ Pure declarations: nothing here loads a library.  ``open_flamingo_amd.hip.lib`` 
 """
 import ctypes as C
 
-OF_ABI_VERSION = 1
+OF_ABI_VERSION = 2
 EPI_STORE_BF16, EPI_GELU, EPI_GATE_RESID, EPI_DGELU_DOT, EPI_SCALE_DOT, EPI_ACC_F32 = range(6)
 
 vp = C.c_void_p
@@ -25,6 +25,7 @@ class OfGemmArgs(C.Structure):
         ("alpha", C.c_float), ("beta", C.c_float),
         ("dot_out", vp),
         ("io_f32", C.c_int), ("safe", C.c_int), ("ksplit", C.c_int),
+        ("workspace", vp), ("workspace_bytes", C.c_size_t),
     ]
 
 
@@ -47,6 +48,7 @@ PROTOTYPES = {
     "of_abi_version": (C.c_int, []),
     "of_build_kind": (C.c_int, []),
     "of_gemm": (C.c_int, [C.POINTER(OfGemmArgs), vp]),
+    "of_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(OfGemmArgs)]),
     "of_layernorm_fwd": (C.c_int, [vp, C.c_int, C.c_long, vp, vp, vp, C.c_long, vp, C.c_long, C.c_int, vp]),
     "of_layernorm_fwd_out": (C.c_int, [vp, C.c_int, C.c_long, vp, vp, vp, C.c_int, C.c_long, vp, C.c_long,
                                        C.c_int, vp]),

@@ -86,6 +86,14 @@ class Ops:
         else:
             assert out.dtype == BF16
         a.safe = safe
+        if epi == abi.EPI_ACC_F32:      # split-K scratch (fp32 slabs); one grow-only buffer, reused in stream order
+            need = self.lib.of_gemm_workspace_bytes(C.byref(a))
+            if need:
+                ws = self.__dict__.get("_gemm_ws")
+                if ws is None or ws.numel() * 4 < need or ws.device != out.device:
+                    ws = torch.empty((need + 3) // 4, dtype=F32, device=out.device)
+                    self._gemm_ws = ws
+                a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
         if self.gemm_timing is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

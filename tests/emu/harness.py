@@ -33,7 +33,7 @@ def bf16(t):
 
 
 def gemm(A, B, *, a_trans=0, b_trans=0, epi=abi.EPI_STORE_BF16, C_out=None, C2=None, aux=None, gate=None,
-         alpha=1.0, beta=0.0, dot_out=None, io_f32=0, safe=0, M=None, N=None, K=None):
+         alpha=1.0, beta=0.0, dot_out=None, io_f32=0, safe=0, M=None, N=None, K=None, workspace=None):
     if M is None:
         M = A.shape[1] if a_trans else A.shape[0]
         K = A.shape[0] if a_trans else A.shape[1]
@@ -51,6 +51,8 @@ def gemm(A, B, *, a_trans=0, b_trans=0, epi=abi.EPI_STORE_BF16, C_out=None, C2=N
     a.alpha, a.beta = alpha, beta
     a.dot_out = dot_out.data_ptr() if dot_out is not None else None
     a.io_f32, a.safe = io_f32, safe
+    if workspace is not None:
+        a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     rc = lib().of_gemm(C.byref(a), None)
     assert rc == 0, f"of_gemm rc={rc}"
     return C_out

@@ -116,10 +116,11 @@ def test_gemm_split_k():
     A, B = _rand((K, M), 21), _rand((K, N), 22)
     ref = _ref(A, B, 1, 1)
     for beta in (0.0, 1.0):
-        c0 = torch.randn(M, N)
-        got = c0.clone()
-        H.gemm(A, B, a_trans=1, b_trans=1, epi=abi.EPI_ACC_F32, C_out=got, beta=beta, alpha=0.5)
-        np.testing.assert_allclose(got.double().numpy(), (0.5 * ref + beta * c0.double()).numpy(), rtol=1e-5, atol=2e-4)
+        for ws in (None, torch.empty(16 * M * N)):       # fp32 atomics / deterministic slab reduction
+            c0 = torch.randn(M, N)
+            got = c0.clone()
+            H.gemm(A, B, a_trans=1, b_trans=1, epi=abi.EPI_ACC_F32, C_out=got, beta=beta, alpha=0.5, workspace=ws)
+            np.testing.assert_allclose(got.double().numpy(), (0.5 * ref + beta * c0.double()).numpy(), rtol=1e-5, atol=2e-4)
 
 
 def test_gemm_pingpong_epilogues():

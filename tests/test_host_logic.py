@@ -51,7 +51,7 @@ def test_synthetic_batch_contract():
 def test_header_and_ctypes_prototypes_agree():
     """Every function declared in include/of_hip.h has a ctypes prototype and vice versa."""
     src = open(os.path.join(ROOT, "include", "of_hip.h")).read()
-    declared = set(re.findall(r"\bint\s+(of_[a-z0-9_]+)\s*\(", src))
+    declared = set(re.findall(r"\b(?:int|size_t)\s+(of_[a-z0-9_]+)\s*\(", src))
     assert declared == set(abi.PROTOTYPES), declared ^ set(abi.PROTOTYPES)
 
 
