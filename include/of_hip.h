@@ -113,7 +113,11 @@ int of_layernorm_fwd_grouped(const void* x, int x_f32, long ldx, const float* w,
 int of_layernorm_bwd(const void* dy, int dy_f32, long lddy, long dy_grp_rows, long dy_grp_stride, const uint16_t* dy2,
                      const void* x, int x_f32, long ldx, const float* stats, const float* w, const void* resid,
                      void* dx_out, int out_f32, long lddx, uint16_t* dx_bf16, float* dw, float* db, long rows, int dim,
-                     void* stream);
+                     float* workspace, size_t workspace_bytes, void* stream);
+/* Optional scratch for of_layernorm_bwd: with this many bytes the dw/db column sums are combined from per-workgroup
+ * partials (16 adds per column instead of one per workgroup); without it every workgroup adds its column sums
+ * with fp32 atomics. */
+size_t of_layernorm_bwd_workspace_bytes(long rows, int dim);
 
 /* ---------------------------------------------------------------------------------------------------
  * Windowed multi-head attention core, head dim 64, flash-style (scores never reach HBM).

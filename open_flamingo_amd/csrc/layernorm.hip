@@ -26,6 +26,7 @@ struct LnArgs {
     bf16_t* dx_bf16;
     float* dw; float* db;
     int rpw;                         // rows per wave (set by the launcher)
+    float* partials;                 // optional [grid][2][dim] scratch: per-workgroup dw/db partial sums (no atomics)
 };
 
 OF_DEV void load8(const void* base, int is_f32, size_t off, float (&v)[8]) {
@@ -218,11 +219,40 @@ OF_GLOBAL void OF_BOUNDS(256, (CPL > 5 ? 1 : 2)) of_ln_bwd_kernel(LnArgs a) {
             }
         }
         of_sync();
-        for (int c = tid; c < a.dim; c += 256) {
-            of_atomic_add(a.dw + c, sw[c]);
-            of_atomic_add(a.db + c, sb[c]);
+        if (a.partials) {   // combined by of_ln_colsum_kernel in workgroup order (deterministic, no same-address atomics)
+            float* pw = a.partials + (size_t)of_bid_x() * 2 * a.dim;
+            for (int c = tid; c < a.dim; c += 256) {
+                pw[c] = sw[c];
+                pw[a.dim + c] = sb[c];
+            }
+        } else {
+            for (int c = tid; c < a.dim; c += 256) {
+                of_atomic_add(a.dw + c, sw[c]);
+                of_atomic_add(a.db + c, sb[c]);
+            }
         }
     }
+}
+
+// dw[c] += sum_b partials[b][0][c], db[c] += sum_b partials[b][1][c].  grid (columns / 256, COLSUM_SLICES): slice y sums
+// its share of the partial rows (coalesced across the 256 columns of the block) and adds once per column.
+constexpr int COLSUM_SLICES = 16;
+OF_GLOBAL void of_ln_colsum_kernel(LnArgs a) {
+    const int i = of_bid_x() * 256 + of_tid();
+    if (i >= 2 * a.dim) return;
+    const int nb = a.rpw;   // number of partial rows (reuses the field)
+    const int per = (nb + COLSUM_SLICES - 1) / COLSUM_SLICES;
+    const int b0 = of_bid_y() * per, b1 = b0 + per < nb ? b0 + per : nb;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = b0;
+    for (; b + 4 <= b1; b += 4) {
+        s0 += a.partials[(size_t)(b + 0) * 2 * a.dim + i];
+        s1 += a.partials[(size_t)(b + 1) * 2 * a.dim + i];
+        s2 += a.partials[(size_t)(b + 2) * 2 * a.dim + i];
+        s3 += a.partials[(size_t)(b + 3) * 2 * a.dim + i];
+    }
+    for (; b < b1; ++b) s0 += a.partials[(size_t)b * 2 * a.dim + i];
+    if (b1 > b0) of_atomic_add(i < a.dim ? a.dw + i : a.db + (i - a.dim), (s0 + s1) + (s2 + s3));
 }
 
 // rows per wave: enough workgroups to give every CU two (8 waves), few enough that the per-workgroup dw/db flush
@@ -249,12 +279,24 @@ int launch_fwd(LnArgs a, of_stream_t s) {
     const size_t smem = 0;
     OF_LN_DISPATCH(of_ln_fwd_kernel)
 }
-int launch_bwd(LnArgs a, of_stream_t s) {
-    const int rpw = a.rpw = pick_rpw(a.rows, 16);
-    const long rows_per_block = 4L * rpw;
-    of_dim3 grid{(unsigned)((a.rows + rows_per_block - 1) / rows_per_block), 1, 1};
-    const size_t smem = a.dw ? (size_t)a.dim * 2 * sizeof(float) : 0;
+long bwd_grid(long rows) {
+    const long rows_per_block = 4L * pick_rpw(rows, 16);
+    return (rows + rows_per_block - 1) / rows_per_block;
+}
+int launch_bwd_main(const LnArgs& a, of_dim3 grid, size_t smem, of_stream_t s) {
     OF_LN_DISPATCH(of_ln_bwd_kernel)
+}
+int launch_bwd(LnArgs a, float* workspace, size_t workspace_bytes, of_stream_t s) {
+    a.rpw = pick_rpw(a.rows, 16);
+    const long nblk = bwd_grid(a.rows);
+    of_dim3 grid{(unsigned)nblk, 1, 1};
+    const size_t smem = a.dw ? (size_t)a.dim * 2 * sizeof(float) : 0;
+    const bool use_ws = a.dw && workspace && nblk > 1 && workspace_bytes >= (size_t)nblk * 2 * a.dim * sizeof(float);
+    a.partials = use_ws ? workspace : nullptr;
+    int rc = launch_bwd_main(a, grid, smem, s);
+    if (rc || !use_ws) return rc;
+    a.rpw = (int)nblk;
+    return of_launch(of_ln_colsum_kernel, of_dim3{(unsigned)((2 * a.dim + 255) / 256), COLSUM_SLICES, 1}, 256, 0, s, a);
 }
 
 int check_common(const void* x, long ldx, long rows, int dim) {
@@ -299,7 +341,8 @@ extern "C" int of_layernorm_fwd_grouped(const void* x, int x_f32, long ldx, cons
 extern "C" int of_layernorm_bwd(const void* dy, int dy_f32, long lddy, long dy_grp_rows, long dy_grp_stride,
                                 const uint16_t* dy2, const void* x, int x_f32, long ldx, const float* stats,
                                 const float* w, const void* resid, void* dx_out, int out_f32, long lddx,
-                                uint16_t* dx_bf16, float* dw, float* db, long rows, int dim, void* stream) {
+                                uint16_t* dx_bf16, float* dw, float* db, long rows, int dim, float* workspace,
+                                size_t workspace_bytes, void* stream) {
     int rc = check_common(x, ldx, rows, dim);
     if (rc) return rc;
     if (!dy || !stats || !w) return OF_E_ARG;
@@ -310,5 +353,11 @@ extern "C" int of_layernorm_bwd(const void* dy, int dy_f32, long lddy, long dy_g
     a.dy = dy; a.dy_f32 = dy_f32; a.lddy = lddy; a.dy_grp_rows = dy_grp_rows; a.dy_grp_stride = dy_grp_stride;
     a.dy2 = dy2; a.resid = resid; a.dx = dx_out; a.dx_f32 = out_f32; a.lddx = lddx;
     a.dx_bf16 = dx_bf16; a.dw = dw; a.db = db;
-    return launch_bwd(a, (of_stream_t)stream);
+    return launch_bwd(a, workspace, workspace_bytes, (of_stream_t)stream);
+}
+
+extern "C" size_t of_layernorm_bwd_workspace_bytes(long rows, int dim) {
+    if (rows <= 0 || dim <= 0) return 0;
+    const long nblk = bwd_grid(rows);
+    return nblk > 1 ? (size_t)nblk * 2 * dim * sizeof(float) : 0;
 }

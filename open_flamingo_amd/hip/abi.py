@@ -55,7 +55,8 @@ PROTOTYPES = {
     "of_layernorm_fwd_grouped": (C.c_int, [vp, C.c_int, C.c_long, vp, vp, vp, C.c_long, C.c_long, C.c_long, vp, vp,
                                            C.c_long, C.c_int, vp]),
     "of_layernorm_bwd": (C.c_int, [vp, C.c_int, C.c_long, C.c_long, C.c_long, vp, vp, C.c_int, C.c_long, vp, vp, vp,
-                                   vp, C.c_int, C.c_long, vp, vp, vp, C.c_long, C.c_int, vp]),
+                                   vp, C.c_int, C.c_long, vp, vp, vp, C.c_long, C.c_int, vp, C.c_size_t, vp]),
+    "of_layernorm_bwd_workspace_bytes": (C.c_size_t, [C.c_long, C.c_int]),
     "of_attn_fwd": (C.c_int, [C.POINTER(OfAttnArgs), vp]),
     "of_attn_bwd": (C.c_int, [C.POINTER(OfAttnArgs), vp]),
     "of_text_time": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

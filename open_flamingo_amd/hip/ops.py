@@ -134,10 +134,19 @@ class Ops:
             assert dx_bf16.stride(0) == lddx
         if resid is not None:
             assert resid.stride(0) == lddx
+        ws, ws_bytes = None, 0
+        if dw is not None:
+            need = self.lib.of_layernorm_bwd_workspace_bytes(rows, dim)
+            if need:
+                ws = self.__dict__.get("_ln_ws")
+                if ws is None or ws.numel() * 4 < need or ws.device != x.device:
+                    ws = torch.empty((need + 3) // 4, dtype=F32, device=x.device)
+                    self._ln_ws = ws
+                ws_bytes = ws.numel() * 4
         self._chk(self.lib.of_layernorm_bwd(dy.data_ptr(), _is_f32(dy), lddy, dy_grp_rows, dy_grp_stride, _p(dy2),
                                             x.data_ptr(), _is_f32(x), x.stride(0), stats.data_ptr(), w.data_ptr(),
                                             _p(resid), _p(dx), out_f32, lddx, _p(dx_bf16), _p(dw), _p(db), rows, dim,
-                                            self._stream()), "of_layernorm_bwd")
+                                            _p(ws), ws_bytes, self._stream()), "of_layernorm_bwd")
 
     # ------------------------------------------------------------------ attention core
     def _attn_args(self, q, k, v, o, lse, batch, Lq, Lk, heads, text_time, n_per_media, T_img, only_immediate, scale,
