@@ -120,7 +120,7 @@ int of_layernorm_bwd(const void* dy, int dy_f32, long lddy, long dy_grp_rows, lo
 size_t of_layernorm_bwd_workspace_bytes(long rows, int dim);
 
 /* ---------------------------------------------------------------------------------------------------
- * Windowed multi-head attention core, head dim 64, flash-style (scores never reach HBM).
+ * Windowed multi-head attention core, head dim 64 (or 128), flash-style (scores never reach HBM).
  * One kernel family serves both hot-path attentions:
  *   - PerceiverAttention core (helpers.py:55-64): text_time == NULL, every query sees all keys.
  *   - MaskedCrossAttention core (helpers.py:192-231): per-query key window derived from text_time
@@ -128,7 +128,7 @@ size_t of_layernorm_bwd_workspace_bytes(long rows, int dim);
  *        only_immediate=1:  1 <= tt <= T -> keys [(tt-1)*n, tt*n);  tt == 0 -> output 0 (helpers.py:223-229);
  *                           tt > T -> every key is masked with -finfo.max, softmax is uniform over all T*n keys
  *        only_immediate=0:  tt >= 1 -> keys [0, min(tt,T)*n);  tt == 0 -> uniform over all keys
- * Layout: q[(batch*Lq + i)*ldq + h*64 + d], k/v[(batch*Lk + j)*ldk + h*64 + d] (k and v may point into one
+ * Layout: q[(batch*Lq + i)*ldq + h*head_dim + d], k/v[(batch*Lk + j)*ldk + h*head_dim + d] (k and v may point into one
  * fused kv buffer), o like q with ldo.  scale = dim_head^-0.5 is applied to the fp32 scores.
  * lse (batch,H,Lq) fp32 = row log-sum-exp saved for backward (+inf marks zeroed rows).
  */
@@ -147,6 +147,11 @@ typedef struct OfAttnArgs {
     uint16_t* dk; uint16_t* dv; long lddk, lddv;
     float* delta;             /* (batch,H,Lq) fp32 scratch: rowsum(dO*O), written by the dq pass */
     int safe;
+    /* causal self-attention with ALiBi (the frozen MPT blocks); all zero/NULL for the two hot-path uses */
+    int head_dim;             /* 0 or 64: 64;  128 */
+    int causal;               /* 1: query i sees keys [0, i + 1 + Lk - Lq); text_time must be NULL */
+    const float* alibi_slopes;/* (heads) fp32 or NULL: score += slope[h] * (j - (i + Lk - Lq)) before the softmax */
+    const int32_t* kv_len;    /* (batch) or NULL, causal only: number of real (non right-padding) keys per sequence */
 } OfAttnArgs;
 
 int of_attn_fwd(const OfAttnArgs* args, void* stream);

@@ -7,6 +7,9 @@
 //                     tt>T  -> all keys masked with -finfo.max => softmax uniform over all T*n keys
 //     otherwise ('ge'): tt==0 -> uniform over all keys; tt>=1 -> keys [0, min(tt,T)*n)
 // Scores, probabilities and the mask never touch HBM.
+// The same kernels also serve causal self-attention with ALiBi (head dim 64 or 128; SURVEY.md 8f N1, the frozen
+// MPT blocks): causal = 1 gives query i the window [0, i + 1 + Lk - Lq), alibi_slopes[h] adds slope * (j - i) to the
+// scaled score (the relative form of MPT's bias: softmax is shift invariant per row).
 //
 // MFMA formulation (v_mfma_f32_16x16x32_bf16, all matrices via of_mfma(A-rows, B-cols)):
 //   forward / dq pass (one wave = 16 query rows, key blocks of 64 staged in LDS):
@@ -26,38 +29,50 @@
 namespace {
 
 constexpr float NEG_BIG = -1.0e30f;
-constexpr int IMG = 64 * 64 * 2;  // one 64x64 bf16 LDS image
+// one [64 rows][DH] bf16 LDS image; two swizzles of the same data:
+//   "normal"    (ds_read_b128 fragments, k = column): 16-B slot s of row r at slot s ^ f(r)
+//   "transpose" (ds_read_b64_tr_b16 fragments, k = row): 32-B chunk c of row r at chunk c ^ f(r)
+// DH = 64: 128-B rows, two rows per 256-B bank row -> f = (r>>1)&7 / (r>>1)&3; DH = 128: 256-B rows -> f = r&15 / r&7.
+template <int DH>
+OF_DEV int img_n_off(int row, int slot) {
+    return DH == 64 ? row * 128 + ((slot ^ ((row >> 1) & 7)) << 4) : row * 256 + ((slot ^ (row & 15)) << 4);
+}
+template <int DH>
+OF_DEV int img_t_off(int row, int col) {
+    return DH == 64 ? row * 128 + ((((col >> 4)) ^ ((row >> 1) & 3)) << 5) + ((col & 15) << 1)
+                    : row * 256 + ((((col >> 4)) ^ (row & 7)) << 5) + ((col & 15) << 1);
+}
 
-OF_DEV int img_n_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
-OF_DEV int img_t_off(int row, int col) { return row * 128 + ((((col >> 4)) ^ ((row >> 1) & 3)) << 5) + ((col & 15) << 1); }
-
-// cooperative load of a 64 x 64 bf16 tile (rows row0.., columns col0..col0+63 of a row-major matrix) into
+// cooperative load of a 64 x DH bf16 tile (rows row0.., columns col0..col0+DH-1 of a row-major matrix) into
 // the "normal" image (ds_read_b128 fragments, k = column) and/or the "transpose" image (tr-read
 // fragments, k = row).  Rows >= nrows are zero-filled.
+template <int DH>
 OF_DEV void load_tile64(const bf16_t* __restrict__ src, long ld, long row0, long nrows, int col0, int tid,
                         char* img_n, char* img_t) {
+    constexpr int SPR = DH / 8;   // 16-byte slots per row
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < SPR / 4; ++c) {
         int id = c * 256 + tid;
-        int row = id >> 3, cs = id & 7;
+        int row = id / SPR, cs = id % SPR;
         u32x4 v = {0u, 0u, 0u, 0u};
         if (row0 + row < nrows) v = *(const u32x4*)(src + (size_t)(row0 + row) * ld + col0 + cs * 8);
-        if (img_n) *(u32x4*)(img_n + img_n_off(row, cs)) = v;
-        if (img_t) *(u32x4*)(img_t + img_t_off(row, cs * 8)) = v;
+        if (img_n) *(u32x4*)(img_n + img_n_off<DH>(row, cs)) = v;
+        if (img_t) *(u32x4*)(img_t + img_t_off<DH>(row, cs * 8)) = v;
     }
 }
+template <int DH>
 OF_DEV s16x8 frag_n(const char* img, int row_base, int kk, int lane) {
-    return *(const s16x8*)(img + img_n_off(row_base + (lane & 15), kk * 4 + (lane >> 4)));
+    return *(const s16x8*)(img + img_n_off<DH>(row_base + (lane & 15), kk * 4 + (lane >> 4)));
 }
 // k-slot e = 4h+j of lane group g  <->  image row kbase + 16h + 4g + j ; matrix column = col_base + (lane&15)
-template <bool SAFE>
+template <int DH, bool SAFE>
 OF_DEV s16x8 frag_t(const char* img, int kbase, int col_base, int lane) {
     const int g = lane >> 4, i = lane & 15;
     s16x8 f;
     if (!SAFE) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            s16x4 t = of_lds_tr(img + img_t_off(kbase + h * 16 + g * 4 + (i >> 2), col_base + (i & 3) * 4));
+            s16x4 t = of_lds_tr(img + img_t_off<DH>(kbase + h * 16 + g * 4 + (i >> 2), col_base + (i & 3) * 4));
             f[h * 4 + 0] = t[0];
             f[h * 4 + 1] = t[1];
             f[h * 4 + 2] = t[2];
@@ -66,7 +81,7 @@ OF_DEV s16x8 frag_t(const char* img, int kbase, int col_base, int lane) {
     } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-            f[e] = *(const short*)(img + img_t_off(kbase + (e >> 2) * 16 + g * 4 + (e & 3), col_base + i));
+            f[e] = *(const short*)(img + img_t_off<DH>(kbase + (e >> 2) * 16 + g * 4 + (e & 3), col_base + i));
     }
     return f;
 }
@@ -92,6 +107,14 @@ struct Window {
 OF_DEV Window row_window(const OfAttnArgs& p, long batch, int row) {
     Window w{0, 0, 0};
     if (row >= p.Lq) return w;
+    if (p.causal) {
+        w.hi = row + 1 + (p.Lk - p.Lq);
+        const int len = p.kv_len ? p.kv_len[batch] : p.Lk;   // right-padded sequences: keys >= len are padding
+        if (w.hi > len) w.hi = len;
+        if (w.hi > p.Lk) w.hi = p.Lk;
+        if (w.hi < 0) w.hi = 0;
+        return w;
+    }
     if (!p.text_time) {
         w.hi = p.Lk;
         return w;
@@ -121,8 +144,9 @@ OF_DEV Window row_window(const OfAttnArgs& p, long batch, int row) {
 
 // ------------------------------------------------------------------------------------------------
 // forward (BWD=false) and dq pass (BWD=true) share the key-block loop
-template <bool BWD, bool SAFE>
+template <int DH, bool BWD, bool SAFE>
 OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
+    constexpr int NKS = DH / 32, NDT = DH / 16, IMG = 64 * DH * 2;
     char* smem = of_smem();
     char* k_n = smem;             // K normal image
     char* v_img = smem + IMG;     // fwd: V transpose image;  dq: V normal image
@@ -131,7 +155,8 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
     const int tid = of_tid(), lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
     const int q0 = of_bid_x() * 64, h = of_bid_y();
     const long batch = of_bid_z();
-    const int hc = h * 64;
+    const int hc = h * DH;
+    const float slope = p.alibi_slopes ? p.alibi_slopes[h] : 0.f;
 
     if (tid < 64) {
         Window w = row_window(p, batch, q0 + tid);
@@ -160,23 +185,22 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
     const bf16_t* qb = p.q + (size_t)batch * p.Lq * p.ldq;
     const bf16_t* kb_ptr = p.k + (size_t)batch * p.Lk * p.ldk;
     const bf16_t* vb_ptr = p.v + (size_t)batch * p.Lk * p.ldv;
-    s16x8 qf[2], dof[2];
-    qf[0] = gload_frag(qb, p.ldq, my_row, p.Lq, hc + g * 8);
-    qf[1] = gload_frag(qb, p.ldq, my_row, p.Lq, hc + 32 + g * 8);
+    s16x8 qf[NKS], dof[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = gload_frag(qb, p.ldq, my_row, p.Lq, hc + ks * 32 + g * 8);
+    const int my_pos = my_row + (p.Lk - p.Lq);   // key index aligned with this query (ALiBi distance origin)
     float m_i = NEG_BIG, l_i = 0.f, lse_i = 0.f, delta_i = 0.f;
     const size_t stat_idx = ((size_t)batch * p.heads + h) * p.Lq + my_row;
     if (BWD) {
         const bf16_t* dob = p.dout + (size_t)batch * p.Lq * p.lddo;
         const bf16_t* ob = p.o + (size_t)batch * p.Lq * p.ldo;
-        dof[0] = gload_frag(dob, p.lddo, my_row, p.Lq, hc + g * 8);
-        dof[1] = gload_frag(dob, p.lddo, my_row, p.Lq, hc + 32 + g * 8);
-        s16x8 o0 = gload_frag(ob, p.ldo, my_row, p.Lq, hc + g * 8);
-        s16x8 o1 = gload_frag(ob, p.ldo, my_row, p.Lq, hc + 32 + g * 8);
         float d = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            d += of_bf16_to_f32((bf16_t)dof[0][e]) * of_bf16_to_f32((bf16_t)o0[e]);
-            d += of_bf16_to_f32((bf16_t)dof[1][e]) * of_bf16_to_f32((bf16_t)o1[e]);
+        for (int ks = 0; ks < NKS; ++ks) {
+            dof[ks] = gload_frag(dob, p.lddo, my_row, p.Lq, hc + ks * 32 + g * 8);
+            const s16x8 o8 = gload_frag(ob, p.ldo, my_row, p.Lq, hc + ks * 32 + g * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d += of_bf16_to_f32((bf16_t)dof[ks][e]) * of_bf16_to_f32((bf16_t)o8[e]);
         }
         d += of_shfl_xor(d, 16);
         d += of_shfl_xor(d, 32);
@@ -184,26 +208,26 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
         lse_i = my_row < p.Lq ? p.lse[stat_idx] : __builtin_inff();
         if (g == 0 && my_row < p.Lq) p.delta[stat_idx] = d;
     }
-    f32x4 acc[4];
+    f32x4 acc[NDT];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < NDT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int kb = kb_lo; kb < kb_hi; ++kb) {
         const long key0 = (long)kb * 64;
         if (!BWD) {
-            load_tile64(kb_ptr, p.ldk, key0, p.Lk, hc, tid, k_n, nullptr);
-            load_tile64(vb_ptr, p.ldv, key0, p.Lk, hc, tid, nullptr, v_img);
+            load_tile64<DH>(kb_ptr, p.ldk, key0, p.Lk, hc, tid, k_n, nullptr);
+            load_tile64<DH>(vb_ptr, p.ldv, key0, p.Lk, hc, tid, nullptr, v_img);
         } else {
-            load_tile64(kb_ptr, p.ldk, key0, p.Lk, hc, tid, k_n, k_t);
-            load_tile64(vb_ptr, p.ldv, key0, p.Lk, hc, tid, v_img, nullptr);
+            load_tile64<DH>(kb_ptr, p.ldk, key0, p.Lk, hc, tid, k_n, k_t);
+            load_tile64<DH>(vb_ptr, p.ldv, key0, p.Lk, hc, tid, v_img, nullptr);
         }
         of_sync();
         f32x4 s[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            s[t] = of_mfma(frag_n(k_n, t * 16, 0, lane), qf[0], s[t]);
-            s[t] = of_mfma(frag_n(k_n, t * 16, 1, lane), qf[1], s[t]);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) s[t] = of_mfma(frag_n<DH>(k_n, t * 16, ks, lane), qf[ks], s[t]);
         }
         // masked scores
         float mb = NEG_BIG;
@@ -213,7 +237,7 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
             for (int r = 0; r < 4; ++r) {
                 const int j = (int)key0 + t * 16 + g * 4 + r;
                 const bool valid = j >= lo_i && j < hi_i;
-                float sv = uni_i ? 0.f : s[t][r] * p.scale;
+                float sv = uni_i ? 0.f : s[t][r] * p.scale + slope * (float)(j - my_pos);
                 sv = valid ? sv : NEG_BIG;
                 s[t][r] = sv;
                 mb = sv > mb ? sv : mb;
@@ -239,7 +263,7 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
             l_i = l_i * alpha + rs;
             m_i = m_new;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < NDT; ++dt) {
                 acc[dt][0] *= alpha;
                 acc[dt][1] *= alpha;
                 acc[dt][2] *= alpha;
@@ -249,16 +273,16 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
             for (int s2 = 0; s2 < 2; ++s2) {
                 const s16x8 pf = pack8(s[2 * s2], s[2 * s2 + 1]);
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    acc[dt] = of_mfma(frag_t<SAFE>(v_img, s2 * 32, dt * 16, lane), pf, acc[dt]);
+                for (int dt = 0; dt < NDT; ++dt)
+                    acc[dt] = of_mfma(frag_t<DH, SAFE>(v_img, s2 * 32, dt * 16, lane), pf, acc[dt]);
             }
         } else {
             f32x4 dp[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                dp[t] = of_mfma(frag_n(v_img, t * 16, 0, lane), dof[0], dp[t]);
-                dp[t] = of_mfma(frag_n(v_img, t * 16, 1, lane), dof[1], dp[t]);
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) dp[t] = of_mfma(frag_n<DH>(v_img, t * 16, ks, lane), dof[ks], dp[t]);
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -271,8 +295,8 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
             for (int s2 = 0; s2 < 2; ++s2) {
                 const s16x8 dsf = pack8(dp[2 * s2], dp[2 * s2 + 1]);
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    acc[dt] = of_mfma(frag_t<SAFE>(k_t, s2 * 32, dt * 16, lane), dsf, acc[dt]);
+                for (int dt = 0; dt < NDT; ++dt)
+                    acc[dt] = of_mfma(frag_t<DH, SAFE>(k_t, s2 * 32, dt * 16, lane), dsf, acc[dt]);
             }
         }
         of_sync();
@@ -282,7 +306,7 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
             const float inv = l_i > 0.f ? 1.0f / l_i : 0.f;
             bf16_t* ob = p.o + ((size_t)batch * p.Lq + my_row) * p.ldo + hc;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < NDT; ++dt) {
                 u32x2 o = {of_pack_bf16(acc[dt][0] * inv, acc[dt][1] * inv),
                            of_pack_bf16(acc[dt][2] * inv, acc[dt][3] * inv)};
                 *(u32x2*)(ob + dt * 16 + g * 4) = o;
@@ -291,7 +315,7 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
         } else {
             bf16_t* dqb = p.dq + ((size_t)batch * p.Lq + my_row) * p.lddq + hc;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < NDT; ++dt) {
                 u32x2 o = {of_pack_bf16(acc[dt][0] * p.scale, acc[dt][1] * p.scale),
                            of_pack_bf16(acc[dt][2] * p.scale, acc[dt][3] * p.scale)};
                 *(u32x2*)(dqb + dt * 16 + g * 4) = o;
@@ -302,8 +326,9 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
 
 // ------------------------------------------------------------------------------------------------
 // dk/dv pass: one workgroup per (key block of 64, head, batch); a wave owns 16 keys.
-template <bool SAFE>
+template <int DH, bool SAFE>
 OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_dkv_kernel(OfAttnArgs p) {
+    constexpr int NKS = DH / 32, NDT = DH / 16, IMG = 64 * DH * 2;
     char* smem = of_smem();
     char* q_n = smem;
     char* do_n = smem + IMG;
@@ -315,7 +340,8 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_dkv_kernel(OfAttnArgs p) {
     const int tid = of_tid(), lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
     const int kblk = of_bid_x(), h = of_bid_y();
     const long batch = of_bid_z();
-    const int hc = h * 64;
+    const int hc = h * DH;
+    const float slope = p.alibi_slopes ? p.alibi_slopes[h] : 0.f;
     const int key_lo = kblk * 64, key_hi = key_lo + 64;
     const int my_key = key_lo + wave * 16 + i16;
 
@@ -323,14 +349,15 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_dkv_kernel(OfAttnArgs p) {
     const bf16_t* vb_ptr = p.v + (size_t)batch * p.Lk * p.ldv;
     const bf16_t* qb = p.q + (size_t)batch * p.Lq * p.ldq;
     const bf16_t* dob = p.dout + (size_t)batch * p.Lq * p.lddo;
-    s16x8 kf[2], vf[2];
-    kf[0] = gload_frag(kb_ptr, p.ldk, my_key, p.Lk, hc + g * 8);
-    kf[1] = gload_frag(kb_ptr, p.ldk, my_key, p.Lk, hc + 32 + g * 8);
-    vf[0] = gload_frag(vb_ptr, p.ldv, my_key, p.Lk, hc + g * 8);
-    vf[1] = gload_frag(vb_ptr, p.ldv, my_key, p.Lk, hc + 32 + g * 8);
-    f32x4 acck[4], accv[4];
+    s16x8 kf[NKS], vf[NKS];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
+    for (int ks = 0; ks < NKS; ++ks) {
+        kf[ks] = gload_frag(kb_ptr, p.ldk, my_key, p.Lk, hc + ks * 32 + g * 8);
+        vf[ks] = gload_frag(vb_ptr, p.ldv, my_key, p.Lk, hc + ks * 32 + g * 8);
+    }
+    f32x4 acck[NDT], accv[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
         acck[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
         accv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -354,24 +381,25 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_dkv_kernel(OfAttnArgs p) {
         of_sync();
         const int hit = s_flag[0];
         if (hit) {
-            load_tile64(qb, p.ldq, q0, p.Lq, hc, tid, q_n, q_t);
-            load_tile64(dob, p.lddo, q0, p.Lq, hc, tid, do_n, do_t);
+            load_tile64<DH>(qb, p.ldq, q0, p.Lq, hc, tid, q_n, q_t);
+            load_tile64<DH>(dob, p.lddo, q0, p.Lq, hc, tid, do_n, do_t);
             of_sync();
             f32x4 pm[4], ds[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-                s = of_mfma(frag_n(q_n, t * 16, 0, lane), kf[0], s);
-                s = of_mfma(frag_n(q_n, t * 16, 1, lane), kf[1], s);
-                dp = of_mfma(frag_n(do_n, t * 16, 0, lane), vf[0], dp);
-                dp = of_mfma(frag_n(do_n, t * 16, 1, lane), vf[1], dp);
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    s = of_mfma(frag_n<DH>(q_n, t * 16, ks, lane), kf[ks], s);
+                    dp = of_mfma(frag_n<DH>(do_n, t * 16, ks, lane), vf[ks], dp);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qr = t * 16 + g * 4 + r;
                     const int lo = s_win[qr * 3 + 0], hi = s_win[qr * 3 + 1], uni = s_win[qr * 3 + 2];
                     const float lse = s_stat[qr * 2 + 0], delta = s_stat[qr * 2 + 1];
                     const bool valid = my_key >= lo && my_key < hi;
-                    const float sv = uni ? 0.f : s[r] * p.scale;
+                    const float sv = uni ? 0.f : s[r] * p.scale + slope * (float)(my_key - (q0 + qr + p.Lk - p.Lq));
                     const float pv = valid ? of_exp(sv - lse) : 0.f;
                     pm[t][r] = pv;
                     ds[t][r] = uni ? 0.f : pv * (dp[r] - delta);
@@ -382,9 +410,9 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_dkv_kernel(OfAttnArgs p) {
                 const s16x8 pf = pack8(pm[2 * s2], pm[2 * s2 + 1]);
                 const s16x8 dsf = pack8(ds[2 * s2], ds[2 * s2 + 1]);
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    accv[dt] = of_mfma(frag_t<SAFE>(do_t, s2 * 32, dt * 16, lane), pf, accv[dt]);
-                    acck[dt] = of_mfma(frag_t<SAFE>(q_t, s2 * 32, dt * 16, lane), dsf, acck[dt]);
+                for (int dt = 0; dt < NDT; ++dt) {
+                    accv[dt] = of_mfma(frag_t<DH, SAFE>(do_t, s2 * 32, dt * 16, lane), pf, accv[dt]);
+                    acck[dt] = of_mfma(frag_t<DH, SAFE>(q_t, s2 * 32, dt * 16, lane), dsf, acck[dt]);
                 }
             }
         }
@@ -394,7 +422,7 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_dkv_kernel(OfAttnArgs p) {
         bf16_t* dkb = p.dk + ((size_t)batch * p.Lk + my_key) * p.lddk + hc;
         bf16_t* dvb = p.dv + ((size_t)batch * p.Lk + my_key) * p.lddv + hc;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
+        for (int dt = 0; dt < NDT; ++dt) {
             u32x2 ok = {of_pack_bf16(acck[dt][0] * p.scale, acck[dt][1] * p.scale),
                         of_pack_bf16(acck[dt][2] * p.scale, acck[dt][3] * p.scale)};
             u32x2 ov = {of_pack_bf16(accv[dt][0], accv[dt][1]), of_pack_bf16(accv[dt][2], accv[dt][3])};
@@ -441,6 +469,8 @@ int check(const OfAttnArgs& a, bool bwd) {
     if ((a.ldq & 7) || (a.ldk & 7) || (a.ldv & 7) || (a.ldo & 7)) return OF_E_ALIGN;
     if (((uintptr_t)a.q & 15) || ((uintptr_t)a.k & 15) || ((uintptr_t)a.v & 15) || ((uintptr_t)a.o & 15)) return OF_E_ALIGN;
     if (a.text_time && (a.n_per_media <= 0 || a.T_img <= 0)) return OF_E_ARG;
+    if (a.head_dim != 0 && a.head_dim != 64 && a.head_dim != 128) return OF_E_SHAPE;
+    if (a.causal && a.text_time) return OF_E_ARG;
     if (bwd) {
         if (!a.dout || !a.dq || !a.dk || !a.dv || !a.delta) return OF_E_ARG;
         if ((a.lddo & 7) || (a.lddq & 7) || (a.lddk & 7) || (a.lddv & 7)) return OF_E_ALIGN;
@@ -450,30 +480,41 @@ int check(const OfAttnArgs& a, bool bwd) {
 
 }  // namespace
 
+namespace {
+template <int DH>
+int launch_fwd(const OfAttnArgs& a, of_stream_t s) {
+    of_dim3 grid{(unsigned)((a.Lq + 63) / 64), (unsigned)a.heads, (unsigned)a.batch};
+    const size_t smem = 3 * (64 * DH * 2) + 196 * sizeof(int);
+    if (a.safe) return of_launch(of_attn_q_kernel<DH, false, true>, grid, 256, smem, s, a);
+    return of_launch(of_attn_q_kernel<DH, false, false>, grid, 256, smem, s, a);
+}
+template <int DH>
+int launch_bwd(const OfAttnArgs& a, of_stream_t s) {
+    constexpr int IMG = 64 * DH * 2;
+    of_dim3 gq{(unsigned)((a.Lq + 63) / 64), (unsigned)a.heads, (unsigned)a.batch};
+    const size_t smem_q = 3 * IMG + 196 * sizeof(int);
+    int rc = a.safe ? of_launch(of_attn_q_kernel<DH, true, true>, gq, 256, smem_q, s, a)
+                    : of_launch(of_attn_q_kernel<DH, true, false>, gq, 256, smem_q, s, a);
+    if (rc) return rc;
+    of_dim3 gk{(unsigned)((a.Lk + 63) / 64), (unsigned)a.heads, (unsigned)a.batch};
+    const size_t smem_k = 4 * IMG + 64 * 3 * sizeof(int) + 128 * sizeof(float) + 16;
+    return a.safe ? of_launch(of_attn_dkv_kernel<DH, true>, gk, 256, smem_k, s, a)
+                  : of_launch(of_attn_dkv_kernel<DH, false>, gk, 256, smem_k, s, a);
+}
+}  // namespace
+
 extern "C" int of_attn_fwd(const OfAttnArgs* args, void* stream) {
     if (!args) return OF_E_ARG;
     int rc = check(*args, false);
     if (rc) return rc;
-    of_dim3 grid{(unsigned)((args->Lq + 63) / 64), (unsigned)args->heads, (unsigned)args->batch};
-    const size_t smem = 3 * IMG + 196 * sizeof(int);
-    if (args->safe) return of_launch(of_attn_q_kernel<false, true>, grid, 256, smem, (of_stream_t)stream, *args);
-    return of_launch(of_attn_q_kernel<false, false>, grid, 256, smem, (of_stream_t)stream, *args);
+    return args->head_dim == 128 ? launch_fwd<128>(*args, (of_stream_t)stream) : launch_fwd<64>(*args, (of_stream_t)stream);
 }
 
 extern "C" int of_attn_bwd(const OfAttnArgs* args, void* stream) {
     if (!args) return OF_E_ARG;
     int rc = check(*args, true);
     if (rc) return rc;
-    of_stream_t s = (of_stream_t)stream;
-    of_dim3 gq{(unsigned)((args->Lq + 63) / 64), (unsigned)args->heads, (unsigned)args->batch};
-    const size_t smem_q = 3 * IMG + 196 * sizeof(int);
-    rc = args->safe ? of_launch(of_attn_q_kernel<true, true>, gq, 256, smem_q, s, *args)
-                    : of_launch(of_attn_q_kernel<true, false>, gq, 256, smem_q, s, *args);
-    if (rc) return rc;
-    of_dim3 gk{(unsigned)((args->Lk + 63) / 64), (unsigned)args->heads, (unsigned)args->batch};
-    const size_t smem_k = 4 * IMG + 64 * 3 * sizeof(int) + 128 * sizeof(float) + 16;
-    return args->safe ? of_launch(of_attn_dkv_kernel<true>, gk, 256, smem_k, s, *args)
-                      : of_launch(of_attn_dkv_kernel<false>, gk, 256, smem_k, s, *args);
+    return args->head_dim == 128 ? launch_bwd<128>(*args, (of_stream_t)stream) : launch_bwd<64>(*args, (of_stream_t)stream);
 }
 
 extern "C" int of_text_time(const uint8_t* media_locations, int32_t* text_time, int B, int Lm, int Lq, int use_cached,

@@ -41,6 +41,7 @@ class OfAttnArgs(C.Structure):
         ("dk", vp), ("dv", vp), ("lddk", C.c_long), ("lddv", C.c_long),
         ("delta", vp),
         ("safe", C.c_int),
+        ("head_dim", C.c_int), ("causal", C.c_int), ("alibi_slopes", vp), ("kv_len", vp),
     ]
 
 

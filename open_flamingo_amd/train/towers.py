@@ -98,6 +98,58 @@ def _alibi_causal_bias(position_bias, attention_mask, q_len, dtype):
     return bias
 
 
+class _CausalAlibiAttention(torch.autograd.Function):
+    """libofhip windowed flash attention (csrc/attention.hip) as causal self-attention with ALiBi over the fused
+    Wqkv output: q/k/v are strided views of one (B*L, 3d) buffer, and the backward writes dq|dk|dv into one buffer of
+    the same layout -- no chunk / transpose / cat copies.  Right padding only (kv_len = real keys per sequence)."""
+
+    @staticmethod
+    def forward(ctx, qkv, slopes, kv_len, heads, head_dim, scale):
+        from ..hip.ops import Ops
+        ops = Ops.default()
+        b, l, three_d = qkv.shape
+        d = heads * head_dim
+        x = qkv.reshape(b * l, three_d)
+        o = torch.empty(b * l, d, dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty(b, heads, l, dtype=torch.float32, device=qkv.device)
+        kw = dict(batch=b, Lq=l, Lk=l, heads=heads, scale=scale, head_dim=head_dim, causal=True, alibi_slopes=slopes,
+                  kv_len=kv_len)
+        ops.attn_fwd(x[:, :d], x[:, d:2 * d], x[:, 2 * d:], o, lse, **kw)
+        ctx.save_for_backward(x, o, lse, slopes, kv_len)
+        ctx.kw, ctx.shape = kw, (b, l, d)
+        return o.view(b, l, d)
+
+    @staticmethod
+    def backward(ctx, do):
+        from ..hip.ops import Ops
+        ops = Ops.default()
+        x, o, lse, slopes, kv_len = ctx.saved_tensors
+        b, l, d = ctx.shape
+        do2 = do.reshape(b * l, d)
+        if not do2.is_contiguous() or do2.dtype != x.dtype:
+            do2 = do2.to(x.dtype).contiguous()
+        dx = torch.empty_like(x)
+        delta = torch.empty(b, ctx.kw["heads"], l, dtype=torch.float32, device=x.device)
+        ops.attn_bwd(x[:, :d], x[:, d:2 * d], x[:, 2 * d:], o, lse, do2, dx[:, :d], dx[:, d:2 * d], dx[:, 2 * d:], delta,
+                     **ctx.kw)
+        return dx.view(b, l, 3 * d), None, None, None, None, None
+
+
+def _alibi_slopes_and_lens(position_bias, attention_mask, q_len):
+    """(heads,) fp32 ALiBi slopes and (B,) int32 real-key counts, derived on the device (no host sync) from the
+    tensors HF hands every block; cached for the duration of one LM forward."""
+    key = ("sl", position_bias.data_ptr(), None if attention_mask is None else (attention_mask.data_ptr(), attention_mask._version), q_len)
+    if _BIAS_CACHE.get("key2") == key:
+        return _BIAS_CACHE["val2"]
+    pb = position_bias[:, 0, :].float()
+    slopes = (pb[:, -1] - pb[:, -2]).contiguous()                 # slope_h * (j - (S-1)): consecutive keys differ by slope_h
+    lens = None
+    if attention_mask is not None:                                 # bool (B,1,L,L), True = masked; last query row sees every real key
+        lens = (~attention_mask[:, 0, -1, -q_len:]).sum(-1).to(torch.int32).contiguous()
+    _BIAS_CACHE["key2"], _BIAS_CACHE["val2"] = key, (slopes, lens)
+    return slopes, lens
+
+
 def _mpt_attention_fused_forward(self, hidden_states, position_bias, past_key_values=None, attention_mask=None, **kwargs):
     """MptAttention.forward with the score/softmax/AV chain as ONE fused attention call (torch SDPA) instead of HF's eager
     chain (matmul, scale, + alibi, masked_fill, fp32 softmax, cast, matmul -- each materialising a (B, H, L, L) tensor).
@@ -108,25 +160,39 @@ def _mpt_attention_fused_forward(self, hidden_states, position_bias, past_key_va
         return self._of_eager_forward(hidden_states, position_bias, past_key_values=past_key_values,
                                       attention_mask=attention_mask, **kwargs)
     b, l = hidden_states.shape[:2]
-    q, k, v = self.Wqkv(hidden_states).chunk(3, dim=2)
+    qkv = self.Wqkv(hidden_states)
+    if (getattr(self, "_of_attention_kernel", "sdpa") == "libofhip" and qkv.is_cuda and qkv.dtype == torch.bfloat16
+            and self.head_dim in (64, 128) and position_bias.shape[-1] >= 2):
+        slopes, lens = _alibi_slopes_and_lens(position_bias, attention_mask, l)
+        ctx = _CausalAlibiAttention.apply(qkv.contiguous(), slopes, lens, self.n_heads, self.head_dim,
+                                          float(self.softmax_scale))
+        return self.out_proj(ctx), None
+    q, k, v = qkv.chunk(3, dim=2)
     q, k, v = (t.reshape(b, l, self.n_heads, self.head_dim).transpose(1, 2) for t in (q, k, v))
     bias = _alibi_causal_bias(position_bias, attention_mask, l, q.dtype)
     ctx = torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=bias, scale=self.softmax_scale)
     return self.out_proj(ctx.transpose(1, 2).reshape(b, l, -1)), None
 
 
-def use_fused_attention_in_mpt(lm):
+def use_fused_attention_in_mpt(lm, kernel="sdpa"):
+    """kernel = "sdpa": torch's fused attention with an additive bias (any mask HF builds).  kernel = "libofhip": this
+    repository's windowed flash-attention kernel as causal + ALiBi self-attention (bf16 on an AMD GPU; batches must be
+    unpadded or RIGHT-padded -- training batches are, train/data.py pads on the right; left-padded generation prompts
+    use a KV cache and therefore the eager path anyway)."""
     import types
+    assert kernel in ("sdpa", "libofhip")
     n = 0
     for mod in lm.modules():
-        if type(mod).__name__ == "MptAttention" and not hasattr(mod, "_of_eager_forward"):
-            mod._of_eager_forward = mod.forward
-            mod.forward = types.MethodType(_mpt_attention_fused_forward, mod)
+        if type(mod).__name__ == "MptAttention":
+            if not hasattr(mod, "_of_eager_forward"):
+                mod._of_eager_forward = mod.forward
+                mod.forward = types.MethodType(_mpt_attention_fused_forward, mod)
+            mod._of_attention_kernel = kernel
             n += 1
     return n
 
 
-def build_lang_encoder(family: str, extra_tokens: int = 3, max_seq_len: int = 2048, fused_attention: bool = True):
+def build_lang_encoder(family: str, extra_tokens: int = 3, max_seq_len: int = 2048, fused_attention=True):
     f = FAMILY[family]
     vocab = f["vocab"] + extra_tokens      # <|endofchunk|>, <image>, <PAD> appended by factory.py:57-63
     if f["lm"] == "mpt":
@@ -135,7 +201,7 @@ def build_lang_encoder(family: str, extra_tokens: int = 3, max_seq_len: int = 20
                         max_seq_len=max_seq_len)
         lm = MptForCausalLM(cfg)
         if fused_attention:
-            use_fused_attention_in_mpt(lm)
+            use_fused_attention_in_mpt(lm, kernel=fused_attention if isinstance(fused_attention, str) else "sdpa")
         return lm, "transformer.blocks"
     from transformers import GPTNeoXConfig, GPTNeoXForCausalLM
     cfg = GPTNeoXConfig(hidden_size=f["d"], num_hidden_layers=f["layers"], num_attention_heads=f["heads"],
@@ -161,7 +227,7 @@ def hold_frozen_linears_in_bf16(model):
 
 def build_flamingo(family: str = "OF-3B", device="cuda", seed: int = 0, gates: float = 0.5, vision_kw=None,
                    freeze_lm_embeddings: bool = False, verbose: bool = False, frozen_bf16: bool = False,
-                   fused_lm_attention: bool = True):
+                   fused_lm_attention=True):
     """Random-init Flamingo of the given family, assembled through the factory path, gates set to ``gates``
     (their init value 0 makes the hot path an exact no-op with zero weight gradients -- SURVEY.md section 7)."""
     from ..src.factory import assemble_flamingo

@@ -5,14 +5,23 @@ post-softmax zeroing)."""
 import torch
 
 
-def dense_attention(q, k, v, heads, text_time=None, n=0, T=0, only_immediate=True, round_p=False):
-    """q (B,Lq,H*64), k/v (B,Lk,H*64) float64 -> o (B,Lq,H*64)."""
+def dense_attention(q, k, v, heads, text_time=None, n=0, T=0, only_immediate=True, round_p=False, head_dim=64,
+                    causal=False, alibi_slopes=None):
+    """q (B,Lq,H*dh), k/v (B,Lk,H*dh) float64 -> o (B,Lq,H*dh).  causal / alibi_slopes: the MPT self-attention form
+    (HF modeling_mpt.MptAttention: scores * scale + slope_h * (j - (Lk - 1)), causal mask, softmax)."""
     B, Lq, _ = q.shape
     Lk = k.shape[1]
-    qh = q.reshape(B, Lq, heads, 64).transpose(1, 2) * 64 ** -0.5
-    kh = k.reshape(B, Lk, heads, 64).transpose(1, 2)
-    vh = v.reshape(B, Lk, heads, 64).transpose(1, 2)
+    dh = head_dim
+    qh = q.reshape(B, Lq, heads, dh).transpose(1, 2) * dh ** -0.5
+    kh = k.reshape(B, Lk, heads, dh).transpose(1, 2)
+    vh = v.reshape(B, Lk, heads, dh).transpose(1, 2)
     sim = qh @ kh.transpose(-1, -2)
+    if alibi_slopes is not None:
+        pos = torch.arange(1 - Lk, 1, dtype=sim.dtype)
+        sim = sim + alibi_slopes.to(sim.dtype).view(1, heads, 1, 1) * pos.view(1, 1, 1, Lk)
+    if causal:
+        i = torch.arange(Lq).view(Lq, 1) + (Lk - Lq)
+        sim = sim.masked_fill(torch.arange(Lk).view(1, Lk) > i, -torch.finfo(torch.float32).max)
     if text_time is not None:
         key_time = (torch.arange(T) + 1).repeat_interleave(n)
         tt = text_time[:, None, :, None]
@@ -25,4 +34,4 @@ def dense_attention(q, k, v, heads, text_time=None, n=0, T=0, only_immediate=Tru
     if round_p:
         attn = attn + (attn.detach().to(torch.bfloat16).to(attn.dtype) - attn.detach())
     out = attn @ vh
-    return out.transpose(1, 2).reshape(B, Lq, heads * 64)
+    return out.transpose(1, 2).reshape(B, Lq, heads * dh)

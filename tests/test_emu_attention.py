@@ -102,3 +102,29 @@ def test_text_time_kernel():
     rc = H.lib().of_text_time(H.ptr(m8), H.ptr(tt2), 3, 150, 7, 1, None)
     assert rc == 0
     assert torch.equal(tt2.long(), ml.sum(-1, keepdim=True).expand(-1, 7))
+
+
+@pytest.mark.parametrize("dh,safe", [(128, 0), (128, 1), (64, 0)])
+@pytest.mark.parametrize("Lq,Lk", [(96, 96), (40, 104)])
+def test_causal_alibi_self_attention(dh, safe, Lq, Lk):
+    """Causal self-attention with ALiBi (the frozen MPT blocks): head dim 128 and 64, ragged lengths, Lq < Lk
+    (queries aligned to the END of the keys, as with a KV prefix)."""
+    heads, B = 2, 2
+    q, k, v = _r((B, Lq, heads * dh), 31), _r((B, Lk, heads * dh), 32), _r((B, Lk, heads * dh), 33)
+    slopes = torch.tensor([0.5, 0.0625])
+    dout = _r(q.shape, 34)
+    o = torch.full_like(q, float("nan"))
+    lse = torch.full((B, heads, Lq), float("nan"))
+    kw = dict(heads=heads, safe=safe, head_dim=dh, causal=1, alibi_slopes=slopes)
+    H.attn_fwd(H.attn_args(q, k, v, o, lse, **kw))
+    dq, dk, dv = torch.full_like(q, float("nan")), torch.full_like(k, float("nan")), torch.full_like(v, float("nan"))
+    delta = torch.zeros(B, heads, Lq)
+    H.attn_bwd(H.attn_args(q, k, v, o, lse, dout=dout, dq=dq, dk=dk, dv=dv, delta=delta, **kw))
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    ref = dense_attention(qd, kd, vd, heads, head_dim=dh, causal=True, alibi_slopes=slopes)
+    ref.backward(dout.double())
+    for name, got, want in (("o", o, ref.detach()), ("dq", dq, qd.grad), ("dk", dk, kd.grad), ("dv", dv, vd.grad)):
+        got = got.double()
+        assert torch.isfinite(got).all(), name
+        err = (got - want).abs().max().item()
+        assert err <= 2e-2 * (want.abs().max().item() + 1e-6), f"{name}: {err:.3e}"

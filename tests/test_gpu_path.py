@@ -84,3 +84,31 @@ def test_fused_step_epilogue_matches_torch_optimizer():
     for k in p0:
         travelled = (p0[k] - init[k]).norm().item()
         assert (p0[k] - p1[k]).norm().item() <= 0.05 * travelled + 1e-7, (k, (p0[k] - p1[k]).norm().item(), travelled)
+
+
+@pytest.mark.parametrize("d,heads", [(256, 4), (512, 4)])      # head dim 64 and 128
+def test_frozen_mpt_attention_kernel_matches_hf_eager(ops, d, heads):
+    """SURVEY 8f N1 (first piece): the frozen MPT blocks' self-attention on the libofhip causal+ALiBi flash kernel vs
+    HF's eager attention, forward logits and the gradient that flows back to the input embeddings, with right padding."""
+    from transformers import MptConfig, MptForCausalLM
+    from open_flamingo_amd.train import towers
+    torch.manual_seed(0)
+    lm = MptForCausalLM(MptConfig(d_model=d, n_heads=heads, n_layers=2, vocab_size=512, max_seq_len=256)).cuda()
+    ids = torch.randint(0, 512, (3, 80), device="cuda")
+    am = torch.ones(3, 80, dtype=torch.long, device="cuda")
+    am[1, 60:] = 0
+    am[2, 33:] = 0
+
+    def run():
+        emb = lm.get_input_embeddings()(ids).detach().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = lm(inputs_embeds=emb, attention_mask=am).logits
+        valid = am.bool()[..., None]
+        (out.float() * valid).square().mean().backward()
+        return out.float().detach() * valid, emb.grad.detach() * valid
+
+    ref_o, ref_g = run()
+    towers.use_fused_attention_in_mpt(lm, kernel="libofhip")
+    got_o, got_g = run()
+    assert PC.rel_err(got_o, ref_o) < 3e-2, PC.rel_err(got_o, ref_o)
+    assert PC.rel_err(got_g, ref_g) < 5e-2, PC.rel_err(got_g, ref_g)
