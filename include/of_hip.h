@@ -188,13 +188,14 @@ int of_add(const void* a, const void* b, void* out, int f32, long n, void* strea
  * clip_grad_norm_ / optimizer.step / zero_grad of open_flamingo/train/train_utils.py:199-216 with the parameter
  * groups of open_flamingo/train/train.py:392-408.
  *   of_sumsq:       *acc += sum(g^2)   (acc zero-initialised by the caller; one call per gradient buffer)
- *   of_adamw_clip:  coef = min(1, max_norm / (sqrt(*sumsq) + 1e-6)) (max_norm <= 0: no clipping); torch.optim.AdamW
- *                   update with gradient coef*g at 1-based `step`; p_bf16 (optional) receives the bf16 copy of the new
+ *   of_adamw_clip:  the effective gradient is grad_scale * g (grad_scale = 1/world_size when g holds the all-reduced SUM);
+ *                   coef = min(1, max_norm / (grad_scale * sqrt(*sumsq) + 1e-6)) (max_norm <= 0: no clipping);
+ *                   torch.optim.AdamW update with gradient coef * grad_scale * g at 1-based `step`; p_bf16 (optional) receives the bf16 copy of the new
  *                   parameters; zero_grad != 0 clears g in the same pass.  No host synchronisation. */
 int of_sumsq(const float* g, long n, float* acc, void* stream);
 int of_adamw_clip(float* p, float* g, float* m, float* v, uint16_t* p_bf16, long n, const float* sumsq,
-                  float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                  int zero_grad, void* stream);
+                  float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                  int step, int zero_grad, void* stream);
 
 #ifdef __cplusplus
 }

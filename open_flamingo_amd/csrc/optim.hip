@@ -17,7 +17,7 @@ struct OptArgs {
     float* p; float* g; float* m; float* v; bf16_t* p_bf16;
     long n;
     float* acc;            // sum of squares (device scalar)
-    float max_norm, lr, beta1, beta2, eps, wd, bc1, bc2;
+    float max_norm, lr, beta1, beta2, eps, wd, bc1, bc2, grad_scale;
     int zero_grad;
 };
 
@@ -53,9 +53,11 @@ OF_DEV float adamw_one(const OptArgs& a, float coef, float step_size, float inv_
 }
 
 OF_GLOBAL void of_adamw_kernel(OptArgs a) {
-    const float norm = sqrtf(*a.acc);
+    // gradients arrive as SUMS over ranks: grad_scale = 1/world turns them into the average DDP would have produced;
+    // *acc is the squared norm of the unscaled buffers
+    const float norm = sqrtf(*a.acc) * a.grad_scale;
     float coef = a.max_norm > 0.f ? a.max_norm / (norm + 1e-6f) : 1.0f;
-    coef = coef < 1.0f ? coef : 1.0f;
+    coef = (coef < 1.0f ? coef : 1.0f) * a.grad_scale;
     const float step_size = a.lr / a.bc1, inv_sqrt_bc2 = 1.0f / sqrtf(a.bc2), decay = 1.0f - a.lr * a.wd;
     const long nv = a.n >> 2;
     const long stride = (long)of_gdim_x() * 256;
@@ -104,13 +106,13 @@ extern "C" int of_sumsq(const float* g, long n, float* acc, void* stream) {
 
 extern "C" int of_adamw_clip(float* p, float* g, float* m, float* v, uint16_t* p_bf16, long n, const float* sumsq,
                              float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
-                             int step, int zero_grad, void* stream) {
+                             float grad_scale, int step, int zero_grad, void* stream) {
     if (!p || !g || !m || !v || !sumsq || n <= 0 || step <= 0) return OF_E_ARG;
     if (((uintptr_t)p & 15) || ((uintptr_t)g & 15) || ((uintptr_t)m & 15) || ((uintptr_t)v & 15) || ((uintptr_t)p_bf16 & 7))
         return OF_E_ALIGN;
     OptArgs a{};
     a.p = p; a.g = g; a.m = m; a.v = v; a.p_bf16 = p_bf16; a.n = n; a.acc = const_cast<float*>(sumsq);
-    a.max_norm = max_norm; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
+    a.grad_scale = grad_scale; a.max_norm = max_norm; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
     a.bc1 = 1.0f - powf(beta1, (float)step);
     a.bc2 = 1.0f - powf(beta2, (float)step);
     a.zero_grad = zero_grad;

@@ -229,12 +229,12 @@ class Ops:
         self._chk(self.lib.of_sumsq(g.data_ptr(), g.numel(), acc.data_ptr(), self._stream()), "of_sumsq")
 
     def adamw_clip(self, p, g, m, v, sumsq, *, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=1.0,
-                   p_bf16=None, zero_grad=True):
+                   p_bf16=None, zero_grad=True, grad_scale=1.0):
         n = p.numel()
         assert all(t.dtype == F32 and t.is_contiguous() and t.numel() == n for t in (p, g, m, v))
         self._chk(self.lib.of_adamw_clip(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(p_bf16), n,
-                                         sumsq.data_ptr(), max_norm, lr, betas[0], betas[1], eps, weight_decay, step,
-                                         int(zero_grad), self._stream()), "of_adamw_clip")
+                                         sumsq.data_ptr(), max_norm, lr, betas[0], betas[1], eps, weight_decay,
+                                         grad_scale, step, int(zero_grad), self._stream()), "of_adamw_clip")
 
     def add(self, a, b, out):
         assert a.dtype == b.dtype == out.dtype and a.is_contiguous() and b.is_contiguous() and out.is_contiguous()

@@ -77,6 +77,9 @@ class FlatAdamW:
     def step(self):
         ops = self._ops()
         self.step_count += 1
+        # GradReducer.finish(average=False) leaves the all-reduced SUM in the buckets; the 1/world is folded into the
+        # AdamW pass instead of 25 extra read-modify-write passes over the gradients
+        gs = 1.0 / self.reducer.world if getattr(self.reducer, "holds_sum", False) else 1.0
         dev = self.reducer.buckets[0]["flat"].device
         if self._sumsq is None:
             self._sumsq = torch.zeros(1, dtype=F32, device=dev)
@@ -90,13 +93,13 @@ class FlatAdamW:
         for b, lr in ((b, self.param_groups[0 if b["wd"] else 1]["lr"]) for b in self.reducer.buckets):
             ops.adamw_clip(b["flat_p"], b["flat"], b["m"], b["v"], self._sumsq, step=self.step_count, lr=lr,
                            betas=self.betas, eps=self.eps, weight_decay=b["wd"], max_norm=self.max_norm,
-                           p_bf16=b["flat_bf16"], zero_grad=True)
+                           p_bf16=b["flat_bf16"], zero_grad=True, grad_scale=gs)
         if g_rows is not None:
             e = self._emb
             p_rows = self.embedding.data.index_select(0, e["rows"]).contiguous()
             ops.adamw_clip(p_rows, g_rows, e["m"], e["v"], self._sumsq, step=self.step_count,
                            lr=self.param_groups[1]["lr"], betas=self.betas, eps=self.eps, weight_decay=0.0,
-                           max_norm=self.max_norm, zero_grad=False)
+                           max_norm=self.max_norm, zero_grad=False, grad_scale=gs)
             self.embedding.data.index_copy_(0, e["rows"], p_rows)
             self.embedding.grad = None
 
@@ -105,4 +108,5 @@ class FlatAdamW:
 
     def grad_norm(self):
         """Global gradient norm of the last step() (device scalar tensor, pre-clip)."""
-        return self._sumsq.sqrt()
+        gs = 1.0 / self.reducer.world if getattr(self.reducer, "holds_sum", False) else 1.0
+        return self._sumsq.sqrt() * gs

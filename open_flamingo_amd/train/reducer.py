@@ -125,19 +125,22 @@ class GradReducer:
         finally:
             self._sync = old
 
-    def finish(self):
-        """Make the compute stream wait for all collectives of this step, apply 1/world (avg), write back."""
+    def finish(self, average=True):
+        """Make the compute stream wait for all collectives of this step and write back.  average=True applies 1/world
+        here (DDP semantics: .grad holds the mean); average=False leaves the SUM and sets ``holds_sum`` for a consumer
+        that folds the 1/world into its own pass over the gradients (train/optim.py)."""
         for work, flat, wire in self._pending:
             work.wait()
             if wire is not None:
                 flat.copy_(wire)
-            if self.world > 1:
+            if self.world > 1 and average:
                 flat.div_(self.world)
         self._pending.clear()
+        self.holds_sum = self.world > 1 and not average
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
         if getattr(self, "_emb_rows", None) is not None:
-            rows, kept = self._emb_rows
+            rows, kept = self._emb_rows     # `kept` is one of the all-reduced buffers above: same sum/mean convention
             self.embedding.grad.index_copy_(0, rows, kept)
             self._emb_rows = None
 

@@ -58,7 +58,8 @@ def train_step(model, reducer, optimizer, batch_mmc4, info, batch_laion=None, lo
         return None
     (loss * loss_multiplier_mmc4).backward()
     if reducer is not None:
-        reducer.finish()                          # waits for the overlapped RCCL all-reduces, masks the embedding grad
+        # waits for the overlapped RCCL all-reduces, restores the two embedding rows; the fused epilogue averages itself
+        reducer.finish(average=not hasattr(optimizer, "reducer"))
     if fused:
         optimizer.max_norm = clip_norm
         optimizer.step()

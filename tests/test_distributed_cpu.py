@@ -63,7 +63,21 @@ def _worker(rank, world, port, q):
     gathered = [torch.zeros_like(chk) for _ in range(world)]
     dist.all_gather(gathered, chk)
     same = all(torch.equal(gathered[0], g) for g in gathered)
-    q.put((rank, max(errs.values()), nz_rows, same, float(loss), len(red.buckets)))
+    # the fused step epilogue (train/optim.py; kernels on the host emulator here) must make the same update as
+    # clip_grad_norm_ + torch AdamW from the same state: the reducer then hands it the all-reduced SUM and it folds the
+    # 1/world into its AdamW pass
+    from open_flamingo_amd.train.optim import FlatAdamW
+    from tests.emu import harness as H
+    finals = []
+    for fused in (False, True):
+        m2, _ = tiny_cpu_flamingo(seed=0)
+        r2 = GradReducer(m2, embedding_rows=rows)
+        o2 = FlatAdamW(r2, lr=1e-3, ops=H.emu_ops()) if fused else step.build_optimizer(m2, lr=1e-3)
+        for _ in range(2):
+            step.train_step(m2, r2, o2, b_mmc4, info, amp=False)
+        finals.append(torch.cat([p.detach().flatten() for _, p in m2.named_parameters() if p.requires_grad]).double())
+    fused_err = (finals[0] - finals[1]).abs().max().item()
+    q.put((rank, max(errs.values()), nz_rows, same, float(loss), len(red.buckets), fused_err))
     dist.destroy_process_group()
 
 
@@ -79,7 +93,8 @@ def test_reducer_and_train_step_world2():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, err, nz_rows, same, loss, nb in res:
+    for rank, err, nz_rows, same, loss, nb, fused_err in res:
+        assert fused_err < 2e-5, f"rank {rank}: fused step epilogue diverges from clip + torch AdamW ({fused_err})"
         assert err < 1e-5, f"rank {rank}: reduced grads differ from mean of local grads ({err})"
         assert nz_rows <= 2, "embedding gradient must be masked to the <image>/<|endofchunk|> rows"
         assert same, "replicas diverged after train_step"

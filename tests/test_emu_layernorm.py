@@ -127,13 +127,14 @@ def test_step_epilogue_matches_torch_adamw_with_clipping():
         torch.nn.utils.clip_grad_norm_(ref, 1.0)
         opt.step()
         acc = torch.zeros(1)
-        gbuf = [gr.clone() for gr in grads]
+        gbuf = [gr.clone() * 4.0 for gr in grads]     # as if 4 ranks' gradients had been SUMMED: grad_scale = 1/4 undoes it
         for gb in gbuf:
             ops.sumsq(gb, acc)
-        np.testing.assert_allclose(float(acc), sum(float((gr.double() ** 2).sum()) for gr in grads), rtol=1e-5)
+        np.testing.assert_allclose(float(acc), 16.0 * sum(float((gr.double() ** 2).sum()) for gr in grads), rtol=1e-5)
         bf = [torch.zeros(n, dtype=torch.bfloat16) for n in sizes]
         for p, gb, m, v, wd, b16 in zip(ps, gbuf, ms, vs, wds, bf):
-            ops.adamw_clip(p, gb, m, v, acc, step=step, lr=1e-2, weight_decay=wd, max_norm=1.0, p_bf16=b16, zero_grad=True)
+            ops.adamw_clip(p, gb, m, v, acc, step=step, lr=1e-2, weight_decay=wd, max_norm=1.0, p_bf16=b16, zero_grad=True,
+                           grad_scale=0.25)
             assert float(gb.abs().max()) == 0.0
         for p, r, b16 in zip(ps, ref, bf):
             np.testing.assert_allclose(p.numpy(), r.detach().numpy(), rtol=2e-5, atol=2e-6)
