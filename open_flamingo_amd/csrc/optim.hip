@@ -27,11 +27,21 @@ OF_GLOBAL void of_sumsq_kernel(OptArgs a) {
     float* red = (float*)of_smem();
     const long nv = a.n >> 2;
     const long stride = (long)of_gdim_x() * 256;
-    float s = 0.f;
-    for (long i = (long)of_bid_x() * 256 + of_tid(); i < nv; i += stride) {
+    float s = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+    long i = (long)of_bid_x() * 256 + of_tid();
+    for (; i + 3 * stride < nv; i += 4 * stride) {   // four independent 16-byte loads in flight per lane
+        const f32x4 g0 = *(const f32x4*)(a.g + i * 4), g1 = *(const f32x4*)(a.g + (i + stride) * 4);
+        const f32x4 g2 = *(const f32x4*)(a.g + (i + 2 * stride) * 4), g3 = *(const f32x4*)(a.g + (i + 3 * stride) * 4);
+        s += g0[0] * g0[0] + g0[1] * g0[1] + g0[2] * g0[2] + g0[3] * g0[3];
+        s2 += g1[0] * g1[0] + g1[1] * g1[1] + g1[2] * g1[2] + g1[3] * g1[3];
+        s3 += g2[0] * g2[0] + g2[1] * g2[1] + g2[2] * g2[2] + g2[3] * g2[3];
+        s4 += g3[0] * g3[0] + g3[1] * g3[1] + g3[2] * g3[2] + g3[3] * g3[3];
+    }
+    for (; i < nv; i += stride) {
         const f32x4 g = *(const f32x4*)(a.g + i * 4);
         s += g[0] * g[0] + g[1] * g[1] + g[2] * g[2] + g[3] * g[3];
     }
+    s += s2 + s3 + s4;
     if (of_bid_x() == 0)
         for (long i = (nv << 2) + of_tid(); i < a.n; i += 256) s += a.g[i] * a.g[i];
     s = of_wave_sum(s);

@@ -33,6 +33,7 @@ class Ops:
         self.lib = lib
         self._stream_fn = stream_fn
         self.gemm_timing = None   # bench.py sets this to a list to collect (key, flops, start_evt, end_evt) per launch
+        self.gemm_timing_only = None   # optional set of (ta, tb, epi) keys: only those launches are bracketed by events
 
     _default = None
 
@@ -94,7 +95,8 @@ class Ops:
                     ws = torch.empty((need + 3) // 4, dtype=F32, device=out.device)
                     self._gemm_ws = ws
                 a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
-        if self.gemm_timing is not None:
+        if self.gemm_timing is not None and (self.gemm_timing_only is None or
+                                             (int(ta), int(tb), epi) in self.gemm_timing_only):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             self._chk(self.lib.of_gemm(C.byref(a), self._stream()), "of_gemm")
