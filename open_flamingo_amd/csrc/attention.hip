@@ -384,31 +384,33 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_dkv_kernel(OfAttnArgs p) {
             load_tile64<DH>(qb, p.ldq, q0, p.Lq, hc, tid, q_n, q_t);
             load_tile64<DH>(dob, p.lddo, q0, p.Lq, hc, tid, do_n, do_t);
             of_sync();
-            f32x4 pm[4], ds[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    s = of_mfma(frag_n<DH>(q_n, t * 16, ks, lane), kf[ks], s);
-                    dp = of_mfma(frag_n<DH>(do_n, t * 16, ks, lane), vf[ks], dp);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int qr = t * 16 + g * 4 + r;
-                    const int lo = s_win[qr * 3 + 0], hi = s_win[qr * 3 + 1], uni = s_win[qr * 3 + 2];
-                    const float lse = s_stat[qr * 2 + 0], delta = s_stat[qr * 2 + 1];
-                    const bool valid = my_key >= lo && my_key < hi;
-                    const float sv = uni ? 0.f : s[r] * p.scale + slope * (float)(my_key - (q0 + qr + p.Lk - p.Lq));
-                    const float pv = valid ? of_exp(sv - lse) : 0.f;
-                    pm[t][r] = pv;
-                    ds[t][r] = uni ? 0.f : pv * (dp[r] - delta);
-                }
-            }
+            // two 16-query tiles at a time (= one 32-deep k-step of the dV / dK MFMAs): keeps only 4 score fragments live
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const s16x8 pf = pack8(pm[2 * s2], pm[2 * s2 + 1]);
-                const s16x8 dsf = pack8(ds[2 * s2], ds[2 * s2 + 1]);
+                f32x4 pm[2], ds[2];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int t = 2 * s2 + tt;
+                    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        s = of_mfma(frag_n<DH>(q_n, t * 16, ks, lane), kf[ks], s);
+                        dp = of_mfma(frag_n<DH>(do_n, t * 16, ks, lane), vf[ks], dp);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int qr = t * 16 + g * 4 + r;
+                        const int lo = s_win[qr * 3 + 0], hi = s_win[qr * 3 + 1], uni = s_win[qr * 3 + 2];
+                        const float lse = s_stat[qr * 2 + 0], delta = s_stat[qr * 2 + 1];
+                        const bool valid = my_key >= lo && my_key < hi;
+                        const float sv = uni ? 0.f : s[r] * p.scale + slope * (float)(my_key - (q0 + qr + p.Lk - p.Lq));
+                        const float pv = valid ? of_exp(sv - lse) : 0.f;
+                        pm[tt][r] = pv;
+                        ds[tt][r] = uni ? 0.f : pv * (dp[r] - delta);
+                    }
+                }
+                const s16x8 pf = pack8(pm[0], pm[1]);
+                const s16x8 dsf = pack8(ds[0], ds[1]);
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) {
                     accv[dt] = of_mfma(frag_t<DH, SAFE>(do_t, s2 * 32, dt * 16, lane), pf, accv[dt]);

@@ -117,5 +117,24 @@ def main():
     print(json.dumps(dict(kernel="perceiver_core_bwd", ms=round(ms, 4))), flush=True)
 
 
+    # frozen-MPT self-attention shape: B=32, 16 heads, head dim 128, L=256, causal + ALiBi, fused qkv layout
+    Bm, Hm, Lm, dh = 32, 16, 256, 128
+    d = Hm * dh
+    qkv = torch.randn(Bm * Lm, 3 * d, device=dev).to(torch.bfloat16)
+    o = torch.empty(Bm * Lm, d, device=dev, dtype=torch.bfloat16)
+    lse = torch.empty(Bm, Hm, Lm, device=dev)
+    slopes = torch.tensor([2.0 ** (-8.0 * (i + 1) / Hm) for i in range(Hm)], device=dev)
+    kw = dict(batch=Bm, Lq=Lm, Lk=Lm, heads=Hm, scale=dh ** -0.5, head_dim=dh, causal=True, alibi_slopes=slopes)
+    ms = timeit(lambda: ops.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, **kw))
+    gf = 4.0 * Bm * Hm * Lm * Lm * dh / 2 / 1e9
+    print(json.dumps(dict(kernel="mpt_causal_alibi_attn_fwd", ms=round(ms, 4), tflops=round(gf / ms, 1))), flush=True)
+    do = torch.randn_like(o)
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(Bm, Hm, Lm, device=dev)
+    ms = timeit(lambda: ops.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, do, dqkv[:, :d], dqkv[:, d:2 * d],
+                                     dqkv[:, 2 * d:], delta, **kw))
+    print(json.dumps(dict(kernel="mpt_causal_alibi_attn_bwd", ms=round(ms, 4), tflops=round(2.5 * gf / ms, 1))), flush=True)
+
+
 if __name__ == "__main__":
     main()
