@@ -60,6 +60,30 @@ OF_DEV void load_tile64(const bf16_t* __restrict__ src, long ld, long row0, long
         if (img_t) *(u32x4*)(img_t + img_t_off<DH>(row, cs * 8)) = v;
     }
 }
+// the same tile load in two halves so that the global loads of tile i+1 can be in flight while tile i is multiplied
+template <int DH>
+OF_DEV void tile_g2r(const bf16_t* __restrict__ src, long ld, long row0, long nrows, int col0, int tid, u32x4 (&r)[DH / 32]) {
+    constexpr int SPR = DH / 8;
+#pragma unroll
+    for (int c = 0; c < SPR / 4; ++c) {
+        int id = c * 256 + tid;
+        int row = id / SPR, cs = id % SPR;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row0 + row < nrows) v = *(const u32x4*)(src + (size_t)(row0 + row) * ld + col0 + cs * 8);
+        r[c] = v;
+    }
+}
+template <int DH>
+OF_DEV void tile_r2s(const u32x4 (&r)[DH / 32], int tid, char* img_n, char* img_t) {
+    constexpr int SPR = DH / 8;
+#pragma unroll
+    for (int c = 0; c < SPR / 4; ++c) {
+        int id = c * 256 + tid;
+        int row = id / SPR, cs = id % SPR;
+        if (img_n) *(u32x4*)(img_n + img_n_off<DH>(row, cs)) = r[c];
+        if (img_t) *(u32x4*)(img_t + img_t_off<DH>(row, cs * 8)) = r[c];
+    }
+}
 template <int DH>
 OF_DEV s16x8 frag_n(const char* img, int row_base, int kk, int lane) {
     return *(const s16x8*)(img + img_n_off<DH>(row_base + (lane & 15), kk * 4 + (lane >> 4)));
@@ -212,16 +236,27 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // K / V tiles are software-pipelined through registers: the global loads of key block kb+1 are issued before key
+    // block kb is multiplied (the kernel is otherwise parked on their latency: SQ_WAIT_ANY was 62 % of the wave cycles)
+    u32x4 rk[DH / 32], rv[DH / 32];
+    if (kb_lo < kb_hi) {
+        tile_g2r<DH>(kb_ptr, p.ldk, (long)kb_lo * 64, p.Lk, hc, tid, rk);
+        tile_g2r<DH>(vb_ptr, p.ldv, (long)kb_lo * 64, p.Lk, hc, tid, rv);
+    }
     for (int kb = kb_lo; kb < kb_hi; ++kb) {
         const long key0 = (long)kb * 64;
         if (!BWD) {
-            load_tile64<DH>(kb_ptr, p.ldk, key0, p.Lk, hc, tid, k_n, nullptr);
-            load_tile64<DH>(vb_ptr, p.ldv, key0, p.Lk, hc, tid, nullptr, v_img);
+            tile_r2s<DH>(rk, tid, k_n, nullptr);
+            tile_r2s<DH>(rv, tid, nullptr, v_img);
         } else {
-            load_tile64<DH>(kb_ptr, p.ldk, key0, p.Lk, hc, tid, k_n, k_t);
-            load_tile64<DH>(vb_ptr, p.ldv, key0, p.Lk, hc, tid, v_img, nullptr);
+            tile_r2s<DH>(rk, tid, k_n, k_t);
+            tile_r2s<DH>(rv, tid, v_img, nullptr);
         }
         of_sync();
+        if (kb + 1 < kb_hi) {
+            tile_g2r<DH>(kb_ptr, p.ldk, key0 + 64, p.Lk, hc, tid, rk);
+            tile_g2r<DH>(vb_ptr, p.ldv, key0 + 64, p.Lk, hc, tid, rv);
+        }
         f32x4 s[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -362,6 +397,14 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_dkv_kernel(OfAttnArgs p) {
         accv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int nqt = (p.Lq + 63) / 64;
+    // head dim 64: Q / dO tiles are software-pipelined through registers like K / V in the q kernel (at head dim 128
+    // the 32 extra VGPRs would spill: that instantiation loads synchronously)
+    constexpr bool PREFETCH = DH == 64;
+    u32x4 rq[DH / 32], rdo[DH / 32];
+    if (PREFETCH) {
+        tile_g2r<DH>(qb, p.ldq, 0, p.Lq, hc, tid, rq);
+        tile_g2r<DH>(dob, p.lddo, 0, p.Lq, hc, tid, rdo);
+    }
     for (int qt = 0; qt < nqt; ++qt) {
         const int q0 = qt * 64;
         if (tid < 64) {
@@ -380,10 +423,23 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_dkv_kernel(OfAttnArgs p) {
         }
         of_sync();
         const int hit = s_flag[0];
+        if (PREFETCH) {
+            if (hit) {
+                tile_r2s<DH>(rq, tid, q_n, q_t);
+                tile_r2s<DH>(rdo, tid, do_n, do_t);
+                of_sync();
+            }
+            if (qt + 1 < nqt) {
+                tile_g2r<DH>(qb, p.ldq, q0 + 64, p.Lq, hc, tid, rq);
+                tile_g2r<DH>(dob, p.lddo, q0 + 64, p.Lq, hc, tid, rdo);
+            }
+        }
         if (hit) {
-            load_tile64<DH>(qb, p.ldq, q0, p.Lq, hc, tid, q_n, q_t);
-            load_tile64<DH>(dob, p.lddo, q0, p.Lq, hc, tid, do_n, do_t);
-            of_sync();
+            if (!PREFETCH) {
+                load_tile64<DH>(qb, p.ldq, q0, p.Lq, hc, tid, q_n, q_t);
+                load_tile64<DH>(dob, p.lddo, q0, p.Lq, hc, tid, do_n, do_t);
+                of_sync();
+            }
             // two 16-query tiles at a time (= one 32-deep k-step of the dV / dK MFMAs): keeps only 4 score fragments live
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
