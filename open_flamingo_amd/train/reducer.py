@@ -25,13 +25,17 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, model, process_group=None, wire_dtype=torch.float32, embedding_rows=None):
+    def __init__(self, model, process_group=None, wire_dtype=torch.float32, embedding_rows=None,
+                 force_collectives=False):
         """model: a Flamingo (or any module exposing .perceiver and .lang_encoder.gated_cross_attn_layers);
         embedding_rows: token ids whose input-embedding gradient rows are kept (media + endofchunk)."""
         self.module = model                      # DDP-style handle (train_utils.py:181 reaches through .module)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.wire_dtype = wire_dtype
+        # run the side-stream collectives even when world_size == 1 (tests: the single-GPU box can then exercise the
+        # exact RCCL / stream code path the multi-GPU runs take)
+        self.force_collectives = bool(force_collectives) and dist.is_initialized()
         self.embedding_rows = list(embedding_rows) if embedding_rows is not None else None
         self._sync = True
         self._pending = []
@@ -79,7 +83,7 @@ class GradReducer:
 
     def _launch(self, flat):
         """all-reduce(avg) of one flat buffer on the side stream (or inline on CPU/gloo)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return
         side = self._side_stream(flat.device)
         if side is not None:

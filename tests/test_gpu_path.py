@@ -112,3 +112,38 @@ def test_frozen_mpt_attention_kernel_matches_hf_eager(ops, d, heads):
     got_o, got_g = run()
     assert PC.rel_err(got_o, ref_o) < 3e-2, PC.rel_err(got_o, ref_o)
     assert PC.rel_err(got_g, ref_g) < 5e-2, PC.rel_err(got_g, ref_g)
+
+
+def test_reducer_rccl_side_stream_path_on_one_gpu():
+    """The multi-GPU code path (RCCL all-reduce of every gradient bucket on a side HIP stream, launched from autograd hooks,
+    joined in finish(), 2-row embedding exchange, fused step epilogue) run with a 1-rank RCCL group: must complete and give
+    the same training trajectory as the plain single-process path."""
+    import os
+    import torch.distributed as dist
+    from open_flamingo_amd.train import step, synthetic, towers
+    from open_flamingo_amd.train.reducer import GradReducer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method="env://", world_size=1, rank=0, device_id=torch.device("cuda", 0))
+    try:
+        out = []
+        for force in (False, True):
+            for wire in ((torch.float32,) if not force else (torch.float32, torch.bfloat16)):
+                model, info = towers.build_flamingo("OF-tiny", device="cuda", seed=0, gates=0.5)
+                model.train()
+                red = GradReducer(model, embedding_rows=[info["media_token_id"], info["eoc_token_id"]],
+                                  force_collectives=force, wire_dtype=wire)
+                red.broadcast_parameters()
+                opt = step.build_optimizer(model, lr=1e-3, reducer=red)
+                batch = synthetic.make_batch(2, 2, 24, info, "cuda", seed=5)
+                b_laion = synthetic.make_batch(2, 1, 16, info, "cuda", seed=6)
+                losses = [float(step.train_step(model, red, opt, batch, info, batch_laion=b_laion)) for _ in range(3)]
+                torch.cuda.synchronize()
+                out.append(losses)
+        base = out[0]
+        for other, tol in ((out[1], 2e-3), (out[2], 2e-2)):      # fp32 wire: same arithmetic; bf16 wire: rounded gradients
+            assert all(abs(a - b) <= tol * abs(a) for a, b in zip(base, other)), (base, other)
+    finally:
+        if created:
+            dist.destroy_process_group()
