@@ -174,8 +174,8 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
     char* smem = of_smem();
     char* k_n = smem;             // K normal image
     char* v_img = smem + IMG;     // fwd: V transpose image;  dq: V normal image
-    char* k_t = smem + 2 * IMG;   // dq only: K transpose image
-    int* s_win = (int*)(smem + 3 * IMG);  // [64][3] lo,hi,uni ; then [2] block range
+    char* k_t = smem + 2 * IMG;   // dq only: K transpose image (the forward launch does not allocate it)
+    int* s_win = (int*)(smem + (BWD ? 3 : 2) * IMG);  // [64][3] lo,hi,uni ; then [2] block range
     const int tid = of_tid(), lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
     const int q0 = of_bid_x() * 64, h = of_bid_y();
     const long batch = of_bid_z();
@@ -542,7 +542,7 @@ namespace {
 template <int DH>
 int launch_fwd(const OfAttnArgs& a, of_stream_t s) {
     of_dim3 grid{(unsigned)((a.Lq + 63) / 64), (unsigned)a.heads, (unsigned)a.batch};
-    const size_t smem = 3 * (64 * DH * 2) + 196 * sizeof(int);
+    const size_t smem = 2 * (64 * DH * 2) + 196 * sizeof(int);
     if (a.safe) return of_launch(of_attn_q_kernel<DH, false, true>, grid, 256, smem, s, a);
     return of_launch(of_attn_q_kernel<DH, false, false>, grid, 256, smem, s, a);
 }
