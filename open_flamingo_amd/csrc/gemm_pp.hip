@@ -250,7 +250,9 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
                 *(f32x4*)(patch + wr_off + (nt * 32 + q * 8) * 4) =
                     f32x4{acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
         of_wave_sync();
-#pragma unroll
+        // not unrolled: four interleaved copies of the erf-GELU math on top of the 128 live accumulator registers spilled
+        // 584 bytes/lane to scratch in the DGELU_DOT instantiation
+#pragma unroll 1
         for (int it = 0; it < 4; ++it) {
             const int r = it * 8 + rd_row;
             const f32x4 v0 = *(const f32x4*)(patch + r * PITCH + rd_col * 4), v1 = *(const f32x4*)(patch + r * PITCH + rd_col * 4 + 16);
