@@ -177,7 +177,8 @@ def main():
             r[2] += 1
         with open(args.gemm_report, "w") as f:
             for (key, shape), (fl, ms, n) in sorted(per.items(), key=lambda kv: -kv[1][1]):
-                f.write(json.dumps({"layout": LAYOUT_NAMES[key[:2]], "epi": EPI_NAMES[key[2]], "MNK": list(shape),
+                f.write(json.dumps({"layout": LAYOUT_NAMES[key[:2]], "epi": EPI_NAMES[key[2]],
+                                    "kernel": "pingpong256" if key[3] else "general128", "MNK": list(shape),
                                     "launches_per_step": n, "ms_per_step": round(ms, 3),
                                     "avg_ms": round(ms / n, 4), "tflops": round(fl / ms / 1e9, 1)}) + "\n")
     if timing:
@@ -189,6 +190,8 @@ def main():
             gsum[2] += 1
         key = max(groups, key=lambda k: groups[k][1])
         fl, ms, n = groups[key]
+        sym = ("of_gemm_pp_kernel" if key[3] else "of_gemm_kernel") + \
+              f"<{str(bool(key[0])).lower()}, {str(bool(key[1])).lower()}, {key[2]}, ...>"
         if survey:      # every of_gemm launch of the last warm-up step
             all_fl = sum(f for _, f, _, _, _ in survey) * args.steps
             all_ms = sum(e0.elapsed_time(e1) for _, _, _, e0, e1 in survey) * args.steps
@@ -198,7 +201,7 @@ def main():
         ach = fl / ms / 1e9
         roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                    "kernel": f"of_gemm[{LAYOUT_NAMES[key[:2]]},{EPI_NAMES[key[2]]}] (of_gemm_pp_kernel / of_gemm_kernel)",
+                    "kernel": f"{sym}  = of_gemm {LAYOUT_NAMES[key[:2]]}, epilogue {EPI_NAMES[key[2]]}",
                     "launches_per_step": n // args.steps, "avg_launch_ms": round(ms / n, 4),
                     "gflop_per_launch": round(fl / n / 1e9, 2),
                     "all_gemm_tflops": round(all_fl / all_ms / 1e9, 1),

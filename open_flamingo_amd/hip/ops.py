@@ -56,6 +56,12 @@ class Ops:
             raise RuntimeError(f"libofhip {what} failed: {_ERR.get(rc, 'hipError ' + str(rc))} ({rc})")
 
     # ------------------------------------------------------------------ GEMM
+    @staticmethod
+    def takes_pingpong_kernel(M, N, K):
+        """Mirror of of_gemm's kernel selection (csrc/gemm.hip): which HIP kernel symbol a launch ends up in -- only
+        used to label timing records (bench.py's roofline names ONE kernel so that it can be checked against rocprofv3)."""
+        return M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and (M // 256) * (N // 256) >= 192
+
     def gemm(self, A, B, out, *, ta=False, tb=False, epi=abi.EPI_STORE_BF16, out2=None, aux=None, gate=None,
              alpha=1.0, beta=0.0, dot=None, safe=0):
         """acc[m][n] = sum_k A(m,k) B(n,k); A is (M,K) or, with ta, (K,M); B is (N,K) or, with tb, (K,N)."""
@@ -96,12 +102,14 @@ class Ops:
                     self._gemm_ws = ws
                 a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
         if self.gemm_timing is not None and (self.gemm_timing_only is None or
-                                             (int(ta), int(tb), epi) in self.gemm_timing_only):
+                                             (int(ta), int(tb), epi, self.takes_pingpong_kernel(M, N, K))
+                                             in self.gemm_timing_only):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             self._chk(self.lib.of_gemm(C.byref(a), self._stream()), "of_gemm")
             e1.record()
-            self.gemm_timing.append(((int(ta), int(tb), epi), 2.0 * M * N * K, (M, N, K), e0, e1))
+            self.gemm_timing.append(((int(ta), int(tb), epi, self.takes_pingpong_kernel(M, N, K)), 2.0 * M * N * K,
+                                     (M, N, K), e0, e1))
             return out
         self._chk(self.lib.of_gemm(C.byref(a), self._stream()), "of_gemm")
         return out
