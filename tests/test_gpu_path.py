@@ -147,3 +147,63 @@ def test_reducer_rccl_side_stream_path_on_one_gpu():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_xattn_single_image_laion_shape(ops):
+    """T = 1 (the LAION pass, train_utils.py:96): every token after the first <image> attends to the only media item."""
+    ml = torch.zeros(2, 32, dtype=torch.bool)
+    ml[:, 0] = True
+    PC.check_xattn(ops, "cuda", B=2, L=32, T=1, n=64, heads=8, d=256, Dv=128, media_locs=ml, seed=11)
+
+
+def test_full_size_properties_cfg2(ops):
+    """BASELINE config 2 sizes (B=32, T=2, L=256, OF-3B widths), where the CPU oracle would take minutes: size-independent
+    properties of the reference instead.
+      * gates = 0 (the reference's init, helpers.py:255,258): the block is the identity, every non-gate gradient is
+        exactly 0 and the gate gradients are not (SURVEY.md appendix A);
+      * the Perceiver treats media items independently: permuting the (b, T) items permutes the outputs;
+      * rows before the first <image> (text_time == 0) get exactly zero attention output, so with ff_gate = 0 they pass
+        through unchanged whatever attn_gate is (helpers.py:223-229)."""
+    from open_flamingo_amd.hip import path
+    from tests.path_checks import make_bf16_weights
+    from oracle import flamingo_oracle as O
+    torch.manual_seed(0)
+    B, T, L, n, heads, d, Dv = 32, 2, 256, 64, 8, 2048, 1024
+    m = O.OracleGatedCrossAttentionBlock(dim=d, dim_visual=Dv)
+    P = {k: v.detach().cuda().contiguous() for k, v in m.named_parameters()}
+    W = make_bf16_weights(ops, P)
+    x = torch.randn(B * L, d, device="cuda")
+    media = torch.randn(B * T * n, Dv, device="cuda").to(torch.bfloat16)
+    ml = torch.zeros(B, L, dtype=torch.uint8, device="cuda")
+    ml[:, 7] = 1
+    ml[:, L // 2] = 1
+    tt = torch.empty(B, L, dtype=torch.int32, device="cuda")
+    ops.text_time(ml, tt, L, False)
+    kw = dict(B=B, L=L, T=T, n=n, heads=heads, only_immediate=True)
+    y, S = path.xattn_block_fwd(ops, P, W, x, media, tt, **kw)
+    assert torch.equal(y, x), "gates = 0 must make the block an exact identity"
+    dy = torch.randn_like(x)
+    dx, dmedia, g = path.xattn_block_bwd(ops, P, W, S, media, tt, dy, **kw)
+    assert torch.equal(dx, dy)
+    assert float(dmedia.abs().max()) == 0.0
+    for k, v in g.items():
+        if k.endswith("_gate"):
+            assert float(v.abs().max()) > 0.0, k
+        else:
+            assert float(v.abs().max()) == 0.0, k
+    P["attn_gate"].fill_(0.7)
+    y2, _ = path.xattn_block_fwd(ops, P, W, x, media, tt, **kw)
+    y2, xv = y2.view(B, L, d), x.view(B, L, d)
+    assert torch.equal(y2[:, :7], xv[:, :7]), "tokens before the first <image> must be untouched"
+    assert not torch.equal(y2[:, 7:], xv[:, 7:])
+    # Perceiver: permutation equivariance over media items
+    pm = O.OraclePerceiverResampler(dim=Dv)
+    PP = {k: v.detach().cuda().contiguous() for k, v in pm.named_parameters()}
+    WP = make_bf16_weights(ops, PP)
+    N, Fv = B * T, 256
+    feats = torch.randn(N, Fv, Dv, device="cuda")
+    perm = torch.randperm(N, device="cuda")
+    pk = dict(N=N, Fv=Fv, n=n, heads=heads, depth=6)
+    out, _ = path.perceiver_fwd(ops, PP, WP, feats.view(N * Fv, Dv), **pk)
+    out_p, _ = path.perceiver_fwd(ops, PP, WP, feats[perm].reshape(N * Fv, Dv).contiguous(), **pk)
+    assert torch.equal(out.view(N, n, Dv)[perm], out_p.view(N, n, Dv))
