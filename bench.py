@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--lm-attention", default="libofhip", choices=["libofhip", "sdpa", "eager"],
                     help="self-attention of the frozen MPT blocks: libofhip causal+ALiBi flash kernel, torch SDPA with a "
                          "bias, or HF's eager chain")
+    ap.add_argument("--tower-layernorm", default="libofhip", choices=["libofhip", "eager"],
+                    help="LayerNorms in front of the frozen towers' Linear layers: libofhip (bf16 operand written directly) or eager")
     ap.add_argument("--torch-optimizer", action="store_true",
                     help="clip_grad_norm_ + torch.optim.AdamW(fused) instead of the libofhip step epilogue")
     ap.add_argument("--gemm-report", default=None, help="write a per-(layout,epilogue,shape) GEMM time table (JSON lines)")
@@ -118,7 +120,8 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     model, info = towers.build_flamingo(args.family, device=device, seed=0, gates=0.5, frozen_bf16=not args.frozen_fp32,
-                                        fused_lm_attention=args.lm_attention if args.lm_attention != "eager" else False)
+                                        fused_lm_attention=args.lm_attention if args.lm_attention != "eager" else False,
+                                        tower_layernorm=args.tower_layernorm)
     model.train()
     reducer = GradReducer(model, wire_dtype=torch.bfloat16 if args.wire_bf16 else torch.float32,
                           embedding_rows=[info["media_token_id"], info["eoc_token_id"]])
@@ -220,7 +223,7 @@ def main():
                           "global_batch": args.batch * world, "images_per_step": images, "seq_len": args.L,
                           "parallelism": f"dp{world}",
                           "frozen_tower_weights": "fp32 (re-cast by autocast)" if args.frozen_fp32 else "bf16 copies held",
-                          "frozen_lm_attention": args.lm_attention,
+                          "frozen_lm_attention": args.lm_attention, "frozen_tower_layernorm": args.tower_layernorm,
                           "grad_wire_dtype": "bf16" if args.wire_bf16 else "fp32"},
                "loss": None if loss is None else round(float(loss), 4)}
         if roofline is not None:

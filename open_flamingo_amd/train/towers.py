@@ -174,6 +174,76 @@ def _mpt_attention_fused_forward(self, hidden_states, position_bias, past_key_va
     return self.out_proj(ctx.transpose(1, 2).reshape(b, l, -1)), None
 
 
+class _FrozenLayerNorm(torch.autograd.Function):
+    """A frozen tower's LayerNorm in front of a Linear, under amp_bf16: eager PyTorch normalises in fp32, writes fp32, and
+    autocast then re-reads it to cast to bf16 (two passes forward; cast-back + LayerNorm backward going back).  libofhip's
+    kernel writes the bf16 operand directly (one pass) and its backward takes the bf16 gradient as it is; no parameter
+    gradients (the tower is frozen).  Same statistics (fp32), same single bf16 rounding of the output."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        from ..hip.ops import Ops
+        ops = Ops.default()
+        dim = x.shape[-1]
+        x2 = x.reshape(-1, dim)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        y = torch.empty(x2.shape, dtype=torch.bfloat16, device=x.device)
+        stats = torch.empty(x2.shape[0], 2, dtype=torch.float32, device=x.device)
+        ops.ln_fwd(x2, w, b, y, stats)
+        ctx.save_for_backward(x2, stats, w)
+        ctx.shape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from ..hip.ops import Ops
+        ops = Ops.default()
+        x2, stats, w = ctx.saved_tensors
+        dy2 = dy.reshape(x2.shape)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dx = torch.empty_like(x2)
+        ops.ln_bwd(dy2, x2, stats, w, dx=dx)
+        return dx.view(ctx.shape), None, None
+
+
+def _layernorm_libofhip_forward(self, x):
+    w = self.weight
+    if (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and w is not None and not w.requires_grad
+            and w.dtype == torch.float32 and abs(self.eps - 1e-5) < 1e-12 and len(self.normalized_shape) == 1
+            and x.shape[-1] % 8 == 0 and x.shape[-1] <= 4096
+            and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+        b = self.bias
+        if b is None:          # HF MPT drops the LayerNorm bias
+            b = self.__dict__.get("_of_zero_bias")
+            if b is None or b.device != w.device:
+                b = self.__dict__["_of_zero_bias"] = torch.zeros_like(w)
+        return _FrozenLayerNorm.apply(x, w, b)
+    return self._of_eager_forward(x)
+
+
+_LN_IN_FRONT_OF_LINEAR = ("norm_1", "norm_2", "norm_f",                                  # HF MPT
+                          "layer_norm1", "layer_norm2",                                   # HF CLIP encoder layers
+                          "input_layernorm", "post_attention_layernorm", "final_layer_norm")  # HF GPT-NeoX
+
+
+def use_libofhip_layernorm(module):
+    """Route the frozen towers' LayerNorms whose only consumers are Linear layers through libofhip (see
+    _FrozenLayerNorm).  Modules keep their class, parameters and state-dict keys; anything the kernel does not cover
+    (trainable weights, no autocast, CPU, other eps) falls through to the original forward.  CLIP's pre/post LayerNorms
+    feed the fp32 residual stream / the Perceiver and are left alone."""
+    import types
+    n = 0
+    for name, mod in module.named_modules():
+        if isinstance(mod, nn.LayerNorm) and name.rsplit(".", 1)[-1] in _LN_IN_FRONT_OF_LINEAR \
+                and not hasattr(mod, "_of_eager_forward"):
+            mod._of_eager_forward = mod.forward
+            mod.forward = types.MethodType(_layernorm_libofhip_forward, mod)
+            n += 1
+    return n
+
+
 def use_fused_attention_in_mpt(lm, kernel="sdpa"):
     """kernel = "sdpa": torch's fused attention with an additive bias (any mask HF builds).  kernel = "libofhip": this
     repository's windowed flash-attention kernel as causal + ALiBi self-attention (bf16 on an AMD GPU; batches must be
@@ -227,7 +297,7 @@ def hold_frozen_linears_in_bf16(model):
 
 def build_flamingo(family: str = "OF-3B", device="cuda", seed: int = 0, gates: float = 0.5, vision_kw=None,
                    freeze_lm_embeddings: bool = False, verbose: bool = False, frozen_bf16: bool = False,
-                   fused_lm_attention=True):
+                   fused_lm_attention=True, tower_layernorm="eager"):
     """Random-init Flamingo of the given family, assembled through the factory path, gates set to ``gates``
     (their init value 0 makes the hot path an exact no-op with zero weight gradients -- SURVEY.md section 7)."""
     from ..src.factory import assemble_flamingo
@@ -245,6 +315,9 @@ def build_flamingo(family: str = "OF-3B", device="cuda", seed: int = 0, gates: f
                                   verbose=verbose)
     if frozen_bf16:
         hold_frozen_linears_in_bf16(model)
+    if tower_layernorm == "libofhip":
+        use_libofhip_layernorm(model.vision_encoder)
+        use_libofhip_layernorm(model.lang_encoder)
     with torch.no_grad():
         for blk in model.lang_encoder.gated_cross_attn_layers:
             if blk is not None:

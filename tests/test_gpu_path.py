@@ -112,6 +112,12 @@ def test_frozen_mpt_attention_kernel_matches_hf_eager(ops, d, heads):
     got_o, got_g = run()
     assert PC.rel_err(got_o, ref_o) < 3e-2, PC.rel_err(got_o, ref_o)
     assert PC.rel_err(got_g, ref_g) < 5e-2, PC.rel_err(got_g, ref_g)
+    # ... and, on top, the frozen LayerNorms in front of the Linear layers on the libofhip kernel
+    lm.requires_grad_(False)
+    assert towers.use_libofhip_layernorm(lm) == 2 * 2 + 1
+    got_o, got_g = run()
+    assert PC.rel_err(got_o, ref_o) < 3e-2, PC.rel_err(got_o, ref_o)
+    assert PC.rel_err(got_g, ref_g) < 5e-2, PC.rel_err(got_g, ref_g)
 
 
 def test_reducer_rccl_side_stream_path_on_one_gpu():
