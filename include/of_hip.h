@@ -180,6 +180,9 @@ int of_add_embs(const void* x, int x_f32, const float* e1, long inner1, int oute
 /* Gradient of one table: dst[o][c] += sum over rows r with (r / inner) % outer == o of src[r][c].  dst fp32. */
 int of_reduce_rows_strided(const void* src, int src_f32, long rows, int dim, long inner, int outer, float* dst,
                            void* stream);
+/* y = x * sigmoid(1.702 x), bf16 -> bf16: the "quick GELU" of the frozen CLIP tower's MLP (HF runs it as
+ * three element-wise passes).  Forward only: the vision tower runs under no_grad (flamingo.py:194-195). */
+int of_quick_gelu(const uint16_t* x, uint16_t* y, long n, void* stream);
 /* out(T) = a(T) + b(T) */
 int of_add(const void* a, const void* b, void* out, int f32, long n, void* stream);
 

@@ -45,6 +45,30 @@ OF_GLOBAL void of_cast_b2f_kernel(EwArgs a) {
         for (long i = (nv << 3) + of_tid(); i < a.n; i += 256) ((float*)a.out)[i] = of_bf16_to_f32(((const bf16_t*)a.a)[i]);
     }
 }
+// y = x * sigmoid(1.702 x)  ("quick GELU" of CLIP's MLP), bf16 -> bf16, 8 elements per lane
+OF_GLOBAL void of_quick_gelu_kernel(EwArgs a) {
+    const long nv = a.n >> 3;
+    const long stride = (long)of_gdim_x() * 256;
+    for (long i = (long)of_bid_x() * 256 + of_tid(); i < nv; i += stride) {
+        const u32x4 r = *(const u32x4*)((const bf16_t*)a.a + i * 8);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] = of_bf16_to_f32((bf16_t)(r[e] & 0xffff));
+            v[2 * e + 1] = of_bf16_to_f32((bf16_t)(r[e] >> 16));
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * of_rcp(1.0f + of_exp(-1.702f * v[e]));
+        *(u32x4*)((bf16_t*)a.out + i * 8) = u32x4{of_pack_bf16(v[0], v[1]), of_pack_bf16(v[2], v[3]), of_pack_bf16(v[4], v[5]),
+                                                 of_pack_bf16(v[6], v[7])};
+    }
+    if (of_bid_x() == 0) {
+        for (long i = (nv << 3) + of_tid(); i < a.n; i += 256) {
+            const float x = of_bf16_to_f32(((const bf16_t*)a.a)[i]);
+            ((bf16_t*)a.out)[i] = of_f32_to_bf16(x * of_rcp(1.0f + of_exp(-1.702f * x)));
+        }
+    }
+}
 OF_GLOBAL void of_add_kernel(EwArgs a) {
     const long stride = (long)of_gdim_x() * 256;
     if (a.f32) {
@@ -192,4 +216,12 @@ extern "C" int of_reduce_rows_strided(const void* src, int src_f32, long rows, i
     const long total = (long)outer * dim;
     return of_launch(of_reduce_rows_strided_kernel, of_dim3{(unsigned)((total + 255) / 256), 1, 1}, 256, 0,
                      (of_stream_t)stream, a);
+}
+
+extern "C" int of_quick_gelu(const uint16_t* x, uint16_t* y, long n, void* stream) {
+    if (!x || !y || n <= 0) return OF_E_ARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return OF_E_ALIGN;
+    EwArgs a{};
+    a.a = x; a.out = y; a.n = n;
+    return of_launch(of_quick_gelu_kernel, of_dim3{grid_for(n >> 3), 1, 1}, 256, 0, (of_stream_t)stream, a);
 }

@@ -66,6 +66,7 @@ PROTOTYPES = {
     "of_broadcast_rows": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_long, C.c_long, C.c_int, vp]),
     "of_reduce_rows": (C.c_int, [vp, C.c_int, C.c_long, C.c_int, vp, C.c_int, vp]),
     "of_add": (C.c_int, [vp, vp, vp, C.c_int, C.c_long, vp]),
+    "of_quick_gelu": (C.c_int, [vp, vp, C.c_long, vp]),
     "of_sumsq": (C.c_int, [vp, C.c_long, vp, vp]),
     "of_adamw_clip": (C.c_int, [vp, vp, vp, vp, vp, C.c_long, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_float, C.c_float, C.c_int, C.c_int, vp]),

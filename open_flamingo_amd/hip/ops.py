@@ -246,6 +246,12 @@ class Ops:
                                          sumsq.data_ptr(), max_norm, lr, betas[0], betas[1], eps, weight_decay,
                                          grad_scale, step, int(zero_grad), self._stream()), "of_adamw_clip")
 
+    def quick_gelu(self, x, out=None):
+        assert x.dtype == BF16 and x.is_contiguous()
+        out = torch.empty_like(x) if out is None else out
+        self._chk(self.lib.of_quick_gelu(x.data_ptr(), out.data_ptr(), x.numel(), self._stream()), "of_quick_gelu")
+        return out
+
     def add(self, a, b, out):
         assert a.dtype == b.dtype == out.dtype and a.is_contiguous() and b.is_contiguous() and out.is_contiguous()
         self._chk(self.lib.of_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), _is_f32(a), a.numel(), self._stream()),

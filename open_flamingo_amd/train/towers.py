@@ -244,6 +244,26 @@ def use_libofhip_layernorm(module):
     return n
 
 
+def _quick_gelu_libofhip_forward(self, x):
+    if x.is_cuda and x.dtype == torch.bfloat16 and not (torch.is_grad_enabled() and x.requires_grad):
+        from ..hip.ops import Ops
+        return Ops.default().quick_gelu(x if x.is_contiguous() else x.contiguous())
+    return self._of_eager_forward(x)
+
+
+def use_libofhip_quick_gelu(module):
+    """CLIP's MLP activation x * sigmoid(1.702 x) as one pass (libofhip) instead of HF's three element-wise kernels; only
+    where no gradient is needed (the vision tower runs under no_grad), otherwise the original forward."""
+    import types
+    n = 0
+    for mod in module.modules():
+        if type(mod).__name__ == "QuickGELUActivation" and not hasattr(mod, "_of_eager_forward"):
+            mod._of_eager_forward = mod.forward
+            mod.forward = types.MethodType(_quick_gelu_libofhip_forward, mod)
+            n += 1
+    return n
+
+
 def use_fused_attention_in_mpt(lm, kernel="sdpa"):
     """kernel = "sdpa": torch's fused attention with an additive bias (any mask HF builds).  kernel = "libofhip": this
     repository's windowed flash-attention kernel as causal + ALiBi self-attention (bf16 on an AMD GPU; batches must be
@@ -315,9 +335,10 @@ def build_flamingo(family: str = "OF-3B", device="cuda", seed: int = 0, gates: f
                                   verbose=verbose)
     if frozen_bf16:
         hold_frozen_linears_in_bf16(model)
-    if tower_layernorm == "libofhip":
+    if tower_layernorm == "libofhip":      # the element-wise pieces of the frozen towers on libofhip
         use_libofhip_layernorm(model.vision_encoder)
         use_libofhip_layernorm(model.lang_encoder)
+        use_libofhip_quick_gelu(model.vision_encoder)
     with torch.no_grad():
         for blk in model.lang_encoder.gated_cross_attn_layers:
             if blk is not None:

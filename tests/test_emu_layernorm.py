@@ -139,3 +139,12 @@ def test_step_epilogue_matches_torch_adamw_with_clipping():
         for p, r, b16 in zip(ps, ref, bf):
             np.testing.assert_allclose(p.numpy(), r.detach().numpy(), rtol=2e-5, atol=2e-6)
             assert torch.equal(b16, p.to(torch.bfloat16))
+
+
+def test_quick_gelu():
+    L = H.lib()
+    x = (torch.randn(1003, generator=torch.Generator().manual_seed(2)) * 3).to(torch.bfloat16)
+    y = torch.zeros_like(x)
+    assert L.of_quick_gelu(H.ptr(x), H.ptr(y), x.numel(), None) == 0
+    want = (x.float() * torch.sigmoid(1.702 * x.float())).to(torch.bfloat16)
+    np.testing.assert_allclose(y.float().numpy(), want.float().numpy(), rtol=1e-2, atol=1e-3)
