@@ -55,8 +55,9 @@ class GradReducer:
         for kind, params in groups:
             if not params:
                 continue
-            # every parameter starts on a 256-byte boundary (64 fp32 = 128 bytes of bf16: whole L2 lines for the operand DMA): the fused step epilogue keeps fp32 master / bf16
-            # operand copies at the same offsets and the GEMM kernels need 16-byte aligned operands
+            # every parameter starts on a 256-byte boundary (64 fp32 = 128 bytes of bf16: whole L2 lines for the
+            # operand DMA): the fused step epilogue keeps fp32 master / bf16 operand copies at the same offsets and
+            # the GEMM kernels need 16-byte aligned operands
             offsets, n = [], 0
             for p in params:
                 offsets.append(n)
@@ -70,6 +71,10 @@ class GradReducer:
             for p in b["params"]:
                 self._param_bucket[p] = bi
                 p.register_post_accumulate_grad_hook(self._hook)
+                # the libofhip backward (src/helpers.py) accumulates straight into the bucket view and then calls
+                # _of_on_grad itself, instead of returning a fresh gradient for autograd to add (one add kernel per
+                # parameter per backward).  Modules that do not know the protocol ignore the attributes.
+                p._of_inplace_grad, p._of_on_grad = True, self._hook
         if self.embedding is not None:
             self.embedding.register_post_accumulate_grad_hook(self._emb_hook)
 

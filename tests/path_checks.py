@@ -14,12 +14,19 @@ def rel_err(got, want):
     return (got - want).abs().max().item() / (want.abs().max().item() + 1e-12)
 
 
+def _prefilled_sinks(P, dev, seed):
+    """In-place accumulation targets holding a known non-zero value (as if an earlier backward had run)."""
+    g = torch.Generator().manual_seed(900 + seed)
+    base = {k: torch.randn(tuple(v.shape), generator=g) for k, v in P.items()}
+    return base, {k: v.clone().to(dev).contiguous() for k, v in base.items()}
+
+
 def make_bf16_weights(ops, P):
     return {k: ops.to_bf16(v.contiguous()) for k, v in P.items() if v.dim() == 2 and not k.endswith("latents") and "embs" not in k}
 
 
 def check_xattn(ops, dev, *, B=2, L=40, T=2, n=16, heads=2, d=64, Dv=48, stream_dtype=torch.float32, media_locs=None,
-                only_immediate=True, gates=(0.6, -0.4), seed=0, fwd_tol=1e-2, bwd_tol=3e-2, safe=0):
+                only_immediate=True, gates=(0.6, -0.4), seed=0, fwd_tol=1e-2, bwd_tol=3e-2, safe=0, inplace=False):
     m = O.OracleGatedCrossAttentionBlock(dim=d, dim_visual=Dv, heads=heads, dim_head=64,
                                          only_attend_immediate_media=only_immediate)
     st = O.seeded_state({k: tuple(v.shape) for k, v in m.state_dict().items()}, 100 + seed)
@@ -52,7 +59,11 @@ def check_xattn(ops, dev, *, B=2, L=40, T=2, n=16, heads=2, d=64, Dv=48, stream_
     kw = dict(B=B, L=L, T=T, n=n, heads=heads, only_immediate=only_immediate, safe=safe)
     y, S = path.xattn_block_fwd(ops, P, W, xd, media_bf, tt, **kw)
     dy = w.to(dev).to(stream_dtype).reshape(B * L, d).contiguous()
-    dx, dmedia, grads = path.xattn_block_bwd(ops, P, W, S, media_bf, tt, dy, **kw)
+    base, sinks = _prefilled_sinks(P, dev, seed) if inplace else (None, None)
+    dx, dmedia, grads = path.xattn_block_bwd(ops, P, W, S, media_bf, tt, dy, sinks=sinks, **kw)
+    if inplace:     # the kernels must have ADDED the gradient to what the sink held, in the sink itself
+        assert all(grads[k] is sinks[k] for k in P)
+        grads = {k: grads[k].cpu() - base[k] for k in P}
     errs = {"y": rel_err(y.reshape(B, L, d), yo.detach())}
     errs["dx"] = rel_err(dx.reshape(B, L, d), xo.grad)
     errs["dmedia"] = rel_err(dmedia.reshape(B, T, n, Dv), mo.grad)
@@ -64,7 +75,7 @@ def check_xattn(ops, dev, *, B=2, L=40, T=2, n=16, heads=2, d=64, Dv=48, stream_
 
 
 def check_perceiver(ops, dev, *, b=1, T=2, Fv=24, n=16, heads=2, D=64, depth=2, stream_dtype=torch.float32, seed=0,
-                    fwd_tol=1e-2, bwd_tol=3e-2, need_dx=True, safe=0, frames=1, embs=False):
+                    fwd_tol=1e-2, bwd_tol=3e-2, need_dx=True, safe=0, frames=1, embs=False, inplace=False):
     m = O.OraclePerceiverResampler(dim=D, depth=depth, dim_head=64, heads=heads, num_latents=n,
                                    max_num_media=(T + 1 if embs else None), max_num_frames=(frames + 1 if embs else None))
     st = O.seeded_state({k: tuple(v.shape) for k, v in m.state_dict().items()}, 300 + seed)
@@ -83,7 +94,11 @@ def check_perceiver(ops, dev, *, b=1, T=2, Fv=24, n=16, heads=2, D=64, depth=2, 
     kw = dict(N=N, Fv=Fv, n=n, heads=heads, depth=depth, safe=safe, T=T, frames=frames)
     y, S = path.perceiver_fwd(ops, P, W, xd, **kw)
     dy = w.to(dev).to(stream_dtype).reshape(N * n, D).contiguous()
-    dx, grads = path.perceiver_bwd(ops, P, W, S, dy, need_dx=need_dx, **kw)
+    base, sinks = _prefilled_sinks(P, dev, seed) if inplace else (None, None)
+    dx, grads = path.perceiver_bwd(ops, P, W, S, dy, need_dx=need_dx, sinks=sinks, **kw)
+    if inplace:
+        assert all(grads[k] is sinks[k] for k in P)
+        grads = {k: grads[k].cpu() - base[k] for k in P}
     errs = {"y": rel_err(y.reshape(b, T, n, D), yo.detach())}
     if need_dx:
         errs["dx"] = rel_err(dx.reshape(b, T, frames, Fv // frames, D), xo.grad)

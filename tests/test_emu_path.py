@@ -37,3 +37,9 @@ def test_perceiver_path_with_frame_and_media_time_embs():
     """helpers.py:117-119,123-124: max_num_frames / max_num_media position tables (F=2 frames)."""
     errs = PC.check_perceiver(H.emu_ops(), "cpu", T=3, Fv=32, frames=2, embs=True, seed=4)
     assert "dframe_embs" in errs and "dmedia_time_embs" in errs
+
+
+def test_paths_accumulate_into_existing_grads():
+    """Gradient sinks (path._GradOut): every parameter gradient is added to the pre-existing buffer, none overwritten."""
+    PC.check_xattn(H.emu_ops(), "cpu", inplace=True, seed=5)
+    PC.check_perceiver(H.emu_ops(), "cpu", T=3, Fv=32, frames=2, embs=True, inplace=True, seed=6)

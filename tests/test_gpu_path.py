@@ -47,6 +47,12 @@ def test_perceiver_of3b_dims(ops):
     print({k: f"{v:.1e}" for k, v in errs.items()})
 
 
+def test_paths_accumulate_into_existing_grads(ops):
+    PC.check_xattn(ops, "cuda", B=2, L=64, T=2, n=64, heads=8, d=512, Dv=256, inplace=True, seed=5)
+    PC.check_perceiver(ops, "cuda", T=3, Fv=32, frames=2, embs=True, inplace=True, seed=6)
+    PC.check_perceiver(ops, "cuda", b=2, T=2, Fv=256, n=64, heads=8, D=1024, depth=2, inplace=True, seed=7)
+
+
 def test_perceiver_frame_and_media_time_embs(ops):
     errs = PC.check_perceiver(ops, "cuda", T=3, Fv=32, frames=2, embs=True, seed=4)
     assert "dframe_embs" in errs and "dmedia_time_embs" in errs
@@ -153,6 +159,41 @@ def test_reducer_rccl_side_stream_path_on_one_gpu():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_inplace_gradient_accumulation_matches_autograd():
+    """With a GradReducer the libofhip backward adds parameter gradients straight into the bucket views (and returns
+    None to autograd); two accumulated backward passes must give what plain autograd accumulation gives, the views must
+    still be attached to the buckets, and the reducer's ready-count callback must have fired once per parameter."""
+    from open_flamingo_amd.train import step, synthetic, towers
+    from open_flamingo_amd.train.reducer import GradReducer
+    got = []
+    for use_reducer in (False, True):
+        model, info = towers.build_flamingo("OF-tiny", device="cuda", seed=0, gates=0.5)
+        model.train()
+        red = GradReducer(model, embedding_rows=None) if use_reducer else None
+        fired = []
+        if red is not None:
+            for b in red.buckets:
+                for p in b["params"]:
+                    assert p._of_inplace_grad
+                    p._of_on_grad = (lambda q, f=p._of_on_grad: (fired.append(q), f(q))[1])
+        b1 = synthetic.make_batch(2, 1, 16, info, "cuda", seed=6)
+        b2 = synthetic.make_batch(2, 2, 24, info, "cuda", seed=5)
+        for b in (b1, b2):
+            step.forward_loss(model, b, info).backward()
+        torch.cuda.synchronize()
+        hot = {k: p for k, p in model.named_parameters() if p.requires_grad and ("gated_cross_attn" in k or "perceiver" in k)}
+        if red is not None:
+            n_params = sum(len(b["params"]) for b in red.buckets)
+            assert len(fired) == 2 * n_params and len({id(q) for q in fired}) == n_params
+            for b in red.buckets:
+                for p, off in zip(b["params"], b["offsets"]):
+                    assert p.grad.data_ptr() == b["flat"].data_ptr() + 4 * off
+        got.append({k: p.grad.detach().float().cpu() for k, p in hot.items()})
+    for k in got[0]:
+        scale = got[0][k].abs().max().item() + 1e-12
+        assert (got[0][k] - got[1][k]).abs().max().item() <= 2e-3 * scale + 1e-7, k
 
 
 def test_xattn_single_image_laion_shape(ops):
