@@ -53,8 +53,18 @@ class _GradOut:
 # =================================================================================================
 # GatedCrossAttentionBlock
 # =================================================================================================
-def xattn_block_fwd(ops, P, W, x, media_bf, tt, *, B, L, T, n, heads, only_immediate, safe=0):
-    """x (B*L, d) stream dtype; media_bf (B*T*n, Dv) bf16; tt (B, L) int32 or None.  Returns (y, saved)."""
+def xattn_project_media(ops, W, media_bf, heads):
+    """k | v = to_kv(media) (helpers.py:189), (B*T*n, 2*inner) bf16.  Depends on the media and the block's weights only,
+    so the decode loop computes it once per block and prompt instead of once per generated token."""
+    kv = _e((media_bf.shape[0], 2 * heads * 64), BF16, media_bf.device)
+    ops.gemm(media_bf, W["attn.to_kv.weight"], kv)
+    return kv
+
+
+def xattn_block_fwd(ops, P, W, x, media_bf, tt, *, B, L, T, n, heads, only_immediate, safe=0, kv=None, keep=True):
+    """x (B*L, d) stream dtype; media_bf (B*T*n, Dv) bf16; tt (B, L) int32 or None.  Returns (y, saved).
+    kv: projected media from xattn_project_media (else computed here).  keep=False (inference): nothing is saved for a
+    backward -- the pre-GELU activations are not written -- and saved is None."""
     dev = x.device
     rows, d = x.shape
     inner = heads * 64
@@ -65,8 +75,8 @@ def xattn_block_fwd(ops, P, W, x, media_bf, tt, *, B, L, T, n, heads, only_immed
     ops.ln_fwd(x, P["attn.norm.weight"], P["attn.norm.bias"], xn, st1)
     q = _e((rows, inner), BF16, dev)
     ops.gemm(xn, W["attn.to_q.weight"], q)                                   # to_q
-    kv = _e((B * T * n, 2 * inner), BF16, dev)
-    ops.gemm(media_bf, W["attn.to_kv.weight"], kv)                           # to_kv (k | v fused)
+    if kv is None:
+        kv = xattn_project_media(ops, W, media_bf, heads)                    # to_kv (k | v fused)
     o = _e((rows, inner), BF16, dev)
     lse = _e((B, heads, L), F32, dev)
     ops.attn_fwd(q, kv[:, :inner], kv[:, inner:], o, lse, batch=B, Lq=L, Lk=T * n, heads=heads, text_time=tt,
@@ -77,11 +87,13 @@ def xattn_block_fwd(ops, P, W, x, media_bf, tt, *, B, L, T, n, heads, only_immed
     u = _e((rows, d), BF16, dev)
     st2 = _e((rows, 2), F32, dev)
     ops.ln_fwd(y1, P["ff.0.weight"], P["ff.0.bias"], u, st2)
-    a = _e((rows, hid), BF16, dev)
+    a = _e((rows, hid), BF16, dev) if keep else None
     b = _e((rows, hid), BF16, dev)
     ops.gemm(u, W["ff.1.weight"], b, epi=EPI_GELU, out2=a)                   # up-projection + erf GELU
     y2 = torch.empty_like(x)
     ops.gemm(b, W["ff.3.weight"], y2, epi=EPI_GATE_RESID, aux=y1, gate=P["ff_gate"])  # down, *tanh(gate), +y1
+    if not keep:
+        return y2, None
     saved = dict(x=x, xn=xn, st1=st1, q=q, kv=kv, o=o, lse=lse, y1=y1, u=u, st2=st2, a=a, b=b)
     return y2, saved
 
@@ -146,7 +158,7 @@ def xattn_block_bwd(ops, P, W, S, media_bf, tt, dy, *, B, L, T, n, heads, only_i
 # =================================================================================================
 # PerceiverResampler
 # =================================================================================================
-def perceiver_fwd(ops, P, W, x, *, N, Fv, n, heads, depth, T=1, frames=1, safe=0):
+def perceiver_fwd(ops, P, W, x, *, N, Fv, n, heads, depth, T=1, frames=1, safe=0, keep=True):
     """x (N*Fv, D) stream dtype (already flattened 'b T (F v) d' rows, N = b*T, Fv = frames*v); returns
     (out (N*n, D) stream, saved).  frame_embs / media_time_embs (helpers.py:117-119,123-124) are added when present
     in P; T and frames give the row structure they index."""
@@ -185,17 +197,20 @@ def perceiver_fwd(ops, P, W, x, *, N, Fv, n, heads, depth, T=1, frames=1, safe=0
         u = _e((N * n, D), BF16, dev)
         st_f = _e((N * n, 2), F32, dev)
         ops.ln_fwd(lat1, P[pf + "0.weight"], P[pf + "0.bias"], u, st_f)
-        a = _e((N * n, hid), BF16, dev)
+        a = _e((N * n, hid), BF16, dev) if keep else None     # pre-GELU activations: only the backward reads them
         b = _e((N * n, hid), BF16, dev)
         ops.gemm(u, W[pf + "1.weight"], b, epi=EPI_GELU, out2=a)
         lat2 = torch.empty_like(lat)
         ops.gemm(b, W[pf + "3.weight"], lat2, epi=EPI_GATE_RESID, aux=lat1)                 # ff(latents) + latents
-        layers.append(dict(lat=lat, kvin=kvin, st_m=st_m, st_l=st_l, ltn=ltn, q=q, kv=kv, o=o, lse=lse, lat1=lat1, u=u,
-                           st_f=st_f, a=a, b=b))
+        if keep:
+            layers.append(dict(lat=lat, kvin=kvin, st_m=st_m, st_l=st_l, ltn=ltn, q=q, kv=kv, o=o, lse=lse, lat1=lat1,
+                               u=u, st_f=st_f, a=a, b=b))
         lat = lat2
     out = torch.empty_like(lat)
     st_o = _e((N * n, 2), F32, dev)
     ops.ln_fwd_out(lat, P["norm.weight"], P["norm.bias"], out, st_o)
+    if not keep:
+        return out, None
     return out, dict(layers=layers, lat_last=lat, st_o=st_o, x=x, embs=embs, T=T, frames=frames)
 
 

@@ -130,3 +130,6 @@ class FlamingoLMMixin(nn.Module):
         for layer in self._flamingo_layers():
             for slot in _CONDITION_SLOTS:
                 setattr(layer, slot, None)
+            release = getattr(layer.gated_cross_attn_layer, "release_media_cache", None)
+            if release is not None:
+                release()            # the block's projected keys/values of the media that were just dropped

@@ -89,6 +89,13 @@ class _HipParamModule(nn.Module):
     def invalidate_weight_cache(self):
         """Call after mutating parameters through ``.data`` (which does not bump the version counter)."""
         self.__dict__.pop("_w_bf16_cache", None)
+        self.__dict__.pop("_kv_cache", None)
+
+    def train(self, mode: bool = True):
+        # the copies cast during the last training forward predate the optimizer step that followed it, and their
+        # version stamp cannot tell (see above): never carry them across a train() / eval() switch
+        self.invalidate_weight_cache()
+        return super().train(mode)
 
     @staticmethod
     def _masters(named):
@@ -154,20 +161,26 @@ class PerceiverAttention(nn.Module):
         raise NotImplementedError("PerceiverAttention runs fused inside PerceiverResampler (libofhip).")
 
 
+def _perceiver_operands(mod, names, x, params):
+    ops = Ops.default()
+    b, T, Fr, v, D = x.shape
+    named = list(zip(names, params))
+    P = mod._masters(named)
+    W = mod._weights_bf16(ops, named)
+    xr = x.detach().reshape(b * T * Fr * v, D)
+    if not xr.is_contiguous():
+        xr = xr.contiguous()
+    assert ("frame_embs" not in P or Fr <= P["frame_embs"].shape[0]) and \
+        ("media_time_embs" not in P or T <= P["media_time_embs"].shape[0]), "more frames/media than embedding rows"
+    dims = dict(N=b * T, Fv=Fr * v, n=P["latents"].shape[0], heads=mod.heads, depth=mod.depth, T=T, frames=Fr)
+    return ops, P, W, xr, dims
+
+
 class _PerceiverFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mod, names, x, *params):
-        ops = Ops.default()
-        b, T, Fr, v, D = x.shape
-        named = list(zip(names, params))
-        P = mod._masters(named)
-        W = mod._weights_bf16(ops, named)
-        xr = x.detach().reshape(b * T * Fr * v, D)
-        if not xr.is_contiguous():
-            xr = xr.contiguous()
-        assert ("frame_embs" not in P or Fr <= P["frame_embs"].shape[0]) and \
-            ("media_time_embs" not in P or T <= P["media_time_embs"].shape[0]), "more frames/media than embedding rows"
-        dims = dict(N=b * T, Fv=Fr * v, n=P["latents"].shape[0], heads=mod.heads, depth=mod.depth, T=T, frames=Fr)
+        b, T, _, _, D = x.shape
+        ops, P, W, xr, dims = _perceiver_operands(mod, names, x, params)
         out, S = _path.perceiver_fwd(ops, P, W, xr, **dims)
         ctx.mod, ctx.names, ctx.dims, ctx.S, ctx.P, ctx.W = mod, names, dims, S, P, W
         ctx.xshape = tuple(x.shape)
@@ -211,6 +224,10 @@ class PerceiverResampler(_HipParamModule):
         assert x.dim() == 5 and x.shape[-1] == self.dim, f"expected (b,T,F,v,{self.dim}), got {tuple(x.shape)}"
         named = list(self.named_parameters())
         names = tuple(k for k, _ in named)
+        if not torch.is_grad_enabled():          # inference: nothing kept for a backward
+            ops, P, W, xr, dims = _perceiver_operands(self, names, x, [p for _, p in named])
+            out, _ = _path.perceiver_fwd(ops, P, W, xr, keep=False, **dims)
+            return out.view(x.shape[0], x.shape[1], dims["n"], x.shape[-1])
         return _PerceiverFn.apply(self, names, x, *[p for _, p in named])
 
 
@@ -236,30 +253,36 @@ _XATTN_NAMES = ("attn_gate", "ff_gate", "attn.norm.weight", "attn.norm.bias", "a
                 "attn.to_out.weight", "ff.0.weight", "ff.0.bias", "ff.1.weight", "ff.3.weight")
 
 
+def _xattn_operands(mod, x, media, media_locations, use_cached_media, params):
+    ops = Ops.default()
+    B, L, d = x.shape
+    _, T, n, Dv = media.shape
+    named = list(zip(_XATTN_NAMES, params))
+    P = mod._masters(named)
+    W = mod._weights_bf16(ops, named)
+    xr = x.detach().reshape(B * L, d)
+    if not xr.is_contiguous():
+        xr = xr.contiguous()
+    med = media.detach()
+    media_bf = _shared.get(media, "bf16", lambda: ops.to_bf16(med.reshape(B * T * n, Dv).contiguous())
+                           if med.dtype == F32 else med.reshape(B * T * n, Dv).contiguous())
+    tt = None
+    if media_locations is not None:
+        def _tt():
+            out = torch.empty(B, L, dtype=torch.int32, device=x.device)
+            ml = media_locations.to(torch.uint8).contiguous()
+            ops.text_time(ml, out, L, bool(use_cached_media))
+            return out
+        tt = _shared.get(media_locations, ("tt", L, bool(use_cached_media)), _tt)
+    dims = dict(B=B, L=L, T=T, n=n, heads=mod.attn.heads, only_immediate=mod.attn.only_attend_immediate_media)
+    return ops, P, W, xr, media_bf, tt, dims
+
+
 class _GatedXAttnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mod, x, media, media_locations, use_cached_media, *params):
-        ops = Ops.default()
         B, L, d = x.shape
-        _, T, n, Dv = media.shape
-        named = list(zip(_XATTN_NAMES, params))
-        P = mod._masters(named)
-        W = mod._weights_bf16(ops, named)
-        xr = x.detach().reshape(B * L, d)
-        if not xr.is_contiguous():
-            xr = xr.contiguous()
-        med = media.detach()
-        media_bf = _shared.get(media, "bf16", lambda: ops.to_bf16(med.reshape(B * T * n, Dv).contiguous())
-                               if med.dtype == F32 else med.reshape(B * T * n, Dv).contiguous())
-        tt = None
-        if media_locations is not None:
-            def _tt():
-                out = torch.empty(B, L, dtype=torch.int32, device=x.device)
-                ml = media_locations.to(torch.uint8).contiguous()
-                ops.text_time(ml, out, L, bool(use_cached_media))
-                return out
-            tt = _shared.get(media_locations, ("tt", L, bool(use_cached_media)), _tt)
-        dims = dict(B=B, L=L, T=T, n=n, heads=mod.attn.heads, only_immediate=mod.attn.only_attend_immediate_media)
+        ops, P, W, xr, media_bf, tt, dims = _xattn_operands(mod, x, media, media_locations, use_cached_media, params)
         y, S = _path.xattn_block_fwd(ops, P, W, xr, media_bf, tt, **dims)
         ctx.mod, ctx.dims, ctx.S, ctx.P, ctx.W, ctx.media_bf, ctx.tt = mod, dims, S, P, W, media_bf, tt
         ctx.xshape, ctx.mshape, ctx.mdtype = tuple(x.shape), tuple(media.shape), media.dtype
@@ -303,5 +326,25 @@ class GatedCrossAttentionBlock(_HipParamModule):
             assert media_locations.shape[1] == x.shape[1], (
                 f"media_location.shape is {media_locations.shape} but x.shape is {x.shape}")
         params = dict(self.named_parameters())
-        return _GatedXAttnFn.apply(self, x, media, media_locations, use_cached_media,
-                                   *[params[k] for k in _XATTN_NAMES])
+        params = [params[k] for k in _XATTN_NAMES]
+        if not torch.is_grad_enabled():
+            return self._forward_inference(x, media, media_locations, use_cached_media, params)
+        return _GatedXAttnFn.apply(self, x, media, media_locations, use_cached_media, *params)
+
+    def release_media_cache(self):
+        self.__dict__.pop("_kv_cache", None)
+
+    def _forward_inference(self, x, media, media_locations, use_cached_media, params):
+        """No-grad forward.  The reference recomputes ``to_kv(media)`` in every block for every generated token
+        (helpers.py:189); here the projected keys/values are kept per block for as long as the caller keeps
+        conditioning on the same media tensor (``Flamingo.generate`` / ``cache_media`` hold one tensor on the layers
+        for the whole decode) and the block's to_kv weights are unchanged.  Nothing is saved for a backward."""
+        ops, P, W, xr, media_bf, tt, dims = _xattn_operands(self, x, media, media_locations, use_cached_media, params)
+        w_kv = W["attn.to_kv.weight"]
+        key = (media.data_ptr(), media._version, tuple(media.shape), media.dtype, w_kv.data_ptr(), w_kv._version)
+        ent = self.__dict__.get("_kv_cache")
+        if ent is None or ent[0] != key or ent[1] is not media:
+            ent = (key, media, w_kv, _path.xattn_project_media(ops, W, media_bf, dims["heads"]))
+            self.__dict__["_kv_cache"] = ent       # holds `media` and the weight copy: their storage cannot be reused
+        y, _ = _path.xattn_block_fwd(ops, P, W, xr, media_bf, tt, kv=ent[3], keep=False, **dims)
+        return y.view(x.shape)

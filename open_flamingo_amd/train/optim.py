@@ -106,6 +106,84 @@ class FlatAdamW:
     def zero_grad(self, set_to_none=True):
         self.reducer.zero_grad()
 
+    # ------------------------------------------------------------------ checkpoint interchange with torch.optim.AdamW
+    def _reference_order(self):
+        """The parameter numbering ``torch.optim.AdamW`` has in the reference (train.py:384-408): trainable parameters
+        in ``named_parameters()`` order, the ``gated_cross_attn`` ones (weight decay) first, then the rest."""
+        named = [(n, p) for n, p in self.reducer.module.named_parameters()
+                 if p.requires_grad and not getattr(p, "exclude_from_optimizer", False)]
+        with_wd = [p for n, p in named if "gated_cross_attn" in n]
+        without = [p for n, p in named if "gated_cross_attn" not in n]
+        return with_wd, without
+
+    def _moments_of(self, p):
+        """(exp_avg, exp_avg_sq) views for a bucketed parameter, or None for the embedding."""
+        bi = self.reducer._param_bucket.get(p)
+        if bi is None:
+            return None
+        b = self.reducer.buckets[bi]
+        off = b["offsets"][[id(q) for q in b["params"]].index(id(p))]
+        n = p.numel()
+        return b["m"][off:off + n].view(p.shape), b["v"][off:off + n].view(p.shape)
+
+    def state_dict(self):
+        """A ``torch.optim.AdamW`` state dict (what train_utils.py:354 saves), so a run can move between the fused
+        step epilogue, ``torch.optim.AdamW`` and the reference's own training script at any checkpoint."""
+        with_wd, without = self._reference_order()
+        state, idx = {}, 0
+        for p in with_wd + without:
+            mom = self._moments_of(p)
+            if mom is None:                                          # input embedding: only two rows have moments
+                m, v = torch.zeros_like(p.data), torch.zeros_like(p.data)
+                m.index_copy_(0, self._emb["rows"], self._emb["m"])
+                v.index_copy_(0, self._emb["rows"], self._emb["v"])
+            else:
+                m, v = mom[0].clone(), mom[1].clone()
+            if self.step_count > 0:
+                state[idx] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m, "exp_avg_sq": v}
+            idx += 1
+        groups = []
+        start = 0
+        for g, members in zip(self.param_groups, (with_wd, without)):
+            groups.append({"lr": g["lr"], "betas": tuple(self.betas), "eps": self.eps,
+                           "weight_decay": g["weight_decay"], "amsgrad": False, "maximize": False, "foreach": None,
+                           "capturable": False, "differentiable": False, "fused": None,
+                           "decoupled_weight_decay": True, **{k: v for k, v in g.items()
+                                                              if k not in ("lr", "params", "weight_decay")},
+                           "params": list(range(start, start + len(members)))})
+            start += len(members)
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        with_wd, without = self._reference_order()
+        params = with_wd + without
+        if sum(len(g["params"]) for g in sd["param_groups"]) != len(params):
+            raise ValueError("optimizer state dict does not match this model's trainable parameters")
+        steps = set()
+        for idx, p in enumerate(params):
+            st = sd["state"].get(idx)
+            mom = self._moments_of(p)
+            if st is None:
+                continue
+            steps.add(int(float(st["step"])))
+            m, v = st["exp_avg"].to(p.device, F32), st["exp_avg_sq"].to(p.device, F32)
+            if mom is None:
+                self._emb["m"].copy_(m.index_select(0, self._emb["rows"]))
+                self._emb["v"].copy_(v.index_select(0, self._emb["rows"]))
+            else:
+                mom[0].copy_(m)
+                mom[1].copy_(v)
+        if len(steps) > 1:
+            raise ValueError(f"parameters at different step counts {sorted(steps)}: not an AdamW run of this model")
+        self.step_count = steps.pop() if steps else 0
+        for g, saved in zip(self.param_groups, sd["param_groups"]):
+            for k, val in saved.items():
+                if k not in ("params", "weight_decay", "betas", "eps") and k in g:
+                    g[k] = val
+            if "initial_lr" in saved:
+                g["initial_lr"] = saved["initial_lr"]
+        self.refresh_bf16()
+
     def grad_norm(self):
         """Global gradient norm of the last step() (device scalar tensor, pre-clip)."""
         gs = 1.0 / self.reducer.world if getattr(self.reducer, "holds_sum", False) else 1.0

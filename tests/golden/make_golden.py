@@ -17,6 +17,8 @@ Files written:
   full_perceiver.npz         OF-3B-sized Perceiver (dim 1024, 6 layers): weights rebuilt from
                              oracle.seeded_state(seed), only output/grad summaries stored
   full_xattn.npz             OF-3B-sized block (d=2048): same idea
+  tiny_flamingo.npz          whole reference Flamingo (tiny towers): loss, gradients, generate(), cached-media logits
+  checkpoint_keys.json       what the reference's checkpoint filter keeps + its AdamW parameter order
 """
 
 import importlib.util
@@ -220,8 +222,53 @@ def tiny_flamingo():
          **{"gradnorm." + k: v.norm() for k, v in grads.items() if "wte" not in k})
 
 
+def checkpoint_keys():
+    """the key set the reference's ``filter_state_dict_to_trainable`` (train_utils.py:299-333) leaves of
+    the tiny reference Flamingo, with the LM input embeddings trainable (the default) and frozen
+    (``freeze_lm_embeddings``), and the parameter order of its AdamW groups (train.py:384-408)."""
+    import json
+    sys.modules.setdefault("open_clip", types.ModuleType("open_clip"))
+    sys.path.insert(0, "/root/reference")
+    from open_flamingo.src.flamingo import Flamingo as RefFlamingo
+    from open_flamingo.src.flamingo_lm import FlamingoLMMixin as RefMixin
+    from open_flamingo.src.utils import extend_instance as ref_extend
+    from open_flamingo_amd.train import towers
+    from tests.cpu_model import tiny_cpu_flamingo
+
+    _, info = tiny_cpu_flamingo(seed=0)        # (imports transformers/accelerate, which probe for a real wandb)
+    sys.modules["wandb"] = types.ModuleType("wandb")          # train_utils imports it at module level; not installed
+    from open_flamingo.train.train_utils import filter_state_dict_to_trainable
+    del sys.modules["wandb"]
+    out = {}
+    for tag, train_emb in (("embeddings_trainable", True), ("embeddings_frozen", False)):
+        torch.manual_seed(123)
+        vision = towers.VisionStandIn(width=64, layers=2, heads=2, patch=14, image=224)
+        lm, attr = towers.build_lang_encoder("OF-tiny")
+        ref_extend(lm, RefMixin)
+        lm.set_decoder_layers_attr_name(attr)
+        ref = RefFlamingo(vision, lm, info["eoc_token_id"], info["media_token_id"], vis_dim=64,
+                          cross_attn_every_n_layers=info["every"])
+        ref.requires_grad_(False)                      # factory.py:104-114
+        ref.perceiver.requires_grad_(True)
+        ref.lang_encoder.gated_cross_attn_layers.requires_grad_(True)
+        if train_emb:
+            ref.lang_encoder.get_input_embeddings().requires_grad_(True)
+        kept = filter_state_dict_to_trainable(ref, ref.state_dict())
+        named = [(n, p) for n, p in ref.named_parameters() if p.requires_grad]
+        out[tag] = dict(checkpoint_keys=sorted(kept.keys()),
+                        adamw_with_wd=[n for n, _ in named if "gated_cross_attn" in n],
+                        adamw_without_wd=[n for n, _ in named if "gated_cross_attn" not in n])
+        print(tag, len(kept), "keys;", len(named), "optimizer params")
+    with open(os.path.join(HERE, "checkpoint_keys.json"), "w") as f:
+        json.dump(out, f, indent=0)
+
+
 if __name__ == "__main__":
+    if "--only-checkpoint-keys" in sys.argv:
+        checkpoint_keys()
+        sys.exit(0)
     tiny_flamingo()
+    checkpoint_keys()
     sys.exit(0) if "--only-flamingo" in sys.argv else None
     torch.set_num_threads(8)
     small_perceiver(False)

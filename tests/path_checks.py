@@ -58,6 +58,10 @@ def check_xattn(ops, dev, *, B=2, L=40, T=2, n=16, heads=2, d=64, Dv=48, stream_
     ops.text_time(media_locs.to(torch.uint8).to(dev).contiguous(), tt, L, False)
     kw = dict(B=B, L=L, T=T, n=n, heads=heads, only_immediate=only_immediate, safe=safe)
     y, S = path.xattn_block_fwd(ops, P, W, xd, media_bf, tt, **kw)
+    # inference entry: projected media computed once, nothing kept -> the same bits as the training forward
+    kv = path.xattn_project_media(ops, W, media_bf, heads)
+    y_inf, none = path.xattn_block_fwd(ops, P, W, xd, media_bf, tt, kv=kv, keep=False, **kw)
+    assert none is None and torch.equal(y_inf, y)
     dy = w.to(dev).to(stream_dtype).reshape(B * L, d).contiguous()
     base, sinks = _prefilled_sinks(P, dev, seed) if inplace else (None, None)
     dx, dmedia, grads = path.xattn_block_bwd(ops, P, W, S, media_bf, tt, dy, sinks=sinks, **kw)
@@ -93,6 +97,8 @@ def check_perceiver(ops, dev, *, b=1, T=2, Fv=24, n=16, heads=2, D=64, depth=2, 
     xd = x.to(dev).to(stream_dtype).reshape(N * Fv, D).contiguous()
     kw = dict(N=N, Fv=Fv, n=n, heads=heads, depth=depth, safe=safe, T=T, frames=frames)
     y, S = path.perceiver_fwd(ops, P, W, xd, **kw)
+    y_inf, none = path.perceiver_fwd(ops, P, W, xd, keep=False, **kw)
+    assert none is None and torch.equal(y_inf, y)
     dy = w.to(dev).to(stream_dtype).reshape(N * n, D).contiguous()
     base, sinks = _prefilled_sinks(P, dev, seed) if inplace else (None, None)
     dx, grads = path.perceiver_bwd(ops, P, W, S, dy, need_dx=need_dx, sinks=sinks, **kw)
