@@ -71,8 +71,9 @@ typedef struct OfGemmArgs {
     float alpha, beta;
     float* dot_out;    /* device scalar accumulated atomically, or NULL */
     int io_f32;        /* OF_EPI_GATE_RESID: 1 = fp32 stream, 0 = bf16 stream */
-    int safe;          /* kernel selection for self-checks: 0 = auto (256x256 LDS-DMA kernel when the shape is tile
-                          aligned, else the general 128x128 kernel); 1 = general kernel with the slow scalar-LDS
+    int safe;          /* kernel selection for self-checks: 0 = auto (M <= 16 untransposed: weight-streaming skinny
+                          kernel; 256x256 LDS-DMA kernel when the shape is tile aligned and fills the chip; else the
+                          general 128x128 kernel, split along K when the output is small); 1 = general kernel with the slow scalar-LDS
                           transposed-fragment path; 2 = general kernel (tr-read path); 4 = ping-pong kernel whenever eligible; >= 16: timing aid of
                           tools/bench_gemm_ablate.py (ablated ping-pong launches, results wrong by design) */
     int ksplit;        /* internal: filled in by of_gemm (number of K slices of a split-K launch); callers pass 0 */

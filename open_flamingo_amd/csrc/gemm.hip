@@ -256,6 +256,7 @@ int pick_ksplit(const OfGemmArgs& a, bool with_workspace) {
 
 extern "C" size_t of_gemm_workspace_bytes(const OfGemmArgs* args) {
     if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return 0;
+    if (of_gemm_is_skinny(*args)) return 0;
     const int split = pick_ksplit(*args, true);
     return split > 1 ? (size_t)split * args->M * args->N * sizeof(float) : 0;
 }
@@ -272,9 +273,13 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
     if ((a.epi == OF_EPI_GATE_RESID || a.epi == OF_EPI_DGELU_DOT || a.epi == OF_EPI_SCALE_DOT) &&
         (!a.aux || (a.ldaux & 3) || ((uintptr_t)a.aux & 15)))
         return OF_E_ARG;
+    of_stream_t s = (of_stream_t)stream;
+    if (of_gemm_is_skinny(a)) {                    // a handful of rows (decode step): stream the weights, no tiles
+        const int rc = of_gemm_skinny_try(a, s);
+        if (rc != OF_E_SHAPE) return rc;
+    }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     of_dim3 grid{(unsigned)(tiles_m * tiles_n), 1, 1};
-    of_stream_t s = (of_stream_t)stream;
     OfGemmArgs b = a;
     b.ksplit = 1;
     // Kernel selection (safe == 0).  The 256x256 ping-pong kernel needs >= ~3/4 of the 256 CUs' worth of tiles to pay;

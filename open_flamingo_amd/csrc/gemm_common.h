@@ -176,6 +176,12 @@ OF_DEV void epilogue_finish(const OfGemmArgs& p, float gv, float dot, int lane, 
 
 }  // namespace ofg
 
+// implemented in gemm_skinny.hip: M <= 16 rows (decode step), HBM-bound weight streaming; OF_E_SHAPE when not eligible
+int of_gemm_skinny_try(const OfGemmArgs& a, of_stream_t s);
+inline bool of_gemm_is_skinny(const OfGemmArgs& a) {
+    return a.safe == 0 && a.M <= 16 && !a.a_trans && !a.b_trans &&
+           (a.epi == OF_EPI_STORE_BF16 || a.epi == OF_EPI_GELU || a.epi == OF_EPI_GATE_RESID);
+}
 // implemented in gemm_pp.hip; returns OF_E_SHAPE when the shape/layout is not eligible (caller falls back)
 int of_gemm_pp_try(const OfGemmArgs& a, of_stream_t s);
 int of_gemm_pp_ablate(const OfGemmArgs& a, int mask, of_stream_t s);

@@ -88,6 +88,10 @@ OF_DEV float of_exp(float x) { return __expf(x); }
 // 1-ulp hardware reciprocal (v_rcp_f32) instead of the ~12-instruction IEEE division sequence
 OF_DEV float of_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 typedef __bf16 of_bf16x2n __attribute__((ext_vector_type(2)));
+// c + a.lo*b.lo + a.hi*b.hi on packed bf16 pairs, fp32 accumulate, ONE v_dot2c_f32_bf16 (gfx950)
+OF_DEV float of_dot2_bf16(unsigned a, unsigned b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(of_bf16x2n, a), __builtin_bit_cast(of_bf16x2n, b), c, false);
+}
 // two fp32 -> packed bf16, round-to-nearest-even, in ONE v_cvt_pk_bf16_f32 (gfx950)
 OF_DEV unsigned of_pack_bf16(float lo, float hi) {
     of_bf16x2n v = {(__bf16)lo, (__bf16)hi};
@@ -130,6 +134,10 @@ OF_DEV bf16_t of_f32_to_bf16(float f) {
     return (bf16_t)(u >> 16);
 }
 #ifdef OF_HOST_EMU
+OF_DEV float of_dot2_bf16(unsigned a, unsigned b, float c) {
+    return c + of_bf16_to_f32((bf16_t)(a & 0xffff)) * of_bf16_to_f32((bf16_t)(b & 0xffff)) +
+           of_bf16_to_f32((bf16_t)(a >> 16)) * of_bf16_to_f32((bf16_t)(b >> 16));
+}
 OF_DEV unsigned of_pack_bf16(float lo, float hi) {
     return (unsigned)of_f32_to_bf16(lo) | ((unsigned)of_f32_to_bf16(hi) << 16);
 }

@@ -53,10 +53,10 @@ class _GradOut:
 # =================================================================================================
 # GatedCrossAttentionBlock
 # =================================================================================================
-def xattn_project_media(ops, W, media_bf, heads):
+def xattn_project_media(ops, W, media_bf, heads, out=None):
     """k | v = to_kv(media) (helpers.py:189), (B*T*n, 2*inner) bf16.  Depends on the media and the block's weights only,
     so the decode loop computes it once per block and prompt instead of once per generated token."""
-    kv = _e((media_bf.shape[0], 2 * heads * 64), BF16, media_bf.device)
+    kv = _e((media_bf.shape[0], 2 * heads * 64), BF16, media_bf.device) if out is None else out
     ops.gemm(media_bf, W["attn.to_kv.weight"], kv)
     return kv
 

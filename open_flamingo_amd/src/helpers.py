@@ -90,6 +90,7 @@ class _HipParamModule(nn.Module):
         """Call after mutating parameters through ``.data`` (which does not bump the version counter)."""
         self.__dict__.pop("_w_bf16_cache", None)
         self.__dict__.pop("_kv_cache", None)
+        self.__dict__.pop("_decode_graph", None)
 
     def train(self, mode: bool = True):
         # the copies cast during the last training forward predate the optimizer step that followed it, and their
@@ -249,6 +250,16 @@ class MaskedCrossAttention(nn.Module):
         raise NotImplementedError("MaskedCrossAttention runs fused inside GatedCrossAttentionBlock (libofhip).")
 
 
+_capture_streams = {}
+
+
+def _capture_stream(device):
+    """HIP graphs are captured on a side stream (capture on the default stream is not allowed)."""
+    if device not in _capture_streams:
+        _capture_streams[device] = torch.cuda.Stream(device=device)
+    return _capture_streams[device]
+
+
 _XATTN_NAMES = ("attn_gate", "ff_gate", "attn.norm.weight", "attn.norm.bias", "attn.to_q.weight", "attn.to_kv.weight",
                 "attn.to_out.weight", "ff.0.weight", "ff.0.bias", "ff.1.weight", "ff.3.weight")
 
@@ -325,11 +336,16 @@ class GatedCrossAttentionBlock(_HipParamModule):
                 raise ValueError("media_locations is required unless use_cached_media=True")
             assert media_locations.shape[1] == x.shape[1], (
                 f"media_location.shape is {media_locations.shape} but x.shape is {x.shape}")
-        params = dict(self.named_parameters())
-        params = [params[k] for k in _XATTN_NAMES]
+        a, f = self.attn, self.ff                        # the parameters in _XATTN_NAMES order
+        params = [self.attn_gate, self.ff_gate, a.norm.weight, a.norm.bias, a.to_q.weight, a.to_kv.weight,
+                  a.to_out.weight, f[0].weight, f[0].bias, f[1].weight, f[3].weight]
         if not torch.is_grad_enabled():
             return self._forward_inference(x, media, media_locations, use_cached_media, params)
         return _GatedXAttnFn.apply(self, x, media, media_locations, use_cached_media, *params)
+
+    # A decode step (T_txt = 1) is ~10 small launches per block whose cost is host time, not GPU time: replay them as
+    # one HIP graph per block.  Class-level switch; set False (on the class or an instance) to launch kernel by kernel.
+    decode_graphs = True
 
     def release_media_cache(self):
         self.__dict__.pop("_kv_cache", None)
@@ -343,8 +359,72 @@ class GatedCrossAttentionBlock(_HipParamModule):
         w_kv = W["attn.to_kv.weight"]
         key = (media.data_ptr(), media._version, tuple(media.shape), media.dtype, w_kv.data_ptr(), w_kv._version)
         ent = self.__dict__.get("_kv_cache")
-        if ent is None or ent[0] != key or ent[1] is not media:
+        fresh = ent is None or ent[0] != key or ent[1] is not media
+        graph = self._decode_graph_for(ops, P, W, xr, tt, dims, params) if x.shape[1] == 1 else None
+        if graph is not None:
+            # the graph reads the projected media from ITS buffer: project into it (new prompt) or move the prompt
+            # pass's projection there once
+            if fresh:
+                _path.xattn_project_media(ops, W, media_bf, dims["heads"], out=graph["kv"])
+            elif ent[3] is not graph["kv"]:
+                graph["kv"].copy_(ent[3])
+            if fresh or ent[3] is not graph["kv"]:
+                self.__dict__["_kv_cache"] = (key, media, w_kv, graph["kv"])
+            if graph.get("tt_src") is not tt:
+                graph["tt"].copy_(tt)
+                graph["tt_src"] = tt
+            graph["x"].copy_(xr)
+            graph["graph"].replay()
+            return graph["y"].clone().view(x.shape)
+        if fresh:
             ent = (key, media, w_kv, _path.xattn_project_media(ops, W, media_bf, dims["heads"]))
             self.__dict__["_kv_cache"] = ent       # holds `media` and the weight copy: their storage cannot be reused
         y, _ = _path.xattn_block_fwd(ops, P, W, xr, media_bf, tt, kv=ent[3], keep=False, **dims)
         return y.view(x.shape)
+
+    def _decode_graph_for(self, ops, P, W, xr, tt, dims, params):
+        """HIP graph of one decode step of this block for the current (batch, images) shape and weights, or None.
+        The graph owns static input buffers (token, text_time, projected media) and its split-K workspace; it is
+        captured the second time a shape is seen (the first call runs kernel by kernel, which also warms every lazily
+        initialised piece outside the capture), and dropped with the weight copies (``invalidate_weight_cache``)."""
+        if not self.decode_graphs or tt is None or not xr.is_cuda:
+            return None
+        sig = (dims["B"], dims["T"], dims["n"], xr.dtype, tt.shape,
+               tuple((w.data_ptr(), w._version) for w in W.values()),
+               tuple((p.data_ptr(), p._version) for p in params))
+        slots = self.__dict__.setdefault("_decode_graph", {})      # a few shapes (e.g. the last, smaller batch of an eval)
+        st = slots.get(sig)
+        if st is None:
+            if len(slots) >= 4:
+                slots.pop(next(iter(slots)))
+            slots[sig] = dict(sig=sig, graph=None)
+            return None
+        if st["graph"] is not None or st.get("failed"):
+            return st if st["graph"] is not None else None
+        inner = dims["heads"] * 64
+        st.update(x=torch.empty_like(xr), tt=torch.empty_like(tt), tt_src=None,
+                  kv=torch.empty(dims["B"] * dims["T"] * dims["n"], 2 * inner, dtype=BF16, device=xr.device),
+                  keep=(P, W))                       # the operands whose addresses the graph holds
+        outer_ws = ops.__dict__.pop("_gemm_ws", None)     # the shared scratch may be re-allocated later: the graph gets
+        try:                                              # its own, allocated from the graph's memory pool
+            g = torch.cuda.CUDAGraph()
+            side = _capture_stream(xr.device)
+            side.wait_stream(torch.cuda.current_stream(xr.device))
+            with torch.cuda.stream(side):                 # (torch.cuda.graph() would add a device sync + gc per block)
+                g.capture_begin()
+                try:
+                    y, _ = _path.xattn_block_fwd(ops, P, W, st["x"], None, st["tt"], kv=st["kv"], keep=False, **dims)
+                finally:
+                    g.capture_end()
+            torch.cuda.current_stream(xr.device).wait_stream(side)
+            st.update(graph=g, y=y, ws=ops.__dict__.pop("_gemm_ws", None))
+        except Exception as exc:                          # same kernels, launched one by one
+            import warnings
+            warnings.warn(f"GatedCrossAttentionBlock: HIP graph capture of the decode step failed ({exc!r}); "
+                          "continuing with per-kernel launches")
+            st.update(graph=None, failed=True)
+        finally:
+            ops.__dict__.pop("_gemm_ws", None)
+            if outer_ws is not None:
+                ops._gemm_ws = outer_ws
+        return st if st["graph"] is not None else None

@@ -163,3 +163,47 @@ def test_fast_erf_gelu_accuracy():
     got = out[:4001, 0].double()
     # one bf16 rounding of the result (2^-8 relative) + the 1.5e-7 absolute error of the erf polynomial (x |a|)
     assert ((got - want).abs() <= 2.0 ** -8 * want.abs() + 2e-6).all()
+
+
+_SKINNY = [(M, 4, 8) for M in (1, 16)] + [(M, 36, 520) for M in (1, 2, 3, 5, 8, 13, 16)] + \
+          [(M, 260, 2048 + 64) for M in (2, 8)] + [(M, 2052, 512) for M in (1, 4, 16)]
+
+
+@pytest.mark.parametrize("M,N,K", _SKINNY)
+def test_skinny_gemm_decode_shapes(M, N, K):
+    """M <= 16 untransposed problems take the weight-streaming kernel (gemm_skinny.hip): every padded-row template,
+    both rows-per-workgroup variants (N <= 2048 / > 2048), ragged N and K tails, all three epilogues -- against fp64
+    and against the tile kernel (safe = 2) on the same operands."""
+    A, B = _rand((M, K), 11 + M), _rand((N, K), 12 + N) * 0.1
+    acc = _ref(A, B, 0, 0)
+    gate = torch.tensor([0.37])
+    g = float(torch.tanh(gate))
+    for safe in (0, 2):
+        out = torch.zeros(M, N, dtype=torch.bfloat16)
+        H.gemm(A, B, C_out=out, alpha=0.5, safe=safe)
+        np.testing.assert_allclose(out.double().numpy(), 0.5 * acc.numpy(), rtol=1e-2, atol=1e-2)
+        b_out, a_out = torch.zeros(M, N, dtype=torch.bfloat16), torch.zeros(M, N, dtype=torch.bfloat16)
+        H.gemm(A, B, epi=abi.EPI_GELU, C_out=b_out, C2=a_out, safe=safe)
+        np.testing.assert_allclose(a_out.double().numpy(), acc.numpy(), rtol=1e-2, atol=1e-2)
+        np.testing.assert_allclose(b_out.double().numpy(), torch.nn.functional.gelu(acc).numpy(), rtol=1e-2, atol=1e-2)
+        b_only = torch.zeros(M, N, dtype=torch.bfloat16)
+        H.gemm(A, B, epi=abi.EPI_GELU, C_out=b_only, safe=safe)                   # inference: no pre-activation output
+        assert torch.equal(b_only, b_out)
+        res = torch.randn(M, N)
+        o32 = torch.zeros(M, N)
+        H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=o32, aux=res, gate=gate, io_f32=1, safe=safe)
+        np.testing.assert_allclose(o32.double().numpy(), (res.double() + g * acc).numpy(), rtol=1e-5, atol=1e-4)
+        resb, o16 = res.to(torch.bfloat16), torch.zeros(M, N, dtype=torch.bfloat16)
+        H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=o16, aux=resb, io_f32=0, safe=safe)   # no gate: plain residual
+        np.testing.assert_allclose(o16.double().numpy(), (resb.double() + acc).numpy(), rtol=1e-2, atol=2e-2)
+
+
+def test_skinny_gemm_strided_operands():
+    """Leading dimensions larger than the logical widths (k | v halves, padded activations)."""
+    M, N, K = 4, 40, 264
+    Abig, Bbig = _rand((M, K + 24), 21), _rand((N, K + 40), 22) * 0.1
+    A, B = Abig[:, 8:8 + K], Bbig[:, 16:16 + K]
+    Cbig = torch.zeros(M, N + 16, dtype=torch.bfloat16)
+    H.gemm(A, B, C_out=Cbig[:, 8:8 + N])
+    np.testing.assert_allclose(Cbig[:, 8:8 + N].double().numpy(), _ref(A, B, 0, 0).numpy(), rtol=1e-2, atol=1e-2)
+    assert Cbig[:, :8].abs().sum() == 0 and Cbig[:, 8 + N:].abs().sum() == 0

@@ -218,3 +218,25 @@ def test_gemm_split_k_weight_gradient(ops, beta):
     assert _rel(got, want) < 1e-5
     ref = float(torch.tanh(gate)) * (A.float().t() @ B.float()) + beta * c0
     assert _rel(got, ref) < 2e-4
+
+
+@pytest.mark.parametrize("M", [1, 3, 8, 16])
+@pytest.mark.parametrize("N,K", [(512, 2048), (2048, 512), (8192, 2048), (2048, 8192), (10240, 2560)])
+def test_skinny_gemm_decode_shapes(ops, M, N, K):
+    """Decode-step projections (OF-3B / OF-4B widths, 1..16 sequences): the weight-streaming kernel (safe = 0 at
+    M <= 16) against fp32 matmul and against the tile kernel (safe = 2), three epilogues."""
+    A, B = _r((M, K), 31 + M), _r((N, K), 32, 0.05)
+    acc = A.float() @ B.float().t()
+    gate = torch.tensor([0.37], device="cuda")
+    g = float(torch.tanh(gate))
+    res = _r((M, N), 33, dtype=torch.float32)
+    for safe in (0, 2):
+        o = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        ops.gemm(A, B, o, safe=safe)
+        assert _rel(o, acc) < 1e-2
+        b = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        ops.gemm(A, B, b, epi=abi.EPI_GELU, safe=safe)
+        assert _rel(b, torch.nn.functional.gelu(acc)) < 1e-2
+        y = torch.empty(M, N, dtype=torch.float32, device="cuda")
+        ops.gemm(A, B, y, epi=abi.EPI_GATE_RESID, aux=res, gate=gate, safe=safe)
+        assert _rel(y, res + g * acc) < 1e-4 + 1e-3 * (K > 4096)

@@ -235,6 +235,58 @@ def test_decode_path_caches_projected_media_per_block():
         assert "_kv_cache" not in blk.__dict__
 
 
+def test_decode_step_hip_graph_matches_per_kernel_launches():
+    """One decode step per block is replayed as a HIP graph (captured the second time a (batch, images) shape is seen).
+    Same kernels, so the bits must equal the per-kernel launches -- across tokens, across prompts (new media, new
+    text_time: the graph's static buffers are refilled, no re-capture), across a batch-shape change (new capture) and
+    after a weight reload (re-capture)."""
+    from open_flamingo_amd.src.helpers import GatedCrossAttentionBlock
+    torch.manual_seed(1)
+    blk = GatedCrossAttentionBlock(dim=256, dim_visual=128, heads=4).cuda().eval()
+    with torch.no_grad():
+        blk.attn_gate.fill_(0.7)
+        blk.ff_gate.fill_(-0.6)
+
+    def decode(media, locs, toks, graphs):
+        blk.decode_graphs = graphs
+        blk.release_media_cache()
+        with torch.no_grad():
+            return [blk(t, media, media_locations=locs, use_cached_media=True) for t in toks]
+
+    captures = []
+    for prompt, B in enumerate((2, 2, 3, 2)):                      # same shape twice, another shape, back again
+        media = torch.randn(B, 3, 64, 128, device="cuda")
+        locs = torch.zeros(B, 12, dtype=torch.bool, device="cuda")
+        locs[:, 1] = True
+        locs[0, 5 + prompt] = True                                   # different text_time per prompt
+        toks = [torch.randn(B, 1, 256, device="cuda") for _ in range(4)]
+        want = decode(media, locs, toks, graphs=False)
+        blk.__dict__.pop("_decode_graph", None) if prompt == 0 else None
+        got = decode(media, locs, toks, graphs=True)
+        st = [v for v in blk.__dict__["_decode_graph"].values() if v["sig"][0] == B][-1]
+        assert st["graph"] is not None, "the second token of a shape must have captured the graph"
+        captures.append(st["graph"])
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    assert captures[0] is captures[1], "a new prompt of the same shape must reuse the graph"
+    assert captures[2] is not captures[1] and captures[3] is captures[0]
+    sd = {k: v.clone() for k, v in blk.state_dict().items()}
+    sd["ff.3.weight"] *= 0.5
+    blk.load_state_dict(sd)
+    media = torch.randn(2, 3, 64, 128, device="cuda")
+    locs = torch.zeros(2, 12, dtype=torch.bool, device="cuda")
+    locs[:, 0] = True
+    toks = [torch.randn(2, 1, 256, device="cuda") for _ in range(3)]
+    want = decode(media, locs, toks, graphs=False)
+    got = decode(media, locs, toks, graphs=True)
+    newest = list(blk.__dict__["_decode_graph"].values())[-1]   # graphs of the old weights no longer match and age out
+    assert newest["graph"] is not None and newest["graph"] not in captures
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    GatedCrossAttentionBlock.decode_graphs = True
+    del blk.decode_graphs
+
+
 def test_xattn_single_image_laion_shape(ops):
     """T = 1 (the LAION pass, train_utils.py:96): every token after the first <image> attends to the only media item."""
     ml = torch.zeros(2, 32, dtype=torch.bool)

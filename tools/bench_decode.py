@@ -66,7 +66,7 @@ def main():
     project, block_fwd = _path.xattn_project_media, _path.xattn_block_fwd
     arms = {
         "cached": (project, block_fwd),
-        "reproject": (lambda *args, **kw: None, lambda *args, kv=None, **kw: block_fwd(*args, kv=None, **kw)),
+        "reproject": (project, lambda *args, kv=None, **kw: block_fwd(*args, kv=None, **kw)),   # ignore the cached kv
     }
     for B in a.batch:
         batch = synthetic.make_batch(B, a.images, a.prompt, info, "cuda", seed=3)
