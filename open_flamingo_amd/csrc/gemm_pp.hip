@@ -92,7 +92,12 @@ OF_DEV s16x8 frag32(const char* oper, int row_base, int h, int ks, int lane) {
 
 // ABL: timing-only ablation mask for tools/bench_gemm_ablate.py (results are wrong when != 0):
 //   1 = no DMA inside the K loop, 2 = no fragment reads, 4 = no MFMAs, 16 = no vmcnt waits (racy)
-template <bool AT, bool BT, int EPI, int ABL = 0>
+//
+// RS = register staging instead of LDS-DMA: the same pieces travel global -> VGPR (global_load_dwordx4, which does not
+// hold the issuing wave) and are stored to the same LDS addresses (ds_write_b128) at the START of the wave's next load
+// segment, i.e. two wall segments later -- exactly when the DMA version's vmcnt(4) declares them landed, so every
+// reader/writer pair below keeps its barrier (the writes only happen LATER than a DMA issue would overwrite).
+template <bool AT, bool BT, int EPI, int ABL = 0, bool RS = false>
 OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
     char* smem = of_smem();
     const int tid = of_tid(), lane = tid & 63;
@@ -125,19 +130,32 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
     const int nd = p.K / DK;
     const int offA = hfA * HALF_BYTES + wn * 1024, offB = OPER_BYTES + hfB * HALF_BYTES + wn * 1024;
 
+    u32x4 stg[4];              // RS: the 4 pieces in flight
+    char* stg_dst = nullptr;   // RS: where they go (piece j at + j * 4096), nullptr = nothing pending
+    auto flush = [&]() {       // RS: store the pieces loaded in this wave's previous load segment
+        if (RS && stg_dst) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(u32x4*)(stg_dst + j * 4096 + lane * 16) = stg[j];
+            stg_dst = nullptr;
+        }
+    };
     auto issueA = [&](char* slot) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            of_glds16(srcA[j], slot + offA + j * 4096);
+            if (RS) stg[j] = *(const u32x4*)srcA[j];
+            else of_glds16(srcA[j], slot + offA + j * 4096);
             srcA[j] += stepA;
         }
+        if (RS) stg_dst = slot + offA;
     };
     auto issueB = [&](char* slot) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            of_glds16(srcB[j], slot + offB + j * 4096);
+            if (RS) stg[j] = *(const u32x4*)srcB[j];
+            else of_glds16(srcB[j], slot + offB + j * 4096);
             srcB[j] += stepB;
         }
+        if (RS) stg_dst = slot + offB;
     };
     s16x8 fa[4][2], fb[2][2];
     auto load_frags = [&](const char* stage, int h, int gi) {
@@ -174,7 +192,7 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
     };
     // end of a load segment: the 4 pieces issued two segments ago have landed (or everything, if nothing was issued now)
     auto publish = [&](bool issued) {
-        if (!(ABL & 16)) {
+        if (!(ABL & 16) && !RS) {      // RS: loads target VGPRs and stay in flight across the barrier
             if (issued) of_wait_vm<4>();
             else of_wait_vm<0>();
         }
@@ -185,13 +203,16 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
 
     // prologue: stage 0 complete for everybody (the 8 waves' duties cover all 64 chunks); G1 starts A rows 0-127 of stage 1
     issueB(smem);
+    flush();
     issueA(smem);
+    flush();
     if (wm == 1 && nd > 1) {
-        issueA(smem + STAGE_BYTES);
-        of_wait_vm<4>();
-    } else {
+        issueA(smem + STAGE_BYTES);     // RS: stays pending until G1's first load segment
+        if (!RS) of_wait_vm<4>();
+    } else if (!RS) {
         of_wait_vm<0>();
     }
+    if (RS) of_wait_lgkm0();
     of_barrier_raw();
     if (wm == 1) of_barrier_raw();   // stagger: G1 runs one segment behind G0
 
@@ -208,18 +229,22 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
         const char* stage = smem + (d & 1) * STAGE_BYTES;
         char* other = smem + ((d + 1) & 1) * STAGE_BYTES;
         // ---- L0
-        load_frags(stage, 0, d);
+        flush();
         const bool i0 = dma && d + 1 < nd;
-        if (i0) issueB(other);
+        if (RS && i0) issueB(other);
+        load_frags(stage, 0, d);
+        if (!RS && i0) issueB(other);
         publish(i0);
         // ---- C0
         compute();
         of_sched_fence();
         of_barrier_raw();
         // ---- L1
-        load_frags(stage, 1, d);
+        flush();
         const bool i1 = dma && (wm == 0 ? d + 1 < nd : d + 2 < nd);
-        if (i1) issueA(wm == 0 ? other : smem + (d & 1) * STAGE_BYTES);
+        if (RS && i1) issueA(wm == 0 ? other : smem + (d & 1) * STAGE_BYTES);
+        load_frags(stage, 1, d);
+        if (!RS && i1) issueA(wm == 0 ? other : smem + (d & 1) * STAGE_BYTES);
         publish(i1);
         // ---- C1
         compute();
@@ -267,6 +292,7 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
 template <bool AT, bool BT, int EPI>
 int launch_pp(const OfGemmArgs& a, of_stream_t s) {
     of_dim3 grid{(unsigned)((a.M / TM) * (a.N / TN)), 1, 1};
+    if (a.safe == 5) return of_launch(of_gemm_pp_kernel<AT, BT, EPI, 0, true>, grid, 512, SMEM_PP, s, a);
     return of_launch(of_gemm_pp_kernel<AT, BT, EPI>, grid, 512, SMEM_PP, s, a);
 }
 
