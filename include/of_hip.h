@@ -74,7 +74,7 @@ typedef struct OfGemmArgs {
     int safe;          /* kernel selection for self-checks: 0 = auto (M <= 16 untransposed: weight-streaming skinny
                           kernel; 256x256 LDS-DMA kernel when the shape is tile aligned and fills the chip; else the
                           general 128x128 kernel, split along K when the output is small); 1 = general kernel with the slow scalar-LDS
-                          transposed-fragment path; 2 = general kernel (tr-read path); 4 = ping-pong kernel whenever eligible; >= 16: timing aid of
+                          transposed-fragment path; 2 = general kernel (tr-read path); 4 = ping-pong kernel whenever eligible; 5 = same with register-staged operands (A/B aid); >= 16: timing aid of
                           tools/bench_gemm_ablate.py (ablated ping-pong launches, results wrong by design) */
     int ksplit;        /* internal: filled in by of_gemm (number of K slices of a split-K launch); callers pass 0 */
     void* workspace;   /* optional scratch for split-K partial sums (fp32 slabs): with at least

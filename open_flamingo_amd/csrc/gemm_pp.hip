@@ -97,8 +97,10 @@ OF_DEV s16x8 frag32(const char* oper, int row_base, int h, int ks, int lane) {
 // hold the issuing wave) and are stored to the same LDS addresses (ds_write_b128) at the START of the wave's next load
 // segment, i.e. two wall segments later -- exactly when the DMA version's vmcnt(4) declares them landed, so every
 // reader/writer pair below keeps its barrier (the writes only happen LATER than a DMA issue would overwrite).
-template <bool AT, bool BT, int EPI, int ABL = 0, bool RS = false>
+// VAR: 0 = LDS-DMA (product), 1 = register staging (measured A/B, safe = 5)
+template <bool AT, bool BT, int EPI, int ABL = 0, int VAR = 0>
 OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
+    constexpr bool RS = VAR == 1;
     char* smem = of_smem();
     const int tid = of_tid(), lane = tid & 63;
     const int wave = of_uniform(tid >> 6);
@@ -292,7 +294,7 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
 template <bool AT, bool BT, int EPI>
 int launch_pp(const OfGemmArgs& a, of_stream_t s) {
     of_dim3 grid{(unsigned)((a.M / TM) * (a.N / TN)), 1, 1};
-    if (a.safe == 5) return of_launch(of_gemm_pp_kernel<AT, BT, EPI, 0, true>, grid, 512, SMEM_PP, s, a);
+    if (a.safe == 5) return of_launch(of_gemm_pp_kernel<AT, BT, EPI, 0, 1>, grid, 512, SMEM_PP, s, a);
     return of_launch(of_gemm_pp_kernel<AT, BT, EPI>, grid, 512, SMEM_PP, s, a);
 }
 

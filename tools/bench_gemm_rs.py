@@ -36,11 +36,14 @@ for name, M, N, K, fn, dt in cases:
         o = torch.empty(M, N, device="cuda", dtype=dt)
         fn(o, 5)
         stable = stable and bool(torch.equal(o, o5))
-    t4, t5 = [], []
+    variants = {"dma": 4, "regs": 5}
+    t = {k: [] for k in variants}
     for _ in range(3):
-        t4.append(timeit(lambda: fn(o4, 4)))
-        t5.append(timeit(lambda: fn(o5, 5)))
+        for k, sf in variants.items():
+            t[k].append(timeit(lambda: fn(o4, sf)))
     fl = 2.0 * M * N * K
-    print(json.dumps(dict(case=name, dma_ms=round(min(t4), 4), regs_ms=round(min(t5), 4),
-                          dma_tflops=round(fl / min(t4) / 1e9, 1), regs_tflops=round(fl / min(t5) / 1e9, 1),
-                          bit_equal=same, repeat_stable=stable)), flush=True)
+    row = dict(case=name, bit_equal=same, repeat_stable=stable)
+    for k in variants:
+        row[k + "_ms"] = round(min(t[k]), 4)
+        row[k + "_tflops"] = round(fl / min(t[k]) / 1e9, 1)
+    print(json.dumps(row), flush=True)
