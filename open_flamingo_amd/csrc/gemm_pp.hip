@@ -92,6 +92,11 @@ OF_DEV s16x8 frag32(const char* oper, int row_base, int h, int ks, int lane) {
 
 // ABL: timing-only ablation mask for tools/bench_gemm_ablate.py (results are wrong when != 0):
 //   1 = no DMA inside the K loop, 2 = no fragment reads, 4 = no MFMAs, 16 = no vmcnt waits (racy)
+//   128 = the MFMAs read constant operand registers; the fragment reads still happen (same LDS traffic) but nothing
+//        in flight reads the registers they overwrite: isolates the VGPR write-after-read interlock between a wave's
+//        queued MFMAs and its next segment's fragment reads
+//   64 = cycle stamps: every wave adds up, over the K loop, the shader cycles it spent in each part of its load and
+//        compute segments and writes 8 counters to p.C2 [(block * 8 + wave) * 8 ...] (results stay correct)
 //
 // RS = register staging instead of LDS-DMA: the same pieces travel global -> VGPR (global_load_dwordx4, which does not
 // hold the issuing wave) and are stored to the same LDS addresses (ds_write_b128) at the START of the wave's next load
@@ -159,6 +164,14 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
         }
         if (RS) stg_dst = slot + offB;
     };
+    unsigned tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;   // ABL & 64
+    auto lap = [&](int slot) {
+        if (ABL & 64) {
+            const unsigned now = of_cycles();
+            tm[slot] += now - t_prev;
+            t_prev = now;
+        }
+    };
     s16x8 fa[4][2], fb[2][2];
     auto load_frags = [&](const char* stage, int h, int gi) {
         if (ABL & 2) {
@@ -179,8 +192,18 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
             for (int t = 0; t < 4; ++t) fa[t][ks] = frag32<AT>(stage, wm * 128 + t * 32, h, ks, lane);
         }
     };
+    s16x8 cfa = {(short)lane, 1, 2, 3, 4, 5, 6, 7}, cfb = {7, 6, 5, 4, 3, 2, 1, (short)lane};   // ABL & 128
     auto compute = [&]() {
         of_sched_fence();
+        if (ABL & 128) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = of_mfma32(cfb, cfa, acc[mt][nt]);
+            return;
+        }
         if (ABL & 4) {
             acc[0][0][0] += __builtin_bit_cast(float, (int)fa[0][0][0] + fa[1][1][1] + fa[2][0][2] + fa[3][1][3] + fb[0][0][4] + fb[1][1][5]);
             return;
@@ -194,13 +217,26 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
     };
     // end of a load segment: the 4 pieces issued two segments ago have landed (or everything, if nothing was issued now)
     auto publish = [&](bool issued) {
+        lap(1);                        // [1] DMA issue
         if (!(ABL & 16) && !RS) {      // RS: loads target VGPRs and stay in flight across the barrier
             if (issued) of_wait_vm<4>();
             else of_wait_vm<0>();
         }
+        lap(2);                        // [2] wait for the pieces issued two segments ago
         of_wait_lgkm0();
+        if (ABL & 128) {               // the reads are real: keep their results alive up to here
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(fa[t][ks]));
+#pragma unroll
+                for (int t = 0; t < 2; ++t) asm volatile("" ::"v"(fb[t][ks]));
+            }
+        }
+        lap(3);                        // [3] wait for this segment's fragment reads
         of_sched_fence();
         of_barrier_raw();
+        lap(4);                        // [4] barrier at the end of a load segment
     };
 
     // prologue: stage 0 complete for everybody (the 8 waves' duties cover all 64 chunks); G1 starts A rows 0-127 of stage 1
@@ -217,6 +253,7 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
     if (RS) of_wait_lgkm0();
     of_barrier_raw();
     if (wm == 1) of_barrier_raw();   // stagger: G1 runs one segment behind G0
+    if (ABL & 64) t_prev = of_cycles();
 
     // Stage p lives in slot p&1.  Reader/writer pairs (T = wall segment, see header):
     //   B rows 0-127 of p+1   written G0 T0(p), landed+published end of T2(p); first read T0(p+1).
@@ -235,23 +272,34 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
         const bool i0 = dma && d + 1 < nd;
         if (RS && i0) issueB(other);
         load_frags(stage, 0, d);
+        lap(0);                        // [0] fragment reads issued AND returned (the stamp waits lgkmcnt(0))
         if (!RS && i0) issueB(other);
         publish(i0);
         // ---- C0
         compute();
+        lap(5);                        // [5] MFMA issue
         of_sched_fence();
         of_barrier_raw();
+        lap(6);                        // [6] barrier at the end of a compute segment
         // ---- L1
         flush();
         const bool i1 = dma && (wm == 0 ? d + 1 < nd : d + 2 < nd);
         if (RS && i1) issueA(wm == 0 ? other : smem + (d & 1) * STAGE_BYTES);
         load_frags(stage, 1, d);
+        lap(0);
         if (!RS && i1) issueA(wm == 0 ? other : smem + (d & 1) * STAGE_BYTES);
         publish(i1);
         // ---- C1
         compute();
+        lap(5);
         of_sched_fence();
         of_barrier_raw();
+        lap(6);
+    }
+    if ((ABL & 64) && p.C2 && lane == 0) {
+        unsigned* out = (unsigned*)p.C2 + ((size_t)of_bid_x() * 8 + wave) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) out[i] = tm[i];
     }
     if (wm == 0) of_barrier_raw();   // balances G1's stagger barrier
 
@@ -323,6 +371,8 @@ int of_gemm_pp_ablate(const OfGemmArgs& a, int mask, of_stream_t s) {
         case 38: return launch_abl<38>(a, s);
         case 54: return launch_abl<54>(a, s);
         case 18: return launch_abl<18>(a, s);
+        case 64: return launch_abl<64>(a, s);
+        case 128: return launch_abl<128>(a, s);
     }
     return OF_E_ARG;
 }

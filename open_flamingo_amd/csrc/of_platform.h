@@ -54,6 +54,13 @@ OF_DEV f32x16 of_mfma32(s16x8 a, s16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(of_bf16x8n, a),
                                                    __builtin_bit_cast(of_bf16x8n, b), c, 0, 0, 0);
 }
+// shader clock (s_memtime; timing aid of the ablation builds).  The value returns through the scalar-memory counter,
+// so reading it also waits for the wave's outstanding LDS operations (lgkmcnt is shared).
+OF_DEV unsigned of_cycles() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return (unsigned)t;
+}
 OF_DEV void of_setprio_hi() { __builtin_amdgcn_s_setprio(1); }
 OF_DEV void of_setprio_lo() { __builtin_amdgcn_s_setprio(0); }
 // pins the instruction scheduler: nothing moves across this point

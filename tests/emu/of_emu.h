@@ -187,6 +187,7 @@ OF_DEV f32x16 of_mfma32(s16x8 a, s16x8 b, f32x16 c) {
     of_emu::wave_barrier();
     return d;
 }
+OF_DEV unsigned of_cycles() { return 0; }
 OF_DEV void of_setprio_hi() {}
 OF_DEV void of_setprio_lo() {}
 OF_DEV void of_sched_fence() {}
