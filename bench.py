@@ -85,6 +85,24 @@ def cpu_baseline(family_info, threads, T=2, L=256):
                       f"scaled to {nblk} blocks; {total * 1e3:.0f} ms per {B * T} images"}
 
 
+def pmc_traffic(key):
+    """HBM-side bytes per launch of the dominant kernel.  PMC counters cannot be collected inside a timed run (rocprofv3
+    --pmc serialises kernels and needs separate passes per counter group), so the live line quotes the committed PMC
+    passes of the same kernel symbol and launch shape (profiles/pmc_traffic.json, refreshed with tools/gpu_pmc_traffic.sh)
+    and says so; null when that file has no entry for the kernel."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+        ent = table["kernels"][" ".join(str(int(k)) for k in key)]
+    except (OSError, KeyError, ValueError):
+        return None, "no PMC pass on record for this kernel (profiles/pmc_traffic.json)"
+    return ent["fetch_bytes"] + ent["write_bytes"], (
+        f"bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE; fetches include "
+        f"Infinity-Cache hits), not collected in this run: {ent['launch']}; algorithmic bytes {ent['algorithmic_bytes']}; "
+        f"L2 hit rate {ent['l2_hit_rate']}; profiles/pmc_traffic.json")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,8 +220,9 @@ def main():
             all_fl = sum(v[0] for v in groups.values())
             all_ms = sum(v[1] for v in groups.values())
         ach = fl / ms / 1e9
+        traffic, traffic_note = pmc_traffic(key)
         roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "kernel": f"{sym}  = of_gemm {LAYOUT_NAMES[key[:2]]}, epilogue {EPI_NAMES[key[2]]}",
                     "launches_per_step": n // args.steps, "avg_launch_ms": round(ms / n, 4),
                     "gflop_per_launch": round(fl / n / 1e9, 2),
