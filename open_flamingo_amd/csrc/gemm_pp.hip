@@ -346,8 +346,6 @@ int launch_pp(const OfGemmArgs& a, of_stream_t s) {
     return of_launch(of_gemm_pp_kernel<AT, BT, EPI>, grid, 512, SMEM_PP, s, a);
 }
 
-
-
 template <int ABL>
 int launch_abl(const OfGemmArgs& a, of_stream_t s) {
     of_dim3 grid{(unsigned)((a.M / TM) * (a.N / TN)), 1, 1};
@@ -377,8 +375,6 @@ int of_gemm_pp_ablate(const OfGemmArgs& a, int mask, of_stream_t s) {
     return OF_E_ARG;
 }
 
-namespace {
-}
 
 int of_gemm_pp_try(const OfGemmArgs& a, of_stream_t s) {
     if ((a.M % TM) || (a.N % TN) || (a.K % DK)) return OF_E_SHAPE;
