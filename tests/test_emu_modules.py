@@ -1,0 +1,127 @@
+"""The PRODUCT host code of the hot path (open_flamingo_amd/src/helpers.py: nn.Modules, autograd Functions, in-place
+gradient sinks, inference path; train/reducer.py + train/optim.py around them) executed on CPU with every libofhip
+kernel running on the host SIMT emulator (tests/emu) -- TEST INFRASTRUCTURE ONLY: the two guards that make the product
+refuse anything but an AMD GPU (`_require_hip`, `Ops.default`) are monkeypatched for the duration of a test.
+
+What this pins without a GPU: the module-level wiring (parameter order, saved tensors, returned gradients), gradient
+accumulation straight into GradReducer buckets, the no-grad decode path with its projected-media cache, and a whole
+train_step (libofhip modules + fused step epilogue) against the oracle modules + torch AdamW from the same weights."""
+import pytest
+import torch
+
+from oracle import flamingo_oracle as O
+from open_flamingo_amd.hip.ops import Ops
+from open_flamingo_amd.src import helpers
+from open_flamingo_amd.train import step, synthetic, towers
+from open_flamingo_amd.train.optim import FlatAdamW
+from open_flamingo_amd.train.reducer import GradReducer
+from tests.cpu_model import swap_in_oracle
+from tests.emu import harness as H
+
+
+@pytest.fixture
+def on_emulator(monkeypatch):
+    monkeypatch.setattr(helpers, "_require_hip", lambda t, what: None)
+    monkeypatch.setattr(Ops, "default", staticmethod(H.emu_ops))
+    helpers._shared.items.clear()
+    yield
+    helpers._shared.items.clear()
+
+
+def _rel(a, b):
+    return (a.double() - b.double()).abs().max().item() / (b.double().abs().max().item() + 1e-12)
+
+
+def _tiny(seed=0):
+    model, info = towers.build_flamingo("OF-tiny", device="cpu", seed=seed, gates=0.5, fused_lm_attention=False)
+    model.train()
+    return model, info
+
+
+def test_block_module_matches_oracle_module(on_emulator):
+    torch.manual_seed(0)
+    blk = helpers.GatedCrossAttentionBlock(dim=128, dim_visual=64, heads=2)
+    ref = O.OracleGatedCrossAttentionBlock(dim=128, dim_visual=64, heads=2)
+    with torch.no_grad():
+        blk.attn_gate.fill_(0.6)
+        blk.ff_gate.fill_(-0.4)
+    ref.load_state_dict(blk.state_dict(), strict=True)
+    x = torch.randn(2, 20, 128)
+    media = torch.randn(2, 2, 64, 64)
+    locs = torch.zeros(2, 20, dtype=torch.bool)
+    locs[:, 1] = locs[0, 9] = True
+    w = torch.randn(2, 20, 128)
+    outs = []
+    for m in (blk, ref):
+        xi, mi = x.clone().requires_grad_(True), media.clone().requires_grad_(True)
+        kw = dict(quant=O.bf16_round) if m is ref else {}
+        y = m(xi, mi, media_locations=locs, **kw)
+        (y * w).sum().backward()
+        outs.append((y.detach(), xi.grad, mi.grad, {k: p.grad for k, p in m.named_parameters()}))
+    (y, dx, dm, g), (y0, dx0, dm0, g0) = outs
+    assert _rel(y, y0) < 1e-2 and _rel(dx, dx0) < 3e-2 and _rel(dm, dm0) < 3e-2
+    for k in g0:
+        assert _rel(g[k], g0[k]) < 3e-2, k
+    # no-grad path (eval mode: weight copies are cached): same bits as the training forward, projected media kept for as
+    # long as the media tensor is the same
+    blk.eval()
+    with torch.no_grad():
+        y_inf = blk(x, media, media_locations=locs)
+        kv = blk._kv_cache[3]
+        tok = blk(x[:, :1], media, media_locations=locs, use_cached_media=True)
+        assert blk._kv_cache[3] is kv
+    assert torch.equal(y_inf, y) and tok.shape == (2, 1, 128)
+    blk.train()
+    assert "_kv_cache" not in blk.__dict__
+
+
+def test_gradients_accumulate_in_place_into_reducer_buckets(on_emulator):
+    """Two backward passes with a GradReducer (libofhip backward adds into the bucket views, returns None to autograd and
+    fires the reducer's callback itself) == plain autograd accumulation without a reducer."""
+    got = []
+    for use_reducer in (False, True):
+        model, info = _tiny()
+        red = GradReducer(model, embedding_rows=None) if use_reducer else None
+        fired = []
+        if red is not None:
+            for b in red.buckets:
+                for p in b["params"]:
+                    p._of_on_grad = (lambda q, f=p._of_on_grad: (fired.append(q), f(q))[1])
+        for b in (synthetic.make_batch(2, 1, 16, info, "cpu", seed=6), synthetic.make_batch(2, 2, 24, info, "cpu", seed=5)):
+            step.forward_loss(model, b, info, amp=False).backward()
+        if red is not None:
+            n_params = sum(len(b["params"]) for b in red.buckets)
+            assert len(fired) == 2 * n_params
+            for b in red.buckets:
+                for p, off in zip(b["params"], b["offsets"]):
+                    assert p.grad.data_ptr() == b["flat"].data_ptr() + 4 * off
+        got.append({k: p.grad.detach().clone() for k, p in model.named_parameters()
+                    if p.requires_grad and ("gated_cross_attn" in k or "perceiver" in k)})
+    for k in got[0]:
+        assert _rel(got[1][k], got[0][k]) < 1e-5, k      # same kernels, same order: only fp32 add order of the two passes
+
+
+def test_train_step_with_product_modules_tracks_oracle_modules(on_emulator):
+    """libofhip modules + GradReducer + fused step epilogue (all kernels emulated) vs the oracle's autograd modules +
+    clip_grad_norm_ + torch AdamW, same initial weights and batch, two optimizer steps.  The product rounds GEMM operands
+    to bf16 and the oracle model here runs plain fp32, and Adam turns small gradient differences into O(lr) parameter
+    differences: trajectories are compared in L2 against the distance travelled (25 %), losses to 0.5 %."""
+    batch = None
+    runs = []
+    for product in (True, False):
+        model, info = _tiny()
+        if not product:
+            swap_in_oracle(model)
+        red = GradReducer(model, embedding_rows=[info["media_token_id"], info["eoc_token_id"]])
+        opt = FlatAdamW(red, lr=1e-3, ops=H.emu_ops()) if product else step.build_optimizer(model, lr=1e-3)
+        batch = batch or synthetic.make_batch(2, 2, 24, info, "cpu", seed=5)
+        init = {k: p.detach().clone() for k, p in model.named_parameters() if p.requires_grad}
+        losses = [float(step.train_step(model, red, opt, batch, info, amp=False)) for _ in range(2)]
+        runs.append((losses, init, {k: p.detach().clone() for k, p in model.named_parameters() if p.requires_grad}))
+    (l1, i1, p1), (l0, i0, p0) = runs
+    assert all(abs(a - b) <= 5e-3 * abs(b) for a, b in zip(l1, l0)), (l1, l0)
+    assert l0[-1] < l0[0]
+    # product parameter names differ from the oracle model's only by module class, not by key
+    for k in p0:
+        travelled = (p0[k] - i0[k]).norm().item()
+        assert (p1[k] - p0[k]).norm().item() <= 0.25 * travelled + 1e-7, k
