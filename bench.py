@@ -125,6 +125,9 @@ def main():
                     help="LayerNorms in front of the frozen towers' Linear layers: libofhip (bf16 operand written directly) or eager")
     ap.add_argument("--torch-optimizer", action="store_true",
                     help="clip_grad_norm_ + torch.optim.AdamW(fused) instead of the libofhip step epilogue")
+    ap.add_argument("--sparse-embedding-rows", action="store_true",
+                    help="opt-in (train/sparse_rows.py): gradient of the two trained embedding rows without the dense "
+                         "(vocab x d) lookup scatter and tied-head weight-gradient GEMM")
     ap.add_argument("--gemm-report", default=None, help="write a per-(layout,epilogue,shape) GEMM time table (JSON lines)")
     args = ap.parse_args()
 
@@ -141,6 +144,10 @@ def main():
                                         fused_lm_attention=args.lm_attention if args.lm_attention != "eager" else False,
                                         tower_layernorm=args.tower_layernorm)
     model.train()
+    if args.sparse_embedding_rows:
+        from open_flamingo_amd.train import sparse_rows
+        assert not args.torch_optimizer, "--sparse-embedding-rows needs the fused step epilogue"
+        sparse_rows.enable(model, [info["media_token_id"], info["eoc_token_id"]])
     reducer = GradReducer(model, wire_dtype=torch.bfloat16 if args.wire_bf16 else torch.float32,
                           embedding_rows=[info["media_token_id"], info["eoc_token_id"]])
     reducer.broadcast_parameters()
@@ -243,7 +250,8 @@ def main():
                           "parallelism": f"dp{world}",
                           "frozen_tower_weights": "fp32 (re-cast by autocast)" if args.frozen_fp32 else "bf16 copies held",
                           "frozen_lm_attention": args.lm_attention, "frozen_tower_layernorm": args.tower_layernorm,
-                          "grad_wire_dtype": "bf16" if args.wire_bf16 else "fp32"},
+                          "grad_wire_dtype": "bf16" if args.wire_bf16 else "fp32",
+                          "embedding_row_gradient": "sparse taps" if args.sparse_embedding_rows else "dense, masked"},
                "loss": None if loss is None else round(float(loss), 4)}
         if roofline is not None:
             out["roofline"] = roofline

@@ -26,10 +26,11 @@ def trainable_state_dict(model, state_dict=None):
       tensors are saved under the decoder-layer names) and everything under ``vision_encoder`` are dropped;
     * buffers stay.
     """
+    from .sparse_rows import is_trainable          # the table in sparse-rows mode is frozen for autograd only
     sd = dict(model.state_dict() if state_dict is None else state_dict)
     frozen = {name.replace("._checkpoint_wrapped_module", "")
               for name, p in model.named_parameters()
-              if not p.requires_grad and "embed" not in name and "fsdp" not in name}
+              if not is_trainable(p) and "embed" not in name and "fsdp" not in name}
     return {k: v for k, v in sd.items()
             if k not in frozen and "vision_encoder" not in k and not any(a in k for a in _ALIAS_PREFIXES)}
 

@@ -87,8 +87,13 @@ class FlatAdamW:
         for b in self.reducer.buckets:
             ops.sumsq(b["flat"], self._sumsq)
         g_rows = None
-        if self.embedding is not None and self.embedding.grad is not None:
+        sparse = getattr(self.reducer, "sparse", None)
+        if sparse is not None:                       # train/sparse_rows.py: the kept rows arrive directly
+            if sparse.grad_rows() is not None:
+                g_rows = sparse.grad_rows().contiguous()
+        elif self.embedding is not None and self.embedding.grad is not None:
             g_rows = self.embedding.grad.index_select(0, self._emb["rows"]).contiguous()
+        if g_rows is not None:
             ops.sumsq(g_rows, self._sumsq)
         for b, lr in ((b, self.param_groups[0 if b["wd"] else 1]["lr"]) for b in self.reducer.buckets):
             ops.adamw_clip(b["flat_p"], b["flat"], b["m"], b["v"], self._sumsq, step=self.step_count, lr=lr,
@@ -102,6 +107,8 @@ class FlatAdamW:
                            max_norm=self.max_norm, zero_grad=False, grad_scale=gs)
             self.embedding.data.index_copy_(0, e["rows"], p_rows)
             self.embedding.grad = None
+            if sparse is not None:
+                sparse.clear()
 
     def zero_grad(self, set_to_none=True):
         self.reducer.zero_grad()
@@ -110,8 +117,9 @@ class FlatAdamW:
     def _reference_order(self):
         """The parameter numbering ``torch.optim.AdamW`` has in the reference (train.py:384-408): trainable parameters
         in ``named_parameters()`` order, the ``gated_cross_attn`` ones (weight decay) first, then the rest."""
+        from .sparse_rows import is_trainable
         named = [(n, p) for n, p in self.reducer.module.named_parameters()
-                 if p.requires_grad and not getattr(p, "exclude_from_optimizer", False)]
+                 if is_trainable(p) and not getattr(p, "exclude_from_optimizer", False)]
         with_wd = [p for n, p in named if "gated_cross_attn" in n]
         without = [p for n, p in named if "gated_cross_attn" not in n]
         return with_wd, without

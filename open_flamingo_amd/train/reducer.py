@@ -49,7 +49,16 @@ class GradReducer:
             groups.append(("perceiver", per))
         self.embedding = None
         emb = lm.get_input_embeddings().weight
-        if emb.requires_grad:
+        # opt-in train/sparse_rows.py: the table is frozen for autograd and the kept rows' gradient arrives in a small
+        # leaf (autograd sums the tied-head tap's and the lookup tap's contributions before it accumulates: one
+        # post-accumulate callback per backward); it is exchanged like a bucket
+        self.sparse = getattr(model, "_of_sparse_rows", None)
+        if self.sparse is not None:
+            assert self.embedding_rows is not None and list(self.sparse.rows.tolist()) == self.embedding_rows, \
+                "sparse_rows.enable(model, rows) and GradReducer(embedding_rows=rows) must name the same rows in the same order"
+            self.embedding = emb
+            self.sparse.leaf.register_post_accumulate_grad_hook(self._sparse_hook)
+        elif emb.requires_grad:
             self.embedding = emb
         self.buckets = []
         for kind, params in groups:
@@ -75,7 +84,7 @@ class GradReducer:
                 # _of_on_grad itself, instead of returning a fresh gradient for autograd to add (one add kernel per
                 # parameter per backward).  Modules that do not know the protocol ignore the attributes.
                 p._of_inplace_grad, p._of_on_grad = True, self._hook
-        if self.embedding is not None:
+        if self.embedding is not None and self.sparse is None:
             self.embedding.register_post_accumulate_grad_hook(self._emb_hook)
 
     # ------------------------------------------------------------------
@@ -115,6 +124,10 @@ class GradReducer:
         if b["ready"] == len(b["params"]):
             b["ready"] = 0
             self._launch(b["flat"])
+
+    def _sparse_hook(self, leaf):
+        if self._sync:
+            self._launch(leaf.grad)
 
     def _emb_hook(self, p):
         if not self._sync or self.embedding_rows is None:
@@ -162,6 +175,8 @@ class GradReducer:
             b["ready"] = 0
         if self.embedding is not None and self.embedding.grad is not None:
             self.embedding.grad = None
+        if self.sparse is not None:
+            self.sparse.clear()
 
     def broadcast_parameters(self, src=0):
         """DDP-constructor equivalent (train.py:366): make every rank start from rank ``src``'s trainable weights."""

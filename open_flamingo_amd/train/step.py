@@ -18,6 +18,9 @@ def build_optimizer(model, lr=1e-4, weight_decay=0.1, reducer=None):
     if reducer is not None and reducer.buckets and reducer.buckets[0]["flat"].is_cuda:
         from .optim import FlatAdamW
         return FlatAdamW(reducer, lr=lr, weight_decay=weight_decay)
+    if getattr(model, "_of_sparse_rows", None) is not None:
+        raise RuntimeError("train/sparse_rows.py froze the embedding table for autograd: its two trained rows are only "
+                           "updated by the fused step epilogue (build_optimizer(model, reducer=GradReducer) on a GPU)")
     with_wd, without_wd = [], []
     for n, p in model.named_parameters():
         if not p.requires_grad or getattr(p, "exclude_from_optimizer", False):

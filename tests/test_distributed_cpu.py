@@ -68,15 +68,21 @@ def _worker(rank, world, port, q):
     # 1/world into its AdamW pass
     from open_flamingo_amd.train.optim import FlatAdamW
     from tests.emu import harness as H
+    # ... and so must the opt-in sparse embedding-row path (train/sparse_rows.py): its (2, d) gradient leaf is exchanged
+    # instead of rows cut out of the dense gradient
+    from open_flamingo_amd.train import sparse_rows
     finals = []
-    for fused in (False, True):
+    for fused, sparse in ((False, False), (True, False), (True, True)):
         m2, _ = tiny_cpu_flamingo(seed=0)
+        if sparse:
+            sparse_rows.enable(m2, rows)
         r2 = GradReducer(m2, embedding_rows=rows)
         o2 = FlatAdamW(r2, lr=1e-3, ops=H.emu_ops()) if fused else step.build_optimizer(m2, lr=1e-3)
         for _ in range(2):
-            step.train_step(m2, r2, o2, b_mmc4, info, amp=False)
-        finals.append(torch.cat([p.detach().flatten() for _, p in m2.named_parameters() if p.requires_grad]).double())
-    fused_err = (finals[0] - finals[1]).abs().max().item()
+            step.train_step(m2, r2, o2, b_mmc4, info, batch_laion=b_laion, amp=False)
+        finals.append(torch.cat([p.detach().flatten() for _, p in m2.named_parameters()
+                                 if sparse_rows.is_trainable(p)]).double())
+    fused_err = max((finals[0] - finals[1]).abs().max().item(), (finals[1] - finals[2]).abs().max().item())
     q.put((rank, max(errs.values()), nz_rows, same, float(loss), len(red.buckets), fused_err))
     dist.destroy_process_group()
 
@@ -94,7 +100,8 @@ def test_reducer_and_train_step_world2():
         p.join(60)
         assert p.exitcode == 0
     for rank, err, nz_rows, same, loss, nb, fused_err in res:
-        assert fused_err < 2e-5, f"rank {rank}: fused step epilogue diverges from clip + torch AdamW ({fused_err})"
+        assert fused_err < 2e-5, (f"rank {rank}: fused step epilogue (dense or sparse embedding rows) diverges from "
+                                  f"clip + torch AdamW ({fused_err})")
         assert err < 1e-5, f"rank {rank}: reduced grads differ from mean of local grads ({err})"
         assert nz_rows <= 2, "embedding gradient must be masked to the <image>/<|endofchunk|> rows"
         assert same, "replicas diverged after train_step"
