@@ -1,7 +1,7 @@
 """bench.py -- OpenFlamingo training-step throughput on MI355X (BASELINE.json metric: train images/sec + step ms,
 OF-3B = ViT-L/14 + MPT-1B, xattn every layer, amp_bf16, synthetic MMC4-style batch B=32 T=2 F=1 L=256 per GPU).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1 without a launcher: spawns the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -11,6 +11,8 @@ embedding gradient, gradient exchange (RCCL, overlapped), global-norm clip, Adam
 the timed region.  Weights are random-init of the named architecture (no network), data synthetic.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus:
+  overlap       -- gradient exchange of the step: bytes all-reduced, wire dtype, collectives per step and the time the
+                   compute stream actually waited for RCCL in GradReducer.finish() (HIP events; 0 at one GPU).
   roofline      -- the dominant libofhip kernel family (the bf16 MFMA GEMM) measured live with HIP events on the
                    compute stream inside the timed region: algorithmic FLOPs / summed launch time vs 2.5 PFLOP/s.
   cpu_baseline  -- the oracle (CPU port of the reference arithmetic) timed on the host cores for a bounded sample.
@@ -103,6 +105,23 @@ def pmc_traffic(key):
         f"L2 hit rate {ent['l2_hit_rate']}; profiles/pmc_traffic.json")
 
 
+def _spawn_ranks(n):
+    """``python bench.py --gpus N`` with no launcher environment: re-run this command line under
+    ``torch.distributed.run`` (one process per GPU, RCCL rendezvous on 127.0.0.1) and pass its output through -- rank 0
+    prints the one JSON line.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,6 +149,8 @@ def main():
                          "(vocab x d) lookup scatter and tied-head weight-gradient GEMM")
     ap.add_argument("--gemm-report", default=None, help="write a per-(layout,epilogue,shape) GEMM time table (JSON lines)")
     args = ap.parse_args()
+    if args.gpus > 1 and not any(k in os.environ for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK")):
+        sys.exit(_spawn_ranks(args.gpus))
 
     from open_flamingo_amd.hip.ops import Ops
     from open_flamingo_amd.train import distributed, step, synthetic, towers
@@ -138,7 +159,8 @@ def main():
     device = distributed.init_distributed_device()
     assert device.type == "cuda", "bench.py needs an AMD GPU"
     local_rank, rank, world = distributed.world_info_from_env()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 
     model, info = towers.build_flamingo(args.family, device=device, seed=0, gates=0.5, frozen_bf16=not args.frozen_fp32,
                                         fused_lm_attention=args.lm_attention if args.lm_attention != "eager" else False,
@@ -180,11 +202,14 @@ def main():
     if not args.no_roofline:
         ops.gemm_timing = []
         ops.gemm_timing_only = {dominant} if dominant is not None else None
+    reducer.overlap_stats(reset=True)
+    reducer.time_waits = world > 1          # two HIP events per step around the compute stream's wait for RCCL
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step.train_step(model, reducer, opt, batch, info)
     sync()
     elapsed = time.perf_counter() - t0
+    overlap = reducer.overlap_stats()
     timing, ops.gemm_timing = ops.gemm_timing, None
     ops.gemm_timing_only = None
     if world > 1:
@@ -253,6 +278,14 @@ def main():
                           "grad_wire_dtype": "bf16" if args.wire_bf16 else "fp32",
                           "embedding_row_gradient": "sparse taps" if args.sparse_embedding_rows else "dense, masked"},
                "loss": None if loss is None else round(float(loss), 4)}
+        out["overlap"] = {"allreduce_bytes_per_step_per_gpu": int(overlap["allreduce_bytes_per_step"]),
+                          "collectives_per_step": overlap["collectives_per_step"], "wire_dtype": overlap["wire_dtype"],
+                          "buckets": overlap["buckets"],
+                          "exposed_wait_ms_per_step": None if overlap["exposed_wait_ms_per_step"] is None
+                          else round(overlap["exposed_wait_ms_per_step"], 3),
+                          "note": "one exchange per optimizer step on a side HIP stream (RCCL all-reduce per gated block + "
+                                  "per Perceiver layer, launched as the backward produces them); exposed_wait = time the "
+                                  "compute stream waited in GradReducer.finish(), HIP events, rank 0"}
         if roofline is not None:
             out["roofline"] = roofline
         if world == 1 and not args.no_cpu_baseline:

@@ -214,8 +214,13 @@ def perceiver_fwd(ops, P, W, x, *, N, Fv, n, heads, depth, T=1, frames=1, safe=0
     return out, dict(layers=layers, lat_last=lat, st_o=st_o, x=x, embs=embs, T=T, frames=frames)
 
 
-def perceiver_bwd(ops, P, W, S, dout, *, N, Fv, n, heads, depth, T=1, frames=1, need_dx=False, safe=0, sinks=None):
-    """Returns (dx (N*Fv, D) stream dtype or None, grads dict keyed like P).  sinks: see _GradOut."""
+def perceiver_bwd(ops, P, W, S, dout, *, N, Fv, n, heads, depth, T=1, frames=1, need_dx=False, safe=0, sinks=None,
+                  on_ready=None):
+    """Returns (dx (N*Fv, D) stream dtype or None, grads dict keyed like P).  sinks: see _GradOut.
+    on_ready(names): called as soon as the kernels producing the FINAL value of those parameters' gradients are enqueued
+    (per layer, last layer first) -- the gradient exchange of a layer can then start while the earlier layers' backward
+    still runs (train/reducer.py buckets the Perceiver per layer)."""
+    ready = on_ready or (lambda names: None)
     dev = dout.device
     x = S["x"]
     want_dx = need_dx
@@ -230,6 +235,7 @@ def perceiver_bwd(ops, P, W, S, dout, *, N, Fv, n, heads, depth, T=1, frames=1, 
     dlat = torch.empty_like(dout)
     ops.ln_bwd(dout, S["lat_last"], S["st_o"], P["norm.weight"], dx=dlat, dw=G.acc("norm.weight", (D,)),
                db=G.acc("norm.bias", (D,)))
+    ready(["norm.weight", "norm.bias"])
     dx = None
     for i in reversed(range(depth)):
         pa, pf = f"layers.{i}.0.", f"layers.{i}.1."
@@ -282,6 +288,7 @@ def perceiver_bwd(ops, P, W, S, dout, *, N, Fv, n, heads, depth, T=1, frames=1, 
                    dy_grp_stride=S_ * D, dy2=dltn, resid=dlat1, dx=dlat_prev, dw=G.acc(pa + "norm_latents.weight", (D,)),
                    db=G.acc(pa + "norm_latents.bias", (D,)))
         dlat = dlat_prev
+        ready([k for k in P if k.startswith(pa) or k.startswith(pf)])
     ops.reduce_rows(dlat, G.acc("latents", tuple(P["latents"].shape)))           # sum over (b, T) of the repeat
     if S.get("embs", False):
         v = Fv // frames
@@ -290,4 +297,5 @@ def perceiver_bwd(ops, P, W, S, dout, *, N, Fv, n, heads, depth, T=1, frames=1, 
             ops.reduce_rows_strided(dx, v, frames, G.acc("frame_embs", tuple(P["frame_embs"].shape)))
         if "media_time_embs" in P:
             ops.reduce_rows_strided(dx, Fv, T, G.acc("media_time_embs", tuple(P["media_time_embs"].shape)))
+    ready([k for k in ("latents", "frame_embs", "media_time_embs") if k in P])
     return (dx if want_dx else None), g

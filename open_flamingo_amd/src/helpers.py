@@ -115,9 +115,10 @@ def _grad_sinks(names, params):
     return sinks
 
 
-def _hand_back(names, params, dtypes, g, sinks):
+def _hand_back(names, params, dtypes, g, sinks, notified=()):
     """Gradients for autograd: None where the kernels already accumulated into ``.grad`` -- for those the owner's
-    post-accumulate callback is run here, since AccumulateGrad (and with it the registered hook) will not fire."""
+    post-accumulate callback is run here (unless the backward already ran it, ``notified``), since AccumulateGrad (and
+    with it the registered hook) will not fire."""
     out = []
     for k, p, dt in zip(names, params, dtypes):
         if k in sinks:
@@ -125,7 +126,7 @@ def _hand_back(names, params, dtypes, g, sinks):
         else:
             out.append(g[k] if g[k].dtype == dt else g[k].to(dt))
     for k, p in zip(names, params):
-        if k in sinks:
+        if k in sinks and k not in notified:
             p._of_on_grad(p)
     return tuple(out)
 
@@ -195,9 +196,19 @@ class _PerceiverFn(torch.autograd.Function):
         D = ctx.xshape[-1]
         need_dx = ctx.needs_input_grad[2]
         sinks = _grad_sinks(ctx.names, ctx.params)
-        dx, g = _path.perceiver_bwd(ops, ctx.P, ctx.W, ctx.S, dout.reshape(-1, D), need_dx=need_dx, sinks=sinks, **dims)
+        by_name = dict(zip(ctx.names, ctx.params))
+        notified = set()
+
+        def on_ready(names):      # a layer's gradients are final: let their owner start the exchange now
+            for k in names:
+                if k in sinks and k not in notified:
+                    notified.add(k)
+                    by_name[k]._of_on_grad(by_name[k])
+
+        dx, g = _path.perceiver_bwd(ops, ctx.P, ctx.W, ctx.S, dout.reshape(-1, D), need_dx=need_dx, sinks=sinks,
+                                    on_ready=on_ready, **dims)
         ctx.S = None
-        grads = _hand_back(ctx.names, ctx.params, ctx.param_dtypes, g, sinks)
+        grads = _hand_back(ctx.names, ctx.params, ctx.param_dtypes, g, sinks, notified)
         return (None, None, dx.view(ctx.xshape) if need_dx else None) + grads
 
 

@@ -18,13 +18,20 @@ import torch
 from ..hip.ops import BF16, F32, Ops
 
 
-class FlatAdamW:
+class FlatAdamW(torch.optim.Optimizer):
+    """A ``torch.optim.Optimizer`` (so ``torch.optim.lr_scheduler.*`` and the HF ``get_*_schedule_with_warmup`` helpers the
+    reference's train.py uses accept it): ``param_groups`` hold the real parameters -- group 0 = gated cross-attention
+    (weight decay), group 1 = the rest -- and every ``step()`` reads each group's current ``lr``."""
+
     def __init__(self, reducer, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1, max_norm=1.0, ops=None):
+        if reducer.embedding is not None and reducer.embedding_rows is None:
+            raise NotImplementedError("FlatAdamW updates only the kept embedding rows; a fully trainable table needs "
+                                      "torch.optim.AdamW (train/step.py::build_optimizer picks it)")
         self.reducer, self.ops = reducer, ops
         self.betas, self.eps, self.max_norm = betas, eps, max_norm
         self.step_count = 0
-        self.param_groups = [{"lr": lr, "params": [], "weight_decay": weight_decay},
-                             {"lr": lr, "params": [], "weight_decay": 0.0}]      # LR schedulers mutate ["lr"]
+        groups = [{"lr": lr, "params": [], "weight_decay": weight_decay},
+                  {"lr": lr, "params": [], "weight_decay": 0.0}]                  # LR schedulers mutate ["lr"]
         self._views = {}            # param.data_ptr() -> (bf16 view, parameter version it mirrors, numel)
         for b in reducer.buckets:
             flat_g = b["flat"]
@@ -36,14 +43,20 @@ class FlatAdamW:
                 p.data = flat_p[off:off + n].view(p.shape)
             b.update(flat_p=flat_p, flat_bf16=flat_b, m=torch.zeros_like(flat_g), v=torch.zeros_like(flat_g),
                      wd=weight_decay if b.get("kind") == "xattn" else 0.0)
-            self.param_groups[0 if b["wd"] else 1]["params"].extend(b["params"])
+            groups[0 if b["wd"] else 1]["params"].extend(b["params"])
         self.embedding = reducer.embedding
         if self.embedding is not None:
             rows = torch.as_tensor(reducer.embedding_rows, device=self.embedding.device)
             d = self.embedding.shape[1]
             self._emb = dict(rows=rows, m=torch.zeros(len(rows), d, device=rows.device),
                              v=torch.zeros(len(rows), d, device=rows.device))
-            self.param_groups[1]["params"].append(self.embedding)
+            groups[1]["params"].append(self.embedding)
+        super().__init__([g for g in groups if g["params"]] or groups,
+                         dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) != 2:      # keep the two-group shape (reference train.py:392-408) even if one is empty
+            have = {g["weight_decay"] != 0.0: g for g in self.param_groups}
+            self.param_groups = [have.get(True, dict(groups[0], betas=tuple(betas), eps=eps)),
+                                 have.get(False, dict(groups[1], betas=tuple(betas), eps=eps))]
         self._sumsq = None
         self.refresh_bf16()
         model = reducer.module
@@ -74,7 +87,9 @@ class FlatAdamW:
         return ent[0]
 
     # ------------------------------------------------------------------ optimizer API subset used by train_step
-    def step(self):
+    @torch.no_grad()
+    def step(self, closure=None):
+        assert closure is None, "FlatAdamW does not re-evaluate the model"
         ops = self._ops()
         self.step_count += 1
         # GradReducer.finish(average=False) leaves the all-reduced SUM in the buckets; the 1/world is folded into the

@@ -8,9 +8,12 @@ reducer all-reduces every trainable gradient inside EACH ``backward()`` -- twice
 
   * one exchange per optimizer step: hooks only fire the collectives during the LAST backward of the step
     (``with reducer.no_sync():`` around the earlier ones, same contract as DDP.no_sync);
-  * buckets follow backward order: one bucket per gated cross-attention block (last block first), then the
-    Perceiver, so each all-reduce overlaps the frozen LM block backward that follows it.  The collectives run on
-    a dedicated side stream; the compute stream only waits in ``finish()`` (before clipping / the optimizer);
+  * buckets follow backward order: one bucket per gated cross-attention block (last block first), then one per
+    Perceiver layer (final norm + last layer first ... first layer + latents last; the hand-written Perceiver backward
+    reports each layer's gradients as soon as its kernels are enqueued), so each all-reduce overlaps the backward work
+    that follows it and the exposed tail is one Perceiver layer (~42 MB fp32), not the whole Perceiver (252 MB).  The
+    collectives run on a dedicated side stream; the compute stream only waits in ``finish()`` (before clipping / the
+    optimizer), and that wait is timed with HIP events (``overlap_stats``);
   * parameter ``.grad``s are views into the flat fp32 bucket buffers: no flatten/unflatten copies;
   * only the ``<image>`` / ``<|endofchunk|>`` rows of the input-embedding gradient travel (2 x d floats instead of
     vocab x d), and the rest of that gradient is zeroed here -- exactly the reference's post-all-reduce mask.
@@ -26,9 +29,10 @@ import torch.distributed as dist
 
 class GradReducer:
     def __init__(self, model, process_group=None, wire_dtype=torch.float32, embedding_rows=None,
-                 force_collectives=False):
+                 force_collectives=False, perceiver_buckets="layer"):
         """model: a Flamingo (or any module exposing .perceiver and .lang_encoder.gated_cross_attn_layers);
-        embedding_rows: token ids whose input-embedding gradient rows are kept (media + endofchunk)."""
+        embedding_rows: token ids whose input-embedding gradient rows are kept (media + endofchunk);
+        perceiver_buckets: "layer" (one bucket per Perceiver layer, backward order) or "one"."""
         self.module = model                      # DDP-style handle (train_utils.py:181 reaches through .module)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -40,13 +44,13 @@ class GradReducer:
         self._sync = True
         self._pending = []
         self._stream = None
+        self.stats = dict(collectives=0, bytes=0, steps=0)
+        self.time_waits, self._wait_events = False, []
         lm = model.lang_encoder
         groups = []
         for blk in reversed([b for b in lm.gated_cross_attn_layers if b is not None]):
             groups.append(("xattn", [p for p in blk.parameters() if p.requires_grad]))
-        per = [p for p in model.perceiver.parameters() if p.requires_grad]
-        if per:
-            groups.append(("perceiver", per))
+        groups.extend(("perceiver", g) for g in self._perceiver_groups(model.perceiver, perceiver_buckets))
         self.embedding = None
         emb = lm.get_input_embeddings().weight
         # opt-in train/sparse_rows.py: the table is frozen for autograd and the kept rows' gradient arrives in a small
@@ -87,6 +91,25 @@ class GradReducer:
         if self.embedding is not None and self.sparse is None:
             self.embedding.register_post_accumulate_grad_hook(self._emb_hook)
 
+    @staticmethod
+    def _perceiver_groups(perceiver, mode):
+        """Trainable Perceiver parameters grouped in the order their gradients become final in the backward
+        (reference helpers.py:129-132 run in reverse): [norm + layers.(depth-1)], layers.(depth-2), ..., [layers.0 +
+        latents + position tables]."""
+        named = [(n, p) for n, p in perceiver.named_parameters() if p.requires_grad]
+        if mode != "layer" or not any(n.startswith("layers.") for n, _ in named):
+            return [[p for _, p in named]] if named else []
+        depth = 1 + max(int(n.split(".")[1]) for n, _ in named if n.startswith("layers."))
+        per_layer = [[] for _ in range(depth)]
+        for n, p in named:
+            if n.startswith("layers."):
+                per_layer[int(n.split(".")[1])].append(p)
+            elif n.startswith("norm."):
+                per_layer[depth - 1].append(p)
+            else:                                   # latents, frame_embs, media_time_embs: final after layer 0
+                per_layer[0].append(p)
+        return [g for g in reversed(per_layer) if g]
+
     # ------------------------------------------------------------------
     def _side_stream(self, device):
         if device.type != "cuda":
@@ -100,16 +123,20 @@ class GradReducer:
         if self.world == 1 and not self.force_collectives:
             return
         side = self._side_stream(flat.device)
+        compute = None
         if side is not None:
-            side.wait_stream(torch.cuda.current_stream(flat.device))
+            compute = torch.cuda.current_stream(flat.device)
+            side.wait_stream(compute)
             ctx = torch.cuda.stream(side)
         else:
             ctx = contextlib.nullcontext()
+        self.stats["collectives"] += 1
+        self.stats["bytes"] += flat.numel() * torch.empty((), dtype=self.wire_dtype).element_size()
         with ctx:
             if self.wire_dtype != flat.dtype:
                 wire = flat.to(self.wire_dtype)
                 if side is not None:
-                    wire.record_stream(torch.cuda.current_stream(flat.device))   # consumed on the compute stream later
+                    wire.record_stream(compute)      # allocated on the side stream, read back on the compute stream in finish()
                 work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 self._pending.append((work, flat, wire))
             else:
@@ -130,7 +157,10 @@ class GradReducer:
             self._launch(leaf.grad)
 
     def _emb_hook(self, p):
-        if not self._sync or self.embedding_rows is None:
+        if not self._sync:
+            return
+        if self.embedding_rows is None:      # a fully trainable table: exchange the dense gradient like DDP would
+            self._launch(p.grad)
             return
         rows = torch.as_tensor(self.embedding_rows, device=p.grad.device)
         kept = p.grad.index_select(0, rows).contiguous()
@@ -160,11 +190,36 @@ class GradReducer:
         self._pending.clear()
         self.holds_sum = self.world > 1 and not average
         if self._stream is not None:
-            torch.cuda.current_stream().wait_stream(self._stream)
+            cur = torch.cuda.current_stream()
+            if self.time_waits:              # how long the compute stream sits waiting for RCCL: the EXPOSED exchange time
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                cur.wait_stream(self._stream)
+                e1.record(cur)
+                self._wait_events.append((e0, e1))
+            else:
+                cur.wait_stream(self._stream)
+        self.stats["steps"] += 1
         if getattr(self, "_emb_rows", None) is not None:
             rows, kept = self._emb_rows     # `kept` is one of the all-reduced buffers above: same sum/mean convention
             self.embedding.grad.index_copy_(0, rows, kept)
             self._emb_rows = None
+
+    def overlap_stats(self, reset=True):
+        """Per-step averages since the last reset: collectives launched, bytes put on the wire by this rank, and -- when
+        ``time_waits`` was set -- the milliseconds the compute stream waited for the side stream in finish()."""
+        n = max(1, self.stats["steps"])
+        waited = None
+        if self._wait_events:
+            torch.cuda.synchronize()
+            waited = sum(a.elapsed_time(b) for a, b in self._wait_events) / len(self._wait_events)
+        out = dict(collectives_per_step=self.stats["collectives"] / n, allreduce_bytes_per_step=self.stats["bytes"] / n,
+                   wire_dtype=str(self.wire_dtype).replace("torch.", ""), buckets=len(self.buckets),
+                   exposed_wait_ms_per_step=waited)
+        if reset:
+            self.stats = dict(collectives=0, bytes=0, steps=0)
+            self._wait_events = []
+        return out
 
     def zero_grad(self, flat_already_zero=False):
         """Zero in place (the .grad views must stay attached to the buckets).  ``flat_already_zero``: the fused step

@@ -82,17 +82,44 @@ def enable(model, rows):
     lm = model.lang_encoder
     emb_mod = lm.get_input_embeddings()
     table = emb_mod.weight
+    kind = _head_kind(lm, emb_mod, table)      # raises before anything is changed
     state = SparseRows(table, rows)
     table.requires_grad_(False)
     table._of_trained_rows = state          # still "trainable" for checkpoints / optimizer-state numbering
     state.handles.append(emb_mod.register_forward_hook(
         lambda mod, inputs, out: _TapLookup.apply(out, inputs[0], state.rows, state.leaf)))
-    head = lm.get_output_embeddings()
-    if head is not None and getattr(head, "weight", None) is table:             # tied head (MPT, GPT-NeoX releases)
+    if kind == "tied_module":                                                     # HF MptForCausalLM / GPT-NeoX: lm_head.weight is wte.weight
+        head = lm.get_output_embeddings()
         state.handles.append(head.register_forward_hook(
             lambda mod, inputs, out: _TapHead.apply(out, inputs[0], state.rows, state.leaf)))
     model._of_sparse_rows = state
     return state
+
+
+def _head_kind(lm, emb_mod, table):
+    """Where the logits come from, decided BEFORE anything is frozen:
+      "tied_module" -- a distinct nn.Module whose weight IS the table (gets the head tap);
+      "untied"      -- a distinct module with its own weight and a config that says the head is not tied (no head part);
+    anything else raises: a head that is the embedding module itself (remote-code MPT-7B returns ``wte`` from
+    get_output_embeddings(): a hook there would see token ids, not hidden states) or no head module at all
+    (mpt-1b-redpajama-200b computes ``F.linear(x, wte.weight)`` inline) would silently lose the tied-head part of the
+    kept rows' gradient."""
+    head = lm.get_output_embeddings() if hasattr(lm, "get_output_embeddings") else None
+    if head is None:
+        raise NotImplementedError("sparse_rows: this LM has no output-embedding module (logits are computed inline from the "
+                                  "embedding table); the tied-head part of the kept rows' gradient cannot be tapped -- "
+                                  "use the dense masked gradient (the default)")
+    if head is emb_mod:
+        raise NotImplementedError("sparse_rows: get_output_embeddings() returns the input-embedding module itself; its "
+                                  "forward hook would see token ids, not hidden states -- use the dense masked gradient")
+    w = getattr(head, "weight", None)
+    if w is table:
+        return "tied_module"
+    tied_cfg = bool(getattr(getattr(lm, "config", None), "tie_word_embeddings", True))
+    if w is not None and w.data_ptr() != table.data_ptr() and not tied_cfg:
+        return "untied"
+    raise NotImplementedError("sparse_rows: cannot prove how the LM head relates to the embedding table (weight is not the "
+                              "table object and config.tie_word_embeddings is not False) -- use the dense masked gradient")
 
 
 def disable(model):

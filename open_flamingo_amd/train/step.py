@@ -15,7 +15,8 @@ def build_optimizer(model, lr=1e-4, weight_decay=0.1, reducer=None):
     """train.py:384-408: wd only on params whose name contains 'gated_cross_attn'.  With a GradReducer on a GPU the
     fused device-side step epilogue (train/optim.py: clip + AdamW over the reducer's flat buckets) is returned; it
     implements the same update."""
-    if reducer is not None and reducer.buckets and reducer.buckets[0]["flat"].is_cuda:
+    dense_table = reducer is not None and reducer.embedding is not None and reducer.embedding_rows is None
+    if reducer is not None and reducer.buckets and reducer.buckets[0]["flat"].is_cuda and not dense_table:
         from .optim import FlatAdamW
         return FlatAdamW(reducer, lr=lr, weight_decay=weight_decay)
     if getattr(model, "_of_sparse_rows", None) is not None:
@@ -35,22 +36,41 @@ def _autocast(device_type, enabled=True):
     return torch.autocast(device_type=device_type, dtype=torch.bfloat16, enabled=enabled)
 
 
-def forward_loss(model, batch, info, amp=True):
+def forward_loss(model, batch, info, amp=True, kind="mmc4"):
+    """kind: "mmc4" (interleaved label rule, train_utils.py:127-150) or "laion" (train_utils.py:102-105)."""
     ids = batch["lang_x"]
-    labels = synthetic.make_labels(ids, info["media_token_id"], info["eoc_token_id"], info["pad_token_id"])
+    if kind == "laion":
+        labels = synthetic.make_labels_laion(ids, info["media_token_id"], info["pad_token_id"])
+    else:
+        assert kind == "mmc4", kind
+        labels = synthetic.make_labels(ids, info["media_token_id"], info["eoc_token_id"], info["pad_token_id"])
     with _autocast(ids.device.type, amp):
         out = model(vision_x=batch["vision_x"], lang_x=ids, attention_mask=batch["attention_mask"], labels=labels)
     return out[0]
 
 
+def mask_embedding_gradient(model, info):
+    """train_utils.py:174-196 as written there: only the <image> / <|endofchunk|> rows of the input-embedding gradient
+    survive.  (With a GradReducer the same mask is applied by the reducer, which exchanges just those rows.)"""
+    w = model.lang_encoder.get_input_embeddings().weight
+    if w.grad is None:
+        return
+    zero_mask = torch.zeros_like(w.grad)
+    zero_mask[info["media_token_id"]] = 1
+    zero_mask[info["eoc_token_id"]] = 1
+    w.grad = w.grad * zero_mask
+
+
 def train_step(model, reducer, optimizer, batch_mmc4, info, batch_laion=None, loss_multiplier_laion=1.0,
-               loss_multiplier_mmc4=1.0, clip_norm=1.0, amp=True, nan_check=True, lr_scheduler=None):
-    """Returns the (detached) MMC4 loss tensor, or None if the step was skipped because the loss was NaN."""
+               loss_multiplier_mmc4=1.0, clip_norm=1.0, amp=True, nan_check=True, lr_scheduler=None,
+               mask_embedding_rows=True):
+    """Returns the (detached) MMC4 loss tensor, or None if the step was skipped because the loss was NaN.
+    reducer=None is the single-process form of the reference loop (embedding-gradient mask applied in place)."""
     fused = hasattr(optimizer, "reducer")         # FlatAdamW: clip + AdamW + zero_grad in two device passes
     params = None if fused else [p for g in optimizer.param_groups for p in g["params"]]
     if batch_laion is not None:
         with reducer.no_sync() if reducer is not None else contextlib.nullcontext():
-            loss_l = forward_loss(model, batch_laion, info, amp)
+            loss_l = forward_loss(model, batch_laion, info, amp, kind="laion")
             (loss_l * loss_multiplier_laion).backward()
     loss = forward_loss(model, batch_mmc4, info, amp)
     if nan_check and torch.isnan(loss):          # train_utils.py:161-169 (host sync, as in the reference)
@@ -60,6 +80,8 @@ def train_step(model, reducer, optimizer, batch_mmc4, info, batch_laion=None, lo
             optimizer.zero_grad(set_to_none=True)
         return None
     (loss * loss_multiplier_mmc4).backward()
+    if reducer is None and mask_embedding_rows:
+        mask_embedding_gradient(model, info)
     if reducer is not None:
         # waits for the overlapped RCCL all-reduces, restores the two embedding rows; the fused epilogue averages itself
         reducer.finish(average=not hasattr(optimizer, "reducer"))

@@ -48,3 +48,12 @@ def make_labels(input_ids, media_token_id, eoc_token_id, pad_token_id):
     labels[ids == pad_token_id] = -100
     labels[is_media] = -100
     return labels
+
+
+def make_labels_laion(input_ids, media_token_id, pad_token_id):
+    """LAION pass (train_utils.py:102-105): only padding and the <image> token are ignored; the trailing
+    <|endofchunk|> / EOS of "<image>caption<|endofchunk|>" ARE trained on (unlike the interleaved rule above)."""
+    labels = input_ids.clone()
+    labels[input_ids == pad_token_id] = -100
+    labels[input_ids == media_token_id] = -100
+    return labels

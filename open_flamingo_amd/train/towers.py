@@ -76,7 +76,22 @@ class VisionStandIn(nn.Module):
         self.visual = ClipVisualStandIn(**kw)
 
 
-_BIAS_CACHE = {}
+_BIAS_CACHE = {}      # one entry per kind; holds the KEY TENSORS themselves and matches by identity (an address / version
+                      # pair can recur across steps once the caching allocator recycles the block: stale padding lengths)
+
+
+def _cache_get(kind, position_bias, attention_mask, extra):
+    hit = _BIAS_CACHE.get(kind)
+    if hit is not None and hit[0] is position_bias and hit[1] is attention_mask and hit[2] == extra \
+            and hit[3] == (position_bias._version, None if attention_mask is None else attention_mask._version):
+        return hit[4]
+    return None
+
+
+def _cache_put(kind, position_bias, attention_mask, extra, val):
+    _BIAS_CACHE[kind] = (position_bias, attention_mask, extra,
+                         (position_bias._version, None if attention_mask is None else attention_mask._version), val)
+    return val
 
 
 def _alibi_causal_bias(position_bias, attention_mask, q_len, dtype):
@@ -84,18 +99,14 @@ def _alibi_causal_bias(position_bias, attention_mask, q_len, dtype):
     per row; the relative form keeps the values small enough to survive bf16) with the masked positions of HF's boolean
     causal/padding mask set to a large negative number (HF fills finfo.min, not -inf: fully masked rows stay finite).
     Built once per LM forward (all blocks receive the same mask / alibi tensors)."""
-    key = (position_bias.data_ptr(), None if attention_mask is None else (attention_mask.data_ptr(), attention_mask._version),
-           q_len, dtype)
-    hit = _BIAS_CACHE.get("key")
-    if hit == key:
-        return _BIAS_CACHE["val"]
+    hit = _cache_get("bias", position_bias, attention_mask, (q_len, dtype))
+    if hit is not None:
+        return hit
     pb = position_bias[:, 0, -q_len:].float()                       # (H, L): slope_h * (j - (S - 1))
     bias = (pb[:, None, :] - pb[:, :, None]).unsqueeze(0)           # (1, H, L, L): slope_h * (j - i)
     if attention_mask is not None:
         bias = bias.masked_fill(attention_mask[..., -q_len:, -q_len:], -30000.0)
-    bias = bias.to(dtype).contiguous()
-    _BIAS_CACHE["key"], _BIAS_CACHE["val"] = key, bias
-    return bias
+    return _cache_put("bias", position_bias, attention_mask, (q_len, dtype), bias.to(dtype).contiguous())
 
 
 class _CausalAlibiAttention(torch.autograd.Function):
@@ -138,16 +149,15 @@ class _CausalAlibiAttention(torch.autograd.Function):
 def _alibi_slopes_and_lens(position_bias, attention_mask, q_len):
     """(heads,) fp32 ALiBi slopes and (B,) int32 real-key counts, derived on the device (no host sync) from the
     tensors HF hands every block; cached for the duration of one LM forward."""
-    key = ("sl", position_bias.data_ptr(), None if attention_mask is None else (attention_mask.data_ptr(), attention_mask._version), q_len)
-    if _BIAS_CACHE.get("key2") == key:
-        return _BIAS_CACHE["val2"]
+    hit = _cache_get("slopes", position_bias, attention_mask, q_len)
+    if hit is not None:
+        return hit
     pb = position_bias[:, 0, :].float()
     slopes = (pb[:, -1] - pb[:, -2]).contiguous()                 # slope_h * (j - (S-1)): consecutive keys differ by slope_h
     lens = None
     if attention_mask is not None:                                 # bool (B,1,L,L), True = masked; last query row sees every real key
         lens = (~attention_mask[:, 0, -1, -q_len:]).sum(-1).to(torch.int32).contiguous()
-    _BIAS_CACHE["key2"], _BIAS_CACHE["val2"] = key, (slopes, lens)
-    return slopes, lens
+    return _cache_put("slopes", position_bias, attention_mask, q_len, (slopes, lens))
 
 
 def _mpt_attention_fused_forward(self, hidden_states, position_bias, past_key_values=None, attention_mask=None, **kwargs):

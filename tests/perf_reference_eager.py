@@ -2,7 +2,9 @@
 >=5x target refers to).  /root/reference does not exist on the GPU box, so the hot-path modules are the oracle's
 nn.Modules -- a line-for-line PyTorch restatement of reference helpers.py, pinned to it by tests/test_oracle_golden.py
 -- plugged into the same Flamingo + the same frozen towers, run as the reference runs them: eager ATen ops under
-torch.autocast(bfloat16), gradients exchanged by nothing (1 GPU), AdamW.  Not part of the product."""
+torch.autocast(bfloat16), gradients exchanged by nothing (1 GPU), the embedding-gradient row mask of
+train_utils.py:174-196 (train_step(reducer=None) applies it as the reference writes it: a dense zero_mask multiply),
+clip_grad_norm_ + AdamW.  Not part of the product."""
 import json
 import os
 import sys
@@ -34,17 +36,18 @@ def main():
     def one():
         return step.train_step(model, None, opt, batch, info)
 
-    for _ in range(warm):
-        one()
+    losses = [float(one()) for _ in range(warm)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = one()
+        losses.append(loss)
     torch.cuda.synchronize()
+    losses = [float(l) for l in losses]
     ms = (time.perf_counter() - t0) / steps * 1e3
     print(json.dumps({"what": "reference-equivalent eager step (oracle modules, autocast bf16) on MI355X", "family": family, "towers": "stock (conv patch embed, fp32 frozen weights, HF eager MPT attention)" if stock else "as bench.py (GEMM patch embed, bf16-held frozen weights, fused LM attention)",
                       "B": B, "T": T, "L": L, "ms_per_step": round(ms, 2), "images_per_s": round(B * T / ms * 1e3, 2),
-                      "loss": float(loss), "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1)}))
+                      "loss": float(loss), "losses_per_step": [round(l, 4) for l in losses], "embedding_row_mask": "train_utils.py:174-196 applied", "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1)}))
 
 
 if __name__ == "__main__":

@@ -113,3 +113,34 @@ def test_checkpoint_round_trip(tmp_path):
     assert (_params(fresh) - _params(model)).abs().max().item() < 2e-5
     with pytest.raises(KeyError):
         checkpoint.load_model_state(fresh, {"perceiver.no_such_parameter": torch.zeros(1)})
+
+
+def test_lr_scheduler_drives_the_fused_step_epilogue():
+    """The reference's train.py wraps its optimizer in a torch LR scheduler (get_constant_schedule_with_warmup etc. are
+    LambdaLR).  FlatAdamW must be accepted by LambdaLR, and the lr the scheduler sets must be the lr the fused AdamW kernel
+    is called with: warm-up factor 0 at step 0 -> parameters do not move; later steps move them."""
+    import torch
+    from open_flamingo_amd.train import step, synthetic
+    from open_flamingo_amd.train.optim import FlatAdamW
+    from open_flamingo_amd.train.reducer import GradReducer
+    from tests.cpu_model import tiny_cpu_flamingo
+    from tests.emu import harness as H
+    model, info = tiny_cpu_flamingo(seed=0)
+    red = GradReducer(model, embedding_rows=[info["media_token_id"], info["eoc_token_id"]])
+    opt = FlatAdamW(red, lr=1e-3, ops=H.emu_ops())
+    assert isinstance(opt, torch.optim.Optimizer) and len(opt.param_groups) == 2
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: min(1.0, s / 2))      # 0, 0.5, 1.0, ...
+    seen = []
+    ops = opt.ops
+    orig = ops.adamw_clip
+    ops.adamw_clip = lambda *a, **kw: (seen.append(kw["lr"]), orig(*a, **kw))[1]
+    batch = synthetic.make_batch(2, 2, 24, info, "cpu", seed=5)
+    p = red.buckets[0]["params"][-1]
+    before = p.detach().clone()
+    step.train_step(model, red, opt, batch, info, amp=False, lr_scheduler=sched)
+    assert set(seen) == {0.0} and torch.equal(p.detach(), before), "warm-up factor 0: no parameter may move"
+    seen.clear()
+    step.train_step(model, red, opt, batch, info, amp=False, lr_scheduler=sched)
+    assert set(seen) == {5e-4} and not torch.equal(p.detach(), before)
+    assert [g["lr"] for g in opt.param_groups] == [1e-3, 1e-3]
+    ops.adamw_clip = orig

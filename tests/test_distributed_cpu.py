@@ -105,4 +105,4 @@ def test_reducer_and_train_step_world2():
         assert err < 1e-5, f"rank {rank}: reduced grads differ from mean of local grads ({err})"
         assert nz_rows <= 2, "embedding gradient must be masked to the <image>/<|endofchunk|> rows"
         assert same, "replicas diverged after train_step"
-        assert nb == 3, "tiny model: 2 xattn block buckets + 1 perceiver bucket"
+        assert nb == 2 + 6, "tiny model: 2 xattn block buckets + one bucket per Perceiver layer (depth 6)"

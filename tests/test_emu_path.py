@@ -43,3 +43,29 @@ def test_paths_accumulate_into_existing_grads():
     """Gradient sinks (path._GradOut): every parameter gradient is added to the pre-existing buffer, none overwritten."""
     PC.check_xattn(H.emu_ops(), "cpu", inplace=True, seed=5)
     PC.check_perceiver(H.emu_ops(), "cpu", T=3, Fv=32, frames=2, embs=True, inplace=True, seed=6)
+
+
+def test_perceiver_backward_reports_layers_as_they_finish():
+    """perceiver_bwd(on_ready=...) names every parameter exactly once, final norm first, then layer by layer from the
+    last to the first, latents last -- the order train/reducer.py's per-layer Perceiver buckets are launched in."""
+    import torch
+    from oracle import flamingo_oracle as O
+    from open_flamingo_amd.hip import path
+    ops = H.emu_ops()
+    m = O.OraclePerceiverResampler(dim=64, depth=3, heads=2, num_latents=16)
+    P = {k: v.detach().contiguous() for k, v in m.named_parameters()}
+    W = PC.make_bf16_weights(ops, P)
+    x = torch.randn(2 * 24, 64)
+    kw = dict(N=2, Fv=24, n=16, heads=2, depth=3)
+    y, S = path.perceiver_fwd(ops, P, W, x, **kw)
+    calls = []
+    path.perceiver_bwd(ops, P, W, S, torch.randn_like(y), on_ready=lambda names: calls.append(list(names)), **kw)
+    flat = [k for c in calls for k in c]
+    assert sorted(flat) == sorted(P) and len(set(flat)) == len(flat)
+    assert calls[0] == ["norm.weight", "norm.bias"] and calls[-1] == ["latents"]
+    assert [c[0].split(".")[1] for c in calls[1:-1]] == ["2", "1", "0"]
+    from open_flamingo_amd.train.reducer import GradReducer
+    groups = GradReducer._perceiver_groups(m, "layer")
+    names = {id(p): k for k, p in m.named_parameters()}
+    order = [[names[id(p)] for p in g] for g in groups]
+    assert len(order) == 3 and "norm.weight" in order[0] and order[0][0].startswith("layers.2.") and "latents" in order[-1]

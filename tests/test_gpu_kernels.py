@@ -240,3 +240,81 @@ def test_skinny_gemm_decode_shapes(ops, M, N, K):
         y = torch.empty(M, N, dtype=torch.float32, device="cuda")
         ops.gemm(A, B, y, epi=abi.EPI_GATE_RESID, aux=res, gate=gate, safe=safe)
         assert _rel(y, res + g * acc) < 1e-4 + 1e-3 * (K > 4096)
+
+
+def _close(got, want, name, rtol=1e-2, atol_rms=2e-3, l2=4e-3):
+    """Element-wise |got - want| <= atol + rtol |want| (atol = atol_rms x rms(want): fp32 summation order near zero;
+    rtol covers ONE bf16 rounding of the stored value, 2^-8) AND relative L2 -- max-abs-over-max alone would hide
+    systematically wrong small elements."""
+    got, want = got.double(), want.double()
+    rms = want.pow(2).mean().sqrt().item()
+    viol = (got - want).abs() - (atol_rms * rms + rtol * want.abs())
+    assert viol.max().item() <= 0, f"{name}: {int((viol > 0).sum())} elements out of tolerance (worst excess {viol.max().item():.3e}, rms {rms:.3e})"
+    e = (got - want).norm().item() / (want.norm().item() + 1e-30)
+    assert e <= l2, f"{name}: rel L2 {e:.3e}"
+
+
+@pytest.mark.parametrize("safe", [0, 4])
+def test_big_tile_gemm_fused_epilogues_at_benchmark_shapes(ops, safe):
+    """The launches bench.py times at BASELINE config 2 (per gated block: rows = B*L = 8192, d = 2048, hidden 8192) run the
+    256x256 kernel with FUSED epilogues; small-batch tests select the 128x128 kernel.  Every (layout, epilogue) pair the
+    step uses, at those shapes, against fp32 torch on the same bf16 operands; safe=0 is of_gemm's own selection (asserted
+    to be the big-tile kernel), safe=4 forces it."""
+    from open_flamingo_amd.hip.ops import Ops
+    gate = torch.tensor([0.37], device="cuda")
+    g = float(torch.tanh(gate))
+    rows, d, hid, inner = 8192, 2048, 8192, 512
+    assert Ops.takes_pingpong_kernel(rows, hid, d) and Ops.takes_pingpong_kernel(rows, d, hid)
+    # ---- up-projection + erf-GELU, two outputs (pre-activation kept for the backward): NT 8192 x 8192 x 2048
+    u, W1 = _r((rows, d), 41), _r((hid, d), 42, d ** -0.5)
+    acc = u.float() @ W1.float().t()
+    b = torch.empty(rows, hid, device="cuda", dtype=torch.bfloat16)
+    a = torch.empty_like(b)
+    ops.gemm(u, W1, b, epi=abi.EPI_GELU, out2=a, safe=safe)
+    _close(a, acc, "pre-GELU")
+    _close(b, torch.nn.functional.gelu(acc), "GELU")
+    # ---- down-projection * tanh(gate) + residual: NT 8192 x 2048 x 8192, fp32 and bf16 residual streams
+    W2 = _r((d, hid), 43, hid ** -0.5)
+    acc2 = b.float() @ W2.float().t()
+    res = _r((rows, d), 44, dtype=torch.float32)
+    y = torch.empty(rows, d, device="cuda")
+    ops.gemm(b, W2, y, epi=abi.EPI_GATE_RESID, aux=res, gate=gate, safe=safe)
+    _close(y, res + g * acc2, "GATE_RESID fp32", rtol=1e-5, atol_rms=1e-4, l2=1e-5)
+    resb = res.to(torch.bfloat16)
+    yb = torch.empty(rows, d, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(b, W2, yb, epi=abi.EPI_GATE_RESID, aux=resb, gate=gate, safe=safe)
+    _close(yb, resb.float() + g * acc2, "GATE_RESID bf16")
+    # ---- dA = (dY W2) * gate * gelu'(a), gate-gradient dot = (1 - g^2) sum(gelu(a) * dY W2): NN 8192 x 8192 x 2048
+    dy = _r((rows, d), 45)
+    accd = dy.float() @ W2.float()
+    da = torch.empty(rows, hid, device="cuda", dtype=torch.bfloat16)
+    dot = torch.zeros(1, device="cuda")
+    ops.gemm(dy, W2, da, tb=True, epi=abi.EPI_DGELU_DOT, aux=a, gate=gate, dot=dot, safe=safe)
+    ad = a.double().requires_grad_(True)
+    ge = torch.nn.functional.gelu(ad)
+    ge.sum().backward()
+    _close(da, g * accd.double() * ad.grad, "DGELU")
+    wdot = (1 - g * g) * (ge.detach() * accd.double()).sum().item()
+    ref_scale = (1 - g * g) * (ge.detach() * accd.double()).abs().sum().item()
+    assert abs(float(dot) - wdot) <= 1e-5 * ref_scale, ("DGELU dot", float(dot), wdot, ref_scale)
+    # ---- dO = (dY1 Wout) * gate, dot = (1 - g^2) sum(o * dY1 Wout): NN 8192 x 512 x 2048 (too few tiles for the big
+    #      kernel by itself: only safe=4 runs it there) and a big-tile-eligible 8192 x 2048 x 512
+    for (M, N, K) in ((rows, inner, d), (rows, d, inner)):
+        dy1, Wo, o = _r((M, K), 46), _r((K, N), 47, K ** -0.5), _r((M, N), 48)
+        acco = dy1.float() @ Wo.float()
+        dO = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        dot = torch.zeros(1, device="cuda")
+        ops.gemm(dy1, Wo, dO, tb=True, epi=abi.EPI_SCALE_DOT, aux=o, gate=gate, dot=dot, safe=safe)
+        _close(dO, g * acco, f"SCALE {M}x{N}x{K}")
+        wdot = (1 - g * g) * (o.double() * acco.double()).sum().item()
+        ref_scale = (1 - g * g) * (o.double() * acco.double()).abs().sum().item()
+        assert abs(float(dot) - wdot) <= 1e-5 * ref_scale, ("SCALE dot", float(dot), wdot)
+    # ---- dW2 += gate * dY^T b (accumulating into an existing fp32 gradient): TN 2048 x 8192 x 8192
+    c = torch.randn(d, hid, device="cuda")
+    want = c + g * (dy.float().t() @ b.float())
+    ops.gemm(dy, b, c, ta=True, tb=True, epi=abi.EPI_ACC_F32, gate=gate, beta=1.0, safe=safe)
+    _close(c, want, "dW2 beta=1", rtol=1e-5, atol_rms=1e-4, l2=1e-5)
+    # ---- plain dX: NN 8192 x 2048 x 8192
+    du = torch.empty(rows, d, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(da, W1, du, tb=True, safe=safe)
+    _close(du, da.float() @ W1.float(), "dU")

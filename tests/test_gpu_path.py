@@ -345,3 +345,207 @@ def test_full_size_properties_cfg2(ops):
     out, _ = path.perceiver_fwd(ops, PP, WP, feats.view(N * Fv, Dv), **pk)
     out_p, _ = path.perceiver_fwd(ops, PP, WP, feats[perm].reshape(N * Fv, Dv).contiguous(), **pk)
     assert torch.equal(out.view(N, n, Dv)[perm], out_p.view(N, n, Dv))
+
+
+# =====================================================================================================================
+# SURVEY.md 8c tolerance rule (error vs the fp32 oracle <= 2 x the reference's own autocast(bf16) error; gradients by
+# relative L2 <= 2e-2) -- tests/path_checks.py::judge_8c.  The oracle is executed on the GPU here (same restatement of
+# helpers.py, torch fp32 / torch.autocast there reproduce the reference's eager arithmetic and cast points).
+# =====================================================================================================================
+def _fmt(rep):
+    return {k: {a: f"{b:.1e}" for a, b in v.items()} for k, v in rep.items()}
+
+
+def test_8c_tolerance_small_and_mask_cases(ops):
+    PC.check_xattn_8c(ops, "cuda", oracle_dev="cuda")
+    ml = torch.zeros(2, 40, dtype=torch.bool)
+    ml[0, [1, 5, 9, 30]] = True          # more <image> tokens than images: uniform rows
+    ml[1, [7]] = True                    # rows before the first image: zero rows
+    PC.check_xattn_8c(ops, "cuda", media_locs=ml, seed=1, oracle_dev="cuda")
+    PC.check_xattn_8c(ops, "cuda", media_locs=ml, only_immediate=False, seed=2, oracle_dev="cuda")
+    PC.check_perceiver_8c(ops, "cuda", oracle_dev="cuda")
+
+
+@pytest.mark.parametrize("d", [2048, 2560, 4096])
+def test_8c_tolerance_model_family_dims(ops, d):
+    print(_fmt(PC.check_xattn_8c(ops, "cuda", B=2, L=256, T=2, n=64, heads=8, d=d, Dv=1024, seed=5, gates=(0.5, 0.5),
+                                 oracle_dev="cuda")))
+    if d == 2048:
+        print(_fmt(PC.check_perceiver_8c(ops, "cuda", b=1, T=2, Fv=256, n=64, heads=8, D=1024, depth=6, seed=6,
+                                         oracle_dev="cuda")))
+
+
+def test_cfg2_full_batch_parity_with_nonzero_gates(ops):
+    """BASELINE config 2 at its FULL per-GPU batch (B=32, T=2, L=256, OF-3B widths, gates = 0.5): these launches select
+    the kernels the benchmark times (256x256 ping-pong GEMM with the GELU / GATE_RESID / DGELU_DOT / SCALE_DOT epilogues,
+    split-K dW, CPL=4 LayerNorm).  (1) everything -- y, dx, dmedia and every parameter gradient of the whole batch --
+    against the oracle executed on the GPU in fp32, by the SURVEY 8c rule; (2) two sampled sequences / media items
+    against the oracle on the host CPU (sequences are independent in forward and in dx)."""
+    rep = PC.check_xattn_8c(ops, "cuda", B=32, L=256, T=2, n=64, heads=8, d=2048, Dv=1024, seed=21, gates=(0.5, 0.5),
+                            oracle_dev="cuda")
+    print(_fmt(rep))
+    rep = PC.check_perceiver_8c(ops, "cuda", b=32, T=2, Fv=256, n=64, heads=8, D=1024, depth=6, seed=22, oracle_dev="cuda")
+    print(_fmt(rep))
+    # ---- sampled sequences on the CPU oracle
+    from oracle import flamingo_oracle as O
+    B, L, T, n, heads, d, Dv = 32, 256, 2, 64, 8, 2048, 1024
+    m = O.OracleGatedCrossAttentionBlock(dim=d, dim_visual=Dv)
+    st = O.seeded_state({k: tuple(v.shape) for k, v in m.state_dict().items()}, 121)
+    st["attn_gate"], st["ff_gate"] = torch.tensor([0.5]), torch.tensor([0.5])
+    m.load_state_dict(st)
+    g = torch.Generator().manual_seed(221)
+    x, media, w = torch.randn(B, L, d, generator=g), torch.randn(B, T, n, Dv, generator=g), torch.randn(B, L, d, generator=g)
+    ml = torch.zeros(B, L, dtype=torch.bool)
+    ml[:, 0] = True
+    ml[:, L // 2] = True
+    y, grads = PC.hip_xattn(ops, m, x, media, ml, w, heads=heads)
+    for s in (3, 29):
+        y32, g32 = PC._oracle_run(m, (x[s:s + 1], media[s:s + 1]), w[s:s + 1], False, media_locations=ml[s:s + 1])
+        assert PC.rel_l2(y[s:s + 1], y32) < 5e-3, (s, PC.rel_l2(y[s:s + 1], y32))
+        assert PC.rel_l2(grads["in0"][s:s + 1], g32["in0"]) < 2e-2
+        assert PC.rel_l2(grads["in1"][s:s + 1], g32["in1"]) < 2e-2
+    pm = O.OraclePerceiverResampler(dim=Dv)
+    pm.load_state_dict(O.seeded_state({k: tuple(v.shape) for k, v in pm.state_dict().items()}, 322))
+    feats, wp = torch.randn(B, T, 1, 256, Dv, generator=g), torch.randn(B, T, n, Dv, generator=g)
+    yp, gp = PC.hip_perceiver(ops, pm, feats, wp, heads=heads)
+    for s in (0, 17):
+        y32, g32 = PC._oracle_run(pm, (feats[s:s + 1],), wp[s:s + 1], False)
+        assert PC.rel_l2(yp[s:s + 1], y32) < 1e-2, (s, PC.rel_l2(yp[s:s + 1], y32))
+        assert PC.rel_l2(gp["in0"][s:s + 1], g32["in0"]) < 2e-2
+
+
+def _summ(t):
+    import numpy as np
+    t = t.detach().double().flatten().cpu()
+    idx = torch.linspace(0, t.numel() - 1, 64).long()
+    return np.concatenate([t[idx].numpy(), [t.sum().item(), t.abs().sum().item(), (t * t).sum().item()]])
+
+
+def _rnd(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float64).float()
+
+
+def _close_to_reference_summary(got, want, name, tol):
+    """64 sampled elements by relative L2, |.|-sum and squared sum by ratio, against a REFERENCE-produced summary
+    (tests/golden/make_golden.py ran the real helpers.py in fp32)."""
+    import numpy as np
+    a, b = _summ(got), want
+    err = np.linalg.norm(a[:64] - b[:64]) / (np.linalg.norm(b[:64]) + 1e-30)
+    assert err <= tol, (name, "samples", err)
+    assert abs(a[65] - b[65]) <= tol * b[65], (name, "abs-sum", a[65], b[65])
+    assert abs(a[66] - b[66]) <= 2 * tol * b[66], (name, "sq-sum", a[66], b[66])
+
+
+def test_hip_path_against_reference_goldens_at_of3b_size(ops, golden_dir):
+    """tests/golden/full_xattn.npz / full_perceiver.npz: outputs and autograd gradients of the REAL reference modules at
+    OF-3B sizes (dim_head 64) -- compared with the HIP path directly (not via the oracle)."""
+    import os
+    import numpy as np
+    from oracle import flamingo_oracle as O
+    z = np.load(os.path.join(golden_dir, "full_xattn.npz"))
+    m = O.OracleGatedCrossAttentionBlock(dim=2048, dim_visual=1024)          # parameter container only
+    m.load_state_dict(O.seeded_state({k: tuple(v.shape) for k, v in m.state_dict().items()}, int(z["seed_params"])))
+    L = int(z["L"])
+    x, media = _rnd((1, L, 2048), int(z["seed_x"])), _rnd((1, 2, 64, 1024), int(z["seed_media"]))
+    ml = torch.zeros(1, L, dtype=torch.bool)
+    ml[0, z["media_positions"].tolist()] = True
+    y, g = PC.hip_xattn(ops, m, x, media, ml, _rnd((1, L, 2048), int(z["seed_w"])), heads=8)
+    head = torch.from_numpy(z["y.head"])
+    assert PC.rel_l2(y[0, :8, :16], head) < 5e-3, PC.rel_l2(y[0, :8, :16], head)
+    _close_to_reference_summary(y, z["y.summary"], "y", 5e-3)
+    _close_to_reference_summary(g["in0"], z["gradsum.x"], "dx", 2e-2)
+    _close_to_reference_summary(g["in1"], z["gradsum.media"], "dmedia", 2e-2)
+    for k, _ in m.named_parameters():
+        if k.endswith("_gate"):
+            assert abs(float(g[k]) - z["gradsum." + k][64]) <= 5e-2 * abs(z["gradsum." + k][64]) + 1e-3, k
+        else:
+            _close_to_reference_summary(g[k], z["gradsum." + k], k, 2e-2)
+    z = np.load(os.path.join(golden_dir, "full_perceiver.npz"))
+    pm = O.OraclePerceiverResampler(dim=1024)
+    pm.load_state_dict(O.seeded_state({k: tuple(v.shape) for k, v in pm.state_dict().items()}, int(z["seed_params"])))
+    yp, gp = PC.hip_perceiver(ops, pm, _rnd((1, 2, 1, 256, 1024), int(z["seed_x"])), _rnd((1, 2, 64, 1024), int(z["seed_w"])),
+                              heads=8, need_dx=False)
+    assert PC.rel_l2(yp[0, :, :4, :16], torch.from_numpy(z["y.head"])) < 1e-2
+    _close_to_reference_summary(yp, z["y.summary"], "perceiver y", 1e-2)
+    for k, _ in pm.named_parameters():
+        _close_to_reference_summary(gp[k], z["gradsum." + k], k, 2e-2)
+
+
+def _rccl_rank(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from open_flamingo_amd.train import distributed, step, synthetic, towers
+    from open_flamingo_amd.train.reducer import GradReducer
+    dev = distributed.init_distributed_device()
+    model, info = towers.build_flamingo("OF-tiny", device=dev, seed=rank, gates=0.5)   # different init per rank on purpose
+    model.train()
+    red = GradReducer(model, embedding_rows=[info["media_token_id"], info["eoc_token_id"]])
+    red.broadcast_parameters()
+    red.time_waits = True
+    opt = step.build_optimizer(model, lr=1e-3, reducer=red)
+    batch = synthetic.make_batch(2, 2, 24, info, dev, seed=5 + rank)
+    losses = [float(step.train_step(model, red, opt, batch, info)) for _ in range(3)]
+    stats = red.overlap_stats()
+    chk = torch.cat([p.detach().flatten()[:256].float() for p in model.parameters() if p.requires_grad]).double()
+    gathered = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(gathered, chk)
+    q.put((rank, losses, all(torch.equal(gathered[0], g) for g in gathered), stats))
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
+def test_two_gpu_rccl_train_step_keeps_replicas_identical():
+    """One process per GPU, real RCCL: after broadcast + three train steps on different per-rank batches the trainable
+    parameters of the ranks are bit-identical and the exchange went over the side stream (collectives counted)."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, losses, same, stats in res:
+        assert same, f"rank {rank}: replicas diverged"
+        assert all(l == l for l in losses)
+        assert stats["collectives_per_step"] >= 3 and stats["exposed_wait_ms_per_step"] is not None
+
+
+@pytest.mark.timeout(900, method="thread")
+def test_cfg2_trajectory_product_vs_reference_eager():
+    """BASELINE config 2 (OF-3B, B=32, T=2, L=256, amp_bf16), identical initial weights and batch: the product step
+    (libofhip hot path + GradReducer + fused step epilogue) and the reference-equivalent eager step (oracle modules under
+    torch.autocast, the reference's dense embedding-gradient mask, clip_grad_norm_ + torch AdamW) must report the same
+    loss, within 1 %, for the first 5 optimizer steps."""
+    from open_flamingo_amd.train import step, synthetic, towers
+    from open_flamingo_amd.train.reducer import GradReducer
+    from tests.cpu_model import swap_in_oracle
+    runs = {}
+    for which in ("product", "eager"):
+        model, info = towers.build_flamingo("OF-3B", device="cuda", seed=0, gates=0.5, frozen_bf16=True,
+                                            fused_lm_attention="libofhip" if which == "product" else "sdpa",
+                                            tower_layernorm="libofhip" if which == "product" else "eager")
+        if which == "eager":
+            swap_in_oracle(model)
+            model.cuda()
+        model.train()
+        red = GradReducer(model, embedding_rows=[info["media_token_id"], info["eoc_token_id"]]) if which == "product" else None
+        opt = step.build_optimizer(model, reducer=red)
+        assert hasattr(opt, "reducer") == (which == "product")
+        batch = synthetic.make_batch(32, 2, 256, info, "cuda", seed=1)
+        runs[which] = [float(step.train_step(model, red, opt, batch, info)) for _ in range(5)]
+        del model, red, opt, batch
+        torch.cuda.empty_cache()
+    print(runs)
+    for a, b in zip(runs["product"], runs["eager"]):
+        assert abs(a - b) <= 1e-2 * abs(b), runs
+    assert runs["eager"][-1] < runs["eager"][0], "the fixed batch must be learnable"

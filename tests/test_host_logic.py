@@ -104,3 +104,26 @@ def test_golden_state_dict_names():
     ref_keys = sorted(k[len("param."):] for k in z.files if k.startswith("param."))
     ours = PerceiverResampler(dim=64, depth=2, heads=2, num_latents=4, max_num_media=4, max_num_frames=3)
     assert ref_keys == sorted(ours.state_dict())
+
+
+def test_laion_label_rule_and_single_process_embedding_mask():
+    """LAION pass labels (train_utils.py:102-105: only pad and <image> ignored, the trailing <|endofchunk|>/EOS trained on)
+    and the single-process form of the embedding-gradient mask (train_utils.py:174-196) in train_step(reducer=None)."""
+    from open_flamingo_amd.train import step
+    from tests.cpu_model import tiny_cpu_flamingo
+    ids = torch.tensor([[9, 3, 4, 10, 5, 11, 11], [9, 1, 2, 3, 10, 6, 11]])   # 9=media 10=eoc 11=pad
+    got = synthetic.make_labels_laion(ids, 9, 11)
+    want = ids.clone()
+    want[want == 11] = -100
+    want[want == 9] = -100
+    assert torch.equal(got, want) and (got == 10).sum() == 2 and (got[0] == 5).any()
+    assert (synthetic.make_labels(ids, 9, 10, 11)[0] == 5).sum() == 0       # the interleaved rule drops what follows <eoc>
+    model, info = tiny_cpu_flamingo(seed=0)
+    opt = step.build_optimizer(model, lr=1e-3)
+    b_laion = synthetic.make_batch(2, 1, 16, info, "cpu", seed=3)
+    b_mmc4 = synthetic.make_batch(2, 2, 24, info, "cpu", seed=4)
+    emb = model.lang_encoder.get_input_embeddings().weight
+    before = emb.detach().clone()
+    step.train_step(model, None, opt, b_mmc4, info, batch_laion=b_laion, amp=False)
+    moved = ((emb.detach() - before).abs().sum(-1) > 0).nonzero().flatten().tolist()
+    assert set(moved) <= {info["media_token_id"], info["eoc_token_id"]} and moved, moved

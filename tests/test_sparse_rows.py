@@ -89,3 +89,25 @@ def test_disable_restores_the_dense_path():
     assert table.requires_grad and not hasattr(model, "_of_sparse_rows") and not hasattr(table, "_of_trained_rows")
     step.forward_loss(model, synthetic.make_batch(2, 2, 24, info, "cpu", seed=5), info, amp=False).backward()
     assert table.grad is not None and table.grad.shape == table.shape
+
+
+def test_enable_refuses_heads_it_cannot_tap():
+    """Remote-code MPT variants (reference factory.py loads them with trust_remote_code): get_output_embeddings() is None
+    (logits = F.linear(x, wte.weight) inline) or the embedding module itself -- the tied-head part of the kept rows'
+    gradient cannot be tapped there, so enable() must raise and leave the model untouched."""
+    import pytest
+    from open_flamingo_amd.train import sparse_rows
+    from tests.cpu_model import tiny_cpu_flamingo
+    model, info = tiny_cpu_flamingo(seed=0)
+    lm = model.lang_encoder
+    rows = [info["media_token_id"], info["eoc_token_id"]]
+    table = lm.get_input_embeddings().weight
+    orig = lm.get_output_embeddings
+    for fake in (lambda: None, lambda: lm.get_input_embeddings()):
+        lm.get_output_embeddings = fake
+        with pytest.raises(NotImplementedError):
+            sparse_rows.enable(model, rows)
+        assert table.requires_grad and not hasattr(model, "_of_sparse_rows")
+    lm.get_output_embeddings = orig
+    sparse_rows.enable(model, rows)
+    assert not table.requires_grad and len(model._of_sparse_rows.handles) == 2
