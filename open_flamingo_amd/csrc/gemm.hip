@@ -310,6 +310,10 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
             return dispatch(b, grid, s);
         }
     }
+    if (a.safe == 6) {                             // force the 4-wave 128x128-per-wave kernel whenever the shape is eligible
+        const int rc = of_gemm_w4_try(a, s);
+        if (rc != OF_E_SHAPE) return rc;
+    }
     if ((a.safe == 0 && pp_ok) || a.safe == 4 || a.safe == 5) {   // 4 / 5 = force the ping-pong kernel (LDS-DMA / register staged) whenever the shape is eligible
         const int rc = of_gemm_pp_try(a, s);   // 256x256 ping-pong LDS-DMA kernel for tile-aligned shapes
         if (rc != OF_E_SHAPE) return rc;

@@ -32,63 +32,10 @@
 //           -> conflict-free ds_read_b64_tr_b16 (transpose) reads: a half-wave covers 4 k-rows x 2 pieces
 //   * The MFMA is issued operand-swapped (D^T = B^T A^T): a lane owns output row m = lane&31 and 4 consecutive n per
 //     accumulator quad, so epilogue loads/stores are 8-byte (bf16) / 16-byte (fp32) vectors (gemm_common.h).
-#include "gemm_common.h"
+#include "gemm_tile256.h"
 
 namespace {
-
-constexpr int TM = 256, TN = 256;
-constexpr int DK = 64;                          // K depth of one DMA stage (full 128-byte lines of a K-contiguous row)
-constexpr int OPER_BYTES = 256 * DK * 2;        // 32 KiB per operand per stage
-constexpr int STAGE_BYTES = 2 * OPER_BYTES;     // 64 KiB
-constexpr int NSLOT = 2;
-constexpr int SMEM_PP = NSLOT * STAGE_BYTES;    // 128 KiB
-
-OF_DEV int fN(int row) { return (4 - ((row >> 2) & 3)) & 3; }
-OF_DEV int fT(int krow) { return (krow & 3) << 1; }
-
-constexpr int HALF_BYTES = OPER_BYTES / 2;        // 16 KiB: tile rows (or columns) 0-127 / 128-255 of one operand
-
-// per-thread global source of 1-KiB chunk c (0..15) of half hf of one operand at k0 = 0 (advanced by DK [* ld] per stage)
-template <bool TR>
-OF_DEV const bf16_t* chunk_src(const bf16_t* __restrict__ base, long ld, int row0, int hf, int c, int lane) {
-    if (!TR) {
-        const int row = hf * 128 + c * 8 + ((lane >> 2) & 7);
-        const int kh = lane >> 5;
-        const int lslot = (lane & 3) ^ fN(row);
-        return base + (size_t)(row0 + row) * ld + kh * 32 + lslot * 8;
-    } else {
-        const int krow = c * 4 + (lane >> 4);
-        const int pc = (lane & 15) >> 1, half16 = lane & 1;
-        const int col = hf * 128 + ((pc ^ fT(krow)) << 4) + half16 * 8;
-        return base + (size_t)krow * ld + row0 + col;
-    }
-}
-
-// this lane's 16-byte piece of a 32-row operand fragment: k-half h (32 deep) of the stage, k-step ks (16 deep) of the half
-template <bool TR>
-OF_DEV s16x8 frag32(const char* oper, int row_base, int h, int ks, int lane) {
-    if (!TR) {
-        const int row = row_base + (lane & 31);
-        const int slot = ks * 2 + (lane >> 5);
-        return *(const s16x8*)(oper + (row >> 7) * HALF_BYTES + ((row & 127) >> 3) * 1024 + h * 512 + (row & 7) * 64 +
-                               ((slot ^ fN(row)) << 4));
-    } else {
-        const int q = lane >> 4, i = lane & 15;
-        s16x8 f;
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int krow = h * 32 + ks * 16 + (q >> 1) * 8 + hh * 4 + (i >> 2);
-            const int col = row_base + (q & 1) * 16 + (i & 3) * 4;
-            const int cw = col & 127;
-            s16x4 t = of_lds_tr(oper + (col >> 7) * HALF_BYTES + krow * 256 + ((((cw >> 4)) ^ fT(krow)) << 5) + ((cw & 15) << 1));
-            f[hh * 4 + 0] = t[0];
-            f[hh * 4 + 1] = t[1];
-            f[hh * 4 + 2] = t[2];
-            f[hh * 4 + 3] = t[3];
-        }
-        return f;
-    }
-}
+using namespace oft;
 
 // ABL: timing-only ablation mask for tools/bench_gemm_ablate.py (results are wrong when != 0):
 //   1 = no DMA inside the K loop, 2 = no fragment reads, 4 = no MFMAs, 16 = no vmcnt waits (racy)

@@ -28,6 +28,7 @@ struct of_dim3 {
 #define OF_DEV __device__ __forceinline__
 #define OF_HOSTDEV __host__ __device__ __forceinline__
 #define OF_GLOBAL __global__
+#define OF_INLINE_LAMBDA __attribute__((always_inline))   // lambdas whose parameters index register arrays must fold
 #define OF_BOUNDS(threads, waves_per_simd) __launch_bounds__(threads, waves_per_simd)
 typedef hipStream_t of_stream_t;
 typedef __bf16 of_bf16x8n __attribute__((ext_vector_type(8)));
@@ -65,6 +66,9 @@ OF_DEV void of_setprio_hi() { __builtin_amdgcn_s_setprio(1); }
 OF_DEV void of_setprio_lo() { __builtin_amdgcn_s_setprio(0); }
 // pins the instruction scheduler: nothing moves across this point
 OF_DEV void of_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// asks the scheduler for exactly `n` instructions of class `mask` at this point of a pinned sequence (LLVM SchedGroupMask:
+// MFMA 0x8, VMEM read 0x20, DS read 0x100, DS write 0x200); compile-time only, the emulator ignores it
+#define OF_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 OF_DEV int of_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // Point where the lanes of ONE wave exchange data through LDS: hardware executes a wave in lock-step and its LDS
 // operations in program order, so this is only a compiler scheduling fence (the emulator needs a real rendezvous).
@@ -79,6 +83,16 @@ OF_DEV s16x4 of_lds_tr(const void* p) {
 OF_DEV void of_glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// Buffer-descriptor loads: wave-uniform 128-bit descriptor (base pointer in SGPRs) + per-lane 32-bit byte offset +
+// scalar byte offset -- no 64-bit per-lane address arithmetic.  `base` must be provably wave-uniform (kernel arguments /
+// blockIdx-derived), or hipcc wraps every load in a waterfall loop.
+typedef __amdgpu_buffer_rsrc_t of_buf_t;
+OF_DEV of_buf_t of_buf_make(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xffffffff, 0x00020000);
+}
+OF_DEV u32x4 of_buf_load16(of_buf_t b, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(b, (int)voff, (int)soff, 0));
 }
 template <int N>
 OF_DEV void of_wait_vm() {

@@ -21,6 +21,7 @@
 
 #define OF_DEV static inline
 #define OF_GLOBAL
+#define OF_INLINE_LAMBDA
 #define OF_BOUNDS(threads, waves_per_simd)
 typedef void* of_stream_t;
 
@@ -191,6 +192,7 @@ OF_DEV unsigned of_cycles() { return 0; }
 OF_DEV void of_setprio_hi() {}
 OF_DEV void of_setprio_lo() {}
 OF_DEV void of_sched_fence() {}
+#define OF_SCHED_GROUP(mask, n) ((void)0)
 OF_DEV int of_uniform(int v) { return v; }
 OF_DEV void of_wave_sync() { of_emu::wave_barrier(); }
 OF_DEV s16x4 of_lds_tr(const void* p) {
@@ -218,6 +220,11 @@ OF_DEV void of_glds16(const void* gsrc, void* lds_wave_base) {
 template <int N>
 OF_DEV void of_wait_vm() {}
 OF_DEV void of_wait_lgkm0() {}
+struct of_buf_t {
+    const char* base;
+};
+OF_DEV of_buf_t of_buf_make(const void* base) { return of_buf_t{(const char*)base}; }
+OF_DEV u32x4 of_buf_load16(of_buf_t b, unsigned voff, unsigned soff) { return *(const u32x4*)(b.base + voff + soff); }
 OF_DEV void of_barrier_raw() { of_emu::block_barrier(); }
 OF_DEV float of_shfl(float v, int src) {
     of_emu::Block* blk = of_emu::g_blk;

