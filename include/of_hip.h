@@ -71,11 +71,15 @@ typedef struct OfGemmArgs {
     float alpha, beta;
     float* dot_out;    /* device scalar accumulated atomically, or NULL */
     int io_f32;        /* OF_EPI_GATE_RESID: 1 = fp32 stream, 0 = bf16 stream */
-    int safe;          /* kernel selection for self-checks: 0 = auto (M <= 16 untransposed: weight-streaming skinny
-                          kernel; 256x256 LDS-DMA kernel when the shape is tile aligned and fills the chip; else the
-                          general 128x128 kernel, split along K when the output is small); 1 = general kernel with the slow scalar-LDS
-                          transposed-fragment path; 2 = general kernel (tr-read path); 4 = ping-pong kernel whenever eligible; 5 = same with register-staged operands (A/B aid); >= 16: timing aid of
-                          tools/bench_gemm_ablate.py (ablated ping-pong launches, results wrong by design) */
+    int safe;          /* DEBUG / SELF-CHECK ONLY -- production callers pass 0 (auto: M <= 16 untransposed -> weight-streaming
+                          skinny kernel; tile-aligned shapes that fill the chip -> a 256x256 big-tile kernel; otherwise the
+                          general 128x128 kernel, split along K when the output is small).  Non-zero values force one
+                          correct kernel so tests can compare kernels with each other: 1 = general kernel, slow scalar-LDS
+                          transposed-fragment path; 2 = general kernel; 4 = 8-wave ping-pong big-tile kernel; 6 / 7 = 4-wave
+                          big-tile kernel (register-staged / LDS-DMA operands); 8..15 = general kernel with 2^(safe-8) K
+                          slices.  Every value the product library accepts gives correct results; anything else returns
+                          OF_E_ARG (timing ablations live in tools/libofhip_tools.so, built with -DOF_TOOLS_BUILD, never
+                          shipped). */
     int ksplit;        /* internal: filled in by of_gemm (number of K slices of a split-K launch); callers pass 0 */
     void* workspace;   /* optional scratch for split-K partial sums (fp32 slabs): with at least
                           of_gemm_workspace_bytes(args) bytes the K slices are combined by a second pass in a fixed

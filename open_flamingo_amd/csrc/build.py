@@ -2,6 +2,9 @@
 
     python -m open_flamingo_amd.csrc.build            # device library  -> open_flamingo_amd/csrc/libofhip.so
     python -m open_flamingo_amd.csrc.build --emu      # host emulator   -> tests/emu/libofhip_emu.so (tests only)
+    python -m open_flamingo_amd.csrc.build --tools    # -DOF_TOOLS_BUILD -> tools/libofhip_tools.so (profiling tools only:
+                                                      #    timing ablations / A-B variants of the GEMM kernels, some of
+                                                      #    them wrong by design; never loaded by the package)
 
 hipcc cross-compiles gfx950 without a GPU.  One translation unit per .hip file, compiled in parallel,
 objects cached by source mtime.
@@ -34,7 +37,10 @@ def _run(cmd):
     return r.stdout + r.stderr
 
 
-def build(emu=False, verbose=False, force=False):
+TOOLS_LIB = os.path.join(ROOT, "tools", "libofhip_tools.so")
+
+
+def build(emu=False, verbose=False, force=False, tools=False):
     srcs = [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
     hdrs = [h if os.path.isabs(h) else os.path.join(HERE, h) for h in HEADERS]
     if emu:
@@ -45,10 +51,12 @@ def build(emu=False, verbose=False, force=False):
         lib = EMU_LIB
         link = ["/opt/rocm/lib/llvm/bin/clang++", "-shared", "-pthread"]
     else:
-        objdir = os.path.join(HERE, "build")
+        objdir = os.path.join(HERE, "build_tools" if tools else "build")
         cc = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-I", HERE,
               "-Wno-unused-function", "-fno-fast-math"]   # erf / tanh / division semantics of the epilogues stay IEEE
-        lib = LIB
+        if tools:
+            cc.append("-DOF_TOOLS_BUILD")
+        lib = TOOLS_LIB if tools else LIB
         link = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"]
     os.makedirs(objdir, exist_ok=True)
     jobs = []
@@ -68,4 +76,4 @@ def build(emu=False, verbose=False, force=False):
 
 
 if __name__ == "__main__":
-    print(build(emu="--emu" in sys.argv, verbose=True, force="--force" in sys.argv))
+    print(build(emu="--emu" in sys.argv, verbose=True, force="--force" in sys.argv, tools="--tools" in sys.argv))

@@ -310,15 +310,21 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
             return dispatch(b, grid, s);
         }
     }
-    if (a.safe == 6) {                             // force the 4-wave 128x128-per-wave kernel whenever the shape is eligible
+    if (a.safe == 6 || a.safe == 7) {              // force the 4-wave 128x128-per-wave kernel (6: register staged, 7: LDS-DMA)
         const int rc = of_gemm_w4_try(a, s);
         if (rc != OF_E_SHAPE) return rc;
     }
-    if ((a.safe == 0 && pp_ok) || a.safe == 4 || a.safe == 5) {   // 4 / 5 = force the ping-pong kernel (LDS-DMA / register staged) whenever the shape is eligible
+#ifdef OF_TOOLS_BUILD      // tools/libofhip_tools.so only: timing ablations and A/B variants (some wrong by design)
+    if (a.safe >= 32) return of_gemm_w4_ablate(a, a.safe - 32, s);
+    if (a.safe >= 16) return of_gemm_pp_ablate(a, a.safe - 16, s);
+    const bool pp_forced = a.safe == 4 || a.safe == 5;
+#else
+    if (a.safe >= 16 || a.safe == 5) return OF_E_ARG;
+    const bool pp_forced = a.safe == 4;
+#endif
+    if ((a.safe == 0 && pp_ok) || pp_forced) {   // 4 = force the ping-pong kernel whenever the shape is eligible
         const int rc = of_gemm_pp_try(a, s);   // 256x256 ping-pong LDS-DMA kernel for tile-aligned shapes
         if (rc != OF_E_SHAPE) return rc;
-    } else if (a.safe >= 16) {
-        return of_gemm_pp_ablate(a, a.safe - 16, s);   // timing-only ablations (wrong results by design)
     }
     return dispatch(b, grid, s);
 }

@@ -289,17 +289,22 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
 template <bool AT, bool BT, int EPI>
 int launch_pp(const OfGemmArgs& a, of_stream_t s) {
     of_dim3 grid{(unsigned)((a.M / TM) * (a.N / TN)), 1, 1};
+#ifdef OF_TOOLS_BUILD
     if (a.safe == 5) return of_launch(of_gemm_pp_kernel<AT, BT, EPI, 0, 1>, grid, 512, SMEM_PP, s, a);
+#endif
     return of_launch(of_gemm_pp_kernel<AT, BT, EPI>, grid, 512, SMEM_PP, s, a);
 }
 
+#ifdef OF_TOOLS_BUILD
 template <int ABL>
 int launch_abl(const OfGemmArgs& a, of_stream_t s) {
     of_dim3 grid{(unsigned)((a.M / TM) * (a.N / TN)), 1, 1};
     return of_launch(of_gemm_pp_kernel<false, false, OF_EPI_STORE_BF16, ABL>, grid, 512, SMEM_PP, s, a);
 }
+#endif
 }  // namespace
 
+#ifdef OF_TOOLS_BUILD
 // timing-only entry (NT layout, bf16 store): mask as documented at the kernel
 int of_gemm_pp_ablate(const OfGemmArgs& a, int mask, of_stream_t s) {
     if ((a.M % TM) || (a.N % TN) || (a.K % DK) || a.a_trans || a.b_trans || a.epi != OF_EPI_STORE_BF16) return OF_E_SHAPE;
@@ -321,7 +326,7 @@ int of_gemm_pp_ablate(const OfGemmArgs& a, int mask, of_stream_t s) {
     }
     return OF_E_ARG;
 }
-
+#endif
 
 int of_gemm_pp_try(const OfGemmArgs& a, of_stream_t s) {
     if ((a.M % TM) || (a.N % TN) || (a.K % DK)) return OF_E_SHAPE;

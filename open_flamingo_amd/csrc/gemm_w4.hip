@@ -16,8 +16,9 @@
 //         phase 3:    MFMAs of k-step 3 | reads k-step 0 of stage d+1 (covered by these 16 MFMAs)
 //     Fragments are double buffered in registers (k-step j+1 is read while k-step j computes); nothing waits on LDS
 //     latency except through the compiler's counted lgkmcnt.
-//   * the instruction interleave of a phase is pinned with sched_group_barrier: 1 MFMA, then <= 1 LDS read,
-//     <= 1 LDS write + 1 global load -- every MFMA gap carries at most ~3 other instructions (the pipe hides ~5).
+//   * the instruction interleave is pinned (a scheduling fence after every MFMA): each of the 64 MFMA gaps of a stage
+//     carries at most ONE LDS instruction -- a fragment read (gaps 0-7 of a phase) or a staging write (gaps 8-15 of
+//     phases 0 and 1) -- and the 16 global loads ride with the reads of phases 1 and 2.
 #include "gemm_tile256.h"
 
 namespace {
@@ -25,7 +26,14 @@ using namespace oft;
 
 constexpr int SMEM_W4 = NSLOT * STAGE_BYTES;    // 128 KiB
 
-template <bool AT, bool BT, int EPI>
+// ABL (tools/libofhip_tools.so only; results are wrong when != 0): timing ablations for tools/bench_w4_ablate.py
+//   1 = no staging writes, 2 = no global loads, 4 = no fragment reads in the K loop, 8 = no barrier,
+//   16 = no MFMAs (NOT meaningful: the compiler then shrinks the fragment reads), 32 = the source never advances along K
+//   (every stage re-reads stage 0: all loads hit L1/L2 -- separates memory latency from the cost of the load path itself)
+// DMA: operands travel global -> LDS directly (buffer_load ... lds, no VGPR round trip, no ds_write) instead of through
+//   staging registers.  A(d+2) is issued in phase 3 of iteration d (into the slot that barrier d just freed), B(d+1) in
+//   phase 0 of iteration d; one s_waitcnt vmcnt(0) in front of the stage's barrier covers both.
+template <bool AT, bool BT, int EPI, int ABL = 0, bool DMA = false>
 OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
     char* smem = of_smem();
     const int tid = of_tid(), lane = tid & 63;
@@ -57,14 +65,15 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
             offA[hf][jj] = 2u * chunk_off<AT>(p.lda, hf, jj * 4 + wave, lane);
             offB[hf][jj] = 2u * chunk_off<BT>(p.ldb, hf, jj * 4 + wave, lane);
         }
-    const unsigned stepA = 2u * (AT ? (unsigned)DK * (unsigned)p.lda : (unsigned)DK);
-    const unsigned stepB = 2u * (BT ? (unsigned)DK * (unsigned)p.ldb : (unsigned)DK);
+    const unsigned stepA = (ABL & 32) ? 0u : 2u * (AT ? (unsigned)DK * (unsigned)p.lda : (unsigned)DK);
+    const unsigned stepB = (ABL & 32) ? 0u : 2u * (BT ? (unsigned)DK * (unsigned)p.ldb : (unsigned)DK);
     const int nd = p.K / DK;
     const int wdst = wave * 1024 + lane * 16;     // + op * OPER_BYTES + hf * HALF_BYTES + jj * 4096
 
     u32x4 stg[16];       // piece j = op * 8 + hf * 4 + jj
     auto load_piece = [&](int j) OF_INLINE_LAMBDA {
         const int op = j >> 3, hf = (j >> 2) & 1, jj = j & 3;
+        if (ABL & 2) return;
         if (op == 0) stg[j] = of_buf_load16(gA, offA[hf][jj], sA);
         else stg[j] = of_buf_load16(gB, offB[hf][jj], sB);
     };
@@ -74,7 +83,20 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
     };
     auto store_piece = [&](char* slot, int j) OF_INLINE_LAMBDA {
         const int op = j >> 3, hf = (j >> 2) & 1, jj = j & 3;
+        if (ABL & 1) {
+            asm volatile("" ::"v"(stg[j]));     // keep the load alive
+            return;
+        }
         *(u32x4*)(slot + op * OPER_BYTES + hf * HALF_BYTES + jj * 4096 + wdst) = stg[j];
+    };
+
+    // DMA variant: piece j of the stage at scalar offsets sA / sB straight into `slot`
+    auto dma_piece = [&](char* slot, int j) OF_INLINE_LAMBDA {
+        const int op = j >> 3, hf = (j >> 2) & 1, jj = j & 3;
+        char* dst = slot + op * OPER_BYTES + hf * HALF_BYTES + jj * 4096 + wave * 1024;
+        if (ABL & 2) return;
+        if (op == 0) of_buf_load16_lds(gA, offA[hf][jj], sA, dst);
+        else of_buf_load16_lds(gB, offB[hf][jj], sB, dst);
     };
 
     s16x8 fa[2][4], fb[2][4];     // [register buffer][32-row fragment]
@@ -87,47 +109,78 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
         else fb[buf][idx[i]] = frag32<BT>(stage + OPER_BYTES, wn * 128 + idx[i] * 32, h, ks, lane);
     };
 
-    // ---- prologue: stage 0 into slot 0, stage 1 in flight in the staging registers
+    // ---- prologue: stage 0 into slot 0; stage 1 in flight (staging registers / DMA variant: its A half into slot 1)
+    if (DMA) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) load_piece(j);
-    next_stage_src();
+        for (int j = 0; j < 16; ++j) dma_piece(smem, j);
+        sA += stepA;
+        sB += stepB;
+        if (nd > 1) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) store_piece(smem, j);
-    if (nd > 1) {
+            for (int j = 0; j < 8; ++j) dma_piece(smem + STAGE_BYTES, j);
+            sA += stepA;
+            of_wait_vm<8>();
+        } else {
+            of_wait_vm<0>();
+        }
+    } else {
 #pragma unroll
         for (int j = 0; j < 16; ++j) load_piece(j);
         next_stage_src();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) store_piece(smem, j);
+        if (nd > 1) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) load_piece(j);
+            next_stage_src();
+        }
     }
     of_wait_lgkm0();
     of_barrier_raw();
 #pragma unroll
     for (int i = 0; i < 8; ++i) read_one(smem, 0, 0, i);
 
-    // One phase = the 16 MFMAs of one k-step (register buffer `buf`), each followed by at most one of: a fragment read
-    // of the next k-step into the other buffer (gaps 0-7), or one staging piece -- its LDS write into `nxt` and the
-    // re-issue of its global load (gaps 8-13).  of_sched_fence() after every gap pins exactly this interleave.
-    auto phase = [&](int buf, const char* rd_stage, int rd_ks16, bool rd, char* nxt, int j0, int nj, bool WR, bool LD) OF_INLINE_LAMBDA {
+    // One phase = the 16 MFMAs of one k-step (register buffer `buf`); every MFMA gap carries at most one LDS instruction:
+    //   gaps 0-7:  one fragment read of the next k-step into the other buffer (+ one global load, gaps of phases 1 / 2)
+    //   gaps 8-15: one staging write (phases 0 / 1)
+    // of_sched_fence() after every gap pins exactly this interleave.  Piece j is written in phase j/8 and re-loaded for
+    // stage d+2 one phase later (a load has 3.5 phases = 7/8 of a stage to land before its write; the last write is a full
+    // phase ahead of the barrier).
+    // DMA variant: gaps 8-15 carry one DMA piece instead (dma0 = first piece, into dma_slot).
+    auto phase = [&](int buf, const char* rd_stage, int rd_ks16, bool rd, char* nxt, int wr0, int ld0, bool WR, bool LD,
+                     char* dma_slot, int dma0) OF_INLINE_LAMBDA {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            acc[i >> 2][i & 3] = of_mfma32(fb[buf][i & 3], fa[buf][i >> 2], acc[i >> 2][i & 3]);
-            if (rd && i < 8) read_one(rd_stage, rd_ks16, buf ^ 1, i);
-            if (i >= 8 && i - 8 < nj) {
-                if (WR) store_piece(nxt, j0 + i - 8);
-                if (LD) load_piece(j0 + i - 8);
+            if (ABL & 16) {
+                if (i == 0) acc[0][0][0] += __builtin_bit_cast(float, (int)fa[buf][0][0] + fa[buf][1][1] + fa[buf][2][2] + fa[buf][3][3] +
+                                                                          fb[buf][0][4] + fb[buf][1][5] + fb[buf][2][6] + fb[buf][3][7]);
+            } else {
+                acc[i >> 2][i & 3] = of_mfma32(fb[buf][i & 3], fa[buf][i >> 2], acc[i >> 2][i & 3]);
+            }
+            if (i < 8) {
+                if (rd && !(ABL & 4)) read_one(rd_stage, rd_ks16, buf ^ 1, i);
+                if (!DMA && LD && ld0 >= 0) load_piece(ld0 + i);
+            } else if (DMA) {
+                if (dma0 >= 0) dma_piece(dma_slot, dma0 + i - 8);
+            } else if (WR && wr0 >= 0) {
+                store_piece(nxt, wr0 + i - 8);
             }
             of_sched_fence();
         }
     };
     // One K stage.  WR: stage d+1 exists (write it), LD: stage d+2 exists (load it).
-    auto stage_body = [&](const char* cur, char* nxt, const bool WR, const bool LD) OF_INLINE_LAMBDA {
-        phase(0, cur, 1, true, nxt, 0, 6, WR, LD);
-        phase(1, cur, 2, true, nxt, 6, 5, WR, LD);
-        phase(0, cur, 3, true, nxt, 11, 5, WR, LD);
-        if (LD) next_stage_src();
+    auto stage_body = [&](char* cur, char* nxt, const bool WR, const bool LD) OF_INLINE_LAMBDA {
+        phase(0, cur, 1, true, nxt, 0, -1, WR, LD, nxt, WR ? 8 : -1);          // DMA: B(d+1) -> nxt
+        if (DMA && WR) sB += stepB;
+        phase(1, cur, 2, true, nxt, 8, 0, WR, LD, nullptr, -1);
+        phase(0, cur, 3, true, nxt, -1, 8, WR, LD, nullptr, -1);
+        if (!DMA && LD) next_stage_src();
+        if (DMA) of_wait_vm<0>();      // own DMA pieces of stage d+1 have landed ...
         of_wait_lgkm0();       // own writes of stage d+1 and reads of this slot are done ...
-        of_barrier_raw();      // ... and so are everybody else's
+        if (!(ABL & 8)) of_barrier_raw();      // ... and so are everybody else's
         of_sched_fence();
-        phase(1, nxt, 0, WR, nxt, 0, 0, false, false);
+        phase(1, nxt, 0, WR, nxt, -1, -1, false, false, cur, LD ? 0 : -1);     // DMA: A(d+2) -> cur (free since the barrier)
+        if (DMA && LD) sA += stepA;
     };
 
     int d = 0;
@@ -178,9 +231,39 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
 template <bool AT, bool BT, int EPI>
 int launch_w4(const OfGemmArgs& a, of_stream_t s) {
     of_dim3 grid{(unsigned)((a.M / TM) * (a.N / TN)), 1, 1};
+    if (a.safe == 7) return of_launch(of_gemm_w4_kernel<AT, BT, EPI, 0, true>, grid, 256, SMEM_W4, s, a);
     return of_launch(of_gemm_w4_kernel<AT, BT, EPI>, grid, 256, SMEM_W4, s, a);
 }
+#ifdef OF_TOOLS_BUILD
+template <int ABL>
+int launch_w4_abl(const OfGemmArgs& a, of_stream_t s) {
+    of_dim3 grid{(unsigned)((a.M / TM) * (a.N / TN)), 1, 1};
+    if (a.C2) return of_launch(of_gemm_w4_kernel<false, false, OF_EPI_STORE_BF16, ABL, true>, grid, 256, SMEM_W4, s, a);   // DMA variant
+    return of_launch(of_gemm_w4_kernel<false, false, OF_EPI_STORE_BF16, ABL>, grid, 256, SMEM_W4, s, a);
+}
+#endif
 }  // namespace
+
+#ifdef OF_TOOLS_BUILD
+// timing-only entry (NT layout, bf16 store): mask as documented at the kernel
+int of_gemm_w4_ablate(const OfGemmArgs& a, int mask, of_stream_t s) {
+    if ((a.M % TM) || (a.N % TN) || (a.K % DK) || a.a_trans || a.b_trans || a.epi != OF_EPI_STORE_BF16) return OF_E_SHAPE;
+    switch (mask) {
+        case 0: return launch_w4_abl<0>(a, s);
+        case 1: return launch_w4_abl<1>(a, s);
+        case 2: return launch_w4_abl<2>(a, s);
+        case 3: return launch_w4_abl<3>(a, s);
+        case 4: return launch_w4_abl<4>(a, s);
+        case 7: return launch_w4_abl<7>(a, s);
+        case 8: return launch_w4_abl<8>(a, s);
+        case 9: return launch_w4_abl<9>(a, s);
+        case 15: return launch_w4_abl<15>(a, s);
+        case 32: return launch_w4_abl<32>(a, s);
+        case 40: return launch_w4_abl<40>(a, s);
+    }
+    return OF_E_ARG;
+}
+#endif
 
 int of_gemm_w4_try(const OfGemmArgs& a, of_stream_t s) {
     if ((a.M % TM) || (a.N % TN) || (a.K % DK)) return OF_E_SHAPE;

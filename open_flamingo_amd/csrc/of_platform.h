@@ -94,6 +94,11 @@ OF_DEV of_buf_t of_buf_make(const void* base) {
 OF_DEV u32x4 of_buf_load16(of_buf_t b, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(b, (int)voff, (int)soff, 0));
 }
+// LDS-DMA through a buffer descriptor: 16 bytes per lane straight into LDS at (wave-uniform base + lane*16); completion is
+// tracked only by the issuing wave's vmcnt (+ a barrier for other waves), like of_glds16
+OF_DEV void of_buf_load16_lds(of_buf_t b, unsigned voff, unsigned soff, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+}
 template <int N>
 OF_DEV void of_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

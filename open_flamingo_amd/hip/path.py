@@ -51,114 +51,233 @@ class _GradOut:
 
 
 # =================================================================================================
-# GatedCrossAttentionBlock
+# FeedForward (helpers.py:15-22) -- as a branch: out = [resid +] [tanh(gate) *] W2 gelu(W1 LN(x))
 # =================================================================================================
-def xattn_project_media(ops, W, media_bf, heads, out=None):
+def _branch_out(ops, A, Wt, x_like, resid, gate):
+    """Final GEMM of a branch.  With a residual: resid + tanh(gate) * acc in the stream dtype, fused in the epilogue;
+    stand-alone (resid None): tanh(gate) * acc (gate None: acc) in the stream dtype of ``x_like``."""
+    out = torch.empty_like(x_like)
+    if resid is not None:
+        ops.gemm(A, Wt, out, epi=EPI_GATE_RESID, aux=resid, gate=gate)
+    elif out.dtype == F32:
+        ops.gemm(A, Wt, out, epi=EPI_ACC_F32, gate=gate)
+    else:
+        ops.gemm(A, Wt, out, epi=EPI_STORE_BF16, gate=gate)
+    return out
+
+
+def feed_forward_fwd(ops, P, W, x, *, prefix="", gate=None, residual=False, keep=True):
+    """x (rows, d) stream dtype.  P/W keys: prefix + {0.weight, 0.bias, 1.weight, 3.weight}.  Returns (y, saved)."""
+    dev = x.device
+    rows, d = x.shape
+    hid = W[prefix + "1.weight"].shape[0]
+    u = _e((rows, d), BF16, dev)
+    st = _e((rows, 2), F32, dev)
+    ops.ln_fwd(x, P[prefix + "0.weight"], P[prefix + "0.bias"], u, st)
+    a = _e((rows, hid), BF16, dev) if keep else None      # pre-GELU activations: only the backward reads them
+    b = _e((rows, hid), BF16, dev)
+    ops.gemm(u, W[prefix + "1.weight"], b, epi=EPI_GELU, out2=a)               # up-projection + erf GELU
+    y = _branch_out(ops, b, W[prefix + "3.weight"], x, x if residual else None, gate)   # down [, *tanh(gate), +x]
+    if not keep:
+        return y, None
+    return y, dict(x=x, u=u, st=st, a=a, b=b)
+
+
+def feed_forward_bwd(ops, P, W, S, dy, G, *, prefix="", gate=None, gate_name=None, residual=False):
+    """dy (rows, d) stream dtype, contiguous.  Returns (dx, dx_bf16 or None): dx = [dy +] LN_bwd(...)."""
+    dev = dy.device
+    rows, d = S["x"].shape
+    hid = W[prefix + "1.weight"].shape[0]
+    dyb = ops.to_bf16(dy)
+    da = _e((rows, hid), BF16, dev)
+    ops.gemm(dyb, W[prefix + "3.weight"], da, tb=True, epi=EPI_DGELU_DOT, aux=S["a"], gate=gate,
+             dot=G.acc(gate_name, (1,)) if gate_name else None)
+    t, beta = G.mat(prefix + "3.weight", (d, hid))
+    ops.gemm(dyb, S["b"], t, ta=True, tb=True, epi=EPI_ACC_F32, gate=gate, beta=beta)         # dW2
+    du = _e((rows, d), BF16, dev)
+    ops.gemm(da, W[prefix + "1.weight"], du, tb=True)
+    t, beta = G.mat(prefix + "1.weight", (hid, d))
+    ops.gemm(da, S["u"], t, ta=True, tb=True, epi=EPI_ACC_F32, beta=beta)                    # dW1
+    dx = torch.empty_like(dy)
+    dxb = _e((rows, d), BF16, dev) if dy.dtype == F32 else None
+    ops.ln_bwd(du, S["x"], S["st"], P[prefix + "0.weight"], resid=dy if residual else None, dx=dx, dx_bf16=dxb,
+               dw=G.acc(prefix + "0.weight", (d,)), db=G.acc(prefix + "0.bias", (d,)))
+    return dx, (dxb if dxb is not None else dx)
+
+
+# =================================================================================================
+# MaskedCrossAttention (helpers.py:160-233) -- as a branch: out = [x +] [tanh(gate) *] attn(x, media)
+# =================================================================================================
+def xattn_project_media(ops, W, media_bf, heads, out=None, prefix="attn.", dim_head=64):
     """k | v = to_kv(media) (helpers.py:189), (B*T*n, 2*inner) bf16.  Depends on the media and the block's weights only,
     so the decode loop computes it once per block and prompt instead of once per generated token."""
-    kv = _e((media_bf.shape[0], 2 * heads * 64), BF16, media_bf.device) if out is None else out
-    ops.gemm(media_bf, W["attn.to_kv.weight"], kv)
+    kv = _e((media_bf.shape[0], 2 * heads * dim_head), BF16, media_bf.device) if out is None else out
+    ops.gemm(media_bf, W[prefix + "to_kv.weight"], kv)
     return kv
 
 
-def xattn_block_fwd(ops, P, W, x, media_bf, tt, *, B, L, T, n, heads, only_immediate, safe=0, kv=None, keep=True):
-    """x (B*L, d) stream dtype; media_bf (B*T*n, Dv) bf16; tt (B, L) int32 or None.  Returns (y, saved).
-    kv: projected media from xattn_project_media (else computed here).  keep=False (inference): nothing is saved for a
-    backward -- the pre-GELU activations are not written -- and saved is None."""
+def masked_cross_attention_fwd(ops, P, W, x, media_bf, tt, *, B, L, T, n, heads, only_immediate, prefix="attn.", gate=None,
+                               residual=False, safe=0, kv=None, dim_head=64):
+    """x (B*L, d) stream dtype; media_bf (B*T*n, Dv) bf16; tt (B, L) int32 or None.  Returns (y, saved)."""
     dev = x.device
     rows, d = x.shape
-    inner = heads * 64
-    hid = W["ff.1.weight"].shape[0]
-    # --- masked cross attention (helpers.py:160-233)
+    inner = heads * dim_head
     xn = _e((rows, d), BF16, dev)
-    st1 = _e((rows, 2), F32, dev)
-    ops.ln_fwd(x, P["attn.norm.weight"], P["attn.norm.bias"], xn, st1)
+    st = _e((rows, 2), F32, dev)
+    ops.ln_fwd(x, P[prefix + "norm.weight"], P[prefix + "norm.bias"], xn, st)
     q = _e((rows, inner), BF16, dev)
-    ops.gemm(xn, W["attn.to_q.weight"], q)                                   # to_q
+    ops.gemm(xn, W[prefix + "to_q.weight"], q)                                   # to_q
     if kv is None:
-        kv = xattn_project_media(ops, W, media_bf, heads)                    # to_kv (k | v fused)
+        kv = xattn_project_media(ops, W, media_bf, heads, prefix=prefix, dim_head=dim_head)   # to_kv (k | v fused)
     o = _e((rows, inner), BF16, dev)
     lse = _e((B, heads, L), F32, dev)
     ops.attn_fwd(q, kv[:, :inner], kv[:, inner:], o, lse, batch=B, Lq=L, Lk=T * n, heads=heads, text_time=tt,
-                 n_per_media=n, T_img=T, only_immediate=only_immediate, safe=safe)
-    y1 = torch.empty_like(x)
-    ops.gemm(o, W["attn.to_out.weight"], y1, epi=EPI_GATE_RESID, aux=x, gate=P["attn_gate"])   # to_out, *tanh(gate), +x
-    # --- gated feed forward (helpers.py:15-22, 277)
-    u = _e((rows, d), BF16, dev)
-    st2 = _e((rows, 2), F32, dev)
-    ops.ln_fwd(y1, P["ff.0.weight"], P["ff.0.bias"], u, st2)
-    a = _e((rows, hid), BF16, dev) if keep else None
-    b = _e((rows, hid), BF16, dev)
-    ops.gemm(u, W["ff.1.weight"], b, epi=EPI_GELU, out2=a)                   # up-projection + erf GELU
-    y2 = torch.empty_like(x)
-    ops.gemm(b, W["ff.3.weight"], y2, epi=EPI_GATE_RESID, aux=y1, gate=P["ff_gate"])  # down, *tanh(gate), +y1
-    if not keep:
-        return y2, None
-    saved = dict(x=x, xn=xn, st1=st1, q=q, kv=kv, o=o, lse=lse, y1=y1, u=u, st2=st2, a=a, b=b)
-    return y2, saved
+                 n_per_media=n, T_img=T, only_immediate=only_immediate, safe=safe, head_dim=dim_head,
+                 scale=dim_head ** -0.5)
+    y = _branch_out(ops, o, W[prefix + "to_out.weight"], x, x if residual else None, gate)   # to_out [, *tanh(gate), +x]
+    return y, dict(x=x, xn=xn, st=st, q=q, kv=kv, o=o, lse=lse)
 
 
-def xattn_block_bwd(ops, P, W, S, media_bf, tt, dy, *, B, L, T, n, heads, only_immediate, need_dmedia=True, safe=0,
-                    sinks=None):
-    """Returns (dx, dmedia fp32 (B*T*n, Dv) or None, grads dict keyed like P).  sinks: see _GradOut."""
+def masked_cross_attention_bwd(ops, P, W, S, media_bf, tt, dy, dyb, G, *, B, L, T, n, heads, only_immediate,
+                               prefix="attn.", gate=None, gate_name=None, residual=False, need_dmedia=True, safe=0,
+                               dim_head=64):
+    """dy stream dtype + its bf16 copy dyb.  Returns (dx, dmedia fp32 or None)."""
     dev = dy.device
     rows, d = S["x"].shape
-    inner = heads * 64
-    hid = W["ff.1.weight"].shape[0]
+    inner = heads * dim_head
     Dv = media_bf.shape[1]
-    G = _GradOut(sinks, dev)
-    g = G.g
-    dy = dy.contiguous()
-    dyb = ops.to_bf16(dy)
-    # ---- feed forward branch: y2 = y1 + tanh(gf) * F(y1)
-    da = _e((rows, hid), BF16, dev)
-    ops.gemm(dyb, W["ff.3.weight"], da, tb=True, epi=EPI_DGELU_DOT, aux=S["a"], gate=P["ff_gate"],
-             dot=G.acc("ff_gate", (1,)))
-    t, beta = G.mat("ff.3.weight", (d, hid))
-    ops.gemm(dyb, S["b"], t, ta=True, tb=True, epi=EPI_ACC_F32, gate=P["ff_gate"], beta=beta)         # dW2
-    du = _e((rows, d), BF16, dev)
-    ops.gemm(da, W["ff.1.weight"], du, tb=True)
-    t, beta = G.mat("ff.1.weight", (hid, d))
-    ops.gemm(da, S["u"], t, ta=True, tb=True, epi=EPI_ACC_F32, beta=beta)                            # dW1
-    dy1 = torch.empty_like(dy)
-    dy1b = _e((rows, d), BF16, dev) if dy.dtype == F32 else None
-    ops.ln_bwd(du, S["y1"], S["st2"], P["ff.0.weight"], resid=dy, dx=dy1, dx_bf16=dy1b, dw=G.acc("ff.0.weight", (d,)),
-               db=G.acc("ff.0.bias", (d,)))
-    if dy1b is None:
-        dy1b = dy1
-    # ---- attention branch: y1 = x + tanh(ga) * A(x, media)
     dO = _e((rows, inner), BF16, dev)
-    ops.gemm(dy1b, W["attn.to_out.weight"], dO, tb=True, epi=EPI_SCALE_DOT, aux=S["o"], gate=P["attn_gate"],
-             dot=G.acc("attn_gate", (1,)))
-    t, beta = G.mat("attn.to_out.weight", (d, inner))
-    ops.gemm(dy1b, S["o"], t, ta=True, tb=True, epi=EPI_ACC_F32, gate=P["attn_gate"], beta=beta)
+    ops.gemm(dyb, W[prefix + "to_out.weight"], dO, tb=True, epi=EPI_SCALE_DOT, aux=S["o"], gate=gate,
+             dot=G.acc(gate_name, (1,)) if gate_name else None)
+    t, beta = G.mat(prefix + "to_out.weight", (d, inner))
+    ops.gemm(dyb, S["o"], t, ta=True, tb=True, epi=EPI_ACC_F32, gate=gate, beta=beta)
     dq = _e((rows, inner), BF16, dev)
     dkv = _e((B * T * n, 2 * inner), BF16, dev)
     delta = _e((B, heads, L), F32, dev)
     kv = S["kv"]
     ops.attn_bwd(S["q"], kv[:, :inner], kv[:, inner:], S["o"], S["lse"], dO, dq, dkv[:, :inner], dkv[:, inner:], delta,
                  batch=B, Lq=L, Lk=T * n, heads=heads, text_time=tt, n_per_media=n, T_img=T,
-                 only_immediate=only_immediate, safe=safe)
+                 only_immediate=only_immediate, safe=safe, head_dim=dim_head, scale=dim_head ** -0.5)
     dxn = _e((rows, d), BF16, dev)
-    ops.gemm(dq, W["attn.to_q.weight"], dxn, tb=True)
-    t, beta = G.mat("attn.to_q.weight", (inner, d))
+    ops.gemm(dq, W[prefix + "to_q.weight"], dxn, tb=True)
+    t, beta = G.mat(prefix + "to_q.weight", (inner, d))
     ops.gemm(dq, S["xn"], t, ta=True, tb=True, epi=EPI_ACC_F32, beta=beta)
     dx = torch.empty_like(dy)
-    ops.ln_bwd(dxn, S["x"], S["st1"], P["attn.norm.weight"], resid=dy1, dx=dx, dw=G.acc("attn.norm.weight", (d,)),
-               db=G.acc("attn.norm.bias", (d,)))
-    t, beta = G.mat("attn.to_kv.weight", (2 * inner, Dv))
+    ops.ln_bwd(dxn, S["x"], S["st"], P[prefix + "norm.weight"], resid=dy if residual else None, dx=dx,
+               dw=G.acc(prefix + "norm.weight", (d,)), db=G.acc(prefix + "norm.bias", (d,)))
+    t, beta = G.mat(prefix + "to_kv.weight", (2 * inner, Dv))
     ops.gemm(dkv, media_bf, t, ta=True, tb=True, epi=EPI_ACC_F32, beta=beta)
     dmedia = None
     if need_dmedia:
         dmedia = _e((B * T * n, Dv), F32, dev)
-        ops.gemm(dkv, W["attn.to_kv.weight"], dmedia, tb=True, epi=EPI_ACC_F32)
-    return dx, dmedia, g
+        ops.gemm(dkv, W[prefix + "to_kv.weight"], dmedia, tb=True, epi=EPI_ACC_F32)
+    return dx, dmedia
+
+
+# =================================================================================================
+# GatedCrossAttentionBlock (helpers.py:260-279) = the two gated branches with fused residuals
+# =================================================================================================
+def xattn_block_fwd(ops, P, W, x, media_bf, tt, *, B, L, T, n, heads, only_immediate, safe=0, kv=None, keep=True,
+                    dim_head=64):
+    """x (B*L, d) stream dtype; media_bf (B*T*n, Dv) bf16; tt (B, L) int32 or None.  Returns (y, saved).
+    kv: projected media from xattn_project_media (else computed here).  keep=False (inference): nothing is saved for a
+    backward -- the pre-GELU activations are not written -- and saved is None."""
+    y1, Sa = masked_cross_attention_fwd(ops, P, W, x, media_bf, tt, B=B, L=L, T=T, n=n, heads=heads,
+                                        only_immediate=only_immediate, gate=P["attn_gate"], residual=True, safe=safe,
+                                        kv=kv, dim_head=dim_head)
+    y2, Sf = feed_forward_fwd(ops, P, W, y1, prefix="ff.", gate=P["ff_gate"], residual=True, keep=keep)
+    if not keep:
+        return y2, None
+    return y2, dict(attn=Sa, ff=Sf)
+
+
+def xattn_block_bwd(ops, P, W, S, media_bf, tt, dy, *, B, L, T, n, heads, only_immediate, need_dmedia=True, safe=0,
+                    sinks=None, dim_head=64):
+    """Returns (dx, dmedia fp32 (B*T*n, Dv) or None, grads dict keyed like P).  sinks: see _GradOut."""
+    G = _GradOut(sinks, dy.device)
+    dy = dy.contiguous()
+    # ---- feed forward branch: y2 = y1 + tanh(gf) * F(y1)
+    dy1, dy1b = feed_forward_bwd(ops, P, W, S["ff"], dy, G, prefix="ff.", gate=P["ff_gate"], gate_name="ff_gate",
+                                 residual=True)
+    # ---- attention branch: y1 = x + tanh(ga) * A(x, media)
+    dx, dmedia = masked_cross_attention_bwd(ops, P, W, S["attn"], media_bf, tt, dy1, dy1b, G, B=B, L=L, T=T, n=n,
+                                            heads=heads, only_immediate=only_immediate, gate=P["attn_gate"],
+                                            gate_name="attn_gate", residual=True, need_dmedia=need_dmedia, safe=safe,
+                                            dim_head=dim_head)
+    return dx, dmedia, G.g
 
 
 # =================================================================================================
 # PerceiverResampler
 # =================================================================================================
-def perceiver_fwd(ops, P, W, x, *, N, Fv, n, heads, depth, T=1, frames=1, safe=0, keep=True):
+def perceiver_attention_fwd(ops, P, W, x, lat, *, N, Fv, n, heads, prefix, residual=False, safe=0, dim_head=64):
+    """PerceiverAttention.forward (helpers.py:39-65).  x (N*Fv, D) media rows, lat (N*n, D) latents, both stream dtype.
+    Returns (out (N*n, D) = attn(x, latents) [+ latents], saved)."""
+    dev = x.device
+    D = x.shape[1]
+    inner = heads * dim_head
+    S_ = Fv + n
+    kvin = _e((N * S_, D), BF16, dev)          # [LN_media(x) rows | LN_latents(latents) rows] per media item
+    st_m = _e((N * Fv, 2), F32, dev)
+    st_l = _e((N * n, 2), F32, dev)
+    ltn = _e((N * n, D), BF16, dev)
+    ops.ln_fwd_grouped(x, P[prefix + "norm_media.weight"], P[prefix + "norm_media.bias"], kvin, D, Fv, S_ * D, None, st_m)
+    ops.ln_fwd_grouped(lat, P[prefix + "norm_latents.weight"], P[prefix + "norm_latents.bias"], kvin[Fv:], D, n, S_ * D,
+                       ltn, st_l)
+    q = _e((N * n, inner), BF16, dev)
+    ops.gemm(ltn, W[prefix + "to_q.weight"], q)
+    kv = _e((N * S_, 2 * inner), BF16, dev)
+    ops.gemm(kvin, W[prefix + "to_kv.weight"], kv)
+    o = _e((N * n, inner), BF16, dev)
+    lse = _e((N, heads, n), F32, dev)
+    ops.attn_fwd(q, kv[:, :inner], kv[:, inner:], o, lse, batch=N, Lq=n, Lk=S_, heads=heads, safe=safe, head_dim=dim_head,
+                 scale=dim_head ** -0.5)
+    out = _branch_out(ops, o, W[prefix + "to_out.weight"], lat, lat if residual else None, None)
+    return out, dict(x=x, lat=lat, kvin=kvin, st_m=st_m, st_l=st_l, ltn=ltn, q=q, kv=kv, o=o, lse=lse)
+
+
+def perceiver_attention_bwd(ops, P, W, S, dout, doutb, G, *, N, Fv, n, heads, prefix, residual=False, need_dx=False,
+                            dx_acc=None, safe=0, dim_head=64):
+    """dout (N*n, D) stream dtype (+ bf16 copy).  Returns (dlat, dx): dlat = [dout +] gradient through norm_latents;
+    dx = (dx_acc or 0) + gradient through norm_media when need_dx, else None (norm_media's dw/db are always produced)."""
+    dev = dout.device
+    x, lat = S["x"], S["lat"]
+    D = x.shape[1]
+    inner = heads * dim_head
+    S_ = Fv + n
+    dO = _e((N * n, inner), BF16, dev)
+    ops.gemm(doutb, W[prefix + "to_out.weight"], dO, tb=True)
+    t, beta = G.mat(prefix + "to_out.weight", (D, inner))
+    ops.gemm(doutb, S["o"], t, ta=True, tb=True, epi=EPI_ACC_F32, beta=beta)
+    dq = _e((N * n, inner), BF16, dev)
+    dkv = _e((N * S_, 2 * inner), BF16, dev)
+    delta = _e((N, heads, n), F32, dev)
+    kv = S["kv"]
+    ops.attn_bwd(S["q"], kv[:, :inner], kv[:, inner:], S["o"], S["lse"], dO, dq, dkv[:, :inner], dkv[:, inner:],
+                 delta, batch=N, Lq=n, Lk=S_, heads=heads, safe=safe, head_dim=dim_head, scale=dim_head ** -0.5)
+    dltn = _e((N * n, D), BF16, dev)
+    ops.gemm(dq, W[prefix + "to_q.weight"], dltn, tb=True)                      # through to_q
+    t, beta = G.mat(prefix + "to_q.weight", (inner, D))
+    ops.gemm(dq, S["ltn"], t, ta=True, tb=True, epi=EPI_ACC_F32, beta=beta)
+    dkvin = _e((N * S_, D), BF16, dev)
+    ops.gemm(dkv, W[prefix + "to_kv.weight"], dkvin, tb=True)                    # through to_kv (media + latent rows)
+    t, beta = G.mat(prefix + "to_kv.weight", (2 * inner, D))
+    ops.gemm(dkv, S["kvin"], t, ta=True, tb=True, epi=EPI_ACC_F32, beta=beta)
+    # norm_media: parameter grads always; dx only if the vision features require grad (they do not in Flamingo,
+    # flamingo.py:194-195 runs the ViT under no_grad)
+    dx_new = torch.empty_like(x) if need_dx else None
+    ops.ln_bwd(dkvin, x, S["st_m"], P[prefix + "norm_media.weight"], lddy=D, dy_grp_rows=Fv, dy_grp_stride=S_ * D,
+               resid=dx_acc if need_dx else None, dx=dx_new, dw=G.acc(prefix + "norm_media.weight", (D,)),
+               db=G.acc(prefix + "norm_media.bias", (D,)))
+    # norm_latents: two upstream gradients (k/v rows of kv_input and the to_q input) [+ the residual]
+    dlat = torch.empty_like(dout)
+    ops.ln_bwd(dkvin[Fv:], lat, S["st_l"], P[prefix + "norm_latents.weight"], lddy=D, dy_grp_rows=n,
+               dy_grp_stride=S_ * D, dy2=dltn, resid=dout if residual else None, dx=dlat,
+               dw=G.acc(prefix + "norm_latents.weight", (D,)), db=G.acc(prefix + "norm_latents.bias", (D,)))
+    return dlat, dx_new
+
+
+def perceiver_fwd(ops, P, W, x, *, N, Fv, n, heads, depth, T=1, frames=1, safe=0, keep=True, dim_head=64):
     """x (N*Fv, D) stream dtype (already flattened 'b T (F v) d' rows, N = b*T, Fv = frames*v); returns
     (out (N*n, D) stream, saved).  frame_embs / media_time_embs (helpers.py:117-119,123-124) are added when present
     in P; T and frames give the row structure they index."""
@@ -170,42 +289,15 @@ def perceiver_fwd(ops, P, W, x, *, N, Fv, n, heads, depth, T=1, frames=1, safe=0
         x_in = x
         x = torch.empty_like(x_in)
         ops.add_embs(x_in, P.get("frame_embs"), v, frames, P.get("media_time_embs"), Fv, T, x)
-    inner = heads * 64
-    S_ = Fv + n
-    hid = W["layers.0.1.1.weight"].shape[0]
     lat = _e((N * n, D), x.dtype, dev)
     ops.broadcast_rows(P["latents"], lat, N * n)                              # repeat(latents, 'n d -> b T n d')
     layers = []
     for i in range(depth):
-        pa, pf = f"layers.{i}.0.", f"layers.{i}.1."
-        kvin = _e((N * S_, D), BF16, dev)          # [LN_media(x) rows | LN_latents(latents) rows] per media item
-        st_m = _e((N * Fv, 2), F32, dev)
-        st_l = _e((N * n, 2), F32, dev)
-        ltn = _e((N * n, D), BF16, dev)
-        ops.ln_fwd_grouped(x, P[pa + "norm_media.weight"], P[pa + "norm_media.bias"], kvin, D, Fv, S_ * D, None, st_m)
-        ops.ln_fwd_grouped(lat, P[pa + "norm_latents.weight"], P[pa + "norm_latents.bias"], kvin[Fv:], D, n, S_ * D,
-                           ltn, st_l)
-        q = _e((N * n, inner), BF16, dev)
-        ops.gemm(ltn, W[pa + "to_q.weight"], q)
-        kv = _e((N * S_, 2 * inner), BF16, dev)
-        ops.gemm(kvin, W[pa + "to_kv.weight"], kv)
-        o = _e((N * n, inner), BF16, dev)
-        lse = _e((N, heads, n), F32, dev)
-        ops.attn_fwd(q, kv[:, :inner], kv[:, inner:], o, lse, batch=N, Lq=n, Lk=S_, heads=heads, safe=safe)
-        lat1 = torch.empty_like(lat)
-        ops.gemm(o, W[pa + "to_out.weight"], lat1, epi=EPI_GATE_RESID, aux=lat)              # attn(x, latents) + latents
-        u = _e((N * n, D), BF16, dev)
-        st_f = _e((N * n, 2), F32, dev)
-        ops.ln_fwd(lat1, P[pf + "0.weight"], P[pf + "0.bias"], u, st_f)
-        a = _e((N * n, hid), BF16, dev) if keep else None     # pre-GELU activations: only the backward reads them
-        b = _e((N * n, hid), BF16, dev)
-        ops.gemm(u, W[pf + "1.weight"], b, epi=EPI_GELU, out2=a)
-        lat2 = torch.empty_like(lat)
-        ops.gemm(b, W[pf + "3.weight"], lat2, epi=EPI_GATE_RESID, aux=lat1)                 # ff(latents) + latents
+        lat1, Sa = perceiver_attention_fwd(ops, P, W, x, lat, N=N, Fv=Fv, n=n, heads=heads, prefix=f"layers.{i}.0.",
+                                           residual=True, safe=safe, dim_head=dim_head)   # attn(x, latents) + latents
+        lat, Sf = feed_forward_fwd(ops, P, W, lat1, prefix=f"layers.{i}.1.", residual=True, keep=keep)   # ff + latents
         if keep:
-            layers.append(dict(lat=lat, kvin=kvin, st_m=st_m, st_l=st_l, ltn=ltn, q=q, kv=kv, o=o, lse=lse, lat1=lat1,
-                               u=u, st_f=st_f, a=a, b=b))
-        lat = lat2
+            layers.append(dict(attn=Sa, ff=Sf))
     out = torch.empty_like(lat)
     st_o = _e((N * n, 2), F32, dev)
     ops.ln_fwd_out(lat, P["norm.weight"], P["norm.bias"], out, st_o)
@@ -215,20 +307,16 @@ def perceiver_fwd(ops, P, W, x, *, N, Fv, n, heads, depth, T=1, frames=1, safe=0
 
 
 def perceiver_bwd(ops, P, W, S, dout, *, N, Fv, n, heads, depth, T=1, frames=1, need_dx=False, safe=0, sinks=None,
-                  on_ready=None):
+                  on_ready=None, dim_head=64):
     """Returns (dx (N*Fv, D) stream dtype or None, grads dict keyed like P).  sinks: see _GradOut.
     on_ready(names): called as soon as the kernels producing the FINAL value of those parameters' gradients are enqueued
     (per layer, last layer first) -- the gradient exchange of a layer can then start while the earlier layers' backward
     still runs (train/reducer.py buckets the Perceiver per layer)."""
     ready = on_ready or (lambda names: None)
     dev = dout.device
-    x = S["x"]
     want_dx = need_dx
     need_dx = need_dx or S.get("embs", False)     # the position tables' gradients are reductions of dx
-    D = x.shape[1]
-    inner = heads * 64
-    S_ = Fv + n
-    hid = W["layers.0.1.1.weight"].shape[0]
+    D = S["x"].shape[1]
     G = _GradOut(sinks, dev)
     g = G.g
     dout = dout.contiguous()
@@ -240,54 +328,10 @@ def perceiver_bwd(ops, P, W, S, dout, *, N, Fv, n, heads, depth, T=1, frames=1, 
     for i in reversed(range(depth)):
         pa, pf = f"layers.{i}.0.", f"layers.{i}.1."
         Lr = S["layers"][i]
-        # ---- ff(latents) + latents
-        dlb = ops.to_bf16(dlat)
-        da = _e((N * n, hid), BF16, dev)
-        ops.gemm(dlb, W[pf + "3.weight"], da, tb=True, epi=EPI_DGELU_DOT, aux=Lr["a"])
-        t, beta = G.mat(pf + "3.weight", (D, hid))
-        ops.gemm(dlb, Lr["b"], t, ta=True, tb=True, epi=EPI_ACC_F32, beta=beta)
-        du = _e((N * n, D), BF16, dev)
-        ops.gemm(da, W[pf + "1.weight"], du, tb=True)
-        t, beta = G.mat(pf + "1.weight", (hid, D))
-        ops.gemm(da, Lr["u"], t, ta=True, tb=True, epi=EPI_ACC_F32, beta=beta)
-        dlat1 = torch.empty_like(dlat)
-        dlat1b = _e((N * n, D), BF16, dev) if dlat.dtype == F32 else None
-        ops.ln_bwd(du, Lr["lat1"], Lr["st_f"], P[pf + "0.weight"], resid=dlat, dx=dlat1, dx_bf16=dlat1b,
-                   dw=G.acc(pf + "0.weight", (D,)), db=G.acc(pf + "0.bias", (D,)))
-        if dlat1b is None:
-            dlat1b = dlat1
-        # ---- attn(x, latents) + latents
-        dO = _e((N * n, inner), BF16, dev)
-        ops.gemm(dlat1b, W[pa + "to_out.weight"], dO, tb=True)
-        t, beta = G.mat(pa + "to_out.weight", (D, inner))
-        ops.gemm(dlat1b, Lr["o"], t, ta=True, tb=True, epi=EPI_ACC_F32, beta=beta)
-        dq = _e((N * n, inner), BF16, dev)
-        dkv = _e((N * S_, 2 * inner), BF16, dev)
-        delta = _e((N, heads, n), F32, dev)
-        kv = Lr["kv"]
-        ops.attn_bwd(Lr["q"], kv[:, :inner], kv[:, inner:], Lr["o"], Lr["lse"], dO, dq, dkv[:, :inner], dkv[:, inner:],
-                     delta, batch=N, Lq=n, Lk=S_, heads=heads, safe=safe)
-        dltn = _e((N * n, D), BF16, dev)
-        ops.gemm(dq, W[pa + "to_q.weight"], dltn, tb=True)                      # through to_q
-        t, beta = G.mat(pa + "to_q.weight", (inner, D))
-        ops.gemm(dq, Lr["ltn"], t, ta=True, tb=True, epi=EPI_ACC_F32, beta=beta)
-        dkvin = _e((N * S_, D), BF16, dev)
-        ops.gemm(dkv, W[pa + "to_kv.weight"], dkvin, tb=True)                    # through to_kv (media + latent rows)
-        t, beta = G.mat(pa + "to_kv.weight", (2 * inner, D))
-        ops.gemm(dkv, Lr["kvin"], t, ta=True, tb=True, epi=EPI_ACC_F32, beta=beta)
-        # norm_media: parameter grads always; dx only if the vision features require grad (they do not in Flamingo,
-        # flamingo.py:194-195 runs the ViT under no_grad)
-        dx_new = torch.empty_like(x) if need_dx else None
-        ops.ln_bwd(dkvin, x, Lr["st_m"], P[pa + "norm_media.weight"], lddy=D, dy_grp_rows=Fv, dy_grp_stride=S_ * D,
-                   resid=dx if need_dx else None, dx=dx_new, dw=G.acc(pa + "norm_media.weight", (D,)),
-                   db=G.acc(pa + "norm_media.bias", (D,)))
-        dx = dx_new
-        # norm_latents: two upstream gradients (k/v rows of kv_input and the to_q input) + the residual
-        dlat_prev = torch.empty_like(dlat)
-        ops.ln_bwd(dkvin[Fv:], Lr["lat"], Lr["st_l"], P[pa + "norm_latents.weight"], lddy=D, dy_grp_rows=n,
-                   dy_grp_stride=S_ * D, dy2=dltn, resid=dlat1, dx=dlat_prev, dw=G.acc(pa + "norm_latents.weight", (D,)),
-                   db=G.acc(pa + "norm_latents.bias", (D,)))
-        dlat = dlat_prev
+        dlat1, dlat1b = feed_forward_bwd(ops, P, W, Lr["ff"], dlat, G, prefix=pf, residual=True)   # ff(latents) + latents
+        dlat, dx = perceiver_attention_bwd(ops, P, W, Lr["attn"], dlat1, dlat1b, G, N=N, Fv=Fv, n=n, heads=heads,
+                                           prefix=pa, residual=True, need_dx=need_dx, dx_acc=dx, safe=safe,
+                                           dim_head=dim_head)                                        # attn + latents
         ready([k for k in P if k.startswith(pa) or k.startswith(pf)])
     ops.reduce_rows(dlat, G.acc("latents", tuple(P["latents"].shape)))           # sum over (b, T) of the repeat
     if S.get("embs", False):

@@ -131,9 +131,36 @@ def _hand_back(names, params, dtypes, g, sinks, notified=()):
     return tuple(out)
 
 
-class FeedForward(nn.Sequential):
-    """Parameter container with the reference's Sequential layout (0: LayerNorm, 1: Linear, 2: GELU, 3: Linear;
-    helpers.py:15-22).  It is executed fused inside its parent block; calling it directly is not supported."""
+class _FeedForwardFn(torch.autograd.Function):
+    """Stand-alone FeedForward (reference helpers.py:15-22): LN -> Linear -> erf-GELU -> Linear, no residual, no gate."""
+    NAMES = ("0.weight", "0.bias", "1.weight", "3.weight")
+
+    @staticmethod
+    def forward(ctx, mod, x, *params):
+        ops = Ops.default()
+        named = list(zip(_FeedForwardFn.NAMES, params))
+        P, W = mod._masters(named), mod._weights_bf16(ops, named)
+        xr = x.detach().reshape(-1, x.shape[-1])
+        xr = xr if xr.is_contiguous() else xr.contiguous()
+        keep = any(ctx.needs_input_grad)
+        y, S = _path.feed_forward_fwd(ops, P, W, xr, keep=keep)
+        ctx.S, ctx.P, ctx.W, ctx.params, ctx.param_dtypes = S, P, W, params, tuple(p.dtype for p in params)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ops = Ops.default()
+        sinks = _grad_sinks(_FeedForwardFn.NAMES, ctx.params)
+        G = _path._GradOut(sinks, dy.device)
+        dx, _ = _path.feed_forward_bwd(ops, ctx.P, ctx.W, ctx.S, dy.reshape(-1, dy.shape[-1]).contiguous(), G)
+        ctx.S = None
+        return (None, dx.view(dy.shape)) + _hand_back(_FeedForwardFn.NAMES, ctx.params, ctx.param_dtypes, G.g, sinks)
+
+
+class FeedForward(nn.Sequential, _HipParamModule):
+    """The reference's Sequential layout (0: LayerNorm, 1: Linear, 2: GELU, 3: Linear; helpers.py:15-22).  Inside
+    PerceiverResampler / GatedCrossAttentionBlock it runs fused with the residual and the tanh gate; called directly it
+    is the same libofhip kernels without them (``ff(x)`` as in the reference: no residual)."""
 
     def __init__(self, dim, mult=4):
         inner_dim = int(dim * mult)
@@ -141,17 +168,61 @@ class FeedForward(nn.Sequential):
                          nn.Linear(inner_dim, dim, bias=False))
 
     def forward(self, x):
-        raise NotImplementedError("FeedForward runs fused inside PerceiverResampler / GatedCrossAttentionBlock "
-                                  "(libofhip); call the parent module.")
+        _require_hip(x, "FeedForward")
+        return _FeedForwardFn.apply(self, x, self[0].weight, self[0].bias, self[1].weight, self[3].weight)
 
 
-class PerceiverAttention(nn.Module):
-    """Parameters of helpers.py:25-38; the arithmetic of helpers.py:39-65 runs in PerceiverResampler.forward."""
+_PATTN_NAMES = ("norm_media.weight", "norm_media.bias", "norm_latents.weight", "norm_latents.bias", "to_q.weight",
+                "to_kv.weight", "to_out.weight")
+
+
+class _PerceiverAttentionFn(torch.autograd.Function):
+    """Stand-alone PerceiverAttention.forward(x, latents) (reference helpers.py:39-65): no residual."""
+
+    @staticmethod
+    def forward(ctx, mod, x, latents, *params):
+        ops = Ops.default()
+        named = list(zip(_PATTN_NAMES, params))
+        P, W = mod._masters(named), mod._weights_bf16(ops, named)
+        b, T, n1, D = x.shape
+        n2 = latents.shape[2]
+        xr = x.detach().reshape(b * T * n1, D).contiguous()
+        lr = latents.detach().reshape(b * T * n2, D).to(xr.dtype).contiguous()
+        dims = dict(N=b * T, Fv=n1, n=n2, heads=mod.heads, prefix="", dim_head=mod.dim_head)
+        out, S = _path.perceiver_attention_fwd(ops, P, W, xr, lr, **dims)
+        ctx.S, ctx.P, ctx.W, ctx.dims, ctx.params, ctx.param_dtypes = S, P, W, dims, params, tuple(p.dtype for p in params)
+        ctx.xshape, ctx.lshape = tuple(x.shape), tuple(latents.shape)
+        return out.view(b, T, n2, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        ops = Ops.default()
+        sinks = _grad_sinks(_PATTN_NAMES, ctx.params)
+        G = _path._GradOut(sinks, dout.device)
+        d2 = dout.reshape(-1, dout.shape[-1]).contiguous()
+        dlat, dx = _path.perceiver_attention_bwd(ops, ctx.P, ctx.W, ctx.S, d2, ops.to_bf16(d2), G,
+                                                 need_dx=ctx.needs_input_grad[1], **ctx.dims)
+        ctx.S = None
+        return (None, dx.view(ctx.xshape) if dx is not None else None, dlat.view(ctx.lshape)) + \
+            _hand_back(_PATTN_NAMES, ctx.params, ctx.param_dtypes, G.g, sinks)
+
+
+def _check_dim_head(dim_head, who):
+    if dim_head not in (64, 128):
+        raise NotImplementedError(f"{who}: the libofhip attention kernels exist for dim_head 64 (every released OpenFlamingo "
+                                  f"model) and 128; got dim_head={dim_head}")
+
+
+class PerceiverAttention(_HipParamModule):
+    """helpers.py:25-65.  Inside PerceiverResampler it runs fused with the residual; called directly it returns
+    attention(x, latents) like the reference."""
 
     def __init__(self, *, dim, dim_head=64, heads=8):
         super().__init__()
+        _check_dim_head(dim_head, "PerceiverAttention")
         self.scale = dim_head ** -0.5
         self.heads = heads
+        self.dim_head = dim_head
         inner_dim = dim_head * heads
         self.norm_media = nn.LayerNorm(dim)
         self.norm_latents = nn.LayerNorm(dim)
@@ -160,7 +231,12 @@ class PerceiverAttention(nn.Module):
         self.to_out = nn.Linear(inner_dim, dim, bias=False)
 
     def forward(self, x, latents):
-        raise NotImplementedError("PerceiverAttention runs fused inside PerceiverResampler (libofhip).")
+        """x (b, T, n1, D) media features, latents (b, T, n2, D) -> (b, T, n2, D)   [reference helpers.py:39-65]"""
+        _require_hip(x, "PerceiverAttention")
+        _require_hip(latents, "PerceiverAttention(latents)")
+        params = [self.norm_media.weight, self.norm_media.bias, self.norm_latents.weight, self.norm_latents.bias,
+                  self.to_q.weight, self.to_kv.weight, self.to_out.weight]
+        return _PerceiverAttentionFn.apply(self, x, latents, *params)
 
 
 def _perceiver_operands(mod, names, x, params):
@@ -174,7 +250,8 @@ def _perceiver_operands(mod, names, x, params):
         xr = xr.contiguous()
     assert ("frame_embs" not in P or Fr <= P["frame_embs"].shape[0]) and \
         ("media_time_embs" not in P or T <= P["media_time_embs"].shape[0]), "more frames/media than embedding rows"
-    dims = dict(N=b * T, Fv=Fr * v, n=P["latents"].shape[0], heads=mod.heads, depth=mod.depth, T=T, frames=Fr)
+    dims = dict(N=b * T, Fv=Fr * v, n=P["latents"].shape[0], heads=mod.heads, depth=mod.depth, T=T, frames=Fr,
+                dim_head=mod.dim_head)
     return ops, P, W, xr, dims
 
 
@@ -216,9 +293,7 @@ class PerceiverResampler(_HipParamModule):
     def __init__(self, *, dim, depth=6, dim_head=64, heads=8, num_latents=64, max_num_media=None,
                  max_num_frames=None, ff_mult=4):
         super().__init__()
-        if dim_head != 64:
-            raise NotImplementedError("libofhip attention kernels are built for dim_head=64 (every released "
-                                      "OpenFlamingo model); got dim_head=%d" % dim_head)
+        _check_dim_head(dim_head, "PerceiverResampler")
         # creation order == reference (helpers.py:82-105) so torch.manual_seed(s) gives identical initial weights
         self.latents = nn.Parameter(torch.randn(num_latents, dim))
         self.frame_embs = nn.Parameter(torch.randn(max_num_frames, dim)) if exists(max_num_frames) else None
@@ -228,7 +303,7 @@ class PerceiverResampler(_HipParamModule):
             self.layers.append(nn.ModuleList([PerceiverAttention(dim=dim, dim_head=dim_head, heads=heads),
                                               FeedForward(dim=dim, mult=ff_mult)]))
         self.norm = nn.LayerNorm(dim)
-        self.heads, self.depth, self.dim = heads, depth, dim
+        self.heads, self.depth, self.dim, self.dim_head = heads, depth, dim, dim_head
 
     def forward(self, x):
         """x (b, T, F, v, D) -> (b, T, num_latents, D)   [reference helpers.py:107-132]"""
@@ -243,13 +318,19 @@ class PerceiverResampler(_HipParamModule):
         return _PerceiverFn.apply(self, names, x, *[p for _, p in named])
 
 
-class MaskedCrossAttention(nn.Module):
-    """Parameters of helpers.py:137-158; the arithmetic of helpers.py:160-233 runs in GatedCrossAttentionBlock."""
+_MCA_NAMES = ("norm.weight", "norm.bias", "to_q.weight", "to_kv.weight", "to_out.weight")
+
+
+class MaskedCrossAttention(_HipParamModule):
+    """helpers.py:137-233.  Inside GatedCrossAttentionBlock it runs fused with the tanh gate and the residual; called
+    directly it returns the attention output like the reference."""
 
     def __init__(self, *, dim, dim_visual, dim_head=64, heads=8, only_attend_immediate_media=True):
         super().__init__()
+        _check_dim_head(dim_head, "MaskedCrossAttention")
         self.scale = dim_head ** -0.5
         self.heads = heads
+        self.dim_head = dim_head
         inner_dim = dim_head * heads
         self.norm = nn.LayerNorm(dim)
         self.to_q = nn.Linear(dim, inner_dim, bias=False)
@@ -258,7 +339,14 @@ class MaskedCrossAttention(nn.Module):
         self.only_attend_immediate_media = only_attend_immediate_media
 
     def forward(self, x, media, media_locations=None, use_cached_media=False):
-        raise NotImplementedError("MaskedCrossAttention runs fused inside GatedCrossAttentionBlock (libofhip).")
+        """x (B, T_txt, D_txt), media (B, T_img, n, D_img), media_locations (B, T_txt) bool   [reference helpers.py:160-233]"""
+        _require_hip(x, "MaskedCrossAttention")
+        _require_hip(media, "MaskedCrossAttention(media)")
+        if not use_cached_media:
+            assert media_locations is None or media_locations.shape[1] == x.shape[1], (
+                f"media_location.shape is {media_locations.shape} but x.shape is {x.shape}")
+        params = [self.norm.weight, self.norm.bias, self.to_q.weight, self.to_kv.weight, self.to_out.weight]
+        return _MaskedCrossAttentionFn.apply(self, x, media, media_locations, use_cached_media, *params)
 
 
 _capture_streams = {}
@@ -275,11 +363,12 @@ _XATTN_NAMES = ("attn_gate", "ff_gate", "attn.norm.weight", "attn.norm.bias", "a
                 "attn.to_out.weight", "ff.0.weight", "ff.0.bias", "ff.1.weight", "ff.3.weight")
 
 
-def _xattn_operands(mod, x, media, media_locations, use_cached_media, params):
+def _xattn_operands(mod, x, media, media_locations, use_cached_media, params, names=None, attn=None):
     ops = Ops.default()
     B, L, d = x.shape
     _, T, n, Dv = media.shape
-    named = list(zip(_XATTN_NAMES, params))
+    named = list(zip(names or _XATTN_NAMES, params))
+    attn = attn if attn is not None else mod.attn
     P = mod._masters(named)
     W = mod._weights_bf16(ops, named)
     xr = x.detach().reshape(B * L, d)
@@ -296,8 +385,36 @@ def _xattn_operands(mod, x, media, media_locations, use_cached_media, params):
             ops.text_time(ml, out, L, bool(use_cached_media))
             return out
         tt = _shared.get(media_locations, ("tt", L, bool(use_cached_media)), _tt)
-    dims = dict(B=B, L=L, T=T, n=n, heads=mod.attn.heads, only_immediate=mod.attn.only_attend_immediate_media)
+    dims = dict(B=B, L=L, T=T, n=n, heads=attn.heads, only_immediate=attn.only_attend_immediate_media,
+                dim_head=attn.dim_head)
     return ops, P, W, xr, media_bf, tt, dims
+
+
+class _MaskedCrossAttentionFn(torch.autograd.Function):
+    """Stand-alone MaskedCrossAttention.forward (reference helpers.py:160-233): no gate, no residual."""
+
+    @staticmethod
+    def forward(ctx, mod, x, media, media_locations, use_cached_media, *params):
+        ops, P, W, xr, media_bf, tt, dims = _xattn_operands(mod, x, media, media_locations, use_cached_media, params,
+                                                            names=_MCA_NAMES, attn=mod)
+        y, S = _path.masked_cross_attention_fwd(ops, P, W, xr, media_bf, tt, prefix="", **dims)
+        ctx.S, ctx.P, ctx.W, ctx.dims, ctx.media_bf, ctx.tt = S, P, W, dims, media_bf, tt
+        ctx.xshape, ctx.mshape, ctx.mdtype = tuple(x.shape), tuple(media.shape), media.dtype
+        ctx.params, ctx.param_dtypes = params, tuple(p.dtype for p in params)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ops = Ops.default()
+        sinks = _grad_sinks(_MCA_NAMES, ctx.params)
+        G = _path._GradOut(sinks, dy.device)
+        d2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        dx, dmedia = _path.masked_cross_attention_bwd(ops, ctx.P, ctx.W, ctx.S, ctx.media_bf, ctx.tt, d2, ops.to_bf16(d2), G,
+                                                      prefix="", need_dmedia=ctx.needs_input_grad[2], **ctx.dims)
+        ctx.S = None
+        if dmedia is not None:
+            dmedia = (dmedia if ctx.mdtype == F32 else ops.to_bf16(dmedia)).view(ctx.mshape)
+        return (None, dx.view(ctx.xshape), dmedia, None, None) + _hand_back(_MCA_NAMES, ctx.params, ctx.param_dtypes, G.g, sinks)
 
 
 class _GatedXAttnFn(torch.autograd.Function):
@@ -329,8 +446,7 @@ class _GatedXAttnFn(torch.autograd.Function):
 class GatedCrossAttentionBlock(_HipParamModule):
     def __init__(self, *, dim, dim_visual, dim_head=64, heads=8, ff_mult=4, only_attend_immediate_media=True):
         super().__init__()
-        if dim_head != 64:
-            raise NotImplementedError("libofhip attention kernels are built for dim_head=64; got %d" % dim_head)
+        _check_dim_head(dim_head, "GatedCrossAttentionBlock")
         self.attn = MaskedCrossAttention(dim=dim, dim_visual=dim_visual, dim_head=dim_head, heads=heads,
                                          only_attend_immediate_media=only_attend_immediate_media)
         self.attn_gate = nn.Parameter(torch.tensor([0.0]))
@@ -376,7 +492,7 @@ class GatedCrossAttentionBlock(_HipParamModule):
             # the graph reads the projected media from ITS buffer: project into it (new prompt) or move the prompt
             # pass's projection there once
             if fresh:
-                _path.xattn_project_media(ops, W, media_bf, dims["heads"], out=graph["kv"])
+                _path.xattn_project_media(ops, W, media_bf, dims["heads"], out=graph["kv"], dim_head=dims["dim_head"])
             elif ent[3] is not graph["kv"]:
                 graph["kv"].copy_(ent[3])
             if fresh or ent[3] is not graph["kv"]:
@@ -388,7 +504,7 @@ class GatedCrossAttentionBlock(_HipParamModule):
             graph["graph"].replay()
             return graph["y"].clone().view(x.shape)
         if fresh:
-            ent = (key, media, w_kv, _path.xattn_project_media(ops, W, media_bf, dims["heads"]))
+            ent = (key, media, w_kv, _path.xattn_project_media(ops, W, media_bf, dims["heads"], dim_head=dims["dim_head"]))
             self.__dict__["_kv_cache"] = ent       # holds `media` and the weight copy: their storage cannot be reused
         y, _ = _path.xattn_block_fwd(ops, P, W, xr, media_bf, tt, kv=ent[3], keep=False, **dims)
         return y.view(x.shape)
@@ -412,7 +528,7 @@ class GatedCrossAttentionBlock(_HipParamModule):
             return None
         if st["graph"] is not None or st.get("failed"):
             return st if st["graph"] is not None else None
-        inner = dims["heads"] * 64
+        inner = dims["heads"] * dims["dim_head"]
         st.update(x=torch.empty_like(xr), tt=torch.empty_like(tt), tt_src=None,
                   kv=torch.empty(dims["B"] * dims["T"] * dims["n"], 2 * inner, dtype=BF16, device=xr.device),
                   keep=(P, W))                       # the operands whose addresses the graph holds

@@ -225,6 +225,9 @@ struct of_buf_t {
 };
 OF_DEV of_buf_t of_buf_make(const void* base) { return of_buf_t{(const char*)base}; }
 OF_DEV u32x4 of_buf_load16(of_buf_t b, unsigned voff, unsigned soff) { return *(const u32x4*)(b.base + voff + soff); }
+OF_DEV void of_buf_load16_lds(of_buf_t b, unsigned voff, unsigned soff, void* lds_wave_base) {
+    *(u32x4*)((char*)lds_wave_base + (of_emu::g_blk->cur & 63) * 16) = *(const u32x4*)(b.base + voff + soff);
+}
 OF_DEV void of_barrier_raw() { of_emu::block_barrier(); }
 OF_DEV float of_shfl(float v, int src) {
     of_emu::Block* blk = of_emu::g_blk;

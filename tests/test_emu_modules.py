@@ -125,3 +125,70 @@ def test_train_step_with_product_modules_tracks_oracle_modules(on_emulator):
     for k in p0:
         travelled = (p0[k] - i0[k]).norm().item()
         assert (p1[k] - p0[k]).norm().item() <= 0.25 * travelled + 1e-7, k
+
+
+def test_submodules_run_stand_alone_like_the_reference(on_emulator):
+    """Reference code may call ``block.ff(x)``, ``block.attn(x, media, ...)`` or a Perceiver layer's attention directly
+    (helpers.py:15-22, 39-65, 160-233): the product submodules run the same libofhip kernels without the fused
+    residual / gate, forward and backward, against the oracle functions with the same parameters."""
+    torch.manual_seed(0)
+    w_ = lambda *s: torch.randn(*s)
+    # ---- FeedForward
+    ff = helpers.FeedForward(64, mult=4)
+    x = w_(2, 10, 64)
+    xo = x.clone().requires_grad_(True)
+    P = {k: v for k, v in ff.named_parameters()}
+    yo = O.feed_forward(xo, P, quant=O.bf16_round)
+    wt = w_(2, 10, 64)
+    (yo * wt).sum().backward()
+    ref = (yo.detach(), xo.grad, {k: p.grad.clone() for k, p in P.items()})
+    ff.zero_grad()
+    xi = x.clone().requires_grad_(True)
+    y = ff(xi)
+    (y * wt).sum().backward()
+    assert _rel(y.detach(), ref[0]) < 1e-2 and _rel(xi.grad, ref[1]) < 3e-2
+    for k, p in ff.named_parameters():
+        assert _rel(p.grad, ref[2][k]) < 3e-2, k
+    # ---- MaskedCrossAttention (dim_head 64 and 128)
+    for dh in (64, 128):
+        att = helpers.MaskedCrossAttention(dim=64, dim_visual=32, dim_head=dh, heads=2)
+        media = w_(2, 2, 64, 32)
+        locs = torch.zeros(2, 10, dtype=torch.bool)
+        locs[:, 1] = locs[0, 6] = True
+        P = {k: v for k, v in att.named_parameters()}
+        xo, mo = x.clone().requires_grad_(True), media.clone().requires_grad_(True)
+        yo = O.masked_cross_attention(xo, mo, locs, P, heads=2, quant=O.bf16_round)
+        (yo * wt).sum().backward()
+        ref = (yo.detach(), xo.grad, mo.grad, {k: p.grad.clone() for k, p in P.items()})
+        att.zero_grad()
+        xi, mi = x.clone().requires_grad_(True), media.clone().requires_grad_(True)
+        y = att(xi, mi, media_locations=locs)
+        (y * wt).sum().backward()
+        assert _rel(y.detach(), ref[0]) < 1e-2 and _rel(xi.grad, ref[1]) < 3e-2 and _rel(mi.grad, ref[2]) < 3e-2, dh
+        for k, p in att.named_parameters():
+            assert _rel(p.grad, ref[3][k]) < 3e-2, (dh, k)
+    # ---- PerceiverAttention
+    pa = helpers.PerceiverAttention(dim=64, dim_head=64, heads=2)
+    feats, lat = w_(1, 2, 24, 64), w_(1, 2, 16, 64)
+    P = {k: v for k, v in pa.named_parameters()}
+    fo, lo = feats.clone().requires_grad_(True), lat.clone().requires_grad_(True)
+    yo = O.perceiver_attention(fo, lo, P, heads=2, quant=O.bf16_round)
+    wl = w_(1, 2, 16, 64)
+    (yo * wl).sum().backward()
+    ref = (yo.detach(), fo.grad, lo.grad, {k: p.grad.clone() for k, p in P.items()})
+    pa.zero_grad()
+    fi, li = feats.clone().requires_grad_(True), lat.clone().requires_grad_(True)
+    y = pa(fi, li)
+    (y * wl).sum().backward()
+    assert _rel(y.detach(), ref[0]) < 1e-2 and _rel(fi.grad, ref[1]) < 3e-2 and _rel(li.grad, ref[2]) < 3e-2
+    for k, p in pa.named_parameters():
+        assert _rel(p.grad, ref[3][k]) < 3e-2, k
+    # a whole block with dim_head = 128 (the reference accepts any dim_head; the kernels exist for 64 and 128)
+    blk = helpers.GatedCrossAttentionBlock(dim=64, dim_visual=32, dim_head=128, heads=2)
+    refb = O.OracleGatedCrossAttentionBlock(dim=64, dim_visual=32, dim_head=128, heads=2)
+    with torch.no_grad():
+        blk.attn_gate.fill_(0.5)
+        blk.ff_gate.fill_(0.5)
+    refb.load_state_dict(blk.state_dict(), strict=True)
+    yb = blk(x, media, media_locations=locs)
+    assert _rel(yb.detach(), refb(x, media, media_locations=locs, quant=O.bf16_round).detach()) < 1e-2

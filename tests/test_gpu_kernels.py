@@ -183,10 +183,12 @@ def test_layernorm(ops, x_f32):
     assert _rel(dw, wd.grad) < 1e-3 and _rel(db, bd.grad) < 1e-3
 
 
+@pytest.mark.parametrize("big", [4, 6, 7])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
-def test_gemm_pingpong_race_screen(ops, ta, tb):
-    """The 256x256 ping-pong kernel's LDS-DMA slots are only ordered by counted vmcnt + the segment barriers; the CPU emulator
-    executes the DMA synchronously and cannot see a race.  Screen on hardware: many shapes (1..64 stages, single and
+def test_gemm_pingpong_race_screen(ops, ta, tb, big):
+    """The 256x256 kernels (safe=4: 8-wave ping-pong, LDS-DMA slots ordered only by counted vmcnt + segment barriers;
+    safe=6: 4-wave register-staged, one barrier per stage): the CPU emulator executes a workgroup's waves cooperatively
+    and cannot see a race.  Screen on hardware: many shapes (1..64 stages, single and
     multi wave-of-blocks grids), repeated launches under load, results must be bit-identical to the general kernel
     (same products, same k order) every time."""
     torch.manual_seed(0)
@@ -200,7 +202,7 @@ def test_gemm_pingpong_race_screen(ops, ta, tb):
         assert _rel(want, ref) < 2e-4
         for it in range(6):
             got = torch.full((M, N), float("nan"), device="cuda")
-            ops.gemm(A, B, got, ta=ta, tb=tb, epi=abi.EPI_ACC_F32, safe=4)
+            ops.gemm(A, B, got, ta=ta, tb=tb, epi=abi.EPI_ACC_F32, safe=big)
             assert torch.equal(got, want), f"{(M, N, K)} iteration {it}: max diff {(got - want).abs().max().item()}"
 
 
@@ -254,7 +256,7 @@ def _close(got, want, name, rtol=1e-2, atol_rms=2e-3, l2=4e-3):
     assert e <= l2, f"{name}: rel L2 {e:.3e}"
 
 
-@pytest.mark.parametrize("safe", [0, 4])
+@pytest.mark.parametrize("safe", [0, 4, 6, 7])
 def test_big_tile_gemm_fused_epilogues_at_benchmark_shapes(ops, safe):
     """The launches bench.py times at BASELINE config 2 (per gated block: rows = B*L = 8192, d = 2048, hidden 8192) run the
     256x256 kernel with FUSED epilogues; small-batch tests select the 128x128 kernel.  Every (layout, epilogue) pair the

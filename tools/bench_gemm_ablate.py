@@ -4,9 +4,10 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from open_flamingo_amd.hip.ops import Ops
+from tools.tools_lib import tools_ops
 from tools.bench_kernels import timeit
 
-ops = Ops.default()
+ops = tools_ops()   # tools/libofhip_tools.so: the ablation / A-B variants are not in the product library
 names = {0: "full", 1: "no-dma", 2: "no-ldsread", 3: "no-dma,no-ldsread", 4: "no-mfma", 5: "no-dma,no-mfma",
          6: "dma-only", 22: "dma-only,no-drain", 16: "full,no-drain(racy)", 18: "dma+mfma,no-drain"}
 for (M, N, K) in [(8192, 2048, 8192), (8192, 8192, 2048)]:

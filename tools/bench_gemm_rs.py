@@ -6,8 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from open_flamingo_amd.hip import abi
 from open_flamingo_amd.hip.ops import Ops
+from tools.tools_lib import tools_ops
 from tools.bench_kernels import timeit
-ops = Ops.default()
+ops = tools_ops()   # tools/libofhip_tools.so: the ablation / A-B variants are not in the product library
 g = torch.Generator(device="cuda").manual_seed(0)
 r = lambda *s: torch.randn(*s, device="cuda", generator=g).to(torch.bfloat16)
 gate = torch.tensor([0.5], device="cuda")

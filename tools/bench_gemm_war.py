@@ -4,8 +4,9 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from open_flamingo_amd.hip.ops import Ops
+from tools.tools_lib import tools_ops
 from tools.bench_kernels import timeit
-ops = Ops.default()
+ops = tools_ops()   # tools/libofhip_tools.so: the ablation / A-B variants are not in the product library
 for (M, N, K) in [(8192, 2048, 8192), (8192, 8192, 2048)]:
     A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
     B = torch.randn(N, K, device="cuda").to(torch.bfloat16)

@@ -3,7 +3,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from open_flamingo_amd.hip.ops import Ops
-ops = Ops.default()
+from tools.tools_lib import tools_ops
+ops = tools_ops()   # tools/libofhip_tools.so: the ablation / A-B variants are not in the product library
 M, N, K = 8192, 2048, 8192
 A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
 B = torch.randn(N, K, device="cuda").to(torch.bfloat16)
