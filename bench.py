@@ -231,7 +231,8 @@ def main():
         with open(args.gemm_report, "w") as f:
             for (key, shape), (fl, ms, n) in sorted(per.items(), key=lambda kv: -kv[1][1]):
                 f.write(json.dumps({"layout": LAYOUT_NAMES[key[:2]], "epi": EPI_NAMES[key[2]],
-                                    "kernel": "pingpong256" if key[3] else "general128", "MNK": list(shape),
+                                    "kernel": (("w4dma256" if key[:2] == (0, 0) else "pingpong256") if key[3] else "general128"),
+                                    "MNK": list(shape),
                                     "launches_per_step": n, "ms_per_step": round(ms, 3),
                                     "avg_ms": round(ms / n, 4), "tflops": round(fl / ms / 1e9, 1)}) + "\n")
     if timing:
@@ -243,8 +244,8 @@ def main():
             gsum[2] += 1
         key = max(groups, key=lambda k: groups[k][1])
         fl, ms, n = groups[key]
-        sym = ("of_gemm_pp_kernel" if key[3] else "of_gemm_kernel") + \
-              f"<{str(bool(key[0])).lower()}, {str(bool(key[1])).lower()}, {key[2]}, ...>"
+        big = "of_gemm_w4_kernel" if key[:2] == (0, 0) else "of_gemm_pp_kernel"      # of_gemm's big-tile choice per layout
+        sym = (big if key[3] else "of_gemm_kernel") + f"<{str(bool(key[0])).lower()}, {str(bool(key[1])).lower()}, {key[2]}, ...>"
         if survey:      # every of_gemm launch of the last warm-up step
             all_fl = sum(f for _, f, _, _, _ in survey) * args.steps
             all_ms = sum(e0.elapsed_time(e1) for _, _, _, e0, e1 in survey) * args.steps

@@ -315,6 +315,7 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
         if (rc != OF_E_SHAPE) return rc;
     }
 #ifdef OF_TOOLS_BUILD      // tools/libofhip_tools.so only: timing ablations and A/B variants (some wrong by design)
+    if (a.safe >= 71 && a.safe <= 73) return of_gemm_w4_try(a, s);
     if (a.safe >= 32) return of_gemm_w4_ablate(a, a.safe - 32, s);
     if (a.safe >= 16) return of_gemm_pp_ablate(a, a.safe - 16, s);
     const bool pp_forced = a.safe == 4 || a.safe == 5;
@@ -322,6 +323,15 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
     if (a.safe >= 16 || a.safe == 5) return OF_E_ARG;
     const bool pp_forced = a.safe == 4;
 #endif
+    // Big-tile selection (measured on MI355X, random operands, profiles/r02_gemm_big_tile_ab.jsonl): both operands
+    // K-contiguous (NT: y = x W^T) -> the 4-wave LDS-DMA kernel (+4..6 % over the ping-pong kernel); a K-strided operand
+    // (NN: dX = dY W, TN: dW = dY^T X) -> the 8-wave ping-pong kernel (the 4-wave DMA schedule loses 15-25 % there).
+    if (a.safe == 0 && pp_ok && !a.a_trans && !a.b_trans) {
+        OfGemmArgs w = a;
+        w.safe = 7;
+        const int rc = of_gemm_w4_try(w, s);
+        if (rc != OF_E_SHAPE) return rc;
+    }
     if ((a.safe == 0 && pp_ok) || pp_forced) {   // 4 = force the ping-pong kernel whenever the shape is eligible
         const int rc = of_gemm_pp_try(a, s);   // 256x256 ping-pong LDS-DMA kernel for tile-aligned shapes
         if (rc != OF_E_SHAPE) return rc;

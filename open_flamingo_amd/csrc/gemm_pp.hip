@@ -274,7 +274,9 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
         of_wave_sync();
         // not unrolled: four interleaved copies of the erf-GELU math on top of the 128 live accumulator registers spilled
         // 584 bytes/lane to scratch in the DGELU_DOT instantiation
-#pragma unroll 1
+        // not unrolled for the *_DOT epilogues: four interleaved copies of the erf-GELU math on top of the live accumulators spilled
+        // to scratch; the cheap epilogues are unrolled so that the patch reads of row group it+1 overlap the stores of it
+#pragma unroll((EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) ? 1 : 4)
         for (int it = 0; it < 4; ++it) {
             const int r = it * 8 + rd_row;
             const f32x4 v0 = *(const f32x4*)(patch + r * PITCH + rd_col * 4), v1 = *(const f32x4*)(patch + r * PITCH + rd_col * 4 + 16);

@@ -33,7 +33,10 @@ constexpr int SMEM_W4 = NSLOT * STAGE_BYTES;    // 128 KiB
 // DMA: operands travel global -> LDS directly (buffer_load ... lds, no VGPR round trip, no ds_write) instead of through
 //   staging registers.  A(d+2) is issued in phase 3 of iteration d (into the slot that barrier d just freed), B(d+1) in
 //   phase 0 of iteration d; one s_waitcnt vmcnt(0) in front of the stage's barrier covers both.
-template <bool AT, bool BT, int EPI, int ABL = 0, bool DMA = false>
+// DPL (DMA variant): where the 16 pieces of a stage are issued inside their window (slot free after barrier d .. wait in
+//   front of barrier d+1): 0 = A in phase 3 gaps 8-15, B in phase 0 gaps 8-15; 1 = all 16 in phase 3; 2 = as 0 but waves
+//   of odd / even index use odd / even gaps of the whole phase (staggered); 3 = A in phase 3 gaps 8-15, B in phase 0 gaps 0-7
+template <bool AT, bool BT, int EPI, int ABL = 0, bool DMA = false, int DPL = 0>
 OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
     char* smem = of_smem();
     const int tid = of_tid(), lane = tid & 63;
@@ -91,12 +94,21 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
     };
 
     // DMA variant: piece j of the stage at scalar offsets sA / sB straight into `slot`
-    auto dma_piece = [&](char* slot, int j) OF_INLINE_LAMBDA {
+    // ahead = 0: the stage at (sA, sB); 1: the stage after it
+    auto dma_piece = [&](char* slot, int j, int ahead) OF_INLINE_LAMBDA {
         const int op = j >> 3, hf = (j >> 2) & 1, jj = j & 3;
         char* dst = slot + op * OPER_BYTES + hf * HALF_BYTES + jj * 4096 + wave * 1024;
         if (ABL & 2) return;
-        if (op == 0) of_buf_load16_lds(gA, offA[hf][jj], sA, dst);
-        else of_buf_load16_lds(gB, offB[hf][jj], sB, dst);
+        if (op == 0) of_buf_load16_lds(gA, offA[hf][jj], sA + (ahead ? stepA : 0u), dst);
+        else of_buf_load16_lds(gB, offB[hf][jj], sB + (ahead ? stepB : 0u), dst);
+    };
+    const int par = wave & 1;
+    // piece issued in gap i of window phase w (0 = phase 3 of the previous iteration, 1 = phase 0, 2 = phase 1), or -1
+    auto dma_at = [&](int w, int i) OF_INLINE_LAMBDA -> int {
+        if (DPL == 0) return (w == 0 && i >= 8) ? i - 8 : (w == 1 && i >= 8) ? i : -1;
+        if (DPL == 1) return w == 0 ? i : -1;
+        if (DPL == 3) return (w == 0 && i >= 8) ? i - 8 : (w == 1 && i < 8) ? 8 + i : -1;
+        return -1;
     };
 
     s16x8 fa[2][4], fb[2][4];     // [register buffer][32-row fragment]
@@ -112,16 +124,19 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
     // ---- prologue: stage 0 into slot 0; stage 1 in flight (staging registers / DMA variant: its A half into slot 1)
     if (DMA) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) dma_piece(smem, j);
-        sA += stepA;
+        for (int j = 0; j < 16; ++j) dma_piece(smem, j, 0);
+        sA += stepA;                       // (sA, sB) = stage 1 from here on: "the next stage"
         sB += stepB;
-        if (nd > 1) {
+        of_wait_vm<0>();
+        if (nd > 1) {                      // what phase 3 of "iteration -1" would have issued for stage 1
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dma_piece(smem + STAGE_BYTES, j);
-            sA += stepA;
-            of_wait_vm<8>();
-        } else {
-            of_wait_vm<0>();
+            for (int i = 0; i < 16; ++i) {
+                if (DPL == 2) {
+                    if ((i & 1) == par) dma_piece(smem + STAGE_BYTES, i >> 1, 0);
+                } else if (dma_at(0, i) >= 0) {
+                    dma_piece(smem + STAGE_BYTES, dma_at(0, i), 0);
+                }
+            }
         }
     } else {
 #pragma unroll
@@ -148,7 +163,7 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
     // phase ahead of the barrier).
     // DMA variant: gaps 8-15 carry one DMA piece instead (dma0 = first piece, into dma_slot).
     auto phase = [&](int buf, const char* rd_stage, int rd_ks16, bool rd, char* nxt, int wr0, int ld0, bool WR, bool LD,
-                     char* dma_slot, int dma0) OF_INLINE_LAMBDA {
+                     char* dma_slot, int win, bool dma_on) OF_INLINE_LAMBDA {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             if (ABL & 16) {
@@ -160,27 +175,34 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
             if (i < 8) {
                 if (rd && !(ABL & 4)) read_one(rd_stage, rd_ks16, buf ^ 1, i);
                 if (!DMA && LD && ld0 >= 0) load_piece(ld0 + i);
-            } else if (DMA) {
-                if (dma0 >= 0) dma_piece(dma_slot, dma0 + i - 8);
-            } else if (WR && wr0 >= 0) {
+            } else if (!DMA && WR && wr0 >= 0) {
                 store_piece(nxt, wr0 + i - 8);
+            }
+            if (DMA && dma_on && win >= 0) {
+                if (DPL == 2) {
+                    if (win < 2 && (i & 1) == par) dma_piece(dma_slot, win * 8 + (i >> 1), win == 0);
+                } else if (dma_at(win, i) >= 0) {
+                    dma_piece(dma_slot, dma_at(win, i), win == 0);
+                }
             }
             of_sched_fence();
         }
     };
     // One K stage.  WR: stage d+1 exists (write it), LD: stage d+2 exists (load it).
     auto stage_body = [&](char* cur, char* nxt, const bool WR, const bool LD) OF_INLINE_LAMBDA {
-        phase(0, cur, 1, true, nxt, 0, -1, WR, LD, nxt, WR ? 8 : -1);          // DMA: B(d+1) -> nxt
-        if (DMA && WR) sB += stepB;
-        phase(1, cur, 2, true, nxt, 8, 0, WR, LD, nullptr, -1);
-        phase(0, cur, 3, true, nxt, -1, 8, WR, LD, nullptr, -1);
+        phase(0, cur, 1, true, nxt, 0, -1, WR, LD, nxt, 1, WR);           // DMA: window phase 1 of stage d+1 -> nxt
+        phase(1, cur, 2, true, nxt, 8, 0, WR, LD, nxt, 2, WR);            // DMA: window phase 2 of stage d+1 -> nxt
+        phase(0, cur, 3, true, nxt, -1, 8, WR, LD, nullptr, -1, false);
         if (!DMA && LD) next_stage_src();
         if (DMA) of_wait_vm<0>();      // own DMA pieces of stage d+1 have landed ...
         of_wait_lgkm0();       // own writes of stage d+1 and reads of this slot are done ...
         if (!(ABL & 8)) of_barrier_raw();      // ... and so are everybody else's
         of_sched_fence();
-        phase(1, nxt, 0, WR, nxt, -1, -1, false, false, cur, LD ? 0 : -1);     // DMA: A(d+2) -> cur (free since the barrier)
-        if (DMA && LD) sA += stepA;
+        phase(1, nxt, 0, WR, nxt, -1, -1, false, false, cur, 0, LD);      // DMA: window phase 0 of stage d+2 -> cur (free since the barrier)
+        if (DMA) {
+            sA += stepA;
+            sB += stepB;
+        }
     };
 
     int d = 0;
@@ -215,7 +237,9 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
                         f32x4{acc[mt][np * 2 + nt][4 * q], acc[mt][np * 2 + nt][4 * q + 1], acc[mt][np * 2 + nt][4 * q + 2],
                               acc[mt][np * 2 + nt][4 * q + 3]};
             of_wave_sync();
-#pragma unroll 1
+            // not unrolled for the *_DOT epilogues (four interleaved copies of its erf-GELU math spill); the cheap epilogues are
+            // unrolled so that the patch reads of row group it+1 overlap the stores of row group it
+#pragma unroll((EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) ? 1 : 4)
             for (int it = 0; it < 4; ++it) {
                 const int r = it * 8 + rd_row;
                 const f32x4 v0 = *(const f32x4*)(patch + r * PITCH + rd_col * 4), v1 = *(const f32x4*)(patch + r * PITCH + rd_col * 4 + 16);
@@ -232,6 +256,11 @@ template <bool AT, bool BT, int EPI>
 int launch_w4(const OfGemmArgs& a, of_stream_t s) {
     of_dim3 grid{(unsigned)((a.M / TM) * (a.N / TN)), 1, 1};
     if (a.safe == 7) return of_launch(of_gemm_w4_kernel<AT, BT, EPI, 0, true>, grid, 256, SMEM_W4, s, a);
+#ifdef OF_TOOLS_BUILD       // DMA placement A/B (tools/bench_gemm_w4.py)
+    if (a.safe == 71) return of_launch(of_gemm_w4_kernel<AT, BT, EPI, 0, true, 1>, grid, 256, SMEM_W4, s, a);
+    if (a.safe == 72) return of_launch(of_gemm_w4_kernel<AT, BT, EPI, 0, true, 2>, grid, 256, SMEM_W4, s, a);
+    if (a.safe == 73) return of_launch(of_gemm_w4_kernel<AT, BT, EPI, 0, true, 3>, grid, 256, SMEM_W4, s, a);
+#endif
     return of_launch(of_gemm_w4_kernel<AT, BT, EPI>, grid, 256, SMEM_W4, s, a);
 }
 #ifdef OF_TOOLS_BUILD
