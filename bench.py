@@ -142,11 +142,14 @@ def main():
                          "bias, or HF's eager chain")
     ap.add_argument("--tower-layernorm", default="libofhip", choices=["libofhip", "eager"],
                     help="LayerNorms in front of the frozen towers' Linear layers: libofhip (bf16 operand written directly) or eager")
+    ap.add_argument("--lm-loss", default="libofhip", choices=["libofhip", "hf"],
+                    help="causal-LM loss over the LM head's logits: fused libofhip cross entropy, or transformers' eager chain")
     ap.add_argument("--torch-optimizer", action="store_true",
                     help="clip_grad_norm_ + torch.optim.AdamW(fused) instead of the libofhip step epilogue")
-    ap.add_argument("--sparse-embedding-rows", action="store_true",
-                    help="opt-in (train/sparse_rows.py): gradient of the two trained embedding rows without the dense "
-                         "(vocab x d) lookup scatter and tied-head weight-gradient GEMM")
+    ap.add_argument("--dense-embedding-rows", action="store_true",
+                    help="form the dense (vocab x d) embedding gradient and mask it down to the two trained rows, as the "
+                         "reference does (train_utils.py:174-196); default: train/sparse_rows.py forms just those two rows "
+                         "(identical values, no dense lookup scatter / tied-head weight-gradient GEMM)")
     ap.add_argument("--gemm-report", default=None, help="write a per-(layout,epilogue,shape) GEMM time table (JSON lines)")
     args = ap.parse_args()
     if args.gpus > 1 and not any(k in os.environ for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK")):
@@ -164,11 +167,11 @@ def main():
 
     model, info = towers.build_flamingo(args.family, device=device, seed=0, gates=0.5, frozen_bf16=not args.frozen_fp32,
                                         fused_lm_attention=args.lm_attention if args.lm_attention != "eager" else False,
-                                        tower_layernorm=args.tower_layernorm)
+                                        tower_layernorm=args.tower_layernorm, lm_loss=args.lm_loss)
     model.train()
+    args.sparse_embedding_rows = not args.dense_embedding_rows and not args.torch_optimizer
     if args.sparse_embedding_rows:
         from open_flamingo_amd.train import sparse_rows
-        assert not args.torch_optimizer, "--sparse-embedding-rows needs the fused step epilogue"
         sparse_rows.enable(model, [info["media_token_id"], info["eoc_token_id"]])
     reducer = GradReducer(model, wire_dtype=torch.bfloat16 if args.wire_bf16 else torch.float32,
                           embedding_rows=[info["media_token_id"], info["eoc_token_id"]])
@@ -276,6 +279,7 @@ def main():
                           "parallelism": f"dp{world}",
                           "frozen_tower_weights": "fp32 (re-cast by autocast)" if args.frozen_fp32 else "bf16 copies held",
                           "frozen_lm_attention": args.lm_attention, "frozen_tower_layernorm": args.tower_layernorm,
+                          "lm_loss": args.lm_loss,
                           "grad_wire_dtype": "bf16" if args.wire_bf16 else "fp32",
                           "embedding_row_gradient": "sparse taps" if args.sparse_embedding_rows else "dense, masked"},
                "loss": None if loss is None else round(float(loss), 4)}

@@ -205,6 +205,20 @@ int of_adamw_clip(float* p, float* g, float* m, float* v, uint16_t* p_bf16, long
                   float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                   int step, int zero_grad, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Token-level cross entropy of the causal-LM loss (the reference's Flamingo.forward passes `labels` to the HF language
+ * model, open_flamingo/src/flamingo.py:112-121; transformers computes logits.float() -> log_softmax -> nll, mean over
+ * labels != ignore_index).  logits: rows x vocab (bf16, or fp32 when logits_f32), row stride ld elements, any 2-byte
+ * alignment; labels: rows int64 (already shifted by the caller).
+ *   of_ce_fwd: lse[row] = log sum_j exp(logit[row][j]) (fp32); loss_rows[row] = lse - logit[row][label], 0 for ignored rows
+ *   of_ce_bwd: dlogits[row][j] = *gscale * (exp(logit - lse[row]) - [j == label]) in the logits' dtype, 0 for ignored rows
+ *              (*gscale = upstream gradient / number of valid rows, a device scalar: no host sync)
+ */
+int of_ce_fwd(const void* logits, int logits_f32, long ld, const long long* labels, long long ignore_index, long rows,
+              int vocab, float* lse, float* loss_rows, void* stream);
+int of_ce_bwd(const void* logits, int logits_f32, long ld, const long long* labels, long long ignore_index, long rows,
+              int vocab, const float* lse, const float* gscale, void* dlogits, long ldd, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

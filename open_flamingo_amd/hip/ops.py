@@ -246,6 +246,20 @@ class Ops:
                                          sumsq.data_ptr(), max_norm, lr, betas[0], betas[1], eps, weight_decay,
                                          grad_scale, step, int(zero_grad), self._stream()), "of_adamw_clip")
 
+    # ------------------------------------------------------------------ causal-LM loss
+    def ce_fwd(self, logits, labels, lse, loss_rows, ignore_index=-100):
+        rows, V = logits.shape
+        assert logits.stride(1) == 1 and labels.dtype == torch.int64 and labels.is_contiguous() and labels.numel() == rows
+        self._chk(self.lib.of_ce_fwd(logits.data_ptr(), _is_f32(logits), logits.stride(0), labels.data_ptr(), ignore_index,
+                                     rows, V, lse.data_ptr(), loss_rows.data_ptr(), self._stream()), "of_ce_fwd")
+
+    def ce_bwd(self, logits, labels, lse, gscale, dlogits, ignore_index=-100):
+        rows, V = logits.shape
+        assert dlogits.dtype == logits.dtype and dlogits.stride(1) == 1 and gscale.dtype == F32
+        self._chk(self.lib.of_ce_bwd(logits.data_ptr(), _is_f32(logits), logits.stride(0), labels.data_ptr(), ignore_index,
+                                     rows, V, lse.data_ptr(), gscale.data_ptr(), dlogits.data_ptr(), dlogits.stride(0),
+                                     self._stream()), "of_ce_bwd")
+
     def quick_gelu(self, x, out=None):
         assert x.dtype == BF16 and x.is_contiguous()
         out = torch.empty_like(x) if out is None else out

@@ -29,13 +29,14 @@ class _GradOut:
     existing fp32 ``.grad``, e.g. a view into a GradReducer bucket) the kernels accumulate into it directly: the dW
     GEMMs run with beta = 1, the LayerNorm / gate / table reductions already add into their output."""
 
-    def __init__(self, sinks, dev):
-        self.sinks, self.dev, self.g = (sinks or {}), dev, {}
+    def __init__(self, sinks, dev, fresh=()):
+        self.sinks, self.dev, self.g, self.fresh = (sinks or {}), dev, {}, fresh
 
     def mat(self, name, shape):
-        """Buffer for a GEMM-produced gradient and the beta to use with it."""
+        """Buffer for a GEMM-produced gradient and the beta to use with it (0 for a sink in ``fresh``: its content is
+        stale -- the step epilogue left it uncleared on purpose -- and this backward is the first to write it)."""
         t = self.sinks.get(name)
-        beta = 1.0
+        beta = 0.0 if name in self.fresh else 1.0
         if t is None:
             t, beta = _e(shape, F32, self.dev), 0.0
         self.g[name] = t
@@ -192,9 +193,9 @@ def xattn_block_fwd(ops, P, W, x, media_bf, tt, *, B, L, T, n, heads, only_immed
 
 
 def xattn_block_bwd(ops, P, W, S, media_bf, tt, dy, *, B, L, T, n, heads, only_immediate, need_dmedia=True, safe=0,
-                    sinks=None, dim_head=64):
-    """Returns (dx, dmedia fp32 (B*T*n, Dv) or None, grads dict keyed like P).  sinks: see _GradOut."""
-    G = _GradOut(sinks, dy.device)
+                    sinks=None, dim_head=64, fresh=()):
+    """Returns (dx, dmedia fp32 (B*T*n, Dv) or None, grads dict keyed like P).  sinks / fresh: see _GradOut."""
+    G = _GradOut(sinks, dy.device, fresh)
     dy = dy.contiguous()
     # ---- feed forward branch: y2 = y1 + tanh(gf) * F(y1)
     dy1, dy1b = feed_forward_bwd(ops, P, W, S["ff"], dy, G, prefix="ff.", gate=P["ff_gate"], gate_name="ff_gate",
@@ -307,7 +308,7 @@ def perceiver_fwd(ops, P, W, x, *, N, Fv, n, heads, depth, T=1, frames=1, safe=0
 
 
 def perceiver_bwd(ops, P, W, S, dout, *, N, Fv, n, heads, depth, T=1, frames=1, need_dx=False, safe=0, sinks=None,
-                  on_ready=None, dim_head=64):
+                  on_ready=None, dim_head=64, fresh=()):
     """Returns (dx (N*Fv, D) stream dtype or None, grads dict keyed like P).  sinks: see _GradOut.
     on_ready(names): called as soon as the kernels producing the FINAL value of those parameters' gradients are enqueued
     (per layer, last layer first) -- the gradient exchange of a layer can then start while the earlier layers' backward
@@ -317,7 +318,7 @@ def perceiver_bwd(ops, P, W, S, dout, *, N, Fv, n, heads, depth, T=1, frames=1, 
     want_dx = need_dx
     need_dx = need_dx or S.get("embs", False)     # the position tables' gradients are reductions of dx
     D = S["x"].shape[1]
-    G = _GradOut(sinks, dev)
+    G = _GradOut(sinks, dev, fresh)
     g = G.g
     dout = dout.contiguous()
     dlat = torch.empty_like(dout)

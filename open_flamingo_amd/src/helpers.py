@@ -58,11 +58,17 @@ _shared = _SharedCache()
 class _HipParamModule(nn.Module):
     """Common: bf16 operand copies of the fp32 master weights.
 
+    ``overwrites_fresh_grads``: protocol flag for train/reducer.py + train/optim.py -- this module's backward writes the
+    gradient of an nn.Linear weight marked ``_of_grad_fresh`` with beta = 0 (and clears the mark) instead of adding to
+    it, so the step epilogue does not have to zero those buffers and the dW GEMM does not have to read them.
+
     Freshness: torch optimizers update parameters WITHOUT bumping ``Tensor._version`` (measured: version stays put
     across ``AdamW.step()``), so a version-keyed cache silently trains on step-0 weights.  Therefore in training mode
     the copies are re-cast on every forward (one HBM pass over the block's weights) unless the libofhip step epilogue
     (``train/optim.py``), which rewrites the bf16 copies in its AdamW pass, vouches for them; in eval mode they are
     cached and re-validated by version/pointer (``load_state_dict`` and other in-place writes do bump the version)."""
+
+    overwrites_fresh_grads = True
 
     def _weights_bf16(self, ops, named):
         cache = self.__dict__.setdefault("_w_bf16_cache", {})
@@ -107,12 +113,15 @@ def _grad_sinks(names, params):
     """Parameters whose owner (train/reducer.py) asked for in-place gradient accumulation: their existing fp32 ``.grad``
     (a view into a reducer bucket) is handed to the backward as the accumulation target.  The saving is autograd's
     AccumulateGrad ``grad += new`` kernel per parameter per backward (~4.8 ms / step in the benchmark)."""
-    sinks = {}
+    sinks, fresh = {}, set()
     for k, p in zip(names, params):
         if getattr(p, "_of_inplace_grad", False) and p.grad is not None and p.grad.dtype == F32 \
                 and p.grad.is_contiguous() and p.grad.shape == p.shape:
             sinks[k] = p.grad
-    return sinks
+            if getattr(p, "_of_grad_fresh", False):      # not cleared by the step epilogue: this backward overwrites it
+                fresh.add(k)
+                p._of_grad_fresh = False
+    return sinks, fresh
 
 
 def _hand_back(names, params, dtypes, g, sinks, notified=()):
@@ -150,8 +159,8 @@ class _FeedForwardFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         ops = Ops.default()
-        sinks = _grad_sinks(_FeedForwardFn.NAMES, ctx.params)
-        G = _path._GradOut(sinks, dy.device)
+        sinks, fresh = _grad_sinks(_FeedForwardFn.NAMES, ctx.params)
+        G = _path._GradOut(sinks, dy.device, fresh)
         dx, _ = _path.feed_forward_bwd(ops, ctx.P, ctx.W, ctx.S, dy.reshape(-1, dy.shape[-1]).contiguous(), G)
         ctx.S = None
         return (None, dx.view(dy.shape)) + _hand_back(_FeedForwardFn.NAMES, ctx.params, ctx.param_dtypes, G.g, sinks)
@@ -197,8 +206,8 @@ class _PerceiverAttentionFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         ops = Ops.default()
-        sinks = _grad_sinks(_PATTN_NAMES, ctx.params)
-        G = _path._GradOut(sinks, dout.device)
+        sinks, fresh = _grad_sinks(_PATTN_NAMES, ctx.params)
+        G = _path._GradOut(sinks, dout.device, fresh)
         d2 = dout.reshape(-1, dout.shape[-1]).contiguous()
         dlat, dx = _path.perceiver_attention_bwd(ops, ctx.P, ctx.W, ctx.S, d2, ops.to_bf16(d2), G,
                                                  need_dx=ctx.needs_input_grad[1], **ctx.dims)
@@ -272,7 +281,7 @@ class _PerceiverFn(torch.autograd.Function):
         dims = ctx.dims
         D = ctx.xshape[-1]
         need_dx = ctx.needs_input_grad[2]
-        sinks = _grad_sinks(ctx.names, ctx.params)
+        sinks, fresh = _grad_sinks(ctx.names, ctx.params)
         by_name = dict(zip(ctx.names, ctx.params))
         notified = set()
 
@@ -283,7 +292,7 @@ class _PerceiverFn(torch.autograd.Function):
                     by_name[k]._of_on_grad(by_name[k])
 
         dx, g = _path.perceiver_bwd(ops, ctx.P, ctx.W, ctx.S, dout.reshape(-1, D), need_dx=need_dx, sinks=sinks,
-                                    on_ready=on_ready, **dims)
+                                    fresh=fresh, on_ready=on_ready, **dims)
         ctx.S = None
         grads = _hand_back(ctx.names, ctx.params, ctx.param_dtypes, g, sinks, notified)
         return (None, None, dx.view(ctx.xshape) if need_dx else None) + grads
@@ -406,8 +415,8 @@ class _MaskedCrossAttentionFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         ops = Ops.default()
-        sinks = _grad_sinks(_MCA_NAMES, ctx.params)
-        G = _path._GradOut(sinks, dy.device)
+        sinks, fresh = _grad_sinks(_MCA_NAMES, ctx.params)
+        G = _path._GradOut(sinks, dy.device, fresh)
         d2 = dy.reshape(-1, dy.shape[-1]).contiguous()
         dx, dmedia = _path.masked_cross_attention_bwd(ops, ctx.P, ctx.W, ctx.S, ctx.media_bf, ctx.tt, d2, ops.to_bf16(d2), G,
                                                       prefix="", need_dmedia=ctx.needs_input_grad[2], **ctx.dims)
@@ -433,9 +442,9 @@ class _GatedXAttnFn(torch.autograd.Function):
         ops = Ops.default()
         d = ctx.xshape[-1]
         need_dmedia = ctx.needs_input_grad[2]
-        sinks = _grad_sinks(_XATTN_NAMES, ctx.params)
+        sinks, fresh = _grad_sinks(_XATTN_NAMES, ctx.params)
         dx, dmedia, g = _path.xattn_block_bwd(ops, ctx.P, ctx.W, ctx.S, ctx.media_bf, ctx.tt, dy.reshape(-1, d),
-                                              need_dmedia=need_dmedia, sinks=sinks, **ctx.dims)
+                                              need_dmedia=need_dmedia, sinks=sinks, fresh=fresh, **ctx.dims)
         ctx.S = None
         if dmedia is not None:
             dmedia = (dmedia if ctx.mdtype == F32 else ops.to_bf16(dmedia)).view(ctx.mshape)

@@ -65,9 +65,22 @@ class GradReducer:
         elif emb.requires_grad:
             self.embedding = emb
         self.buckets = []
+        # Weight matrices whose gradient the libofhip backward produces with ONE GEMM can be overwritten (beta = 0) instead
+        # of zeroed by the step epilogue and then read-modify-written (beta = 1): they go to the back of their bucket so
+        # that the epilogue only has to clear the (tiny) front part.  Only modules that implement the protocol
+        # (src/helpers.py: `overwrites_fresh_grads`) take part; see FlatAdamW.step.
+        owner = set()
+        for mod in (model.perceiver, *[b for b in lm.gated_cross_attn_layers if b is not None]):
+            if getattr(mod, "overwrites_fresh_grads", False):
+                for sub in mod.modules():
+                    if isinstance(sub, torch.nn.Linear):
+                        owner.add(id(sub.weight))
         for kind, params in groups:
             if not params:
                 continue
+            front = [p for p in params if id(p) not in owner]
+            back = [p for p in params if id(p) in owner]
+            params = front + back
             # every parameter starts on a 256-byte boundary (64 fp32 = 128 bytes of bf16: whole L2 lines for the
             # operand DMA): the fused step epilogue keeps fp32 master / bf16 operand copies at the same offsets and
             # the GEMM kernels need 16-byte aligned operands
@@ -78,7 +91,8 @@ class GradReducer:
             flat = torch.zeros(n, dtype=torch.float32, device=params[0].device)
             for p, off in zip(params, offsets):
                 p.grad = flat[off:off + p.numel()].view_as(p)      # gradient-as-bucket-view
-            self.buckets.append(dict(flat=flat, params=params, offsets=offsets, ready=0, kind=kind))
+            self.buckets.append(dict(flat=flat, params=params, offsets=offsets, ready=0, kind=kind,
+                                     overwritable_from=(offsets[len(front)] if back else n), overwritable=back))
         self._param_bucket = {}
         for bi, b in enumerate(self.buckets):
             for p in b["params"]:
@@ -227,6 +241,8 @@ class GradReducer:
         for b in self.buckets:
             if not flat_already_zero:
                 b["flat"].zero_()
+                for p in b["overwritable"]:
+                    p._of_grad_fresh = False
             b["ready"] = 0
         if self.embedding is not None and self.embedding.grad is not None:
             self.embedding.grad = None

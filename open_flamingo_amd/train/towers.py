@@ -274,6 +274,59 @@ def use_libofhip_quick_gelu(module):
     return n
 
 
+class _FusedCausalLMLoss(torch.autograd.Function):
+    """mean over (label != ignore) of  log-sum-exp(logits) - logits[label]  straight from the LM head's bf16 logits
+    (libofhip of_ce_fwd / of_ce_bwd): what transformers' ForCausalLMLoss computes via logits.float() -> log_softmax ->
+    nll_loss, in two passes over the logits instead of ~12 GB of eager traffic at OF-3B cfg-2.  Same fp32 arithmetic; the
+    gradient is written in the logits' dtype directly (autograd casts the eager fp32 gradient back to bf16 the same way)."""
+
+    @staticmethod
+    def forward(ctx, logits2d, labels1d, ignore_index):
+        from ..hip.ops import Ops
+        ops = Ops.default()
+        rows = logits2d.shape[0]
+        lse = torch.empty(rows, dtype=torch.float32, device=logits2d.device)
+        loss_rows = torch.empty(rows, dtype=torch.float32, device=logits2d.device)
+        ops.ce_fwd(logits2d, labels1d, lse, loss_rows, ignore_index)
+        n_valid = (labels1d != ignore_index).sum().to(torch.float32)
+        ctx.save_for_backward(logits2d, labels1d, lse, n_valid)
+        ctx.ignore_index = ignore_index
+        return loss_rows.sum() / n_valid             # nan when every label is ignored, like F.cross_entropy
+
+    @staticmethod
+    def backward(ctx, g):
+        from ..hip.ops import Ops
+        ops = Ops.default()
+        logits2d, labels1d, lse, n_valid = ctx.saved_tensors
+        gscale = (g.to(torch.float32) / n_valid).reshape(1).contiguous()
+        d = torch.empty_like(logits2d)
+        ops.ce_bwd(logits2d, labels1d, lse, gscale, d, ctx.ignore_index)
+        return d, None, None
+
+
+def _causal_lm_loss_libofhip(logits, labels, vocab_size, num_items_in_batch=None, ignore_index=-100, shift_labels=None,
+                             **kwargs):
+    """Drop-in for transformers.loss.loss_utils.ForCausalLMLoss (the `loss_function` of MptForCausalLM / GPTNeoXForCausalLM)."""
+    if (not logits.is_cuda or logits.dtype not in (torch.bfloat16, torch.float32) or num_items_in_batch is not None
+            or kwargs or logits.shape[-1] != vocab_size):
+        from transformers.loss.loss_utils import ForCausalLMLoss
+        return ForCausalLMLoss(logits, labels, vocab_size, num_items_in_batch=num_items_in_batch, ignore_index=ignore_index,
+                               shift_labels=shift_labels, **kwargs)
+    if shift_labels is None:        # tokens < n predict n
+        shift_labels = torch.nn.functional.pad(labels, (0, 1), value=ignore_index)[..., 1:]
+    l2 = logits.reshape(-1, vocab_size)
+    if l2.stride(1) != 1:
+        l2 = l2.contiguous()
+    return _FusedCausalLMLoss.apply(l2, shift_labels.reshape(-1).to(torch.int64).contiguous(), int(ignore_index))
+
+
+def use_libofhip_lm_loss(lm):
+    """Route the HF causal-LM loss (``self.loss_function`` in MptForCausalLM / GPTNeoXForCausalLM.forward) through the fused
+    libofhip cross-entropy.  Unsupported calls (CPU tensors, num_items_in_batch, extra kwargs) fall through to HF's own."""
+    lm.loss_function = _causal_lm_loss_libofhip
+    return lm
+
+
 def use_fused_attention_in_mpt(lm, kernel="sdpa"):
     """kernel = "sdpa": torch's fused attention with an additive bias (any mask HF builds).  kernel = "libofhip": this
     repository's windowed flash-attention kernel as causal + ALiBi self-attention (bf16 on an AMD GPU; batches must be
@@ -327,7 +380,7 @@ def hold_frozen_linears_in_bf16(model):
 
 def build_flamingo(family: str = "OF-3B", device="cuda", seed: int = 0, gates: float = 0.5, vision_kw=None,
                    freeze_lm_embeddings: bool = False, verbose: bool = False, frozen_bf16: bool = False,
-                   fused_lm_attention=True, tower_layernorm="eager"):
+                   fused_lm_attention=True, tower_layernorm="eager", lm_loss="hf"):
     """Random-init Flamingo of the given family, assembled through the factory path, gates set to ``gates``
     (their init value 0 makes the hot path an exact no-op with zero weight gradients -- SURVEY.md section 7)."""
     from ..src.factory import assemble_flamingo
@@ -349,6 +402,8 @@ def build_flamingo(family: str = "OF-3B", device="cuda", seed: int = 0, gates: f
         use_libofhip_layernorm(model.vision_encoder)
         use_libofhip_layernorm(model.lang_encoder)
         use_libofhip_quick_gelu(model.vision_encoder)
+    if lm_loss == "libofhip":
+        use_libofhip_lm_loss(model.lang_encoder)
     with torch.no_grad():
         for blk in model.lang_encoder.gated_cross_attn_layers:
             if blk is not None:

@@ -33,7 +33,8 @@ def make_bf16_weights(ops, P):
 
 
 def check_xattn(ops, dev, *, B=2, L=40, T=2, n=16, heads=2, d=64, Dv=48, stream_dtype=torch.float32, media_locs=None,
-                only_immediate=True, gates=(0.6, -0.4), seed=0, fwd_tol=1e-2, bwd_tol=3e-2, safe=0, inplace=False):
+                only_immediate=True, gates=(0.6, -0.4), seed=0, fwd_tol=1e-2, bwd_tol=3e-2, safe=0, inplace=False,
+                fresh=False):
     m = O.OracleGatedCrossAttentionBlock(dim=d, dim_visual=Dv, heads=heads, dim_head=64,
                                          only_attend_immediate_media=only_immediate)
     st = O.seeded_state({k: tuple(v.shape) for k, v in m.state_dict().items()}, 100 + seed)
@@ -71,10 +72,12 @@ def check_xattn(ops, dev, *, B=2, L=40, T=2, n=16, heads=2, d=64, Dv=48, stream_
     assert none is None and torch.equal(y_inf, y)
     dy = w.to(dev).to(stream_dtype).reshape(B * L, d).contiguous()
     base, sinks = _prefilled_sinks(P, dev, seed) if inplace else (None, None)
-    dx, dmedia, grads = path.xattn_block_bwd(ops, P, W, S, media_bf, tt, dy, sinks=sinks, **kw)
+    # "fresh" Linear weights: the sink holds stale values the step epilogue did not clear; the backward must OVERWRITE them
+    stale = {k for k in P if k.endswith(".weight") and P[k].dim() == 2} if (inplace and fresh) else set()
+    dx, dmedia, grads = path.xattn_block_bwd(ops, P, W, S, media_bf, tt, dy, sinks=sinks, fresh=stale, **kw)
     if inplace:     # the kernels must have ADDED the gradient to what the sink held, in the sink itself
         assert all(grads[k] is sinks[k] for k in P)
-        grads = {k: grads[k].cpu() - base[k] for k in P}
+        grads = {k: (grads[k].cpu() if k in stale else grads[k].cpu() - base[k]) for k in P}
     errs = {"y": rel_err(y.reshape(B, L, d), yo.detach())}
     errs["dx"] = rel_err(dx.reshape(B, L, d), xo.grad)
     errs["dmedia"] = rel_err(dmedia.reshape(B, T, n, Dv), mo.grad)
@@ -86,7 +89,7 @@ def check_xattn(ops, dev, *, B=2, L=40, T=2, n=16, heads=2, d=64, Dv=48, stream_
 
 
 def check_perceiver(ops, dev, *, b=1, T=2, Fv=24, n=16, heads=2, D=64, depth=2, stream_dtype=torch.float32, seed=0,
-                    fwd_tol=1e-2, bwd_tol=3e-2, need_dx=True, safe=0, frames=1, embs=False, inplace=False):
+                    fwd_tol=1e-2, bwd_tol=3e-2, need_dx=True, safe=0, frames=1, embs=False, inplace=False, fresh=False):
     m = O.OraclePerceiverResampler(dim=D, depth=depth, dim_head=64, heads=heads, num_latents=n,
                                    max_num_media=(T + 1 if embs else None), max_num_frames=(frames + 1 if embs else None))
     st = O.seeded_state({k: tuple(v.shape) for k, v in m.state_dict().items()}, 300 + seed)
@@ -108,10 +111,11 @@ def check_perceiver(ops, dev, *, b=1, T=2, Fv=24, n=16, heads=2, D=64, depth=2, 
     assert none is None and torch.equal(y_inf, y)
     dy = w.to(dev).to(stream_dtype).reshape(N * n, D).contiguous()
     base, sinks = _prefilled_sinks(P, dev, seed) if inplace else (None, None)
-    dx, grads = path.perceiver_bwd(ops, P, W, S, dy, need_dx=need_dx, sinks=sinks, **kw)
+    stale = {k for k in P if k.endswith(".weight") and P[k].dim() == 2} if (inplace and fresh) else set()
+    dx, grads = path.perceiver_bwd(ops, P, W, S, dy, need_dx=need_dx, sinks=sinks, fresh=stale, **kw)
     if inplace:
         assert all(grads[k] is sinks[k] for k in P)
-        grads = {k: grads[k].cpu() - base[k] for k in P}
+        grads = {k: (grads[k].cpu() if k in stale else grads[k].cpu() - base[k]) for k in P}
     errs = {"y": rel_err(y.reshape(b, T, n, D), yo.detach())}
     if need_dx:
         errs["dx"] = rel_err(dx.reshape(b, T, frames, Fv // frames, D), xo.grad)
@@ -156,6 +160,10 @@ def judge_8c(hip, ref32, refac, *, grad_tol=2e-2, factor=2.0, floor=1e-6, scalar
     how much they cancel, not by the kernels: 2e-2 at model sizes (millions of terms); the toy-size callers pass 5e-2
     (a few thousand terms: the reference's own autocast run lands anywhere in 0.2-3 % there, seed by seed)."""
     rep, bad = {}, {}
+    # (1,)-shaped gate gradients are sums of B*L*d signed terms: how much they cancel differs between the two gates of
+    # one block by orders of magnitude, so each is also allowed an ABSOLUTE error of grad_tol x the larger gate gradient
+    scalars = [float(v.abs().max()) for v in ref32[1].values() if v.numel() == 1]
+    scalar_abs = grad_tol * max(scalars) if scalars else 0.0
     y, y32 = hip[0], ref32[0]
     e_l2, e_mx = rel_l2(y, y32), max_abs(y, y32)
     if refac is not None:
@@ -178,6 +186,8 @@ def judge_8c(hip, ref32, refac, *, grad_tol=2e-2, factor=2.0, floor=1e-6, scalar
             ent["autocast_rel_l2"] = a
             if g32.numel() == 1:           # gate gradients: whole-tensor sums that cancel
                 ok = ok or e <= factor * a + floor
+        if g32.numel() == 1:
+            ok = ok or max_abs(hip[1][k], g32) <= scalar_abs
         rep["d" + k] = ent
         if not ok:
             bad["d" + k] = ent

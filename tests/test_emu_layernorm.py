@@ -148,3 +148,30 @@ def test_quick_gelu():
     assert L.of_quick_gelu(H.ptr(x), H.ptr(y), x.numel(), None) == 0
     want = (x.float() * torch.sigmoid(1.702 * x.float())).to(torch.bfloat16)
     np.testing.assert_allclose(y.float().numpy(), want.float().numpy(), rtol=1e-2, atol=1e-3)
+
+
+def test_fused_cross_entropy_matches_torch():
+    """of_ce_fwd / of_ce_bwd (csrc/loss.hip) vs F.cross_entropy on the fp32 upcast of the same bf16 logits: odd vocab (rows
+    start at 2-byte alignment), ignored rows, both dtypes."""
+    import torch.nn.functional as F
+    from tests.emu import harness as H
+    ops = H.emu_ops()
+    torch.manual_seed(0)
+    for dt in (torch.bfloat16, torch.float32):
+        rows, V = 37, 2051 + 300
+        logits = (torch.randn(rows, V) * 3).to(dt)
+        labels = torch.randint(0, V, (rows,))
+        labels[[3, 11, 36]] = -100
+        lse, loss_rows = torch.empty(rows), torch.empty(rows)
+        ops.ce_fwd(logits, labels, lse, loss_rows)
+        xf = logits.float().requires_grad_(True)
+        want = F.cross_entropy(xf, labels, ignore_index=-100)
+        n = (labels != -100).sum()
+        assert abs(float(loss_rows.sum() / n) - float(want)) < 1e-5 * abs(float(want))
+        assert torch.allclose(lse, torch.logsumexp(logits.float(), -1), rtol=1e-6, atol=1e-5)
+        (want * 0.7).backward()
+        d = torch.full_like(logits, float("nan"))
+        ops.ce_bwd(logits, labels, lse, torch.tensor([0.7 / float(n)]), d)
+        tol = 1e-6 if dt == torch.float32 else 4e-3
+        assert (d.float() - xf.grad).abs().max() <= tol * xf.grad.abs().max() + 1e-9
+        assert (d[[3, 11, 36]] == 0).all()

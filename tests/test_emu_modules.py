@@ -192,3 +192,35 @@ def test_submodules_run_stand_alone_like_the_reference(on_emulator):
     refb.load_state_dict(blk.state_dict(), strict=True)
     yb = blk(x, media, media_locations=locs)
     assert _rel(yb.detach(), refb(x, media, media_locations=locs, quant=O.bf16_round).detach()) < 1e-2
+
+
+def test_step_epilogue_leaves_weight_gradients_for_the_backward_to_overwrite(on_emulator):
+    """CPU twin of the GPU test of the same name: after a fused step the nn.Linear weight gradients are stale and marked
+    fresh, everything else is cleared; two accumulated backward passes on top of the stale content equal the same passes
+    on cleared buffers; a step with no backward in between clears the stale matrices instead of re-applying them."""
+    model, info = _tiny()
+    red = GradReducer(model, embedding_rows=[info["media_token_id"], info["eoc_token_id"]])
+    opt = FlatAdamW(red, lr=1e-3, ops=H.emu_ops())
+    b1 = synthetic.make_batch(2, 1, 16, info, "cpu", seed=6)
+    b2 = synthetic.make_batch(2, 2, 24, info, "cpu", seed=5)
+    step.train_step(model, red, opt, b2, info, amp=False)
+    mats = [p for b in red.buckets for p in b["overwritable"]]
+    small = [p for b in red.buckets for p in b["params"] if all(p is not q for q in b["overwritable"])]
+    assert mats and small and all(p._of_grad_fresh for p in mats)
+    assert any(float(p.grad.abs().sum()) > 0 for p in mats) and all(float(p.grad.abs().sum()) == 0 for p in small)
+    for b in (b1, b2):
+        step.forward_loss(model, b, info, amp=False).backward()
+    assert not any(p._of_grad_fresh for p in mats)
+    got = [p.grad.detach().clone() for p in mats + small]
+    red.zero_grad()
+    for b in (b1, b2):
+        step.forward_loss(model, b, info, amp=False).backward()
+    for g, p in zip(got, mats + small):
+        assert _rel(g, p.grad) < 1e-5
+    red.zero_grad()
+    step.train_step(model, red, opt, b2, info, amp=False)
+    m_before = [opt._moments_of(p)[0].clone() for p in mats]
+    opt.step()
+    for p, m0 in zip(mats, m_before):
+        assert float(p.grad.abs().sum()) == 0
+        assert torch.allclose(opt._moments_of(p)[0], 0.9 * m0, rtol=1e-5, atol=1e-12)

@@ -43,6 +43,9 @@ def test_paths_accumulate_into_existing_grads():
     """Gradient sinks (path._GradOut): every parameter gradient is added to the pre-existing buffer, none overwritten."""
     PC.check_xattn(H.emu_ops(), "cpu", inplace=True, seed=5)
     PC.check_perceiver(H.emu_ops(), "cpu", T=3, Fv=32, frames=2, embs=True, inplace=True, seed=6)
+    # Linear weights marked fresh (left uncleared by the step epilogue) are overwritten, everything else still adds
+    PC.check_xattn(H.emu_ops(), "cpu", inplace=True, fresh=True, seed=7)
+    PC.check_perceiver(H.emu_ops(), "cpu", T=3, Fv=32, frames=2, embs=True, inplace=True, fresh=True, seed=8)
 
 
 def test_perceiver_backward_reports_layers_as_they_finish():

@@ -51,6 +51,8 @@ def test_paths_accumulate_into_existing_grads(ops):
     PC.check_xattn(ops, "cuda", B=2, L=64, T=2, n=64, heads=8, d=512, Dv=256, inplace=True, seed=5)
     PC.check_perceiver(ops, "cuda", T=3, Fv=32, frames=2, embs=True, inplace=True, seed=6)
     PC.check_perceiver(ops, "cuda", b=2, T=2, Fv=256, n=64, heads=8, D=1024, depth=2, inplace=True, seed=7)
+    PC.check_xattn(ops, "cuda", B=2, L=64, T=2, n=64, heads=8, d=512, Dv=256, inplace=True, fresh=True, seed=8)
+    PC.check_perceiver(ops, "cuda", b=2, T=2, Fv=256, n=64, heads=8, D=1024, depth=2, inplace=True, fresh=True, seed=9)
 
 
 def test_perceiver_frame_and_media_time_embs(ops):
@@ -90,6 +92,44 @@ def test_fused_step_epilogue_matches_torch_optimizer():
     for k in p0:
         travelled = (p0[k] - init[k]).norm().item()
         assert (p0[k] - p1[k]).norm().item() <= 0.05 * travelled + 1e-7, (k, (p0[k] - p1[k]).norm().item(), travelled)
+
+
+def test_step_epilogue_leaves_weight_gradients_for_the_backward_to_overwrite():
+    """FlatAdamW does not clear the gradients of the nn.Linear weights (the next backward's dW GEMM overwrites them,
+    beta = 0) but does clear everything its kernels add into; a step without a backward in between must not re-apply
+    the stale gradients; two accumulated backward passes after a step = overwrite, then add."""
+    from open_flamingo_amd.train import step, synthetic, towers
+    from open_flamingo_amd.train.reducer import GradReducer
+    model, info = towers.build_flamingo("OF-tiny", device="cuda", seed=0, gates=0.5)
+    model.train()
+    red = GradReducer(model, embedding_rows=[info["media_token_id"], info["eoc_token_id"]])
+    opt = step.build_optimizer(model, lr=1e-3, reducer=red)
+    b1 = synthetic.make_batch(2, 1, 16, info, "cuda", seed=6)
+    b2 = synthetic.make_batch(2, 2, 24, info, "cuda", seed=5)
+    step.train_step(model, red, opt, b2, info)
+    mats = [p for b in red.buckets for p in b["overwritable"]]
+    small = [p for b in red.buckets for p in b["params"] if all(p is not q for q in b["overwritable"])]
+    assert mats and small and all(p._of_grad_fresh for p in mats)
+    assert any(float(p.grad.abs().sum()) > 0 for p in mats), "left uncleared on purpose"
+    assert all(float(p.grad.abs().sum()) == 0 for p in small)
+    # gradients of two passes on top of the stale content == gradients of the same two passes on cleared buffers
+    for b in (b1, b2):
+        step.forward_loss(model, b, info).backward()
+    assert not any(p._of_grad_fresh for p in mats)
+    got = [p.grad.detach().clone() for p in mats]
+    red.zero_grad()
+    for b in (b1, b2):
+        step.forward_loss(model, b, info).backward()
+    for g, p in zip(got, mats):
+        assert (g - p.grad).abs().max().item() <= 2e-3 * p.grad.abs().max().item() + 1e-7
+    red.zero_grad()
+    # a step with no backward since the last one: stale matrices are cleared first, nothing but weight decay / momentum acts
+    step.train_step(model, red, opt, b2, info)
+    m_before = [opt._moments_of(p)[0].clone() for p in mats]
+    opt.step()
+    for p, m0 in zip(mats, m_before):
+        assert float(p.grad.abs().sum()) == 0
+        assert torch.allclose(opt._moments_of(p)[0], 0.9 * m0, rtol=1e-5, atol=1e-12), "exp_avg must only decay"
 
 
 @pytest.mark.parametrize("d,heads", [(256, 4), (512, 4)])      # head dim 64 and 128
