@@ -315,7 +315,7 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
         if (rc != OF_E_SHAPE) return rc;
     }
 #ifdef OF_TOOLS_BUILD      // tools/libofhip_tools.so only: timing ablations and A/B variants (some wrong by design)
-    if (a.safe >= 71 && a.safe <= 73) return of_gemm_w4_try(a, s);
+    if (a.safe >= 70 && a.safe <= 73) return of_gemm_w4_try(a, s);
     if (a.safe >= 32) return of_gemm_w4_ablate(a, a.safe - 32, s);
     if (a.safe >= 16) return of_gemm_pp_ablate(a, a.safe - 16, s);
     const bool pp_forced = a.safe == 4 || a.safe == 5;

@@ -19,6 +19,7 @@
 //   * the instruction interleave is pinned (a scheduling fence after every MFMA): each of the 64 MFMA gaps of a stage
 //     carries at most ONE LDS instruction -- a fragment read (gaps 0-7 of a phase) or a staging write (gaps 8-15 of
 //     phases 0 and 1) -- and the 16 global loads ride with the reads of phases 1 and 2.
+#include <type_traits>
 #include "gemm_tile256.h"
 
 namespace {
@@ -155,63 +156,70 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) read_one(smem, 0, 0, i);
 
-    // One phase = the 16 MFMAs of one k-step (register buffer `buf`); every MFMA gap carries at most one LDS instruction:
-    //   gaps 0-7:  one fragment read of the next k-step into the other buffer (+ one global load, gaps of phases 1 / 2)
-    //   gaps 8-15: one staging write (phases 0 / 1)
-    // of_sched_fence() after every gap pins exactly this interleave.  Piece j is written in phase j/8 and re-loaded for
-    // stage d+2 one phase later (a load has 3.5 phases = 7/8 of a stage to land before its write; the last write is a full
-    // phase ahead of the barrier).
-    // DMA variant: gaps 8-15 carry one DMA piece instead (dma0 = first piece, into dma_slot).
-    auto phase = [&](int buf, const char* rd_stage, int rd_ks16, bool rd, char* nxt, int wr0, int ld0, bool WR, bool LD,
-                     char* dma_slot, int win, bool dma_on) OF_INLINE_LAMBDA {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (ABL & 16) {
-                if (i == 0) acc[0][0][0] += __builtin_bit_cast(float, (int)fa[buf][0][0] + fa[buf][1][1] + fa[buf][2][2] + fa[buf][3][3] +
-                                                                          fb[buf][0][4] + fb[buf][1][5] + fb[buf][2][6] + fb[buf][3][7]);
-            } else {
-                acc[i >> 2][i & 3] = of_mfma32(fb[buf][i & 3], fa[buf][i >> 2], acc[i >> 2][i & 3]);
-            }
-            if (i < 8) {
-                if (rd && !(ABL & 4)) read_one(rd_stage, rd_ks16, buf ^ 1, i);
-                if (!DMA && LD && ld0 >= 0) load_piece(ld0 + i);
-            } else if (!DMA && WR && wr0 >= 0) {
-                store_piece(nxt, wr0 + i - 8);
-            }
-            if (DMA && dma_on && win >= 0) {
-                if (DPL == 2) {
-                    if (win < 2 && (i & 1) == par) dma_piece(dma_slot, win * 8 + (i >> 1), win == 0);
-                } else if (dma_at(win, i) >= 0) {
-                    dma_piece(dma_slot, dma_at(win, i), win == 0);
+    // The K loop, compiled once per wave parity for DPL == 2 (odd waves issue their DMA pieces in odd gaps, even waves in
+    // even gaps: half as many waves meet at the texture unit per gap) -- the parity is a compile-time constant inside.
+    auto main_loop = [&](auto parc) OF_INLINE_LAMBDA {
+        constexpr int PARC = decltype(parc)::value;
+        // One phase = the 16 MFMAs of one k-step (register buffer `buf`); every MFMA gap carries at most one LDS instruction:
+        //   gaps 0-7:  one fragment read of the next k-step into the other buffer (+ one global load, gaps of phases 1 / 2)
+        //   gaps 8-15: one staging write (phases 0 / 1)
+        // of_sched_fence() after every gap pins exactly this interleave.  Piece j is written in phase j/8 and re-loaded for
+        // stage d+2 one phase later (a load has 3.5 phases = 7/8 of a stage to land before its write; the last write is a full
+        // phase ahead of the barrier).
+        // DMA variant: gaps 8-15 carry one DMA piece instead (dma0 = first piece, into dma_slot).
+        auto phase = [&](int buf, const char* rd_stage, int rd_ks16, bool rd, char* nxt, int wr0, int ld0, bool WR, bool LD,
+                         char* dma_slot, int win, bool dma_on) OF_INLINE_LAMBDA {
+    #pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (ABL & 16) {
+                    if (i == 0) acc[0][0][0] += __builtin_bit_cast(float, (int)fa[buf][0][0] + fa[buf][1][1] + fa[buf][2][2] + fa[buf][3][3] +
+                                                                              fb[buf][0][4] + fb[buf][1][5] + fb[buf][2][6] + fb[buf][3][7]);
+                } else {
+                    acc[i >> 2][i & 3] = of_mfma32(fb[buf][i & 3], fa[buf][i >> 2], acc[i >> 2][i & 3]);
                 }
+                if (i < 8) {
+                    if (rd && !(ABL & 4)) read_one(rd_stage, rd_ks16, buf ^ 1, i);
+                    if (!DMA && LD && ld0 >= 0) load_piece(ld0 + i);
+                } else if (!DMA && WR && wr0 >= 0) {
+                    store_piece(nxt, wr0 + i - 8);
+                }
+                if (DMA && dma_on && win >= 0) {
+                    if (DPL == 2) {
+                        if (win < 2 && (i & 1) == PARC) dma_piece(dma_slot, win * 8 + (i >> 1), win == 0);
+                    } else if (dma_at(win, i) >= 0) {
+                        dma_piece(dma_slot, dma_at(win, i), win == 0);
+                    }
+                }
+                of_sched_fence();
             }
+        };
+        // One K stage.  WR: stage d+1 exists (write it), LD: stage d+2 exists (load it).
+        auto stage_body = [&](char* cur, char* nxt, const bool WR, const bool LD) OF_INLINE_LAMBDA {
+            phase(0, cur, 1, true, nxt, 0, -1, WR, LD, nxt, 1, WR);           // DMA: window phase 1 of stage d+1 -> nxt
+            phase(1, cur, 2, true, nxt, 8, 0, WR, LD, nxt, 2, WR);            // DMA: window phase 2 of stage d+1 -> nxt
+            phase(0, cur, 3, true, nxt, -1, 8, WR, LD, nullptr, -1, false);
+            if (!DMA && LD) next_stage_src();
+            if (DMA) of_wait_vm<0>();      // own DMA pieces of stage d+1 have landed ...
+            of_wait_lgkm0();       // own writes of stage d+1 and reads of this slot are done ...
+            if (!(ABL & 8)) of_barrier_raw();      // ... and so are everybody else's
             of_sched_fence();
-        }
-    };
-    // One K stage.  WR: stage d+1 exists (write it), LD: stage d+2 exists (load it).
-    auto stage_body = [&](char* cur, char* nxt, const bool WR, const bool LD) OF_INLINE_LAMBDA {
-        phase(0, cur, 1, true, nxt, 0, -1, WR, LD, nxt, 1, WR);           // DMA: window phase 1 of stage d+1 -> nxt
-        phase(1, cur, 2, true, nxt, 8, 0, WR, LD, nxt, 2, WR);            // DMA: window phase 2 of stage d+1 -> nxt
-        phase(0, cur, 3, true, nxt, -1, 8, WR, LD, nullptr, -1, false);
-        if (!DMA && LD) next_stage_src();
-        if (DMA) of_wait_vm<0>();      // own DMA pieces of stage d+1 have landed ...
-        of_wait_lgkm0();       // own writes of stage d+1 and reads of this slot are done ...
-        if (!(ABL & 8)) of_barrier_raw();      // ... and so are everybody else's
-        of_sched_fence();
-        phase(1, nxt, 0, WR, nxt, -1, -1, false, false, cur, 0, LD);      // DMA: window phase 0 of stage d+2 -> cur (free since the barrier)
-        if (DMA) {
-            sA += stepA;
-            sB += stepB;
-        }
-    };
+            phase(1, nxt, 0, WR, nxt, -1, -1, false, false, cur, 0, LD);      // DMA: window phase 0 of stage d+2 -> cur (free since the barrier)
+            if (DMA) {
+                sA += stepA;
+                sB += stepB;
+            }
+        };
 
-    int d = 0;
-    for (; d + 2 < nd; ++d) stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, true, true);
-    if (d + 1 < nd) {
-        stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, true, false);
-        ++d;
-    }
-    stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, false, false);
+        int d = 0;
+        for (; d + 2 < nd; ++d) stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, true, true);
+        if (d + 1 < nd) {
+            stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, true, false);
+            ++d;
+        }
+        stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, false, false);
+    };
+    if (DPL == 2 && par) main_loop(std::integral_constant<int, 1>{});
+    else main_loop(std::integral_constant<int, 0>{});
     of_barrier_raw();          // the last stage's k-step-3 fragments were read before its barrier: LDS is idle from here
 
     // ---------------------------------------------------------------- epilogue, staged through LDS (as gemm_pp.hip)
@@ -255,10 +263,12 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
 template <bool AT, bool BT, int EPI>
 int launch_w4(const OfGemmArgs& a, of_stream_t s) {
     of_dim3 grid{(unsigned)((a.M / TM) * (a.N / TN)), 1, 1};
-    if (a.safe == 7) return of_launch(of_gemm_w4_kernel<AT, BT, EPI, 0, true>, grid, 256, SMEM_W4, s, a);
-#ifdef OF_TOOLS_BUILD       // DMA placement A/B (tools/bench_gemm_w4.py)
+    // product DMA placement = 2 (A in phase 3, B in phase 0, odd / even waves in odd / even gaps): +1..3 % over the
+    // unstaggered form on MI355X (profiles/r02_gemm_big_tile_ab.jsonl)
+    if (a.safe == 7) return of_launch(of_gemm_w4_kernel<AT, BT, EPI, 0, true, 2>, grid, 256, SMEM_W4, s, a);
+#ifdef OF_TOOLS_BUILD       // DMA placement A/B (tools/bench_gemm_w4b.py)
+    if (a.safe == 70) return of_launch(of_gemm_w4_kernel<AT, BT, EPI, 0, true, 0>, grid, 256, SMEM_W4, s, a);
     if (a.safe == 71) return of_launch(of_gemm_w4_kernel<AT, BT, EPI, 0, true, 1>, grid, 256, SMEM_W4, s, a);
-    if (a.safe == 72) return of_launch(of_gemm_w4_kernel<AT, BT, EPI, 0, true, 2>, grid, 256, SMEM_W4, s, a);
     if (a.safe == 73) return of_launch(of_gemm_w4_kernel<AT, BT, EPI, 0, true, 3>, grid, 256, SMEM_W4, s, a);
 #endif
     return of_launch(of_gemm_w4_kernel<AT, BT, EPI>, grid, 256, SMEM_W4, s, a);

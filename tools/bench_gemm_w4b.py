@@ -27,7 +27,7 @@ def run(name, M, N, K, ta, tb, arms_sel):
     B = r((K, N) if tb else (N, K), K ** -0.5)
     out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     Am, Bm = (A.t() if ta else A), (B if tb else B.t())
-    arms = {"pp": 4, "w4": 6, "dma0": 7, "dma1": 71, "dma2": 72, "dma3": 73}
+    arms = {"pp": 4, "w4": 6, "dma0": 70, "dma1": 71, "dma2": 7, "dma3": 73}
     fns = {k: (lambda sf=sf: ops.gemm(A, B, out, ta=ta, tb=tb, safe=sf)) for k, sf in arms.items() if k in arms_sel}
     fns["blaslt"] = lambda: torch.matmul(Am, Bm)
     ref = torch.empty_like(out)
