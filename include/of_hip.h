@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OF_ABI_VERSION 2
+#define OF_ABI_VERSION 3
 #define OF_E_ARG (-1)      /* null pointer / negative size */
 #define OF_E_SHAPE (-2)    /* shape not supported by the kernels (see each function) */
 #define OF_E_ALIGN (-3)    /* pointer or leading dimension not 16-byte aligned */
@@ -85,6 +85,17 @@ typedef struct OfGemmArgs {
                           of_gemm_workspace_bytes(args) bytes the K slices are combined by a second pass in a fixed
                           order (deterministic); without it they are combined with fp32 atomics */
     size_t workspace_bytes;
+    /* Grouped B operand (0 / NULL = off): `groups` is a DEVICE array of n pointers, each a B matrix of its own.
+     *   group_kind 1 (b_trans = 0): B is grouped along N -- output columns [g*E, (g+1)*E) use groups[g] (an [E][K] matrix):
+     *       one launch computes y[:, gE:(g+1)E] = x W_g^T for every g (all gated blocks' to_kv of the same media tensor,
+     *       helpers.py:189 called from 24 blocks);
+     *   group_kind 2 (b_trans = 1): B is grouped along K -- k in [g*E, (g+1)*E) uses groups[g] (an [E][N] matrix):
+     *       one launch computes dX = sum_g dY[:, gE:(g+1)E] W_g (the media gradient of all blocks).
+     * E = group_extent, a multiple of 256 (kind 1) / 64 (kind 2); shapes must be big-tile eligible (M, N % 256, K % 64);
+     * args->B is ignored, ldb applies to every group. */
+    const void* const* groups;
+    int group_kind;
+    int group_extent;
 } OfGemmArgs;
 
 int of_gemm(const OfGemmArgs* args, void* stream);

@@ -261,8 +261,28 @@ extern "C" size_t of_gemm_workspace_bytes(const OfGemmArgs* args) {
     return split > 1 ? (size_t)split * args->M * args->N * sizeof(float) : 0;
 }
 
+// grouped-B launches (OfGemmArgs.group_kind): big-tile kernels only
+static int gemm_grouped(const OfGemmArgs& a, of_stream_t s) {
+    if (!a.groups || a.group_extent <= 0) return OF_E_ARG;
+    if ((a.M % 256) || (a.N % 256) || (a.K % 64) || a.a_trans) return OF_E_SHAPE;
+    if ((a.lda & 7) || (a.ldb & 7) || (a.ldc & 3) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.C & 15)) return OF_E_ALIGN;
+    if (a.group_kind == 1) {              // y[:, gE:(g+1)E] = x W_g^T
+        if (a.b_trans || (a.group_extent % 256) || (a.N % a.group_extent)) return OF_E_SHAPE;
+        OfGemmArgs w = a;
+        w.safe = 7;
+        return of_gemm_w4_try(w, s);
+    }
+    if (a.group_kind == 2) {              // dX = sum_g dY[:, gE:(g+1)E] W_g
+        if (!a.b_trans || (a.group_extent % 64) || (a.K % a.group_extent)) return OF_E_SHAPE;
+        return of_gemm_pp_try(a, s);
+    }
+    return OF_E_ARG;
+}
+
 extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
-    if (!args || !args->A || !args->B || !args->C) return OF_E_ARG;
+    if (!args || !args->A || !args->C) return OF_E_ARG;
+    if (args->group_kind) return gemm_grouped(*args, (of_stream_t)stream);
+    if (!args->B) return OF_E_ARG;
     const OfGemmArgs& a = *args;
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return OF_E_ARG;
     // vector-loaded (contiguous) extents must be multiples of 8 elements; outputs are written 4 wide

@@ -77,8 +77,12 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         srcA[j] = chunk_src<AT>(p.A, p.lda, m0, hfA, j * 4 + wn, lane);
-        srcB[j] = chunk_src<BT>(p.B, p.ldb, n0, hfB, j * 4 + wn, lane);
+        srcB[j] = chunk_src<BT>((BT && p.group_kind == 2) ? (const bf16_t*)p.groups[0] : p.B, p.ldb, n0, hfB, j * 4 + wn, lane);
     }
+    // grouped B along K (OfGemmArgs.group_kind 2, K-strided B only): stage s reads rows [s*64, s*64+64) of the virtual
+    // [K][N] matrix, which live in weight matrix s / spg at local row (s % spg) * 64
+    const int spg = (BT && p.group_kind == 2) ? p.group_extent / DK : 0;
+    int b_stage = 0;              // K stage the next issueB will fetch
     const size_t stepA = AT ? (size_t)DK * p.lda : (size_t)DK;
     const size_t stepB = BT ? (size_t)DK * p.ldb : (size_t)DK;
     const int nd = p.K / DK;
@@ -103,6 +107,11 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
         if (RS) stg_dst = slot + offA;
     };
     auto issueB = [&](char* slot) {
+        if (spg && b_stage && b_stage % spg == 0) {     // first stage of the next weight matrix: re-base the sources
+#pragma unroll
+            for (int j = 0; j < 4; ++j) srcB[j] = chunk_src<BT>((const bf16_t*)p.groups[b_stage / spg], p.ldb, n0, hfB, j * 4 + wn, lane);
+        }
+        ++b_stage;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (RS) stg[j] = *(const u32x4*)srcB[j];

@@ -59,7 +59,15 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
     // staging duty of this wave: 1-KiB chunks c = jj*4 + wave (jj = 0..3) of both halves of both operands = 16 pieces.
     // Source = wave-uniform base (advanced per stage on the scalar unit) + per-lane 32-bit byte offset (loop invariant).
     const of_buf_t gA = of_buf_make(chunk_base<AT>(p.A, p.lda, m0));
-    const of_buf_t gB = of_buf_make(chunk_base<BT>(p.B, p.ldb, n0));
+    // grouped B along N (OfGemmArgs.group_kind 1): this tile's columns belong to weight matrix n0 / extent
+    const bf16_t* Bmat = p.B;
+    int nB = n0;
+    if (!BT && p.group_kind == 1) {
+        const int grp = n0 / p.group_extent;
+        Bmat = (const bf16_t*)p.groups[grp];
+        nB = n0 - grp * p.group_extent;
+    }
+    const of_buf_t gB = of_buf_make(chunk_base<BT>(Bmat, p.ldb, nB));
     unsigned sA = 0, sB = 0;          // scalar byte offsets of the stage being loaded
     unsigned offA[2][4], offB[2][4];
 #pragma unroll

@@ -151,7 +151,8 @@ OF_GLOBAL void OF_BOUNDS(256, (CPL > 5 ? 1 : 2)) of_ln_bwd_kernel(LnArgs a) {
         const size_t go = a.dy_grp_rows > 0 ? (size_t)(row / a.dy_grp_rows) * a.dy_grp_stride + (size_t)(row % a.dy_grp_rows) * a.lddy
                                             : (size_t)row * a.lddy;
         const size_t dxo = (size_t)row * a.lddx;
-        float xh[CPL][8], gv[CPL][8];
+        constexpr bool PRE = CPL <= 4;     // wider rows: the 8 extra registers per chunk would spill
+        float xh[CPL][8], gv[CPL][8], rv[PRE ? CPL : 1][8];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
@@ -159,6 +160,9 @@ OF_GLOBAL void OF_BOUNDS(256, (CPL > 5 ? 1 : 2)) of_ln_bwd_kernel(LnArgs a) {
             if (c < nchunk) {
                 load8(a.x, a.x_f32, xo + c * 8, xh[j]);
                 load8(a.dy, a.dy_f32, go + c * 8, gv[j]);
+                // the residual gradient is only needed after the two row reductions: issue its loads with the others so
+                // that a row pays ONE memory latency, not two (8 waves per CU: latency, not bandwidth, bounds this kernel)
+                if (PRE && wr && a.resid) load8(a.resid, a.dx_f32, dxo + c * 8, rv[PRE ? j : 0]);
                 if (a.dy2) {
                     float g2[8];
                     load8(a.dy2, 0, (size_t)row * a.dim + c * 8, g2);
@@ -195,10 +199,9 @@ OF_GLOBAL void OF_BOUNDS(256, (CPL > 5 ? 1 : 2)) of_ln_bwd_kernel(LnArgs a) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = rstd * (gv[j][e] - c1 - xh[j][e] * c2);
                     if (a.resid) {
-                        float rv[8];
-                        load8(a.resid, a.dx_f32, dxo + c * 8, rv);
+                        if (!PRE) load8(a.resid, a.dx_f32, dxo + c * 8, rv[0]);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] += rv[e];
+                        for (int e = 0; e < 8; ++e) o[e] += rv[PRE ? j : 0][e];
                     }
                     if (a.dx) store8(a.dx, a.dx_f32, dxo + c * 8, o);
                     if (a.dx_bf16) store8(a.dx_bf16, 0, dxo + c * 8, o);

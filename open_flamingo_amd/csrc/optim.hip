@@ -111,7 +111,11 @@ extern "C" int of_sumsq(const float* g, long n, float* acc, void* stream) {
     if ((uintptr_t)g & 15) return OF_E_ALIGN;
     OptArgs a{};
     a.g = const_cast<float*>(g); a.n = n; a.acc = acc;
-    return of_launch(of_sumsq_kernel, of_dim3{opt_grid(n), 1, 1}, 256, 4 * sizeof(float), (of_stream_t)stream, a);
+    // every workgroup ends with ONE atomic on the same scalar and same-address device atomics serialise (~12 ns each):
+    // 4096 workgroups spent 49 us there for a 59-us launch (rocprofv3, round 2) -- two workgroups per CU are enough
+    unsigned grid = opt_grid(n);
+    if (grid > 512) grid = 512;
+    return of_launch(of_sumsq_kernel, of_dim3{grid, 1, 1}, 256, 4 * sizeof(float), (of_stream_t)stream, a);
 }
 
 extern "C" int of_adamw_clip(float* p, float* g, float* m, float* v, uint16_t* p_bf16, long n, const float* sumsq,

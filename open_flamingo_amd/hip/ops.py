@@ -114,6 +114,30 @@ class Ops:
         self._chk(self.lib.of_gemm(C.byref(a), self._stream()), "of_gemm")
         return out
 
+    def gemm_grouped(self, A, Bs, table, out, *, kind, epi=abi.EPI_STORE_BF16, beta=0.0):
+        """One launch over several B matrices (OfGemmArgs.group_kind): kind 1 -- out[:, gE:(g+1)E] = A @ Bs[g]^T with
+        Bs[g] (E, K); kind 2 -- out = sum_g A[:, gE:(g+1)E] @ Bs[g] with Bs[g] (E, N).  ``table``: int64 device tensor
+        holding the data pointers of Bs (built by the caller, kept alive with them)."""
+        E = Bs[0].shape[0]
+        assert all(b.dtype == BF16 and b.shape == Bs[0].shape and b.stride() == Bs[0].stride() and b.stride(1) == 1 for b in Bs)
+        assert A.dtype == BF16 and A.stride(1) == 1 and out.stride(1) == 1 and table.dtype == torch.int64 and table.numel() == len(Bs)
+        a = abi.OfGemmArgs()
+        a.A = A.data_ptr()
+        a.M, a.lda = A.shape[0], A.stride(0)
+        if kind == 1:
+            a.N, a.K, a.b_trans = E * len(Bs), A.shape[1], 0
+            assert Bs[0].shape[1] == a.K
+        else:
+            a.N, a.K, a.b_trans = Bs[0].shape[1], A.shape[1], 1
+            assert a.K == E * len(Bs)
+        assert tuple(out.shape) == (a.M, a.N)
+        a.ldb = Bs[0].stride(0)
+        a.epi, a.C, a.ldc = epi, out.data_ptr(), out.stride(0)
+        a.alpha, a.beta = 1.0, float(beta)
+        a.groups, a.group_kind, a.group_extent = table.data_ptr(), kind, E
+        self._chk(self.lib.of_gemm(C.byref(a), self._stream()), "of_gemm(grouped)")
+        return out
+
     # ------------------------------------------------------------------ LayerNorm
     def ln_fwd(self, x, w, b, y, stats):
         rows, dim = x.shape

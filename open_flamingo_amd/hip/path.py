@@ -141,8 +141,11 @@ def masked_cross_attention_fwd(ops, P, W, x, media_bf, tt, *, B, L, T, n, heads,
 
 def masked_cross_attention_bwd(ops, P, W, S, media_bf, tt, dy, dyb, G, *, B, L, T, n, heads, only_immediate,
                                prefix="attn.", gate=None, gate_name=None, residual=False, need_dmedia=True, safe=0,
-                               dim_head=64):
-    """dy stream dtype + its bf16 copy dyb.  Returns (dx, dmedia fp32 or None)."""
+                               dim_head=64, dkv_out=None):
+    """dy stream dtype + its bf16 copy dyb.  Returns (dx, dmedia fp32 or None).
+    dkv_out: (B*T*n, 2*inner) bf16 destination of d(k|v) owned by the caller (a column block of the buffer shared by all
+    blocks when their to_kv projections are grouped); the caller then forms the media gradient of all
+    blocks in one GEMM and passes need_dmedia=False."""
     dev = dy.device
     rows, d = S["x"].shape
     inner = heads * dim_head
@@ -153,7 +156,7 @@ def masked_cross_attention_bwd(ops, P, W, S, media_bf, tt, dy, dyb, G, *, B, L, 
     t, beta = G.mat(prefix + "to_out.weight", (d, inner))
     ops.gemm(dyb, S["o"], t, ta=True, tb=True, epi=EPI_ACC_F32, gate=gate, beta=beta)
     dq = _e((rows, inner), BF16, dev)
-    dkv = _e((B * T * n, 2 * inner), BF16, dev)
+    dkv = _e((B * T * n, 2 * inner), BF16, dev) if dkv_out is None else dkv_out
     delta = _e((B, heads, L), F32, dev)
     kv = S["kv"]
     ops.attn_bwd(S["q"], kv[:, :inner], kv[:, inner:], S["o"], S["lse"], dO, dq, dkv[:, :inner], dkv[:, inner:], delta,
@@ -193,7 +196,7 @@ def xattn_block_fwd(ops, P, W, x, media_bf, tt, *, B, L, T, n, heads, only_immed
 
 
 def xattn_block_bwd(ops, P, W, S, media_bf, tt, dy, *, B, L, T, n, heads, only_immediate, need_dmedia=True, safe=0,
-                    sinks=None, dim_head=64, fresh=()):
+                    sinks=None, dim_head=64, fresh=(), dkv_out=None):
     """Returns (dx, dmedia fp32 (B*T*n, Dv) or None, grads dict keyed like P).  sinks / fresh: see _GradOut."""
     G = _GradOut(sinks, dy.device, fresh)
     dy = dy.contiguous()
@@ -204,7 +207,7 @@ def xattn_block_bwd(ops, P, W, S, media_bf, tt, dy, *, B, L, T, n, heads, only_i
     dx, dmedia = masked_cross_attention_bwd(ops, P, W, S["attn"], media_bf, tt, dy1, dy1b, G, B=B, L=L, T=T, n=n,
                                             heads=heads, only_immediate=only_immediate, gate=P["attn_gate"],
                                             gate_name="attn_gate", residual=True, need_dmedia=need_dmedia, safe=safe,
-                                            dim_head=dim_head)
+                                            dim_head=dim_head, dkv_out=dkv_out)
     return dx, dmedia, G.g
 
 

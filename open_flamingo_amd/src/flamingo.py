@@ -35,6 +35,8 @@ class Flamingo(nn.Module):
         self._use_gradient_checkpointing = gradient_checkpointing
         self.perceiver._use_gradient_checkpointing = gradient_checkpointing
 
+    group_media_projections = True     # class-level switch (instance attribute overrides): see _encode_vision_x
+
     # ------------------------------------------------------------------------------------------------ conditioning
     def _layers(self):
         return self.lang_encoder._get_decoder_layers()
@@ -48,6 +50,10 @@ class Flamingo(nn.Module):
         with torch.no_grad():
             tokens = self.vision_encoder(vision_x.flatten(0, 2))[1]           # (b*T*F, patches, vis_dim)
         latents = self.perceiver(tokens.unflatten(0, (batch, n_media, n_frames)))
+        if self.group_media_projections and torch.is_grad_enabled():
+            # every gated block applies its own to_kv to this one tensor: one grouped GEMM for all of them
+            from . import helpers
+            helpers.group_media_projections(list(self.lang_encoder.gated_cross_attn_layers), latents)
         for layer in self._layers():
             layer.condition_vis_x(latents)
 

@@ -426,12 +426,111 @@ class _MaskedCrossAttentionFn(torch.autograd.Function):
         return (None, dx.view(ctx.xshape), dmedia, None, None) + _hand_back(_MCA_NAMES, ctx.params, ctx.param_dtypes, G.g, sinks)
 
 
+class MediaKVGroup:
+    """All gated blocks project the SAME media tensor with their own to_kv (reference helpers.py:187-189, called from every
+    FlamingoLayer with the one tensor flamingo.py:199-200 hands out): SURVEY appendix B3.  One grouped GEMM right after the
+    Perceiver computes every block's keys/values (``kv_all``, block i owns columns [i*E, (i+1)*E)), every block's backward
+    writes its d(k|v) into the matching columns of ``dkv_all``, and ONE K-grouped GEMM forms the media gradient of all
+    blocks (instead of 24 small GEMMs whose fp32 results autograd then adds with 23 more kernels).  The weight gradients
+    of to_kv stay in the blocks' own backward, so they are ready block by block for the gradient exchange."""
+
+    def __init__(self, blocks, media):
+        self.blocks = list(blocks)
+        self.index = {id(b): i for i, b in enumerate(self.blocks)}
+        self.media = media
+        self.kv_all = self.dkv_all = self.token = None
+
+    def kv_of(self, block):
+        i = self.index[id(block)]
+        return self.kv_all[:, i * self.E:(i + 1) * self.E]
+
+    def dkv_of(self, block):
+        if self.dkv_all is None:        # every column block is fully written by its block's attention backward
+            self.dkv_all = torch.empty_like(self.kv_all)
+            self.written = set()
+        i = self.index[id(block)]
+        self.written.add(i)
+        return self.dkv_all[:, i * self.E:(i + 1) * self.E]
+
+
+_media_groups = []        # [(media tensor, MediaKVGroup)]: identity-keyed, a handful of entries (LAION + MMC4 passes)
+
+
+def can_group_media(media):
+    return media.is_cuda
+
+
+def group_media_projections(blocks, media):
+    """Called by Flamingo._encode_vision_x under autograd on the GPU; blocks that find their media tensor here use the
+    grouped projection (``GatedCrossAttentionBlock.forward``)."""
+    blocks = [b for b in blocks if b is not None]
+    if len(blocks) < 2 or not can_group_media(media) or not torch.is_grad_enabled():
+        return None
+    a0 = blocks[0].attn
+    E = a0.to_kv.weight.shape[0]
+    if any(b.attn.to_kv.weight.shape != a0.to_kv.weight.shape for b in blocks) or E % 256 or media.shape[-1] % 64 \
+            or (media.shape[0] * media.shape[1] * media.shape[2]) % 256:
+        return None                       # not big-tile eligible: the blocks project on their own
+    grp = MediaKVGroup(blocks, media)
+    grp.E = E
+    grp.token = _GroupedMediaKVFn.apply(grp, media)
+    _media_groups.append((media, grp))
+    del _media_groups[:-4]
+    return grp
+
+
+def _media_group_of(block, media):
+    for m, grp in _media_groups:
+        if m is media and id(block) in grp.index:
+            return grp
+    return None
+
+
+def drop_media_groups():
+    _media_groups.clear()
+
+
+class _GroupedMediaKVFn(torch.autograd.Function):
+    _table = None        # ((weight pointers, device), device table of them): rebuilt only when a pointer changes
+
+    @staticmethod
+    def forward(ctx, grp, media):
+        ops = Ops.default()
+        B, T, n, Dv = media.shape
+        med = media.detach()
+        grp.media_bf = _shared.get(media, "bf16", lambda: ops.to_bf16(med.reshape(B * T * n, Dv).contiguous())
+                                   if med.dtype == F32 else med.reshape(B * T * n, Dv).contiguous())
+        grp.Ws = [b._weights_bf16(ops, [("attn.to_kv.weight", b.attn.to_kv.weight)])["attn.to_kv.weight"] for b in grp.blocks]
+        ptrs = tuple(w.data_ptr() for w in grp.Ws)           # stable while the step epilogue owns the bf16 copies
+        if _GroupedMediaKVFn._table is None or _GroupedMediaKVFn._table[0] != (ptrs, media.device):
+            _GroupedMediaKVFn._table = ((ptrs, media.device), torch.tensor(ptrs, dtype=torch.int64, device=media.device))
+        grp.table = _GroupedMediaKVFn._table[1]
+        grp.kv_all = torch.empty(B * T * n, grp.E * len(grp.Ws), dtype=BF16, device=media.device)
+        ops.gemm_grouped(grp.media_bf, grp.Ws, grp.table, grp.kv_all, kind=1)
+        ctx.grp, ctx.mshape, ctx.mdtype = grp, tuple(media.shape), media.dtype
+        return torch.zeros(1, device=media.device)          # token: ties every block's backward to this node
+
+    @staticmethod
+    def backward(ctx, _g):
+        grp = ctx.grp
+        if not ctx.needs_input_grad[1] or grp.dkv_all is None:
+            return None, None
+        assert len(grp.written) == len(grp.blocks), "a gated block of the group did not run its backward"
+        ops = Ops.default()
+        from ..hip.abi import EPI_ACC_F32
+        dmedia = torch.empty(grp.kv_all.shape[0], ctx.mshape[-1], dtype=F32, device=grp.kv_all.device)
+        ops.gemm_grouped(grp.dkv_all, grp.Ws, grp.table, dmedia, kind=2, epi=EPI_ACC_F32)
+        grp.kv_all = grp.dkv_all = None
+        return None, (dmedia if ctx.mdtype == F32 else ops.to_bf16(dmedia)).view(ctx.mshape)
+
+
 class _GatedXAttnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mod, x, media, media_locations, use_cached_media, *params):
+    def forward(ctx, mod, x, media, media_locations, use_cached_media, grp, token, *params):
         B, L, d = x.shape
         ops, P, W, xr, media_bf, tt, dims = _xattn_operands(mod, x, media, media_locations, use_cached_media, params)
-        y, S = _path.xattn_block_fwd(ops, P, W, xr, media_bf, tt, **dims)
+        y, S = _path.xattn_block_fwd(ops, P, W, xr, media_bf, tt, kv=grp.kv_of(mod) if grp is not None else None, **dims)
+        ctx.grp = grp
         ctx.mod, ctx.dims, ctx.S, ctx.P, ctx.W, ctx.media_bf, ctx.tt = mod, dims, S, P, W, media_bf, tt
         ctx.xshape, ctx.mshape, ctx.mdtype = tuple(x.shape), tuple(media.shape), media.dtype
         ctx.params, ctx.param_dtypes = params, tuple(p.dtype for p in params)
@@ -441,15 +540,20 @@ class _GatedXAttnFn(torch.autograd.Function):
     def backward(ctx, dy):
         ops = Ops.default()
         d = ctx.xshape[-1]
-        need_dmedia = ctx.needs_input_grad[2]
+        grp = ctx.grp
+        need_dmedia = ctx.needs_input_grad[2] and grp is None      # grouped: the group's node forms the media gradient
         sinks, fresh = _grad_sinks(_XATTN_NAMES, ctx.params)
         dx, dmedia, g = _path.xattn_block_bwd(ops, ctx.P, ctx.W, ctx.S, ctx.media_bf, ctx.tt, dy.reshape(-1, d),
-                                              need_dmedia=need_dmedia, sinks=sinks, fresh=fresh, **ctx.dims)
+                                              need_dmedia=need_dmedia, sinks=sinks, fresh=fresh,
+                                              dkv_out=grp.dkv_of(ctx.mod) if grp is not None else None, **ctx.dims)
         ctx.S = None
         if dmedia is not None:
             dmedia = (dmedia if ctx.mdtype == F32 else ops.to_bf16(dmedia)).view(ctx.mshape)
         grads = _hand_back(_XATTN_NAMES, ctx.params, ctx.param_dtypes, g, sinks)
-        return (None, dx.view(ctx.xshape), dmedia, None, None) + grads
+        # the token's gradient carries no value (the group's node reads dkv_all); a defined tensor from the block that
+        # runs LAST in the backward (first in the forward) is enough to schedule the group's node after every block
+        dtok = torch.zeros(1, device=dy.device) if (grp is not None and grp.index[id(ctx.mod)] == 0) else None
+        return (None, dx.view(ctx.xshape), dmedia, None, None, None, dtok) + grads
 
 
 class GatedCrossAttentionBlock(_HipParamModule):
@@ -477,7 +581,9 @@ class GatedCrossAttentionBlock(_HipParamModule):
                   a.to_out.weight, f[0].weight, f[0].bias, f[1].weight, f[3].weight]
         if not torch.is_grad_enabled():
             return self._forward_inference(x, media, media_locations, use_cached_media, params)
-        return _GatedXAttnFn.apply(self, x, media, media_locations, use_cached_media, *params)
+        grp = _media_group_of(self, media)
+        return _GatedXAttnFn.apply(self, x, media, media_locations, use_cached_media, grp,
+                                   grp.token if grp is not None else None, *params)
 
     # A decode step (T_txt = 1) is ~10 small launches per block whose cost is host time, not GPU time: replay them as
     # one HIP graph per block.  Class-level switch; set False (on the class or an instance) to launch kernel by kernel.
@@ -485,6 +591,7 @@ class GatedCrossAttentionBlock(_HipParamModule):
 
     def release_media_cache(self):
         self.__dict__.pop("_kv_cache", None)
+        drop_media_groups()
 
     def _forward_inference(self, x, media, media_locations, use_cached_media, params):
         """No-grad forward.  The reference recomputes ``to_kv(media)`` in every block for every generated token

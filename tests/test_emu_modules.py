@@ -224,3 +224,34 @@ def test_step_epilogue_leaves_weight_gradients_for_the_backward_to_overwrite(on_
     for p, m0 in zip(mats, m_before):
         assert float(p.grad.abs().sum()) == 0
         assert torch.allclose(opt._moments_of(p)[0], 0.9 * m0, rtol=1e-5, atol=1e-12)
+
+
+def test_grouped_media_projections_match_per_block_projections(on_emulator, monkeypatch):
+    """with Flamingo.group_media_projections the to_kv of every gated block runs as ONE grouped GEMM
+    right after the Perceiver and the media gradient of all blocks as ONE K-grouped GEMM; loss and every gradient must
+    equal the per-block form (same kernels per element, only the launch structure differs)."""
+    monkeypatch.setattr(helpers, "can_group_media", lambda media: True)
+    from open_flamingo_amd.train.towers import FAMILY
+    monkeypatch.setitem(FAMILY, "OF-tiny", dict(FAMILY["OF-tiny"], every=1))     # 4 gated blocks
+    results = []
+    for grouped in (False, True):
+        model, info = towers.build_flamingo("OF-tiny", device="cpu", seed=0, gates=0.5, fused_lm_attention=False,
+                                            vision_kw=dict(width=256, layers=1, heads=2, patch=14, image=224))
+        model.train()
+        model.group_media_projections = grouped
+        batch = synthetic.make_batch(2, 2, 24, info, "cpu", seed=5)
+        calls = []
+        orig = Ops.gemm_grouped
+        monkeypatch.setattr(Ops, "gemm_grouped", lambda self, *a, **kw: (calls.append(kw["kind"]), orig(self, *a, **kw))[1])
+        loss = step.forward_loss(model, batch, info, amp=False)
+        loss.backward()
+        monkeypatch.setattr(Ops, "gemm_grouped", orig)
+        assert calls == ([1, 2] if grouped else []), calls      # one grouped projection forward, one grouped media gradient
+        results.append((float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters()
+                                      if p.requires_grad and p.grad is not None}))
+        assert not helpers._media_groups        # dropped with the conditioning at the end of Flamingo.forward
+    (l0, g0), (l1, g1) = results
+    assert abs(l0 - l1) <= 2e-5 * abs(l0), (l0, l1)      # other GEMM kernel (fp32 summation order) before the bf16 rounding of k|v
+    assert g0.keys() == g1.keys()
+    for k in g0:
+        assert _rel(g1[k], g0[k]) < 2e-2, (k, _rel(g1[k], g0[k]))     # Perceiver grads: dmedia summed in fp32 once vs 4 bf16->fp32 partial sums

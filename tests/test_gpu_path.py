@@ -589,3 +589,31 @@ def test_cfg2_trajectory_product_vs_reference_eager():
     for a, b in zip(runs["product"], runs["eager"]):
         assert abs(a - b) <= 1e-2 * abs(b), runs
     assert runs["eager"][-1] < runs["eager"][0], "the fixed batch must be learnable"
+
+
+def test_grouped_media_projections_match_per_block_projections():
+    """SURVEY appendix B3 on hardware: one grouped to_kv GEMM (4-wave LDS-DMA kernel, B grouped along N) + one K-grouped
+    media-gradient GEMM (ping-pong kernel) vs the per-block launches: same loss, same gradients (fp32 summation order and
+    one bf16 rounding apart), and the grouped launches really happen."""
+    from open_flamingo_amd.hip.ops import Ops
+    from open_flamingo_amd.train import step, synthetic, towers
+    res = []
+    for grouped in (False, True):
+        model, info = towers.build_flamingo("OF-tiny", device="cuda", seed=0, gates=0.5)
+        model.train()
+        model.group_media_projections = grouped
+        batch = synthetic.make_batch(2, 2, 24, info, "cuda", seed=5)
+        calls, orig = [], Ops.gemm_grouped
+        Ops.gemm_grouped = lambda self, *a, **kw: (calls.append(kw["kind"]), orig(self, *a, **kw))[1]
+        try:
+            loss = step.forward_loss(model, batch, info)
+            loss.backward()
+        finally:
+            Ops.gemm_grouped = orig
+        assert calls == ([1, 2] if grouped else []), calls
+        res.append((float(loss), {k: p.grad.detach().float().cpu() for k, p in model.named_parameters()
+                                  if p.requires_grad and p.grad is not None}))
+    (l0, g0), (l1, g1) = res
+    assert abs(l0 - l1) <= 1e-3 * abs(l0), (l0, l1)
+    for k in g0:
+        assert PC.rel_err(g1[k], g0[k]) < 3e-2, (k, PC.rel_err(g1[k], g0[k]))
