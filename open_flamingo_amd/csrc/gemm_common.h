@@ -97,8 +97,30 @@ OF_DEV u32x4 pack8(const float (&o)[8]) {
 }
 // Eight consecutive n of one output row (tile-aligned shapes only: no bounds checks): 16-byte bf16 / 2 x 16-byte fp32
 // loads and stores, eight lanes cover one full 128-byte (bf16) or 256-byte (fp32) row segment.
+// The aux operand of a row segment (residual / saved activation), loaded AHEAD of the epilogue math so that its global
+// latency overlaps the LDS transposition of the accumulators instead of being paid once per row group.
+struct AuxPre {
+    u32x4 lo, hi;      // bf16 aux: lo only (8 values); fp32 aux: lo | hi (2 x 4 values)
+};
 template <int EPI>
-OF_DEV void epilogue_row8(const OfGemmArgs& p, const float (&a)[8], int m, int n, float gv, float sc, float& dot) {
+OF_DEV AuxPre epilogue_aux_load(const OfGemmArgs& p, int m, int n) {
+    AuxPre r{};
+    if (EPI == OF_EPI_GATE_RESID) {
+        const size_t aoff = (size_t)m * p.ldaux + n;
+        if (p.io_f32) {
+            r.lo = *(const u32x4*)((const float*)p.aux + aoff);
+            r.hi = *(const u32x4*)((const float*)p.aux + aoff + 4);
+        } else {
+            r.lo = *(const u32x4*)((const bf16_t*)p.aux + aoff);
+        }
+    } else if (EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) {
+        r.lo = *(const u32x4*)((const bf16_t*)p.aux + (size_t)m * p.ldaux + n);
+    }
+    return r;
+}
+template <int EPI>
+OF_DEV void epilogue_row8(const OfGemmArgs& p, const float (&a)[8], int m, int n, float gv, float sc, float& dot,
+                          const AuxPre* pre = nullptr) {
     const size_t off = (size_t)m * p.ldc + n;
     float o[8];
     if (EPI == OF_EPI_STORE_BF16) {
@@ -113,19 +135,20 @@ OF_DEV void epilogue_row8(const OfGemmArgs& p, const float (&a)[8], int m, int n
     } else if (EPI == OF_EPI_GATE_RESID) {
         const size_t aoff = (size_t)m * p.ldaux + n;
         if (p.io_f32) {
-            const f32x4 r0 = *(const f32x4*)((const float*)p.aux + aoff), r1 = *(const f32x4*)((const float*)p.aux + aoff + 4);
+            const f32x4 r0 = pre ? __builtin_bit_cast(f32x4, pre->lo) : *(const f32x4*)((const float*)p.aux + aoff);
+            const f32x4 r1 = pre ? __builtin_bit_cast(f32x4, pre->hi) : *(const f32x4*)((const float*)p.aux + aoff + 4);
             *(f32x4*)((float*)p.C + off) = f32x4{r0[0] + sc * a[0], r0[1] + sc * a[1], r0[2] + sc * a[2], r0[3] + sc * a[3]};
             *(f32x4*)((float*)p.C + off + 4) = f32x4{r1[0] + sc * a[4], r1[1] + sc * a[5], r1[2] + sc * a[6], r1[3] + sc * a[7]};
         } else {
             float r[8];
-            unpack8(*(const u32x4*)((const bf16_t*)p.aux + aoff), r);
+            unpack8(pre ? pre->lo : *(const u32x4*)((const bf16_t*)p.aux + aoff), r);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = r[e] + sc * a[e];
             *(u32x4*)((bf16_t*)p.C + off) = pack8(o);
         }
     } else if (EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) {
         float x[8];
-        unpack8(*(const u32x4*)((const bf16_t*)p.aux + (size_t)m * p.ldaux + n), x);
+        unpack8(pre ? pre->lo : *(const u32x4*)((const bf16_t*)p.aux + (size_t)m * p.ldaux + n), x);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             if (EPI == OF_EPI_DGELU_DOT) {

@@ -272,8 +272,19 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
     char* patch = smem + wave * (32 * PITCH);
     const int wr_off = (lane & 31) * PITCH + (lane >> 5) * 16;
     const int rd_row = lane >> 3, rd_col = (lane & 7) * 8;
+    constexpr bool HAS_AUX = EPI == OF_EPI_GATE_RESID || EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
+        // The aux row segments (residual / saved activation) are requested ahead of their use so that their global latency
+        // overlaps the LDS transposition and the previous row group's math.  Cheap epilogues: all four up front, loop
+        // unrolled.  *_DOT epilogues: the loop stays rolled (four interleaved copies of the erf-GELU math on top of the live
+        // accumulators spilled to scratch) and the next group's segment is requested one iteration ahead.
+        constexpr bool ROLLED = EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT;
+        ofg::AuxPre pre[4];
+        if (HAS_AUX) {
+#pragma unroll
+            for (int it = 0; it < (ROLLED ? 1 : 4); ++it) pre[it] = ofg::epilogue_aux_load<EPI>(p, m0 + wm * 128 + mt * 32 + it * 8 + rd_row, n0 + wn * 64 + rd_col);
+        }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -281,16 +292,24 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
                 *(f32x4*)(patch + wr_off + (nt * 32 + q * 8) * 4) =
                     f32x4{acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
         of_wave_sync();
-        // not unrolled: four interleaved copies of the erf-GELU math on top of the 128 live accumulator registers spilled
-        // 584 bytes/lane to scratch in the DGELU_DOT instantiation
-        // not unrolled for the *_DOT epilogues: four interleaved copies of the erf-GELU math on top of the live accumulators spilled
-        // to scratch; the cheap epilogues are unrolled so that the patch reads of row group it+1 overlap the stores of it
-#pragma unroll((EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) ? 1 : 4)
-        for (int it = 0; it < 4; ++it) {
-            const int r = it * 8 + rd_row;
-            const f32x4 v0 = *(const f32x4*)(patch + r * PITCH + rd_col * 4), v1 = *(const f32x4*)(patch + r * PITCH + rd_col * 4 + 16);
-            const float a8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            ofg::epilogue_row8<EPI>(p, a8, m0 + wm * 128 + mt * 32 + r, n0 + wn * 64 + rd_col, gv, sc, dot);
+        if (ROLLED) {
+#pragma unroll 1
+            for (int it = 0; it < 4; ++it) {
+                const int r = it * 8 + rd_row;
+                const ofg::AuxPre cur = pre[0];
+                if (it < 3) pre[0] = ofg::epilogue_aux_load<EPI>(p, m0 + wm * 128 + mt * 32 + r + 8, n0 + wn * 64 + rd_col);
+                const f32x4 v0 = *(const f32x4*)(patch + r * PITCH + rd_col * 4), v1 = *(const f32x4*)(patch + r * PITCH + rd_col * 4 + 16);
+                const float a8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                ofg::epilogue_row8<EPI>(p, a8, m0 + wm * 128 + mt * 32 + r, n0 + wn * 64 + rd_col, gv, sc, dot, &cur);
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = it * 8 + rd_row;
+                const f32x4 v0 = *(const f32x4*)(patch + r * PITCH + rd_col * 4), v1 = *(const f32x4*)(patch + r * PITCH + rd_col * 4 + 16);
+                const float a8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                ofg::epilogue_row8<EPI>(p, a8, m0 + wm * 128 + mt * 32 + r, n0 + wn * 64 + rd_col, gv, sc, dot, HAS_AUX ? &pre[it] : nullptr);
+            }
         }
         of_wave_sync();
     }

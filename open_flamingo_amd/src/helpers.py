@@ -468,9 +468,10 @@ def group_media_projections(blocks, media):
         return None
     a0 = blocks[0].attn
     E = a0.to_kv.weight.shape[0]
-    if any(b.attn.to_kv.weight.shape != a0.to_kv.weight.shape for b in blocks) or E % 256 or media.shape[-1] % 64 \
+    if any(b.attn.to_kv.weight.shape != a0.to_kv.weight.shape for b in blocks) or E % 256 or media.shape[-1] % 256 \
             or (media.shape[0] * media.shape[1] * media.shape[2]) % 256:
-        return None                       # not big-tile eligible: the blocks project on their own
+        return None                       # not big-tile eligible (forward: N = E, K = D_img; backward: N = D_img, K = E
+                                          # per group; both M = B*T*n): the blocks project on their own
     grp = MediaKVGroup(blocks, media)
     grp.E = E
     grp.token = _GroupedMediaKVFn.apply(grp, media)

@@ -599,7 +599,8 @@ def test_grouped_media_projections_match_per_block_projections():
     from open_flamingo_amd.train import step, synthetic, towers
     res = []
     for grouped in (False, True):
-        model, info = towers.build_flamingo("OF-tiny", device="cuda", seed=0, gates=0.5)
+        model, info = towers.build_flamingo("OF-tiny", device="cuda", seed=0, gates=0.5,
+                                            vision_kw=dict(width=256, layers=1, heads=2, patch=14, image=224))
         model.train()
         model.group_media_projections = grouped
         batch = synthetic.make_batch(2, 2, 24, info, "cuda", seed=5)
