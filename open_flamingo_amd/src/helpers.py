@@ -464,7 +464,8 @@ def group_media_projections(blocks, media):
     """Called by Flamingo._encode_vision_x under autograd on the GPU; blocks that find their media tensor here use the
     grouped projection (``GatedCrossAttentionBlock.forward``)."""
     blocks = [b for b in blocks if b is not None]
-    if len(blocks) < 2 or not can_group_media(media) or not torch.is_grad_enabled():
+    if len(blocks) < 2 or not can_group_media(media) or not torch.is_grad_enabled() \
+            or not all(isinstance(b, GatedCrossAttentionBlock) for b in blocks):
         return None
     a0 = blocks[0].attn
     E = a0.to_kv.weight.shape[0]

@@ -8,9 +8,10 @@ ops = Ops.default()
 def r(*s): return torch.randn(*s, device="cuda").to(torch.bfloat16)
 # dW1 = da^T u : (TN) M=8192 N=2048 K=8192 tokens, fp32 out
 A, B, C = r(8192, 8192), r(8192, 2048), torch.empty(8192, 2048, device="cuda")
-for _ in range(2): ops.gemm(A, B, C, ta=True, tb=True, epi=abi.EPI_ACC_F32)
-# the same launch accumulating into an existing gradient (beta = 1: what the training step runs since the weight
-# gradients are added in place into the reducer buckets) -- launches 3 and 4 of this kernel symbol
+for _ in range(2): ops.gemm(A, B, C, ta=True, tb=True, epi=abi.EPI_ACC_F32)      # beta = 0: what the training step runs
+# since the step epilogue leaves the weight gradients for the backward to overwrite (launches 1 and 2 of this symbol)
+# the same launch accumulating into an existing gradient (beta = 1: a second backward of the same optimizer step,
+# e.g. LAION + MMC4) -- launches 3 and 4 of this kernel symbol
 for _ in range(2): ops.gemm(A, B, C, ta=True, tb=True, epi=abi.EPI_ACC_F32, beta=1.0)
 # ffn down + gate + residual : (NT) M=8192 N=2048 K=8192
 A, W, res, out = r(8192, 8192), r(2048, 8192), torch.randn(8192, 2048, device="cuda"), torch.empty(8192, 2048, device="cuda")
