@@ -106,3 +106,78 @@ def test_reducer_and_train_step_world2():
         assert nz_rows <= 2, "embedding gradient must be masked to the <image>/<|endofchunk|> rows"
         assert same, "replicas diverged after train_step"
         assert nb == 2 + 6, "tiny model: 2 xattn block buckets + one bucket per Perceiver layer (depth 6)"
+
+
+def _worker_product_modules(rank, world, port, q):
+    """The PRODUCT modules (libofhip kernels on the host emulator) under a world-2 gloo group: gradients are accumulated in
+    place into the reducer's buckets, the Perceiver reports its layers as they finish (per-layer buckets), the step
+    epilogue leaves weight gradients for the next backward to overwrite, the grouped media projection is on."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from open_flamingo_amd.hip.ops import Ops
+    from open_flamingo_amd.src import helpers
+    from open_flamingo_amd.train import distributed, step, synthetic, towers
+    from open_flamingo_amd.train.optim import FlatAdamW
+    from open_flamingo_amd.train.reducer import GradReducer
+    from tests.emu import harness as H
+    helpers._require_hip = lambda t, what: None                  # test-only: kernels run on the host emulator
+    helpers.can_group_media = lambda media: True
+    Ops.default = staticmethod(H.emu_ops)
+    distributed.init_distributed_device(backend="gloo")
+    model, info = towers.build_flamingo("OF-tiny", device="cpu", seed=rank, gates=0.5, fused_lm_attention=False,
+                                        vision_kw=dict(width=256, layers=1, heads=2, patch=14, image=224))
+    model.train()
+    rows = [info["media_token_id"], info["eoc_token_id"]]
+    red = GradReducer(model, embedding_rows=rows)
+    red.broadcast_parameters()                                    # ranks started from different seeds on purpose
+    opt = FlatAdamW(red, lr=1e-3, ops=H.emu_ops())
+    launches = []
+    orig = red._launch
+    red._launch = lambda flat: (launches.append(flat.numel()), orig(flat))[1]
+    b_laion = synthetic.make_batch(2, 1, 16, info, "cpu", seed=10 + rank)
+    b_mmc4 = synthetic.make_batch(2, 2, 24, info, "cpu", seed=20 + rank)
+    # exchanged buckets == mean over ranks of the local buckets (a bucket exchanged before all of its gradients exist, or
+    # twice, would not be)
+    with red.no_sync():
+        step.forward_loss(model, b_mmc4, info, amp=False).backward()
+    want = []
+    for b in red.buckets:
+        t = b["flat"].clone()
+        dist.all_reduce(t)
+        want.append(t / world)
+    red.zero_grad()
+    step.forward_loss(model, b_mmc4, info, amp=False).backward()
+    red.finish()
+    bucket_err = max(((b["flat"] - w).abs().max() / (w.abs().max() + 1e-12)).item() for b, w in zip(red.buckets, want))
+    red.zero_grad()
+    launches.clear()
+    losses = [float(step.train_step(model, red, opt, b_mmc4, info, batch_laion=b_laion, amp=False)) for _ in range(2)]
+    per_step = len(launches) // 2
+    chk = torch.cat([p.detach().flatten()[:128] for p in model.parameters() if p.requires_grad]).double()
+    gathered = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(gathered, chk)
+    same = all(torch.equal(gathered[0], g) for g in gathered)
+    fresh = all(p._of_grad_fresh for b in red.buckets for p in b["overwritable"])
+    q.put((rank, losses, same, per_step, len(red.buckets), fresh, bucket_err))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_product_modules_world2_inplace_buckets_and_per_layer_exchange():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_product_modules, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=800) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, losses, same, per_step, nb, fresh, bucket_err in res:
+        assert bucket_err < 1e-5, f"rank {rank}: exchanged buckets differ from the mean of the local buckets ({bucket_err})"
+        assert same, f"rank {rank}: replicas diverged"
+        assert all(l == l for l in losses)
+        assert nb == 2 + 6 and per_step == nb + 1, (nb, per_step)     # one all-reduce per bucket + the two embedding rows, once per step
+        assert fresh, "the step epilogue must leave the nn.Linear gradients marked for overwrite"
