@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OF_ABI_VERSION 3
+#define OF_ABI_VERSION 4
 #define OF_E_ARG (-1)      /* null pointer / negative size */
 #define OF_E_SHAPE (-2)    /* shape not supported by the kernels (see each function) */
 #define OF_E_ALIGN (-3)    /* pointer or leading dimension not 16-byte aligned */
@@ -206,12 +206,17 @@ int of_add(const void* a, const void* b, void* out, int f32, long n, void* strea
  * Step epilogue over flat fp32 buffers: global-norm clip + AdamW, replacing
  * clip_grad_norm_ / optimizer.step / zero_grad of open_flamingo/train/train_utils.py:199-216 with the parameter
  * groups of open_flamingo/train/train.py:392-408.
- *   of_sumsq:       *acc += sum(g^2)   (acc zero-initialised by the caller; one call per gradient buffer)
+ *   of_sumsq_partial: partials[0..OF_SUMSQ_PARTS) = per-workgroup sums of g^2 (every slot written; one call per gradient
+ *                   buffer, each with its own OF_SUMSQ_PARTS slots);  of_sumsq_finish: *acc = sum of `count` partial slots in a
+ *                   fixed order.  Together they are the reference's clip_grad_norm_ total, with no floating-point atomics: the
+ *                   same gradients give the same bits on every rank and run, so replicas stay identical.
  *   of_adamw_clip:  the effective gradient is grad_scale * g (grad_scale = 1/world_size when g holds the all-reduced SUM);
  *                   coef = min(1, max_norm / (grad_scale * sqrt(*sumsq) + 1e-6)) (max_norm <= 0: no clipping);
  *                   torch.optim.AdamW update with gradient coef * grad_scale * g at 1-based `step`; p_bf16 (optional) receives the bf16 copy of the new
  *                   parameters; zero_grad != 0 clears g in the same pass.  No host synchronisation. */
-int of_sumsq(const float* g, long n, float* acc, void* stream);
+#define OF_SUMSQ_PARTS 512
+int of_sumsq_partial(const float* g, long n, float* partials, void* stream);
+int of_sumsq_finish(const float* partials, long count, float* acc, void* stream);
 int of_adamw_clip(float* p, float* g, float* m, float* v, uint16_t* p_bf16, long n, const float* sumsq,
                   float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                   int step, int zero_grad, void* stream);

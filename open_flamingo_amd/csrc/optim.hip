@@ -1,7 +1,10 @@
 // Step epilogue of the trainable parameters (gfx950, HBM-bound): global-norm gradient clipping + AdamW in two passes
 // over flat fp32 buffers, replacing  torch.nn.utils.clip_grad_norm_(params, 1.0); optimizer.step(); zero_grad()
 // of open_flamingo/train/train_utils.py:199-216 with the AdamW groups of open_flamingo/train/train.py:392-408.
-//   pass 1  of_sumsq:        *acc += sum g^2                                   (4 B/element)
+//   pass 1  of_sumsq_partial: OF_SUMSQ_PARTS per-workgroup partial sums of g^2 per buffer (4 B/element), then ONE
+//           of_sumsq_finish:  *acc = the partials of all buffers summed in a fixed order.  No floating-point atomics:
+//                             the clip coefficient is bit-identical on every rank and every run, so data-parallel
+//                             replicas cannot drift apart by an ulp of the global norm.
 //   pass 2  of_adamw_clip:   c = min(1, max_norm / (sqrt(*acc) + 1e-6));  g' = c g
 //                            p <- p (1 - lr wd);  m <- b1 m + (1-b1) g';  v <- b2 v + (1-b2) g'^2
 //                            p <- p - (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps)           (torch.optim.AdamW, eps outside
@@ -16,7 +19,7 @@ namespace {
 struct OptArgs {
     float* p; float* g; float* m; float* v; bf16_t* p_bf16;
     long n;
-    float* acc;            // sum of squares (device scalar)
+    float* acc;            // sum of squares (device scalar); of_sumsq_partial: the OF_SUMSQ_PARTS partial slots
     float max_norm, lr, beta1, beta2, eps, wd, bc1, bc2, grad_scale;
     int zero_grad;
 };
@@ -48,7 +51,19 @@ OF_GLOBAL void of_sumsq_kernel(OptArgs a) {
     const int tid = of_tid();
     if ((tid & 63) == 0) red[tid >> 6] = s;
     of_sync();
-    if (tid == 0) of_atomic_add(a.acc, red[0] + red[1] + red[2] + red[3]);
+    if (tid == 0) a.acc[of_bid_x()] = (red[0] + red[1]) + (red[2] + red[3]);   // workgroups without work store 0
+}
+
+// one workgroup: lane t sums slots t, t+256, ... in index order, then the fixed wave/LDS tree
+OF_GLOBAL void of_sumsq_finish_kernel(OptArgs a) {
+    float* red = (float*)of_smem();
+    float s = 0.f;
+    for (long i = of_tid(); i < a.n; i += 256) s += a.g[i];
+    s = of_wave_sum(s);
+    const int tid = of_tid();
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    of_sync();
+    if (tid == 0) *a.acc = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 OF_DEV float adamw_one(const OptArgs& a, float coef, float step_size, float inv_sqrt_bc2, float decay, float& p, float g,
@@ -106,16 +121,22 @@ unsigned opt_grid(long n) {
 
 }  // namespace
 
-extern "C" int of_sumsq(const float* g, long n, float* acc, void* stream) {
-    if (!g || !acc || n <= 0) return OF_E_ARG;
+extern "C" int of_sumsq_partial(const float* g, long n, float* partials, void* stream) {
+    if (!g || !partials || n <= 0) return OF_E_ARG;
     if ((uintptr_t)g & 15) return OF_E_ALIGN;
     OptArgs a{};
-    a.g = const_cast<float*>(g); a.n = n; a.acc = acc;
-    // every workgroup ends with ONE atomic on the same scalar and same-address device atomics serialise (~12 ns each):
-    // 4096 workgroups spent 49 us there for a 59-us launch (rocprofv3, round 2) -- two workgroups per CU are enough
-    unsigned grid = opt_grid(n);
-    if (grid > 512) grid = 512;
-    return of_launch(of_sumsq_kernel, of_dim3{grid, 1, 1}, 256, 4 * sizeof(float), (of_stream_t)stream, a);
+    a.g = const_cast<float*>(g); a.n = n; a.acc = partials;
+    // a fixed grid: the slot -> element assignment depends on n alone, never on the device or the launch.  Two
+    // workgroups per CU keep the HBM pipes full (round 2: one same-address atomic per workgroup cost 49 us of a 59-us
+    // launch at 4096 workgroups, which is how this kernel came to have few, fat workgroups).
+    return of_launch(of_sumsq_kernel, of_dim3{OF_SUMSQ_PARTS, 1, 1}, 256, 4 * sizeof(float), (of_stream_t)stream, a);
+}
+
+extern "C" int of_sumsq_finish(const float* partials, long count, float* acc, void* stream) {
+    if (!partials || !acc || count <= 0) return OF_E_ARG;
+    OptArgs a{};
+    a.g = const_cast<float*>(partials); a.n = count; a.acc = acc;
+    return of_launch(of_sumsq_finish_kernel, of_dim3{1, 1, 1}, 256, 4 * sizeof(float), (of_stream_t)stream, a);
 }
 
 extern "C" int of_adamw_clip(float* p, float* g, float* m, float* v, uint16_t* p_bf16, long n, const float* sumsq,

@@ -258,9 +258,28 @@ class Ops:
                                                   dst.data_ptr(), self._stream()), "of_reduce_rows_strided")
 
     # ------------------------------------------------------------------ step epilogue
-    def sumsq(self, g, acc):
-        assert g.dtype == F32 and g.is_contiguous() and acc.dtype == F32
-        self._chk(self.lib.of_sumsq(g.data_ptr(), g.numel(), acc.data_ptr(), self._stream()), "of_sumsq")
+    SUMSQ_PARTS = abi.OF_SUMSQ_PARTS
+
+    def sumsq_partial(self, g, partials):
+        """partials[0:SUMSQ_PARTS] = per-workgroup sums of g*g (deterministic: no floating-point atomics)."""
+        assert g.dtype == F32 and g.is_contiguous() and partials.dtype == F32 and partials.is_contiguous()
+        assert partials.numel() >= self.SUMSQ_PARTS
+        self._chk(self.lib.of_sumsq_partial(g.data_ptr(), g.numel(), partials.data_ptr(), self._stream()), "of_sumsq_partial")
+
+    def sumsq_finish(self, partials, acc):
+        """acc[0] = sum(partials) in a fixed order."""
+        assert partials.dtype == F32 and partials.is_contiguous() and acc.dtype == F32
+        self._chk(self.lib.of_sumsq_finish(partials.data_ptr(), partials.numel(), acc.data_ptr(), self._stream()), "of_sumsq_finish")
+
+    def sumsq(self, bufs, acc, scratch=None):
+        """acc[0] = sum over the buffers of sum(g*g): one partial launch per buffer + one finish."""
+        bufs = list(bufs)
+        if scratch is None or scratch.numel() < len(bufs) * self.SUMSQ_PARTS:
+            scratch = torch.empty(len(bufs) * self.SUMSQ_PARTS, dtype=F32, device=acc.device)
+        for i, g in enumerate(bufs):
+            self.sumsq_partial(g, scratch[i * self.SUMSQ_PARTS:(i + 1) * self.SUMSQ_PARTS])
+        self.sumsq_finish(scratch[:len(bufs) * self.SUMSQ_PARTS], acc)
+        return scratch
 
     def adamw_clip(self, p, g, m, v, sumsq, *, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=1.0,
                    p_bf16=None, zero_grad=True, grad_scale=1.0):

@@ -6,7 +6,7 @@ Replaces, with the same arithmetic, the reference's
 cross-attention parameters (open_flamingo/train/train.py:392-408).  Differences, all result-preserving:
 
 * parameters, gradients and both AdamW moments of a bucket are contiguous fp32 buffers (the ``nn.Parameter``s become
-  views), so one ``of_sumsq`` + one ``of_adamw_clip`` launch per bucket replace ~160 multi-tensor launches; the clip
+  views), so one ``of_sumsq_partial`` + one ``of_adamw_clip`` launch per bucket (plus one ``of_sumsq_finish``) replace ~160 multi-tensor launches; the clip
   coefficient is computed on the device, gradients are zeroed and the bf16 GEMM-operand copies of the new weights are
   written in the same pass (the modules pick them up instead of re-casting every step);
 * the input embedding: only the ``<image>`` / ``<|endofchunk|>`` rows ever receive gradient (train_utils.py:174-196) and
@@ -103,9 +103,6 @@ class FlatAdamW(torch.optim.Optimizer):
         dev = self.reducer.buckets[0]["flat"].device
         if self._sumsq is None:
             self._sumsq = torch.zeros(1, dtype=F32, device=dev)
-        self._sumsq.zero_()
-        for b in self.reducer.buckets:
-            ops.sumsq(b["flat"], self._sumsq)
         g_rows = None
         sparse = getattr(self.reducer, "sparse", None)
         if sparse is not None:                       # train/sparse_rows.py: the kept rows arrive directly
@@ -113,8 +110,10 @@ class FlatAdamW(torch.optim.Optimizer):
                 g_rows = sparse.grad_rows().contiguous()
         elif self.embedding is not None and self.embedding.grad is not None:
             g_rows = self.embedding.grad.index_select(0, self._emb["rows"]).contiguous()
-        if g_rows is not None:
-            ops.sumsq(g_rows, self._sumsq)
+        # global norm without floating-point atomics (of_sumsq_partial / of_sumsq_finish): every rank computes the same
+        # bits from the same all-reduced buffers, so the clip coefficient cannot differ between replicas
+        self._parts = ops.sumsq([b["flat"] for b in self.reducer.buckets] + ([g_rows] if g_rows is not None else []),
+                                self._sumsq, getattr(self, "_parts", None))
         for b, lr in ((b, self.param_groups[0 if b["wd"] else 1]["lr"]) for b in self.reducer.buckets):
             # front part: small vectors whose kernels ADD into the gradient -> cleared here; back part: weight matrices
             # the next backward overwrites (their "fresh" mark makes its dW GEMM run with beta = 0): no zero pass, and no

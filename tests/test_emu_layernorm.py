@@ -110,7 +110,7 @@ def test_layernorm_grouped_rows_and_second_gradient():
 
 
 def test_step_epilogue_matches_torch_adamw_with_clipping():
-    """of_sumsq + of_adamw_clip vs clip_grad_norm_ + torch.optim.AdamW over several steps, two parameter
+    """of_sumsq_partial/finish + of_adamw_clip vs clip_grad_norm_ + torch.optim.AdamW over several steps, two parameter
     groups (weight decay 0.1 / 0.0) sharing one global norm, odd sizes (vector body + scalar tail)."""
     ops = H.emu_ops()
     g = torch.Generator().manual_seed(3)
@@ -128,8 +128,10 @@ def test_step_epilogue_matches_torch_adamw_with_clipping():
         opt.step()
         acc = torch.zeros(1)
         gbuf = [gr.clone() * 4.0 for gr in grads]     # as if 4 ranks' gradients had been SUMMED: grad_scale = 1/4 undoes it
-        for gb in gbuf:
-            ops.sumsq(gb, acc)
+        ops.sumsq(gbuf, acc)
+        again = torch.zeros(1)
+        ops.sumsq(gbuf, again)
+        assert torch.equal(acc, again)      # fixed summation order: bit-identical on every call (and so on every rank)
         np.testing.assert_allclose(float(acc), 16.0 * sum(float((gr.double() ** 2).sum()) for gr in grads), rtol=1e-5)
         bf = [torch.zeros(n, dtype=torch.bfloat16) for n in sizes]
         for p, gb, m, v, wd, b16 in zip(ps, gbuf, ms, vs, wds, bf):
