@@ -97,12 +97,16 @@ XATTN_CASES = {
     "attend_all_previous": ([[1, 0, 0, 0, 1, 0, 0, 1, 0, 0, 0, 0], [0, 0, 1, 0, 0, 0, 1, 0, 0, 1, 0, 0]], 3, False, False, None),
     "cached_media_decode": ([[1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]], 3, True, True, 2),
     "no_media_locations_cached": (None, 3, True, True, 5),
+    # train/data.py:205-215 pads a sample's image list with all-zero images up to MAX_NUM_IMAGES: fewer <image> tokens than
+    # media slots, the unused slots hold zeros (the flag in position 5 zeroes media[b, t] for t >= number of <image> tokens)
+    "zero_padded_images": ([[1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]], 3, True, False, None, True),
 }
 
 
 def small_xattn(case, gates=None):
     dt = torch.float64
-    locs, T_img, only_imm, cached, t_txt = XATTN_CASES[case]
+    locs, T_img, only_imm, cached, t_txt = XATTN_CASES[case][:5]
+    zero_pad = len(XATTN_CASES[case]) > 5 and XATTN_CASES[case][5]
     m = ref.GatedCrossAttentionBlock(dim=32, dim_visual=24, dim_head=8, heads=2,
                                      only_attend_immediate_media=only_imm)
     st = load_seeded(m, 21, dt)
@@ -116,9 +120,13 @@ def small_xattn(case, gates=None):
         tag = f"{case}_gate{gates:g}"
     L = 12 if t_txt is None else t_txt
     x = rnd((2, L, 32), 22, dt).requires_grad_(True)
-    media = rnd((2, T_img, 4, 24), 23, dt).requires_grad_(True)
-    w = rnd((2, L, 32), 24, dt)
+    media = rnd((2, T_img, 4, 24), 23, dt)
     ml = None if locs is None else torch.tensor(locs, dtype=torch.bool)
+    if zero_pad:
+        for b in range(2):
+            media[b, int(ml[b].sum()):] = 0
+    media.requires_grad_(True)
+    w = rnd((2, L, 32), 24, dt)
     y = m(x, media, media_locations=ml, use_cached_media=cached)
     (y * w).sum().backward()
     save(f"small_xattn_{tag}.npz", **{"param." + k: v for k, v in st.items()}, x=x, media=media, w=w, y=y,
@@ -146,6 +154,21 @@ def full_perceiver():
     for k, v in m.named_parameters():
         out["gradsum." + k] = summarize(v.grad)
     save("full_perceiver.npz", seed_params=31, seed_x=32, seed_w=33, **out)
+
+
+def full_perceiver_b2t3():
+    """KAT-1 second shape of SURVEY 8c: x (2, 3, 1, 256, 1024)."""
+    dt = torch.float32
+    m = ref.PerceiverResampler(dim=1024)
+    load_seeded(m, 31, dt)
+    x = rnd((2, 3, 1, 256, 1024), 34, dt)
+    w = rnd((2, 3, 64, 1024), 35, dt)
+    y = m(x)
+    (y * w).sum().backward()
+    out = {"y.summary": summarize(y), "y.head": y[1, :, :4, :16].detach().numpy()}
+    for k, v in m.named_parameters():
+        out["gradsum." + k] = summarize(v.grad)
+    save("full_perceiver_b2t3.npz", seed_params=31, seed_x=34, seed_w=35, **out)
 
 
 def full_xattn():
@@ -222,6 +245,47 @@ def tiny_flamingo():
          **{"gradnorm." + k: v.norm() for k, v in grads.items() if "wte" not in k})
 
 
+def tiny_flamingo_generate_margins():
+    """Greedy generate() of the REAL reference on the tiny model with the per-step logit margins (top-1 minus top-2): a
+    bf16 implementation must reproduce every token until the first step whose margin is within bf16 noise of a tie."""
+    sys.modules.setdefault("open_clip", types.ModuleType("open_clip"))
+    sys.path.insert(0, "/root/reference")
+    from open_flamingo.src.flamingo import Flamingo as RefFlamingo
+    from open_flamingo.src.flamingo_lm import FlamingoLMMixin as RefMixin
+    from open_flamingo.src.utils import extend_instance as ref_extend
+    from open_flamingo_amd.train import synthetic, towers
+    from tests.cpu_model import tiny_cpu_flamingo
+
+    mine, info = tiny_cpu_flamingo(seed=0)
+    torch.manual_seed(123)
+    vision = towers.VisionStandIn(width=64, layers=2, heads=2, patch=14, image=224)
+    lm, attr = towers.build_lang_encoder("OF-tiny")
+    ref_extend(lm, RefMixin)
+    lm.set_decoder_layers_attr_name(attr)
+    refm = RefFlamingo(vision, lm, info["eoc_token_id"], info["media_token_id"], vis_dim=64,
+                       cross_attn_every_n_layers=info["every"])
+    refm.load_state_dict(mine.state_dict(), strict=True)
+    refm.eval()
+    batch = synthetic.make_batch(2, 2, 24, info, "cpu", seed=5)
+    toks, margins, scales = [], [], []
+    with torch.no_grad():
+        for prompt_len in (8, 13):
+            ids = batch["lang_x"][:1, :prompt_len]
+            for _ in range(10):         # greedy decoding step by step through the reference's forward
+                out = refm(vision_x=batch["vision_x"][:1], lang_x=ids, attention_mask=torch.ones_like(ids))
+                last = out.logits[0, -1].double()
+                top = last.topk(2)
+                toks.append(int(top.indices[0]))
+                margins.append(float(top.values[0] - top.values[1]))
+                scales.append(float(last.std()))
+                ids = torch.cat([ids, top.indices[:1].view(1, 1)], dim=1)
+            toks.append(-1)
+            margins.append(0.0)
+            scales.append(0.0)
+    save("tiny_flamingo_generate.npz", tokens=np.array(toks), margins=np.array(margins), logit_std=np.array(scales),
+         prompt_lens=np.array([8, 13]), steps=10)
+
+
 def checkpoint_keys():
     """the key set the reference's ``filter_state_dict_to_trainable`` (train_utils.py:299-333) leaves of
     the tiny reference Flamingo, with the LM input embeddings trainable (the default) and frozen
@@ -264,6 +328,12 @@ def checkpoint_keys():
 
 
 if __name__ == "__main__":
+    if "--round2" in sys.argv:          # fixtures added in round 2 (the earlier files stay byte-identical)
+        torch.set_num_threads(8)
+        small_xattn("zero_padded_images")
+        full_perceiver_b2t3()
+        tiny_flamingo_generate_margins()
+        sys.exit(0)
     if "--only-checkpoint-keys" in sys.argv:
         checkpoint_keys()
         sys.exit(0)

@@ -34,7 +34,7 @@ def make_bf16_weights(ops, P):
 
 def check_xattn(ops, dev, *, B=2, L=40, T=2, n=16, heads=2, d=64, Dv=48, stream_dtype=torch.float32, media_locs=None,
                 only_immediate=True, gates=(0.6, -0.4), seed=0, fwd_tol=1e-2, bwd_tol=3e-2, safe=0, inplace=False,
-                fresh=False):
+                fresh=False, zero_pad=False):
     m = O.OracleGatedCrossAttentionBlock(dim=d, dim_visual=Dv, heads=heads, dim_head=64,
                                          only_attend_immediate_media=only_immediate)
     st = O.seeded_state({k: tuple(v.shape) for k, v in m.state_dict().items()}, 100 + seed)
@@ -49,6 +49,9 @@ def check_xattn(ops, dev, *, B=2, L=40, T=2, n=16, heads=2, d=64, Dv=48, stream_
         media_locs[:, 2] = True
         media_locs[0, L // 2] = True
         media_locs[1, L - 3] = True
+    if zero_pad:                  # data.py:205-215: unused image slots are all-zero images
+        for bi in range(B):
+            media[bi, int(media_locs[bi].sum()):] = 0
     w = torch.randn(B, L, d, generator=g)
     if stream_dtype == torch.bfloat16:
         x = x.to(torch.bfloat16).float()
@@ -81,6 +84,10 @@ def check_xattn(ops, dev, *, B=2, L=40, T=2, n=16, heads=2, d=64, Dv=48, stream_
     errs = {"y": rel_err(y.reshape(B, L, d), yo.detach())}
     errs["dx"] = rel_err(dx.reshape(B, L, d), xo.grad)
     errs["dmedia"] = rel_err(dmedia.reshape(B, T, n, Dv), mo.grad)
+    if zero_pad:
+        for bi in range(B):
+            used = int(media_locs[bi].sum())
+            assert float(dmedia.reshape(B, T, n, Dv)[bi, used:].abs().max()) == 0.0 == float(mo.grad[bi, used:].abs().max())
     for k, p in m.named_parameters():
         errs["d" + k] = rel_err(grads[k], p.grad)
     bad = {k: v for k, v in errs.items() if v > (fwd_tol if k == "y" else bwd_tol) * (4 if stream_dtype == torch.bfloat16 else 1)}

@@ -72,3 +72,11 @@ def test_perceiver_backward_reports_layers_as_they_finish():
     names = {id(p): k for k, p in m.named_parameters()}
     order = [[names[id(p)] for p in g] for g in groups]
     assert len(order) == 3 and "norm.weight" in order[0] and order[0][0].startswith("layers.2.") and "latents" in order[-1]
+
+
+def test_xattn_zero_padded_images():
+    """KAT-3 zero-padded images (train/data.py:205-215) on the emulator: see tests/test_gpu_path.py."""
+    ml = torch.zeros(2, 40, dtype=torch.bool)
+    ml[0, [0, 12]] = True
+    ml[1, 0] = True
+    PC.check_xattn(H.emu_ops(), "cpu", T=3, media_locs=ml, seed=13, zero_pad=True)

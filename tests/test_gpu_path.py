@@ -327,6 +327,17 @@ def test_decode_step_hip_graph_matches_per_kernel_launches():
     del blk.decode_graphs
 
 
+def test_xattn_zero_padded_images(ops):
+    """KAT-3 "zero-padded images" (train/data.py:205-215 pads a sample's image list with all-zero images): fewer <image>
+    tokens than media slots, the unused slots hold zeros -- nothing attends to them, their media gradient is exactly 0."""
+    B, L, T, n, Dv, d = 2, 32, 3, 64, 128, 256
+    ml = torch.zeros(B, L, dtype=torch.bool)
+    ml[0, [0, 12]] = True          # 2 of 3 slots used
+    ml[1, 0] = True                # 1 of 3
+    errs = PC.check_xattn(ops, "cuda", B=B, L=L, T=T, n=n, heads=4, d=d, Dv=Dv, media_locs=ml, seed=13, zero_pad=True)
+    print(errs)
+
+
 def test_xattn_single_image_laion_shape(ops):
     """T = 1 (the LAION pass, train_utils.py:96): every token after the first <image> attends to the only media item."""
     ml = torch.zeros(2, 32, dtype=torch.bool)
@@ -501,15 +512,16 @@ def test_hip_path_against_reference_goldens_at_of3b_size(ops, golden_dir):
             assert abs(float(g[k]) - z["gradsum." + k][64]) <= 5e-2 * abs(z["gradsum." + k][64]) + 1e-3, k
         else:
             _close_to_reference_summary(g[k], z["gradsum." + k], k, 2e-2)
-    z = np.load(os.path.join(golden_dir, "full_perceiver.npz"))
-    pm = O.OraclePerceiverResampler(dim=1024)
-    pm.load_state_dict(O.seeded_state({k: tuple(v.shape) for k, v in pm.state_dict().items()}, int(z["seed_params"])))
-    yp, gp = PC.hip_perceiver(ops, pm, _rnd((1, 2, 1, 256, 1024), int(z["seed_x"])), _rnd((1, 2, 64, 1024), int(z["seed_w"])),
-                              heads=8, need_dx=False)
-    assert PC.rel_l2(yp[0, :, :4, :16], torch.from_numpy(z["y.head"])) < 1e-2
-    _close_to_reference_summary(yp, z["y.summary"], "perceiver y", 1e-2)
-    for k, _ in pm.named_parameters():
-        _close_to_reference_summary(gp[k], z["gradsum." + k], k, 2e-2)
+    for name, shape, head_b in (("full_perceiver.npz", (1, 2, 1, 256, 1024), 0), ("full_perceiver_b2t3.npz", (2, 3, 1, 256, 1024), 1)):
+        z = np.load(os.path.join(golden_dir, name))          # KAT-1 of SURVEY 8c, both shapes
+        pm = O.OraclePerceiverResampler(dim=1024)
+        pm.load_state_dict(O.seeded_state({k: tuple(v.shape) for k, v in pm.state_dict().items()}, int(z["seed_params"])))
+        yp, gp = PC.hip_perceiver(ops, pm, _rnd(shape, int(z["seed_x"])), _rnd((shape[0], shape[1], 64, 1024), int(z["seed_w"])),
+                                  heads=8, need_dx=False)
+        assert PC.rel_l2(yp[head_b, :, :4, :16], torch.from_numpy(z["y.head"])) < 1e-2
+        _close_to_reference_summary(yp, z["y.summary"], name + " y", 1e-2)
+        for k, _ in pm.named_parameters():
+            _close_to_reference_summary(gp[k], z["gradsum." + k], name + " " + k, 2e-2)
 
 
 def _rccl_rank(rank, world, port, q):

@@ -79,16 +79,18 @@ def _close_summary(a, b, name):
     np.testing.assert_allclose(a[65:], b[65:], rtol=2e-4, err_msg=name)
 
 
-def test_full_size_perceiver_matches_reference_summaries():
-    z = np.load(os.path.join(GOLD, "full_perceiver.npz"))
+@pytest.mark.parametrize("name,shape,head_b", [("full_perceiver.npz", (1, 2, 1, 256, 1024), 0),
+                                               ("full_perceiver_b2t3.npz", (2, 3, 1, 256, 1024), 1)])   # KAT-1, both shapes
+def test_full_size_perceiver_matches_reference_summaries(name, shape, head_b):
+    z = np.load(os.path.join(GOLD, name))
     m = O.OraclePerceiverResampler(dim=1024)
     st = O.seeded_state({k: tuple(v.shape) for k, v in m.state_dict().items()}, int(z["seed_params"]))
     m.load_state_dict(st, strict=True)
-    x = _rnd((1, 2, 1, 256, 1024), int(z["seed_x"]))
+    x = _rnd(shape, int(z["seed_x"]))
     y = m(x)
-    np.testing.assert_allclose(y[0, :, :4, :16].detach().numpy(), z["y.head"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(y[head_b, :, :4, :16].detach().numpy(), z["y.head"], rtol=2e-4, atol=2e-5)
     _close_summary(_summ(y), z["y.summary"], "y")
-    (y * _rnd((1, 2, 64, 1024), int(z["seed_w"]))).sum().backward()
+    (y * _rnd((shape[0], shape[1], 64, 1024), int(z["seed_w"]))).sum().backward()
     for k, v in m.named_parameters():
         _close_summary(_summ(v.grad), z["gradsum." + k], k)
 
