@@ -140,6 +140,12 @@ def main():
     ap.add_argument("--lm-attention", default="libofhip", choices=["libofhip", "sdpa", "eager"],
                     help="self-attention of the frozen MPT blocks: libofhip causal+ALiBi flash kernel, torch SDPA with a "
                          "bias, or HF's eager chain")
+    ap.add_argument("--lm-blocks", default="fused", choices=["fused", "modules"],
+                    help="frozen MPT blocks: one autograd node per block (train/frozen_blocks.py: residual adds fused into the "
+                         "LayerNorm kernels, no gradient casts / adds) or the HF modules with their pieces patched one by one")
+    ap.add_argument("--vision", default="libofhip", choices=["libofhip", "sdpa", "modules"],
+                    help="frozen CLIP tower: fused encoder forward (train/frozen_blocks.py) with this repository's attention kernel "
+                         "or torch SDPA, or the HF modules")
     ap.add_argument("--tower-layernorm", default="libofhip", choices=["libofhip", "eager"],
                     help="LayerNorms in front of the frozen towers' Linear layers: libofhip (bf16 operand written directly) or eager")
     ap.add_argument("--lm-loss", default="libofhip", choices=["libofhip", "hf"],
@@ -167,7 +173,9 @@ def main():
 
     model, info = towers.build_flamingo(args.family, device=device, seed=0, gates=0.5, frozen_bf16=not args.frozen_fp32,
                                         fused_lm_attention=args.lm_attention if args.lm_attention != "eager" else False,
-                                        tower_layernorm=args.tower_layernorm, lm_loss=args.lm_loss)
+                                        tower_layernorm=args.tower_layernorm, lm_loss=args.lm_loss,
+                                        fused_lm_blocks=args.lm_blocks == "fused" and not args.frozen_fp32,
+                                        fused_vision=False if (args.vision == "modules" or args.frozen_fp32) else args.vision)
     model.train()
     args.sparse_embedding_rows = not args.dense_embedding_rows and not args.torch_optimizer
     if args.sparse_embedding_rows:
@@ -278,6 +286,7 @@ def main():
                           "global_batch": args.batch * world, "images_per_step": images, "seq_len": args.L,
                           "parallelism": f"dp{world}",
                           "frozen_tower_weights": "fp32 (re-cast by autocast)" if args.frozen_fp32 else "bf16 copies held",
+                          "frozen_vision_tower": args.vision if not args.frozen_fp32 else "modules", "frozen_lm_blocks": args.lm_blocks if not args.frozen_fp32 else "modules",
                           "frozen_lm_attention": args.lm_attention, "frozen_tower_layernorm": args.tower_layernorm,
                           "lm_loss": args.lm_loss,
                           "grad_wire_dtype": "bf16" if args.wire_bf16 else "fp32",

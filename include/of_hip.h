@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OF_ABI_VERSION 4
+#define OF_ABI_VERSION 5
 #define OF_E_ARG (-1)      /* null pointer / negative size */
 #define OF_E_SHAPE (-2)    /* shape not supported by the kernels (see each function) */
 #define OF_E_ALIGN (-3)    /* pointer or leading dimension not 16-byte aligned */
@@ -113,6 +113,13 @@ int of_layernorm_fwd(const void* x, int x_f32, long ldx, const float* w, const f
                      float* stats, long rows, int dim, void* stream);
 int of_layernorm_fwd_out(const void* x, int x_f32, long ldx, const float* w, const float* b, void* y, int y_f32,
                          long ldy, float* stats, long rows, int dim, void* stream);
+/* Residual add + LayerNorm in one pass: s = x + add (add: bf16 branch output, row stride ldadd) is written to xsum in x's
+ * dtype (row stride ldsum; may alias x) and y = LN(s) in bf16 (y_f32 = 0) or fp32 -- "hidden = hidden + f(...); LN(hidden)"
+ * between two sub-layers of a frozen tower (HF MptBlock / CLIPEncoderLayer residual adds) without the
+ * separate mixed-dtype add kernel. */
+int of_layernorm_fwd_add(const void* x, int x_f32, long ldx, const uint16_t* add, long ldadd, void* xsum, long ldsum,
+                         const float* w, const float* b, void* y, int y_f32, long ldy, float* stats, long rows, int dim,
+                         void* stream);
 /* Grouped destination: row r is written at y + (r / grp_rows) * grp_stride + (r % grp_rows) * ldy (elements), so
  * LN_media(x) and LN_latents(latents) land directly in the [N][v+n][D] key/value input of helpers.py:53 without
  * a torch.cat copy.  y2 (optional) receives a second contiguous bf16 copy (the to_q operand, helpers.py:52). */

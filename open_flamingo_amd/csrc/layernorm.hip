@@ -15,6 +15,8 @@ struct LnArgs {
     void* y; int y_f32; long ldy;
     long y_grp_rows, y_grp_stride;   // grp_rows > 0: row r lands at (r / grp_rows) * grp_stride + (r % grp_rows) * ldy
     bf16_t* y2;                      // optional second, contiguous bf16 copy (row stride dim)
+    const bf16_t* add; long ldadd;   // optional bf16 branch output added to x before the statistics (x + add is the new
+    void* xsum; long ldsum;          //   residual stream, written to xsum in x's dtype): "x = x + f(x); LN(x)" in one pass
     float* stats;
     long rows; int dim;
     // backward
@@ -84,6 +86,13 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_ln_fwd_kernel(LnArgs a) {
             const int c = lane + j * 64;
             if (c < nchunk) {
                 load8(a.x, a.x_f32, xo + c * 8, v[j]);
+                if (a.add) {
+                    float t[8];
+                    load8(a.add, 0, (size_t)row * a.ldadd + c * 8, t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[j][e] += t[e];
+                    store8(a.xsum, a.x_f32, (size_t)row * a.ldsum + c * 8, v[j]);
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) sum += v[j][e];
             }
@@ -121,15 +130,16 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_ln_fwd_kernel(LnArgs a) {
     }
 }
 
-template <int CPL>
-OF_GLOBAL void OF_BOUNDS(256, (CPL > 5 ? 1 : 2)) of_ln_bwd_kernel(LnArgs a) {
+// RED = false: no dw/db (a frozen tower's LayerNorm): without the 16 * CPL column accumulators a row's working set fits
+// 128 registers, twice the waves per SIMD hide the row's one memory latency.
+template <int CPL, bool RED>
+OF_GLOBAL void OF_BOUNDS(256, (RED ? (CPL > 5 ? 1 : 2) : (CPL <= 2 ? 4 : (CPL <= 5 ? 3 : 2)))) of_ln_bwd_kernel(LnArgs a) {
     const int rpw = a.rpw;
     float* sw = (float*)of_smem();
     float* sb = sw + a.dim;
     const int tid = of_tid(), lane = tid & 63, wave = tid >> 6;
     const int nchunk = a.dim >> 3;
-    const bool red = a.dw != nullptr;
-    if (red) {
+    if constexpr (RED) {
         for (int c = tid; c < a.dim; c += 256) {
             sw[c] = 0.f;
             sb[c] = 0.f;
@@ -137,9 +147,9 @@ OF_GLOBAL void OF_BOUNDS(256, (CPL > 5 ? 1 : 2)) of_ln_bwd_kernel(LnArgs a) {
         of_sync();
     }
     const float inv_dim = 1.0f / (float)a.dim;
-    float aw[CPL][8], ab[CPL][8];
+    float aw[RED ? CPL : 1][8], ab[RED ? CPL : 1][8];
 #pragma unroll
-    for (int j = 0; j < CPL; ++j)
+    for (int j = 0; j < (RED ? CPL : 1); ++j)
 #pragma unroll
         for (int e = 0; e < 8; ++e) aw[j][e] = ab[j][e] = 0.f;
     const bool wr = a.dx || a.dx_bf16;
@@ -180,8 +190,10 @@ OF_GLOBAL void OF_BOUNDS(256, (CPL > 5 ? 1 : 2)) of_ln_bwd_kernel(LnArgs a) {
                 for (int e = 0; e < 8; ++e) {
                     const float wgt = e < 4 ? w0[e] : w1[e - 4];
                     xh[j][e] = (xh[j][e] - mean) * rstd;
-                    aw[j][e] += gv[j][e] * xh[j][e];
-                    ab[j][e] += gv[j][e];
+                    if constexpr (RED) {
+                        aw[j][e] += gv[j][e] * xh[j][e];
+                        ab[j][e] += gv[j][e];
+                    }
                     gv[j][e] *= wgt;
                     c1 += gv[j][e];
                     c2 += gv[j][e] * xh[j][e];
@@ -209,7 +221,7 @@ OF_GLOBAL void OF_BOUNDS(256, (CPL > 5 ? 1 : 2)) of_ln_bwd_kernel(LnArgs a) {
             }
         }
     }
-    if (red) {
+    if constexpr (RED) {
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
             const int c = lane + j * 64;
@@ -266,13 +278,13 @@ int pick_rpw(long rows, int cap) {
     return rpw;
 }
 
-#define OF_LN_DISPATCH(KERNEL)                                                                       \
-    if (a.dim <= 512) return of_launch(KERNEL<1>, grid, 256, smem, s, a);                      \
-    if (a.dim <= 1024) return of_launch(KERNEL<2>, grid, 256, smem, s, a);                     \
-    if (a.dim <= 1536) return of_launch(KERNEL<3>, grid, 256, smem, s, a);                     \
-    if (a.dim <= 2048) return of_launch(KERNEL<4>, grid, 256, smem, s, a);                     \
-    if (a.dim <= 2560) return of_launch(KERNEL<5>, grid, 256, smem, s, a);                     \
-    if (a.dim <= 4096) return of_launch(KERNEL<8>, grid, 256, smem, s, a);                     \
+#define OF_LN_DISPATCH(KERNEL, ...)                                                                  \
+    if (a.dim <= 512) return of_launch(KERNEL<1 __VA_ARGS__>, grid, 256, smem, s, a);           \
+    if (a.dim <= 1024) return of_launch(KERNEL<2 __VA_ARGS__>, grid, 256, smem, s, a);          \
+    if (a.dim <= 1536) return of_launch(KERNEL<3 __VA_ARGS__>, grid, 256, smem, s, a);          \
+    if (a.dim <= 2048) return of_launch(KERNEL<4 __VA_ARGS__>, grid, 256, smem, s, a);          \
+    if (a.dim <= 2560) return of_launch(KERNEL<5 __VA_ARGS__>, grid, 256, smem, s, a);          \
+    if (a.dim <= 4096) return of_launch(KERNEL<8 __VA_ARGS__>, grid, 256, smem, s, a);          \
     return OF_E_SHAPE;
 
 int launch_fwd(LnArgs a, of_stream_t s) {
@@ -286,8 +298,14 @@ long bwd_grid(long rows) {
     const long rows_per_block = 4L * pick_rpw(rows, 16);
     return (rows + rows_per_block - 1) / rows_per_block;
 }
+int launch_bwd_red(const LnArgs& a, of_dim3 grid, size_t smem, of_stream_t s) {
+    OF_LN_DISPATCH(of_ln_bwd_kernel, , true)
+}
+int launch_bwd_nored(const LnArgs& a, of_dim3 grid, size_t smem, of_stream_t s) {
+    OF_LN_DISPATCH(of_ln_bwd_kernel, , false)
+}
 int launch_bwd_main(const LnArgs& a, of_dim3 grid, size_t smem, of_stream_t s) {
-    OF_LN_DISPATCH(of_ln_bwd_kernel)
+    return a.dw ? launch_bwd_red(a, grid, smem, s) : launch_bwd_nored(a, grid, smem, s);
 }
 int launch_bwd(LnArgs a, float* workspace, size_t workspace_bytes, of_stream_t s) {
     a.rpw = pick_rpw(a.rows, 16);
@@ -312,12 +330,15 @@ int check_common(const void* x, long ldx, long rows, int dim) {
 }  // namespace
 
 static int ln_fwd_impl(const void* x, int x_f32, long ldx, const float* w, const float* b, void* y, int y_f32, long ldy,
-                       long grp_rows, long grp_stride, bf16_t* y2, float* stats, long rows, int dim, void* stream) {
+                       long grp_rows, long grp_stride, bf16_t* y2, float* stats, long rows, int dim, void* stream,
+                       const bf16_t* add = nullptr, long ldadd = 0, void* xsum = nullptr, long ldsum = 0) {
     int rc = check_common(x, ldx, rows, dim);
     if (rc) return rc;
     if (!w || !b || !y) return OF_E_ARG;
     if ((ldy & 7) || (grp_stride & 7) || ((uintptr_t)y & 15) || ((uintptr_t)y2 & 15)) return OF_E_ALIGN;
+    if ((ldadd & 7) || (ldsum & 7) || ((uintptr_t)add & 15) || ((uintptr_t)xsum & 15)) return OF_E_ALIGN;
     LnArgs a{};
+    a.add = add; a.ldadd = ldadd; a.xsum = xsum; a.ldsum = ldsum;
     a.x = x; a.x_f32 = x_f32; a.ldx = ldx; a.w = w; a.b = b; a.y = y; a.y_f32 = y_f32; a.ldy = ldy;
     a.y_grp_rows = grp_rows; a.y_grp_stride = grp_stride; a.y2 = y2;
     a.stats = stats; a.rows = rows; a.dim = dim;
@@ -327,6 +348,13 @@ static int ln_fwd_impl(const void* x, int x_f32, long ldx, const float* w, const
 extern "C" int of_layernorm_fwd_out(const void* x, int x_f32, long ldx, const float* w, const float* b, void* y,
                                     int y_f32, long ldy, float* stats, long rows, int dim, void* stream) {
     return ln_fwd_impl(x, x_f32, ldx, w, b, y, y_f32, ldy, 0, 0, nullptr, stats, rows, dim, stream);
+}
+
+extern "C" int of_layernorm_fwd_add(const void* x, int x_f32, long ldx, const uint16_t* add, long ldadd, void* xsum,
+                                    long ldsum, const float* w, const float* b, void* y, int y_f32, long ldy,
+                                    float* stats, long rows, int dim, void* stream) {
+    if (!add || !xsum) return OF_E_ARG;
+    return ln_fwd_impl(x, x_f32, ldx, w, b, y, y_f32, ldy, 0, 0, nullptr, stats, rows, dim, stream, add, ldadd, xsum, ldsum);
 }
 
 extern "C" int of_layernorm_fwd(const void* x, int x_f32, long ldx, const float* w, const float* b, uint16_t* y,

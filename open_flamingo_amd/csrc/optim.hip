@@ -32,13 +32,17 @@ OF_GLOBAL void of_sumsq_kernel(OptArgs a) {
     const long stride = (long)of_gdim_x() * 256;
     float s = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
     long i = (long)of_bid_x() * 256 + of_tid();
-    for (; i + 3 * stride < nv; i += 4 * stride) {   // four independent 16-byte loads in flight per lane
-        const f32x4 g0 = *(const f32x4*)(a.g + i * 4), g1 = *(const f32x4*)(a.g + (i + stride) * 4);
-        const f32x4 g2 = *(const f32x4*)(a.g + (i + 2 * stride) * 4), g3 = *(const f32x4*)(a.g + (i + 3 * stride) * 4);
-        s += g0[0] * g0[0] + g0[1] * g0[1] + g0[2] * g0[2] + g0[3] * g0[3];
-        s2 += g1[0] * g1[0] + g1[1] * g1[1] + g1[2] * g1[2] + g1[3] * g1[3];
-        s3 += g2[0] * g2[0] + g2[1] * g2[1] + g2[2] * g2[2] + g2[3] * g2[3];
-        s4 += g3[0] * g3[0] + g3[1] * g3[1] + g3[2] * g3[2] + g3[3] * g3[3];
+    for (; i + 7 * stride < nv; i += 8 * stride) {   // eight independent 16-byte loads in flight per lane (the grid is
+        f32x4 g[8];                                   // capped at OF_SUMSQ_PARTS workgroups: depth, not width, hides latency)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) g[u] = *(const f32x4*)(a.g + (i + u * stride) * 4);
+#pragma unroll
+        for (int u = 0; u < 8; u += 4) {
+            s += g[u][0] * g[u][0] + g[u][1] * g[u][1] + g[u][2] * g[u][2] + g[u][3] * g[u][3];
+            s2 += g[u + 1][0] * g[u + 1][0] + g[u + 1][1] * g[u + 1][1] + g[u + 1][2] * g[u + 1][2] + g[u + 1][3] * g[u + 1][3];
+            s3 += g[u + 2][0] * g[u + 2][0] + g[u + 2][1] * g[u + 2][1] + g[u + 2][2] * g[u + 2][2] + g[u + 2][3] * g[u + 2][3];
+            s4 += g[u + 3][0] * g[u + 3][0] + g[u + 3][1] * g[u + 3][1] + g[u + 3][2] * g[u + 3][2] + g[u + 3][3] * g[u + 3][3];
+        }
     }
     for (; i < nv; i += stride) {
         const f32x4 g = *(const f32x4*)(a.g + i * 4);

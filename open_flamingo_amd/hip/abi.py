@@ -5,7 +5,7 @@ Pure declarations: nothing here loads a library.  ``open_flamingo_amd.hip.lib`` 
 """
 import ctypes as C
 
-OF_ABI_VERSION = 4
+OF_ABI_VERSION = 5
 OF_SUMSQ_PARTS = 512
 EPI_STORE_BF16, EPI_GELU, EPI_GATE_RESID, EPI_DGELU_DOT, EPI_SCALE_DOT, EPI_ACC_F32 = range(6)
 
@@ -55,6 +55,8 @@ PROTOTYPES = {
     "of_layernorm_fwd": (C.c_int, [vp, C.c_int, C.c_long, vp, vp, vp, C.c_long, vp, C.c_long, C.c_int, vp]),
     "of_layernorm_fwd_out": (C.c_int, [vp, C.c_int, C.c_long, vp, vp, vp, C.c_int, C.c_long, vp, C.c_long,
                                        C.c_int, vp]),
+    "of_layernorm_fwd_add": (C.c_int, [vp, C.c_int, C.c_long, vp, C.c_long, vp, C.c_long, vp, vp, vp, C.c_int, C.c_long, vp,
+                                       C.c_long, C.c_int, vp]),
     "of_layernorm_fwd_grouped": (C.c_int, [vp, C.c_int, C.c_long, vp, vp, vp, C.c_long, C.c_long, C.c_long, vp, vp,
                                            C.c_long, C.c_int, vp]),
     "of_layernorm_bwd": (C.c_int, [vp, C.c_int, C.c_long, C.c_long, C.c_long, vp, vp, C.c_int, C.c_long, vp, vp, vp,

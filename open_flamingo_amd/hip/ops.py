@@ -151,6 +151,16 @@ class Ops:
                                                 y.data_ptr(), _is_f32(y), y.stride(0), _p(stats), rows, dim,
                                                 self._stream()), "of_layernorm_fwd_out")
 
+    def ln_fwd_add(self, x, add, xsum, w, b, y, stats):
+        """xsum = x + add (add bf16; xsum in x's dtype, may be x itself); y = LN(xsum) in y's dtype (bf16 / fp32)."""
+        rows, dim = x.shape
+        assert add.dtype == BF16 and add.shape == x.shape and xsum.dtype == x.dtype and xsum.shape == x.shape
+        assert add.stride(1) == 1 and xsum.stride(1) == 1 and y.stride(1) == 1
+        self._chk(self.lib.of_layernorm_fwd_add(x.data_ptr(), _is_f32(x), x.stride(0), add.data_ptr(), add.stride(0),
+                                                xsum.data_ptr(), xsum.stride(0), w.data_ptr(), b.data_ptr(), y.data_ptr(),
+                                                _is_f32(y), y.stride(0), _p(stats), rows, dim, self._stream()),
+                  "of_layernorm_fwd_add")
+
     def ln_fwd_grouped(self, x, w, b, y_base, ldy, grp_rows, grp_stride, y2, stats):
         """y_base: bf16 tensor whose data_ptr is the first destination row."""
         rows, dim = x.shape

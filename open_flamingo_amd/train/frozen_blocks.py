@@ -1,0 +1,240 @@
+"""Whole frozen transformer blocks as ONE autograd node each (the frozen half of the train step).
+
+The reference runs the frozen towers as stock modules (open_flamingo/src/flamingo_lm.py:63-65 calls the HF decoder layer,
+flamingo.py:194-195 the CLIP tower under no_grad).  Under amp_bf16 every residual add of those blocks is a separate
+mixed-dtype element-wise kernel (fp32 stream + bf16 branch), and the backward re-creates them as gradient adds and
+fp32 -> bf16 casts in front of every dX GEMM.  Nothing in a frozen block has a weight gradient, so the whole block is a
+fixed chain  LN -> GEMM -> attention -> GEMM -> (+, LN) -> GEMM -> GELU -> GEMM -> +  whose backward is the same chain
+reversed with dX GEMMs only.  Here that chain is written out once:
+
+  * the plain GEMMs stay on the vendor library (torch.mm -> hipBLASLt; frozen bf16 weights, no epilogue worth fusing:
+    DESIGN.md 4.1 measures this repository's fused GELU / residual epilogues at break-even against hipBLASLt + one
+    element-wise pass);
+  * LayerNorm, residual add + LayerNorm in one pass (of_layernorm_fwd_add), causal + ALiBi attention, and in backward
+    LayerNorm-backward + residual-gradient add + bf16 operand copy in one pass (of_layernorm_bwd) run on libofhip;
+  * no activation that only a weight gradient would need is kept.
+
+Arithmetic = the eager chain's: fp32 residual stream, bf16 GEMM operands and outputs, fp32 LayerNorm statistics, exact
+(erf) GELU on the bf16 pre-activation.  Anything the fused form does not cover (KV cache, dropout, trainable weights, fp32
+weights, no autocast, CPU tensors) takes the module's original forward.
+"""
+import types
+
+import torch
+from torch import nn
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _ops():
+    from ..hip.ops import Ops
+    return Ops.default()
+
+
+def _zero_bias(norm):
+    """HF MPT drops the LayerNorm bias; the kernels take one."""
+    b = norm.bias
+    if b is None:
+        b = norm.__dict__.get("_of_zero_bias")
+        if b is None or b.device != norm.weight.device:
+            b = norm.__dict__["_of_zero_bias"] = torch.zeros_like(norm.weight)
+    return b
+
+
+class _FrozenMptBlockFn(torch.autograd.Function):
+    """HF MptBlock (norm_1 -> Wqkv -> causal ALiBi attention -> out_proj -> + -> norm_2 -> up_proj -> GELU -> down_proj -> +)
+    with frozen weights.  x: (B, L, d) fp32 residual stream; returns the new stream (fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, Wqkv, Wo, Wup, Wdown, slopes, kv_len, heads, head_dim, scale):
+        ops = _ops()
+        B, L, d = x.shape
+        rows = B * L
+        x2 = x.reshape(rows, d)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        dev = x.device
+        a = torch.empty(rows, d, dtype=BF16, device=dev)
+        st1 = torch.empty(rows, 2, dtype=F32, device=dev)
+        ops.ln_fwd(x2, w1, b1, a, st1)
+        qkv = torch.mm(a, Wqkv.t())                                  # (rows, 3d) bf16: q | k | v column blocks
+        o = torch.empty(rows, d, dtype=BF16, device=dev)
+        lse = torch.empty(B, heads, L, dtype=F32, device=dev)
+        kw = dict(batch=B, Lq=L, Lk=L, heads=heads, scale=scale, head_dim=head_dim, causal=True, alibi_slopes=slopes,
+                  kv_len=kv_len)
+        ops.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, **kw)
+        t = torch.mm(o, Wo.t())
+        x1 = torch.empty(rows, d, dtype=F32, device=dev)
+        m = torch.empty(rows, d, dtype=BF16, device=dev)
+        st2 = torch.empty(rows, 2, dtype=F32, device=dev)
+        ops.ln_fwd_add(x2, t, x1, w2, b2, m, st2)                    # x1 = x + attn branch;  m = norm_2(x1)
+        h = torch.mm(m, Wup.t())
+        u = torch.mm(torch.nn.functional.gelu(h), Wdown.t())
+        y = torch.add(x1, u)                                         # fp32 stream + bf16 branch -> fp32
+        ctx.save_for_backward(x2, st1, qkv, o, lse, x1, st2, h, w1, w2, Wqkv, Wo, Wup, Wdown, slopes, kv_len)
+        ctx.kw, ctx.shape = kw, (B, L, d)
+        return y.view(B, L, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ops = _ops()
+        x2, st1, qkv, o, lse, x1, st2, h, w1, w2, Wqkv, Wo, Wup, Wdown, slopes, kv_len = ctx.saved_tensors
+        B, L, d = ctx.shape
+        rows = B * L
+        dev = dy.device
+        dy2 = dy.reshape(rows, d)
+        if dy2.dtype != F32 or not dy2.is_contiguous():
+            dy2 = dy2.to(F32).contiguous()
+        dact = torch.mm(ops.to_bf16(dy2), Wdown)                     # (rows, 4d)
+        dh = torch.ops.aten.gelu_backward(dact, h, approximate="none")
+        del dact
+        dm = torch.mm(dh, Wup)                                       # (rows, d)
+        del dh
+        dx1 = torch.empty(rows, d, dtype=F32, device=dev)
+        dx1b = torch.empty(rows, d, dtype=BF16, device=dev)
+        ops.ln_bwd(dm, x1, st2, w2, resid=dy2, dx=dx1, dx_bf16=dx1b)  # dx1 = dy + norm_2'(dm), plus its bf16 operand copy
+        do = torch.mm(dx1b, Wo)
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty(B, ctx.kw["heads"], L, dtype=F32, device=dev)
+        ops.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, do, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
+                     delta, **ctx.kw)
+        da = torch.mm(dqkv, Wqkv)                                    # (rows, d)
+        ops.ln_bwd(da, x2, st1, w1, resid=dx1, dx=dx1)               # in place: dx = dx1 + norm_1'(da)
+        return (dx1.view(B, L, d),) + (None,) * 13
+
+
+def _frozen_bf16(*linears):
+    return all(lin.bias is None and lin.weight.dtype == BF16 and not lin.weight.requires_grad for lin in linears)
+
+
+def _mpt_block_fused_forward(self, hidden_states, position_bias, attention_mask, layer_past=None, use_cache=False,
+                             output_attentions=False, **kwargs):
+    attn, ffn = self.attn, self.ffn
+    x = hidden_states
+    ok = (layer_past is None and not output_attentions and position_bias is not None and position_bias.shape[-1] >= 2
+          and x.dim() == 3 and x.dtype == F32 and (x.is_cuda or getattr(self, "_of_allow_cpu", False))
+          and x.shape[-1] % 8 == 0 and x.shape[-1] <= 4096 and attn.head_dim in (64, 128) and not attn.clip_qkv
+          and not (self.training and (self.dropout_rate > 0.0 or attn.attn_dropout_p > 0.0 or ffn.hidden_dropout > 0.0))
+          and _frozen_bf16(attn.Wqkv, attn.out_proj, ffn.up_proj, ffn.down_proj)
+          and not self.norm_1.weight.requires_grad and not self.norm_2.weight.requires_grad
+          and self.norm_1.weight.dtype == F32 and abs(self.norm_1.eps - 1e-5) < 1e-12 and abs(self.norm_2.eps - 1e-5) < 1e-12
+          and isinstance(ffn.act, nn.GELU) and ffn.act.approximate == "none"
+          and (getattr(self, "_of_allow_cpu", False)
+               or (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == BF16)))
+    if not ok:
+        return self._of_eager_forward(hidden_states, position_bias, attention_mask, layer_past=layer_past,
+                                      use_cache=use_cache, output_attentions=output_attentions, **kwargs)
+    from .towers import _alibi_slopes_and_lens
+    slopes, lens = _alibi_slopes_and_lens(position_bias, attention_mask, x.shape[1])
+    y = _FrozenMptBlockFn.apply(x, self.norm_1.weight, _zero_bias(self.norm_1), self.norm_2.weight, _zero_bias(self.norm_2),
+                                attn.Wqkv.weight, attn.out_proj.weight, ffn.up_proj.weight, ffn.down_proj.weight,
+                                slopes, lens, attn.n_heads, attn.head_dim, float(attn.softmax_scale))
+    return y, None
+
+
+def use_fused_frozen_mpt_blocks(lm, allow_cpu=False):
+    """Route every HF MptBlock of ``lm`` through _FrozenMptBlockFn when its weights are frozen bf16 copies (see
+    towers.hold_frozen_linears_in_bf16) and the call is a plain training / scoring forward; the module keeps its class,
+    parameters and state-dict keys.  ``allow_cpu``: tests only (the host-emulator build of the kernels)."""
+    n = 0
+    for mod in lm.modules():
+        if type(mod).__name__ == "MptBlock":
+            if not hasattr(mod, "_of_eager_forward"):
+                mod._of_eager_forward = mod.forward
+                mod.forward = types.MethodType(_mpt_block_fused_forward, mod)
+            mod._of_allow_cpu = bool(allow_cpu)
+            n += 1
+    return n
+
+
+# ------------------------------------------------------------------------------------------------ CLIP vision tower
+def _fused_qkv(attn):
+    """(3D, D) weight and (3D,) bias of the three projections of one CLIPAttention as ONE GEMM operand (the three eager
+    GEMMs read the same LayerNorm output); cached on the module, rebuilt when a source tensor is replaced or modified."""
+    srcs = (attn.q_proj.weight, attn.k_proj.weight, attn.v_proj.weight, attn.q_proj.bias, attn.k_proj.bias, attn.v_proj.bias)
+    key = tuple((t.data_ptr(), t._version) for t in srcs)
+    hit = attn.__dict__.get("_of_qkv")
+    if hit is None or hit[0] != key:
+        hit = attn.__dict__["_of_qkv"] = (key, torch.cat(srcs[:3], 0).contiguous(), torch.cat(srcs[3:], 0).contiguous())
+    return hit[1], hit[2]
+
+
+def _clip_layer_ok(layer):
+    at, mlp = layer.self_attn, layer.mlp
+    lins = (at.q_proj, at.k_proj, at.v_proj, at.out_proj, mlp.fc1, mlp.fc2)
+    return (all(lin.bias is not None and lin.weight.dtype == BF16 and lin.bias.dtype == BF16
+                and not lin.weight.requires_grad for lin in lins)
+            and at.head_dim in (64, 128) and type(mlp.activation_fn).__name__ == "QuickGELUActivation"
+            and all(n.weight.dtype == F32 and n.bias is not None and abs(n.eps - 1e-5) < 1e-12
+                    for n in (layer.layer_norm1, layer.layer_norm2)))
+
+
+def clip_encoder_fused(encoder, x, attention="libofhip"):
+    """All CLIPEncoderLayers of a frozen tower, forward only (flamingo.py:194-195 runs the tower under no_grad), on the fp32
+    stream x (N, S, D).  Returns (stream, pending): the stream BEFORE the last MLP branch is added and that bf16 branch
+    output -- the caller folds the last add into whatever LayerNorm comes next (of_layernorm_fwd_add).
+    Per layer: LN (or add + LN) -> ONE q|k|v GEMM with bias -> attention -> out_proj -> add + LN -> fc1 -> quick-GELU -> fc2;
+    every residual add rides in a LayerNorm pass, no q/k/v/context transposes."""
+    ops = _ops()
+    N, S, D = x.shape
+    rows = N * S
+    dev = x.device
+    x2 = x.reshape(rows, D)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    a = torch.empty(rows, D, dtype=BF16, device=dev)
+    xs = None                       # our own stream buffer (x is never written)
+    pending = None
+    for layer in encoder.layers:
+        at, mlp = layer.self_attn, layer.mlp
+        n1, n2 = layer.layer_norm1, layer.layer_norm2
+        if pending is None:
+            ops.ln_fwd(x2, n1.weight, n1.bias, a, None)
+        else:
+            ops.ln_fwd_add(xs, pending, xs, n1.weight, n1.bias, a, None)
+        w, b = _fused_qkv(at)
+        qkv = torch.addmm(b, a, w.t())                                   # (rows, 3D)
+        H, dh = at.num_heads, at.head_dim
+        if attention == "libofhip":
+            o = torch.empty(rows, D, dtype=BF16, device=dev)
+            lse = torch.empty(N, H, S, dtype=F32, device=dev)
+            ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, lse, batch=N, Lq=S, Lk=S, heads=H,
+                         scale=float(at.scale), head_dim=dh)
+        else:
+            q, k, v = (qkv[:, i * D:(i + 1) * D].view(N, S, H, dh).transpose(1, 2) for i in range(3))
+            o = torch.nn.functional.scaled_dot_product_attention(q, k, v, scale=float(at.scale))
+            o = o.transpose(1, 2).reshape(rows, D)
+        t = torch.addmm(at.out_proj.bias, o, at.out_proj.weight.t())
+        src = x2 if xs is None else xs
+        if xs is None:
+            xs = torch.empty(rows, D, dtype=F32, device=dev)
+        ops.ln_fwd_add(src, t, xs, n2.weight, n2.bias, a, None)          # xs = stream + attention branch; a = LN2(xs)
+        h = torch.addmm(mlp.fc1.bias, a, mlp.fc1.weight.t())
+        pending = torch.addmm(mlp.fc2.bias, ops.quick_gelu(h), mlp.fc2.weight.t())
+    return xs, pending
+
+
+def clip_tower_tokens_fused(vm, pixel_values, attention="libofhip"):
+    """post_layernorm(encoder(pre_layrnorm(embeddings(pixels)))) for a frozen HF CLIP vision tower whose Linear weights are
+    held in bf16, or None when the fused form does not apply (the caller then runs the modules)."""
+    layers = vm.encoder.layers
+    x = pixel_values
+    if (torch.is_grad_enabled() and any(p.requires_grad for p in vm.parameters())) or not (x.is_cuda or getattr(vm, "_of_allow_cpu", False)):
+        return None
+    if not getattr(vm, "_of_allow_cpu", False) and not (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == BF16):
+        return None
+    if len(layers) == 0 or not all(_clip_layer_ok(layer) for layer in layers):
+        return None
+    post = vm.post_layernorm
+    D = post.weight.shape[0]
+    if post.weight.dtype != F32 or post.bias is None or abs(post.eps - 1e-5) > 1e-12 or D % 8 or D > 4096:
+        return None
+    h = vm.pre_layrnorm(vm.embeddings(pixel_values))
+    if h.dtype != F32:
+        h = h.float()
+    N, S, _ = h.shape
+    xs, pending = clip_encoder_fused(vm.encoder, h, attention=attention)
+    y = torch.empty(N * S, D, dtype=F32, device=h.device)
+    _ops().ln_fwd_add(xs, pending, xs, post.weight, post.bias, y, None)   # last residual add + post_layernorm, fp32 out
+    return y.view(N, S, D)

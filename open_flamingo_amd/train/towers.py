@@ -50,7 +50,7 @@ class ClipVisualStandIn(nn.Module):
     """``visual(x) -> (pooled, tokens)`` like open_clip's VisionTransformer with output_tokens=True
     (reference factory.py:48, flamingo.py:195): tokens = ln_post(transformer(x))[:, 1:]."""
 
-    def __init__(self, width=1024, layers=24, heads=16, patch=14, image=224, mlp=None, patch_embed="gemm"):
+    def __init__(self, width=1024, layers=24, heads=16, patch=14, image=224, mlp=None, patch_embed="gemm", fused=False):
         super().__init__()
         from transformers import CLIPVisionConfig, CLIPVisionModel
         cfg = CLIPVisionConfig(hidden_size=width, intermediate_size=mlp or 4 * width, num_hidden_layers=layers,
@@ -60,10 +60,16 @@ class ClipVisualStandIn(nn.Module):
             emb = getattr(self.model, "vision_model", self.model).embeddings
             emb.patch_embedding = PatchEmbedAsGemm(emb.patch_embedding)
         self.width = width
+        self.fused = fused          # False | "libofhip" | "sdpa": train/frozen_blocks.py::clip_tower_tokens_fused, attention kernel
 
     def forward(self, x):
         m = self.model
         vm = getattr(m, "vision_model", m)       # transformers < 5 nests the tower under .vision_model
+        if self.fused:
+            from .frozen_blocks import clip_tower_tokens_fused
+            h = clip_tower_tokens_fused(vm, x, attention=self.fused)
+            if h is not None:
+                return h[:, 0], h[:, 1:]
         h = vm.post_layernorm(m(pixel_values=x).last_hidden_state)
         return h[:, 0], h[:, 1:]
 
@@ -380,7 +386,7 @@ def hold_frozen_linears_in_bf16(model):
 
 def build_flamingo(family: str = "OF-3B", device="cuda", seed: int = 0, gates: float = 0.5, vision_kw=None,
                    freeze_lm_embeddings: bool = False, verbose: bool = False, frozen_bf16: bool = False,
-                   fused_lm_attention=True, tower_layernorm="eager", lm_loss="hf"):
+                   fused_lm_attention=True, tower_layernorm="eager", lm_loss="hf", fused_lm_blocks=False, fused_vision=False):
     """Random-init Flamingo of the given family, assembled through the factory path, gates set to ``gates``
     (their init value 0 makes the hot path an exact no-op with zero weight gradients -- SURVEY.md section 7)."""
     from ..src.factory import assemble_flamingo
@@ -404,6 +410,11 @@ def build_flamingo(family: str = "OF-3B", device="cuda", seed: int = 0, gates: f
         use_libofhip_quick_gelu(model.vision_encoder)
     if lm_loss == "libofhip":
         use_libofhip_lm_loss(model.lang_encoder)
+    if fused_vision:                       # the CLIP tower's encoder as one fused forward (train/frozen_blocks.py)
+        model.vision_encoder.fused = fused_vision
+    if fused_lm_blocks:                    # whole frozen MPT blocks as one autograd node each (train/frozen_blocks.py)
+        from .frozen_blocks import use_fused_frozen_mpt_blocks
+        use_fused_frozen_mpt_blocks(model.lang_encoder)
     with torch.no_grad():
         for blk in model.lang_encoder.gated_cross_attn_layers:
             if blk is not None:

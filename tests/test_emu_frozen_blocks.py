@@ -1,0 +1,136 @@
+"""Frozen-tower blocks as single autograd nodes (open_flamingo_amd/train/frozen_blocks.py) executed on CPU
+with the libofhip kernels on the host SIMT emulator (tests/emu -- TEST INFRASTRUCTURE ONLY) against the HF modules' own
+eager forward / autograd under bf16 autocast: same logits, same gradient back to the input embeddings."""
+import pytest
+import torch
+
+from open_flamingo_amd.hip.ops import Ops
+from open_flamingo_amd.train import frozen_blocks, towers
+from tests.emu import harness as H
+
+
+@pytest.fixture
+def on_emulator(monkeypatch):
+    monkeypatch.setattr(Ops, "default", staticmethod(H.emu_ops))
+    yield
+
+
+def _rel(a, b):
+    return (a.double() - b.double()).norm().item() / (b.double().norm().item() + 1e-30)
+
+
+def test_layernorm_fwd_add_matches_torch(on_emulator):
+    torch.manual_seed(0)
+    ops = Ops.default()
+    for dim, xdt, ydt in ((256, torch.float32, torch.bfloat16), (640, torch.float32, torch.float32), (128, torch.bfloat16, torch.bfloat16)):
+        rows = 37
+        x = torch.randn(rows, dim).to(xdt)
+        add = torch.randn(rows, dim).to(torch.bfloat16)
+        w, b = torch.randn(dim), torch.randn(dim)
+        xsum = torch.empty_like(x)
+        y = torch.empty(rows, dim, dtype=ydt)
+        st = torch.empty(rows, 2)
+        ops.ln_fwd_add(x, add, xsum, w, b, y, st)
+        want_sum = (x.float() + add.float()).to(xdt)
+        assert torch.equal(xsum, want_sum)
+        # statistics are taken over the fp32 sum (before it is rounded to a bf16 stream, like a fused add would)
+        s = x.float() + add.float()
+        want = torch.nn.functional.layer_norm(s, (dim,), w, b, 1e-5)
+        assert torch.allclose(y.float(), want, atol=2e-2 if ydt == torch.bfloat16 else 2e-5, rtol=1e-2 if ydt == torch.bfloat16 else 1e-5)
+        assert torch.allclose(st[:, 0], s.mean(-1), atol=1e-5)
+        # in place: xsum may alias x
+        x2 = x.clone()
+        ops.ln_fwd_add(x2, add, x2, w, b, y, st)
+        assert torch.equal(x2, want_sum)
+
+
+def test_layernorm_bwd_without_parameter_gradients_matches_with(on_emulator):
+    """The dw/db-free instantiation (frozen towers) returns the same dx / bf16 copy as the reducing one."""
+    torch.manual_seed(0)
+    ops = Ops.default()
+    for dim in (256, 1024, 2048):
+        rows = 19
+        x = torch.randn(rows, dim)
+        w, b = torch.randn(dim), torch.zeros(dim)
+        y = torch.empty(rows, dim, dtype=torch.bfloat16)
+        st = torch.empty(rows, 2)
+        ops.ln_fwd(x, w, b, y, st)
+        dy = torch.randn(rows, dim).to(torch.bfloat16)
+        resid = torch.randn(rows, dim)
+        outs = []
+        for red in (False, True):
+            dx, dxb = torch.empty(rows, dim), torch.empty(rows, dim, dtype=torch.bfloat16)
+            kw = dict(dw=torch.zeros(dim), db=torch.zeros(dim)) if red else {}
+            ops.ln_bwd(dy, x, st, w, resid=resid, dx=dx, dx_bf16=dxb, **kw)
+            outs.append((dx, dxb))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        xr = x.clone().requires_grad_(True)
+        torch.nn.functional.layer_norm(xr, (dim,), w, b, 1e-5).backward(dy.float())
+        assert torch.allclose(outs[0][0], xr.grad + resid, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("d,heads", [(128, 2), (256, 2)])      # head dim 64 and 128
+def test_fused_frozen_mpt_block_matches_hf_eager(on_emulator, d, heads):
+    from transformers import MptConfig, MptForCausalLM
+    torch.manual_seed(0)
+    lm = MptForCausalLM(MptConfig(d_model=d, n_heads=heads, n_layers=2, vocab_size=128, max_seq_len=64))
+    lm.requires_grad_(False)
+    for mod in lm.modules():       # what towers.hold_frozen_linears_in_bf16 does to the frozen Linear layers
+        if isinstance(mod, torch.nn.Linear) and mod is not lm.get_output_embeddings():
+            mod.weight.data = mod.weight.data.to(torch.bfloat16)
+    ids = torch.randint(0, 128, (3, 40))
+    am = torch.ones(3, 40, dtype=torch.long)
+    am[1, 30:] = 0
+    am[2, 17:] = 0
+
+    def run():
+        emb = lm.get_input_embeddings()(ids).detach().requires_grad_(True)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            out = lm(inputs_embeds=emb, attention_mask=am, use_cache=False).logits
+        valid = am.bool()[..., None]
+        (out.float() * valid).square().mean().backward()
+        return out.float().detach() * valid, emb.grad.detach() * valid
+
+    ref_o, ref_g = run()
+    assert frozen_blocks.use_fused_frozen_mpt_blocks(lm, allow_cpu=True) == 2
+    calls = []
+    orig = frozen_blocks._FrozenMptBlockFn.apply
+    frozen_blocks._FrozenMptBlockFn.apply = staticmethod(lambda *a: (calls.append(1), orig(*a))[1])
+    try:
+        got_o, got_g = run()
+    finally:
+        frozen_blocks._FrozenMptBlockFn.apply = orig
+    assert len(calls) == 2, "the fused path must have been taken by both blocks"
+    assert _rel(got_o, ref_o) < 2e-2, _rel(got_o, ref_o)
+    assert _rel(got_g, ref_g) < 3e-2, _rel(got_g, ref_g)
+    # a call the fused form does not cover (KV cache) goes through the module's own forward
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        out = lm(input_ids=ids[:1, :5], use_cache=True)
+    assert out.past_key_values is not None
+
+
+@pytest.mark.parametrize("attention", ["libofhip", "sdpa"])
+def test_fused_clip_tower_matches_hf_modules(on_emulator, attention):
+    """The frozen CLIP tower's fused forward (one q|k|v GEMM, residual adds inside the LayerNorm passes, last add folded into
+    post_layernorm) vs the HF modules under bf16 autocast."""
+    torch.manual_seed(0)
+    vis = towers.ClipVisualStandIn(width=128, layers=3, heads=2, patch=14, image=56)     # head dim 64, 17 tokens (ragged)
+    vis.requires_grad_(False)
+    for mod in vis.modules():
+        if isinstance(mod, torch.nn.Linear):
+            mod.weight.data = mod.weight.data.to(torch.bfloat16)
+            mod.bias.data = mod.bias.data.to(torch.bfloat16)
+    x = torch.randn(3, 3, 56, 56)
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        ref_pooled, ref_tok = vis(x)
+        vm = getattr(vis.model, "vision_model", vis.model)
+        vm._of_allow_cpu = True
+        vis.fused = attention
+        got_pooled, got_tok = vis(x)
+        assert got_tok.dtype == torch.float32 and got_tok.shape == ref_tok.shape
+        assert _rel(got_tok, ref_tok) < 2e-2, _rel(got_tok, ref_tok)
+        assert _rel(got_pooled, ref_pooled) < 2e-2
+        # a tower the fused form does not cover (fp32 weights) runs its modules
+        vis.model.float()
+        from open_flamingo_amd.train.frozen_blocks import clip_tower_tokens_fused
+        assert clip_tower_tokens_fused(vm, x) is None

@@ -166,6 +166,96 @@ def test_frozen_mpt_attention_kernel_matches_hf_eager(ops, d, heads):
     assert PC.rel_err(got_g, ref_g) < 5e-2, PC.rel_err(got_g, ref_g)
 
 
+@pytest.mark.parametrize("d,heads", [(256, 4), (512, 4)])      # head dim 64 and 128
+def test_fused_frozen_mpt_block_matches_hf_eager(ops, d, heads):
+    """whole frozen MPT blocks as one autograd node each (train/frozen_blocks.py: residual adds inside the
+    LayerNorm passes, dX-only backward with fused gradient adds) vs the HF modules' eager forward / autograd under
+    autocast(bf16), with right padding: logits and the gradient that reaches the input embeddings."""
+    from transformers import MptConfig, MptForCausalLM
+    from open_flamingo_amd.train import frozen_blocks
+    torch.manual_seed(0)
+    lm = MptForCausalLM(MptConfig(d_model=d, n_heads=heads, n_layers=2, vocab_size=512, max_seq_len=256)).cuda()
+    lm.requires_grad_(False)
+    for mod in lm.modules():
+        if isinstance(mod, torch.nn.Linear) and mod is not lm.get_output_embeddings():
+            mod.weight.data = mod.weight.data.to(torch.bfloat16)
+    ids = torch.randint(0, 512, (3, 80), device="cuda")
+    am = torch.ones(3, 80, dtype=torch.long, device="cuda")
+    am[1, 60:] = 0
+    am[2, 33:] = 0
+
+    def run():
+        emb = lm.get_input_embeddings()(ids).detach().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = lm(inputs_embeds=emb, attention_mask=am, use_cache=False).logits
+        valid = am.bool()[..., None]
+        (out.float() * valid).square().mean().backward()
+        return out.float().detach() * valid, emb.grad.detach() * valid
+
+    ref_o, ref_g = run()
+    assert frozen_blocks.use_fused_frozen_mpt_blocks(lm) == 2
+    calls = []
+    orig = frozen_blocks._FrozenMptBlockFn.apply
+    frozen_blocks._FrozenMptBlockFn.apply = staticmethod(lambda *a: (calls.append(1), orig(*a))[1])
+    try:
+        got_o, got_g = run()
+    finally:
+        frozen_blocks._FrozenMptBlockFn.apply = orig
+    assert len(calls) == 2
+    assert PC.rel_err(got_o, ref_o) < 3e-2, PC.rel_err(got_o, ref_o)
+    assert PC.rel_err(got_g, ref_g) < 5e-2, PC.rel_err(got_g, ref_g)
+
+
+@pytest.mark.parametrize("attention", ["libofhip", "sdpa"])
+def test_fused_clip_tower_matches_hf_modules(ops, attention):
+    """the frozen CLIP tower's fused forward vs the HF modules under autocast(bf16), ViT-L/14-like widths
+    (head dim 64, 257 tokens: the ragged last query / key block of the attention kernel)."""
+    from open_flamingo_amd.train import towers
+    torch.manual_seed(0)
+    vis = towers.ClipVisualStandIn(width=256, layers=3, heads=4, patch=14, image=224).cuda()
+    vis.requires_grad_(False)
+    for mod in vis.modules():
+        if isinstance(mod, torch.nn.Linear):
+            mod.weight.data = mod.weight.data.to(torch.bfloat16)
+            mod.bias.data = mod.bias.data.to(torch.bfloat16)
+    x = torch.randn(5, 3, 224, 224, device="cuda")
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        ref_pooled, ref_tok = vis(x)
+        vis.fused = attention
+        got_pooled, got_tok = vis(x)
+    assert got_tok.dtype == torch.float32 and got_tok.shape == ref_tok.shape == (5, 256, 256)
+    assert PC.rel_err(got_tok, ref_tok) < 2e-2, PC.rel_err(got_tok, ref_tok)
+    assert PC.rel_err(got_pooled, ref_pooled) < 2e-2
+
+
+def test_layernorm_fwd_add_and_parameter_free_backward(ops):
+    torch.manual_seed(0)
+    for dim in (1024, 2048, 2560, 4096):
+        rows = 1000
+        x = torch.randn(rows, dim, device="cuda")
+        add = torch.randn(rows, dim, device="cuda").to(torch.bfloat16)
+        w, b = torch.randn(dim, device="cuda"), torch.randn(dim, device="cuda")
+        xsum, y, st = torch.empty_like(x), torch.empty(rows, dim, device="cuda", dtype=torch.bfloat16), torch.empty(rows, 2, device="cuda")
+        ops.ln_fwd_add(x, add, xsum, w, b, y, st)
+        s = x + add.float()
+        assert torch.equal(xsum, s)
+        want = torch.nn.functional.layer_norm(s, (dim,), w, b, 1e-5)
+        assert torch.allclose(y.float(), want, atol=3e-2, rtol=1e-2)
+        dy = torch.randn(rows, dim, device="cuda").to(torch.bfloat16)
+        resid = torch.randn(rows, dim, device="cuda")
+        outs = []
+        for red in (False, True):
+            dx, dxb = torch.empty_like(x), torch.empty_like(y)
+            kw = dict(dw=torch.zeros(dim, device="cuda"), db=torch.zeros(dim, device="cuda")) if red else {}
+            ops.ln_bwd(dy, xsum, st, w, resid=resid, dx=dx, dx_bf16=dxb, **kw)
+            outs.append((dx, dxb))
+        # two instantiations of one kernel: the compiler contracts their fp32 expressions differently (last-bit differences)
+        assert torch.allclose(outs[0][0], outs[1][0], atol=1e-5, rtol=1e-5) and torch.allclose(outs[0][1].float(), outs[1][1].float(), atol=2e-2, rtol=1e-2)
+        xr = s.clone().requires_grad_(True)
+        torch.nn.functional.layer_norm(xr, (dim,), w, b, 1e-5).backward(dy.float())
+        assert torch.allclose(outs[0][0], xr.grad + resid, atol=2e-3, rtol=2e-3)
+
+
 def test_reducer_rccl_side_stream_path_on_one_gpu():
     """The multi-GPU code path (RCCL all-reduce of every gradient bucket on a side HIP stream, launched from autograd hooks,
     joined in finish(), 2-row embedding exchange, fused step epilogue) run with a 1-rank RCCL group: must complete and give

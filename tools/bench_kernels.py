@@ -83,6 +83,27 @@ def main():
     ms = timeit(lambda: ops.ln_bwd(dy, x, st, w, resid=x, dx=dx, dx_bf16=dxb, dw=dw, db=db))
     by = 8192 * 2048 * (2 + 4 + 4 + 4 + 2)
     print(json.dumps(dict(kernel="ln_bwd", rows=8192, dim=2048, ms=round(ms, 4), GBps=round(by / ms / 1e6, 1))), flush=True)
+    ms = timeit(lambda: ops.ln_bwd(dy, x, st, w, resid=x, dx=dx, dx_bf16=dxb))
+    print(json.dumps(dict(kernel="ln_bwd_no_dw (frozen towers)", rows=8192, dim=2048, ms=round(ms, 4), GBps=round(by / ms / 1e6, 1))), flush=True)
+    ms = timeit(lambda: ops.ln_bwd(dy, x, st, w, resid=x, dx=dx))
+    print(json.dumps(dict(kernel="ln_bwd_no_dw_no_bf16_copy", rows=8192, dim=2048, ms=round(ms, 4), GBps=round((by - 8192 * 2048 * 2) / ms / 1e6, 1))), flush=True)
+    xs = torch.empty_like(x)
+    ms = timeit(lambda: ops.ln_fwd_add(x, dy, xs, w, b, y, st))
+    print(json.dumps(dict(kernel="ln_fwd_add", rows=8192, dim=2048, ms=round(ms, 4), GBps=round(8192 * 2048 * (4 + 2 + 4 + 2) / ms / 1e6, 1))), flush=True)
+    g = torch.randn(36_700_000, device=dev)
+    parts = torch.empty(ops.SUMSQ_PARTS, device=dev)
+    ms = timeit(lambda: ops.sumsq_partial(g, parts))
+    print(json.dumps(dict(kernel="sumsq_partial (one gated-block bucket)", n=g.numel(), ms=round(ms, 4), GBps=round(g.numel() * 4 / ms / 1e6, 1))), flush=True)
+    del g
+    # CLIP ViT-L/14 self-attention at cfg-2: 64 images x 16 heads x 257 tokens, head dim 64, fused q|k|v buffer
+    Nv, Hv, Sv = 64, 16, 257
+    qkv = torch.randn(Nv * Sv, 3 * 1024, device=dev).to(torch.bfloat16)
+    ov = torch.empty(Nv * Sv, 1024, device=dev, dtype=torch.bfloat16)
+    lsev = torch.empty(Nv, Hv, Sv, device=dev)
+    ms = timeit(lambda: ops.attn_fwd(qkv[:, :1024], qkv[:, 1024:2048], qkv[:, 2048:], ov, lsev, batch=Nv, Lq=Sv, Lk=Sv, heads=Hv))
+    qv, kv_, vv = (qkv[:, i * 1024:(i + 1) * 1024].view(Nv, Sv, Hv, 64).transpose(1, 2) for i in range(3))
+    ms_t = timeit(lambda: torch.nn.functional.scaled_dot_product_attention(qv, kv_, vv))
+    print(json.dumps(dict(kernel="vit_attn_fwd", ms=round(ms, 4), torch_sdpa_ms=round(ms_t, 4))), flush=True)
     # attention cores
     B_, L, T, n, H = 32, 256, 2, 64, 8
     q = torch.randn(B_ * L, H * 64, device=dev).to(torch.bfloat16)
