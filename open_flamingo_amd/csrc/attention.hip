@@ -177,7 +177,9 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
     char* k_t = smem + 2 * IMG;   // dq only: K transpose image (the forward launch does not allocate it)
     int* s_win = (int*)(smem + (BWD ? 3 : 2) * IMG);  // [64][3] lo,hi,uni ; then [2] block range
     const int tid = of_tid(), lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
-    const int q0 = of_bid_x() * 64, h = of_bid_y();
+    // grid (heads, query tiles, batch): workgroup ids round-robin over the 8 XCDs, so with the head index fastest every
+    // query tile of one (batch, head) runs on XCD h % 8 and re-reads its K / V blocks from that XCD's own L2
+    const int q0 = of_bid_y() * 64, h = of_bid_x();
     const long batch = of_bid_z();
     const int hc = h * DH;
     const float slope = p.alibi_slopes ? p.alibi_slopes[h] : 0.f;
@@ -373,7 +375,7 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_dkv_kernel(OfAttnArgs p) {
     float* s_stat = (float*)(s_win + 64 * 3);   // [64][2] lse, delta
     int* s_flag = (int*)(s_stat + 128);
     const int tid = of_tid(), lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
-    const int kblk = of_bid_x(), h = of_bid_y();
+    const int kblk = of_bid_y(), h = of_bid_x();     // head fastest: see of_attn_q_kernel
     const long batch = of_bid_z();
     const int hc = h * DH;
     const float slope = p.alibi_slopes ? p.alibi_slopes[h] : 0.f;
@@ -541,7 +543,7 @@ int check(const OfAttnArgs& a, bool bwd) {
 namespace {
 template <int DH>
 int launch_fwd(const OfAttnArgs& a, of_stream_t s) {
-    of_dim3 grid{(unsigned)((a.Lq + 63) / 64), (unsigned)a.heads, (unsigned)a.batch};
+    of_dim3 grid{(unsigned)a.heads, (unsigned)((a.Lq + 63) / 64), (unsigned)a.batch};
     const size_t smem = 2 * (64 * DH * 2) + 196 * sizeof(int);
     if (a.safe) return of_launch(of_attn_q_kernel<DH, false, true>, grid, 256, smem, s, a);
     return of_launch(of_attn_q_kernel<DH, false, false>, grid, 256, smem, s, a);
@@ -549,12 +551,12 @@ int launch_fwd(const OfAttnArgs& a, of_stream_t s) {
 template <int DH>
 int launch_bwd(const OfAttnArgs& a, of_stream_t s) {
     constexpr int IMG = 64 * DH * 2;
-    of_dim3 gq{(unsigned)((a.Lq + 63) / 64), (unsigned)a.heads, (unsigned)a.batch};
+    of_dim3 gq{(unsigned)a.heads, (unsigned)((a.Lq + 63) / 64), (unsigned)a.batch};
     const size_t smem_q = 3 * IMG + 196 * sizeof(int);
     int rc = a.safe ? of_launch(of_attn_q_kernel<DH, true, true>, gq, 256, smem_q, s, a)
                     : of_launch(of_attn_q_kernel<DH, true, false>, gq, 256, smem_q, s, a);
     if (rc) return rc;
-    of_dim3 gk{(unsigned)((a.Lk + 63) / 64), (unsigned)a.heads, (unsigned)a.batch};
+    of_dim3 gk{(unsigned)a.heads, (unsigned)((a.Lk + 63) / 64), (unsigned)a.batch};
     const size_t smem_k = 4 * IMG + 64 * 3 * sizeof(int) + 128 * sizeof(float) + 16;
     return a.safe ? of_launch(of_attn_dkv_kernel<DH, true>, gk, 256, smem_k, s, a)
                   : of_launch(of_attn_dkv_kernel<DH, false>, gk, 256, smem_k, s, a);

@@ -249,6 +249,136 @@ OF_GLOBAL void OF_BOUNDS(256, (RED ? (CPL > 5 ? 1 : 2) : (CPL <= 2 ? 4 : (CPL <=
     }
 }
 
+// Backward WITH dw/db for wide rows (dim >= 1536): one WORKGROUP per row instead of one wave.  A lane then owns CPT (1-2)
+// 8-column chunks of the row instead of CPL (4-8): the dw/db column accumulators shrink from 16*CPL to 16*CPT registers
+// and R rows can be in flight per workgroup at 3 workgroups per CU (the wave-per-row form needs 242 registers at
+// dim 2048: 2 waves per SIMD, 87-104 us for 8192 x 2048 where the traffic is worth ~55).  The two row sums cross the four
+// waves through LDS (one barrier per R rows, double-buffered slots).  Every column has exactly one owner lane per
+// workgroup, so the per-workgroup partial rows are written straight from registers (no LDS atomics).
+template <int CPT, int R>
+OF_GLOBAL void OF_BOUNDS(256, 3) of_ln_bwd_wg_kernel(LnArgs a) {
+    float* red = (float*)of_smem();     // [2][R][2][4]
+    const int tid = of_tid(), lane = tid & 63, wave = tid >> 6;
+    const int nchunk = a.dim >> 3;
+    const float inv_dim = 1.0f / (float)a.dim;
+    const long r_begin = (long)of_bid_x() * a.rpw;
+    const long r_end = r_begin + a.rpw < a.rows ? r_begin + a.rpw : a.rows;
+    float wv[CPT][8], aw[CPT][8], ab[CPT][8];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = tid + j * 256;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            aw[j][e] = ab[j][e] = 0.f;
+            wv[j][e] = c < nchunk ? a.w[c * 8 + e] : 0.f;
+        }
+    }
+    const bool wr = a.dx || a.dx_bf16;
+    int buf = 0;
+    for (long r0 = r_begin; r0 < r_end; r0 += R) {
+        float xh[R][CPT][8], gv[R][CPT][8], rv[R][CPT][8];
+        float mean[R], rstd[R], c1[R], c2[R];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const long row = r0 + rr;
+            c1[rr] = c2[rr] = 0.f;
+            mean[rr] = rstd[rr] = 0.f;
+            if (row < r_end) {   // workgroup-uniform
+                mean[rr] = a.stats[row * 2];
+                rstd[rr] = a.stats[row * 2 + 1];
+                const size_t xo = (size_t)row * a.ldx;
+                const size_t go = a.dy_grp_rows > 0 ? (size_t)(row / a.dy_grp_rows) * a.dy_grp_stride + (size_t)(row % a.dy_grp_rows) * a.lddy
+                                                    : (size_t)row * a.lddy;
+                const size_t dxo = (size_t)row * a.lddx;
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) {
+                    const int c = tid + j * 256;
+                    if (c < nchunk) {
+                        load8(a.x, a.x_f32, xo + c * 8, xh[rr][j]);
+                        load8(a.dy, a.dy_f32, go + c * 8, gv[rr][j]);
+                        if (wr && a.resid) load8(a.resid, a.dx_f32, dxo + c * 8, rv[rr][j]);
+                        if (a.dy2) {
+                            float g2[8];
+                            load8(a.dy2, 0, (size_t)row * a.dim + c * 8, g2);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) gv[rr][j][e] += g2[e];
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            if (r0 + rr < r_end) {
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) {
+                    if (tid + j * 256 < nchunk) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            xh[rr][j][e] = (xh[rr][j][e] - mean[rr]) * rstd[rr];
+                            aw[j][e] += gv[rr][j][e] * xh[rr][j][e];
+                            ab[j][e] += gv[rr][j][e];
+                            gv[rr][j][e] *= wv[j][e];
+                            c1[rr] += gv[rr][j][e];
+                            c2[rr] += gv[rr][j][e] * xh[rr][j][e];
+                        }
+                    }
+                }
+            }
+            c1[rr] = of_wave_sum(c1[rr]);
+            c2[rr] = of_wave_sum(c2[rr]);
+            if (lane == 0) {
+                red[((buf * R + rr) * 2 + 0) * 4 + wave] = c1[rr];
+                red[((buf * R + rr) * 2 + 1) * 4 + wave] = c2[rr];
+            }
+        }
+        of_sync();
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const long row = r0 + rr;
+            if (row < r_end && wr) {
+                const float* q1 = red + ((buf * R + rr) * 2 + 0) * 4;
+                const float* q2 = red + ((buf * R + rr) * 2 + 1) * 4;
+                const float s1 = ((q1[0] + q1[1]) + (q1[2] + q1[3])) * inv_dim;
+                const float s2 = ((q2[0] + q2[1]) + (q2[2] + q2[3])) * inv_dim;
+                const size_t dxo = (size_t)row * a.lddx;
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) {
+                    const int c = tid + j * 256;
+                    if (c < nchunk) {
+                        float o[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            o[e] = rstd[rr] * (gv[rr][j][e] - s1 - xh[rr][j][e] * s2);
+                            if (a.resid) o[e] += rv[rr][j][e];
+                        }
+                        if (a.dx) store8(a.dx, a.dx_f32, dxo + c * 8, o);
+                        if (a.dx_bf16) store8(a.dx_bf16, 0, dxo + c * 8, o);
+                    }
+                }
+            }
+        }
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = tid + j * 256;
+        if (c < nchunk) {
+            if (a.partials) {   // combined by of_ln_colsum_kernel in workgroup order (deterministic)
+                float* pw = a.partials + (size_t)of_bid_x() * 2 * a.dim + c * 8;
+                store8(pw, 1, 0, aw[j]);
+                store8(pw + a.dim, 1, 0, ab[j]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    of_atomic_add(a.dw + c * 8 + e, aw[j][e]);
+                    of_atomic_add(a.db + c * 8 + e, ab[j][e]);
+                }
+            }
+        }
+    }
+}
+
 // dw[c] += sum_b partials[b][0][c], db[c] += sum_b partials[b][1][c].  grid (columns / 256, COLSUM_SLICES): slice y sums
 // its share of the partial rows (coalesced across the 256 columns of the block) and adds once per column.
 constexpr int COLSUM_SLICES = 16;
@@ -294,7 +424,10 @@ int launch_fwd(LnArgs a, of_stream_t s) {
     const size_t smem = 0;
     OF_LN_DISPATCH(of_ln_fwd_kernel)
 }
-long bwd_grid(long rows) {
+constexpr int WG_ROWS = 16;          // rows per workgroup of of_ln_bwd_wg_kernel
+bool use_wg_bwd(long rows, int dim, bool red) { return red && dim >= 1536 && dim <= 4096 && rows >= 4 * WG_ROWS; }
+long bwd_grid(long rows, int dim, bool red) {
+    if (use_wg_bwd(rows, dim, red)) return (rows + WG_ROWS - 1) / WG_ROWS;
     const long rows_per_block = 4L * pick_rpw(rows, 16);
     return (rows + rows_per_block - 1) / rows_per_block;
 }
@@ -308,13 +441,19 @@ int launch_bwd_main(const LnArgs& a, of_dim3 grid, size_t smem, of_stream_t s) {
     return a.dw ? launch_bwd_red(a, grid, smem, s) : launch_bwd_nored(a, grid, smem, s);
 }
 int launch_bwd(LnArgs a, float* workspace, size_t workspace_bytes, of_stream_t s) {
-    a.rpw = pick_rpw(a.rows, 16);
-    const long nblk = bwd_grid(a.rows);
+    const bool wg = use_wg_bwd(a.rows, a.dim, a.dw != nullptr);
+    a.rpw = wg ? WG_ROWS : pick_rpw(a.rows, 16);
+    const long nblk = bwd_grid(a.rows, a.dim, a.dw != nullptr);
     of_dim3 grid{(unsigned)nblk, 1, 1};
-    const size_t smem = a.dw ? (size_t)a.dim * 2 * sizeof(float) : 0;
     const bool use_ws = a.dw && workspace && nblk > 1 && workspace_bytes >= (size_t)nblk * 2 * a.dim * sizeof(float);
     a.partials = use_ws ? workspace : nullptr;
-    int rc = launch_bwd_main(a, grid, smem, s);
+    int rc;
+    if (wg) {
+        if (a.dim <= 2048) rc = of_launch(of_ln_bwd_wg_kernel<1, 2>, grid, 256, 2 * 2 * 2 * 4 * sizeof(float), s, a);
+        else rc = of_launch(of_ln_bwd_wg_kernel<2, 1>, grid, 256, 2 * 1 * 2 * 4 * sizeof(float), s, a);
+    } else {
+        rc = launch_bwd_main(a, grid, a.dw ? (size_t)a.dim * 2 * sizeof(float) : 0, s);
+    }
     if (rc || !use_ws) return rc;
     a.rpw = (int)nblk;
     return of_launch(of_ln_colsum_kernel, of_dim3{(unsigned)((2 * a.dim + 255) / 256), COLSUM_SLICES, 1}, 256, 0, s, a);
@@ -389,6 +528,6 @@ extern "C" int of_layernorm_bwd(const void* dy, int dy_f32, long lddy, long dy_g
 
 extern "C" size_t of_layernorm_bwd_workspace_bytes(long rows, int dim) {
     if (rows <= 0 || dim <= 0) return 0;
-    const long nblk = bwd_grid(rows);
+    const long nblk = bwd_grid(rows, dim, true);
     return nblk > 1 ? (size_t)nblk * 2 * dim * sizeof(float) : 0;
 }
