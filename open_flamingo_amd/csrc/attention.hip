@@ -114,12 +114,49 @@ OF_DEV s16x8 gload_frag(const bf16_t* __restrict__ base, long ld, long row, long
     if (row < nrows) z = *(const s16x8*)(base + (size_t)row * ld + col);
     return z;
 }
+// two score fragments -> one bf16 MFMA operand (v_cvt_pk_bf16_f32: round-to-nearest-even, two values per instruction)
 OF_DEV s16x8 pack8(const f32x4& a, const f32x4& b) {
+    const u32x4 r = {of_pack_bf16(a[0], a[1]), of_pack_bf16(a[2], a[3]), of_pack_bf16(b[0], b[1]), of_pack_bf16(b[2], b[3])};
+    return __builtin_bit_cast(s16x8, r);
+}
+
+// Per-lane byte offsets of the fragment reads, computed ONCE per kernel: inside the key-block loops every LDS address is
+// (block base + lane offset) + immediate.  (Recomputing the swizzles per read was ~340 of the ~680 VALU instructions a
+// wave spent per 16-query x 64-key step -- the attention kernels were VALU-issue bound, not MFMA- or LDS-bound.)
+//   n[ks]: row (lane&15) of a 16-row fragment, k-slot ks*4 + (lane>>4)            -> + t*16 rows as an immediate
+//   t[dt]: transpose-read address of row 4*(lane>>4) + ((lane&15)>>2), columns dt*16 + 4*(lane&3)
+//                                                                                   -> + (kbase + 16h) rows as an immediate
+// (adding a multiple of 16 rows never changes the swizzle term of either image: see img_n_off / img_t_off)
+template <int DH>
+struct FragOff {
+    int n[DH / 32];
+    int t[DH / 16];
+};
+template <int DH>
+OF_DEV FragOff<DH> make_frag_off(int lane) {
+    FragOff<DH> f;
+    const int g = lane >> 4, i = lane & 15;
+#pragma unroll
+    for (int ks = 0; ks < DH / 32; ++ks) f.n[ks] = img_n_off<DH>(i, ks * 4 + g);
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) f.t[dt] = img_t_off<DH>(g * 4 + (i >> 2), dt * 16 + (i & 3) * 4);
+    return f;
+}
+template <int DH>
+OF_DEV s16x8 frag_n2(const char* img, int off_ks, int row_base) {
+    return *(const s16x8*)(img + off_ks + row_base * (DH * 2));
+}
+template <int DH, bool SAFE>
+OF_DEV s16x8 frag_t2(const char* img, int off_dt, int kbase, int col_base, int lane) {
+    if (SAFE) return frag_t<DH, true>(img, kbase, col_base, lane);
     s16x8 f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        f[r] = (short)of_f32_to_bf16(a[r]);
-        f[4 + r] = (short)of_f32_to_bf16(b[r]);
+    for (int h = 0; h < 2; ++h) {
+        const s16x4 t = of_lds_tr(img + off_dt + (kbase + h * 16) * (DH * 2));
+        f[h * 4 + 0] = t[0];
+        f[h * 4 + 1] = t[1];
+        f[h * 4 + 2] = t[2];
+        f[h * 4 + 3] = t[3];
     }
     return f;
 }
@@ -166,6 +203,118 @@ OF_DEV Window row_window(const OfAttnArgs& p, long batch, int row) {
     return w;
 }
 
+// What a lane needs to know about ITS query row inside the key-block loops.  Scores live in the LOG2 domain (scale and
+// slope carry a factor log2 e) so that a probability is one v_sub + one bare v_exp_f32:
+// key j is visible iff (unsigned)(j - lo) < (unsigned)width; score2 = s * scale + slope * (j - pos), with scale = slope = 0
+// for a "uniform" row (every key of the window scores 0: helpers.py:223-229).
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+struct RowCtx {
+    int lo, width, pos;
+    float scale, slope;
+};
+OF_DEV RowCtx make_row_ctx(int lo, int hi, int uni, int pos, float scale, float slope) {
+    RowCtx rc;
+    rc.lo = lo;
+    rc.width = hi > lo ? hi - lo : 0;
+    rc.pos = pos;
+    rc.scale = uni ? 0.f : scale * LOG2E;
+    rc.slope = uni ? 0.f : slope * LOG2E;
+    return rc;
+}
+// The visible key range shared by ALL 16 query rows of a wave's tile: [max lo, min hi) (wave-uniform).  A key block inside
+// it needs no per-element window test -- the common case (Perceiver / ViT: every block but a ragged tail; causal: every
+// block left of the diagonal one; gated cross-attention: the 64 latents of one image).
+struct TileRange {
+    int max_lo, min_hi;
+};
+OF_DEV TileRange make_tile_range(int lo, int hi) {
+    if (hi <= lo) {          // empty window (zeroed row, or a row past Lq): never "fully visible"
+        lo = 0x7fffffff;
+        hi = 0;
+    }
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) {
+        const int olo = of_shfl_xor_i(lo, m), ohi = of_shfl_xor_i(hi, m);
+        lo = olo > lo ? olo : lo;
+        hi = ohi < hi ? ohi : hi;
+    }
+    return TileRange{of_uniform(lo), of_uniform(hi)};
+}
+// s[tt][r] = raw dot product of query row (lane&15) with key key0 + 16 tt + 4 (lane>>4) + r  ->  scaled, biased (and, if
+// MASKED, windowed: NEG_BIG outside the row's window) log2-domain score; returns the lane's maximum.
+template <bool MASKED>
+OF_DEV float score_block(f32x4 (&s)[4], const RowCtx& rc, int key0, int g, bool has_alibi) {
+    const int jg = key0 + g * 4 - rc.lo;
+    float mb = NEG_BIG;
+    if (has_alibi) {   // kernel-uniform
+        const float bl = rc.slope * (float)(key0 + g * 4 - rc.pos);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float sv = s[tt][r] * rc.scale + (rc.slope * (float)(tt * 16 + r) + bl);
+                if (MASKED) sv = (unsigned)(jg + tt * 16 + r) < (unsigned)rc.width ? sv : NEG_BIG;
+                s[tt][r] = sv;
+                mb = of_max(mb, sv);
+            }
+    } else {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float sv = s[tt][r] * rc.scale;
+                if (MASKED) sv = (unsigned)(jg + tt * 16 + r) < (unsigned)rc.width ? sv : NEG_BIG;
+                s[tt][r] = sv;
+                mb = of_max(mb, sv);
+            }
+    }
+    return mb;
+}
+OF_DEV float score_block_any(f32x4 (&s)[4], const RowCtx& rc, const TileRange& tr, int key0, int nkeys, int g, bool has_alibi) {
+    if (key0 >= tr.max_lo && key0 + nkeys <= tr.min_hi) return score_block<false>(s, rc, key0, g, has_alibi);   // wave-uniform
+    return score_block<true>(s, rc, key0, g, has_alibi);
+}
+// One online-softmax step of the forward: log2-domain scores of 16 queries x (16 NSUB) keys -> running max / sum,
+// O^T += V^T P^T.  vimg = transpose image of the key block; NSUB = 16-key sub-tiles the block holds (4; 2 for the tail block
+// of a resident image).
+template <int DH, bool SAFE, int NSUB>
+OF_DEV void softmax_pv(f32x4 (&s)[4], float mb, const char* vimg, const FragOff<DH>& fo, int lane, f32x4 (&acc)[DH / 16],
+                       float& m_i, float& l_i) {
+    constexpr int NDT = DH / 16;
+    mb = of_rows_max(mb);
+    const float m_new = of_max(mb, m_i);
+    const float alpha = of_exp2(m_i - m_new);
+    const float m_sub = m_new > 0.5f * NEG_BIG ? m_new : 0.f;   // nothing visible yet: exp2(NEG_BIG - 0) = 0 for every masked key
+    float rs = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < NSUB; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float pv = of_exp2(s[tt][r] - m_sub);
+            s[tt][r] = pv;
+            rs += pv;
+        }
+    rs = of_rows_sum(rs);
+    l_i = l_i * alpha + rs;
+    if (of_wave_any(m_new != m_i)) {     // wave-uniform: an unchanged maximum (alpha = 1 in every lane) leaves O alone
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            acc[dt][0] *= alpha;
+            acc[dt][1] *= alpha;
+            acc[dt][2] *= alpha;
+            acc[dt][3] *= alpha;
+        }
+    }
+    m_i = m_new;
+#pragma unroll
+    for (int s2 = 0; s2 < NSUB / 2; ++s2) {
+        const s16x8 pf = pack8(s[2 * s2], s[2 * s2 + 1]);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+            acc[dt] = of_mfma(frag_t2<DH, SAFE>(vimg, fo.t[dt], s2 * 32, dt * 16, lane), pf, acc[dt]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward (BWD=false) and dq pass (BWD=true) share the key-block loop
 template <int DH, bool BWD, bool SAFE>
@@ -206,7 +355,7 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
     const int lo_i = s_win[(wave * 16 + i16) * 3 + 0], hi_i = s_win[(wave * 16 + i16) * 3 + 1],
               uni_i = s_win[(wave * 16 + i16) * 3 + 2];
     const int rlo = s_win[192], rhi = s_win[193];
-    const int kb_lo = rhi > rlo ? rlo / 64 : 0, kb_hi = rhi > rlo ? (rhi + 63) / 64 : 0;
+    const int kb_lo = of_uniform(rhi > rlo ? rlo / 64 : 0), kb_hi = of_uniform(rhi > rlo ? (rhi + 63) / 64 : 0);
 
     const bf16_t* qb = p.q + (size_t)batch * p.Lq * p.ldq;
     const bf16_t* kb_ptr = p.k + (size_t)batch * p.Lk * p.ldk;
@@ -215,6 +364,11 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) qf[ks] = gload_frag(qb, p.ldq, my_row, p.Lq, hc + ks * 32 + g * 8);
     const int my_pos = my_row + (p.Lk - p.Lq);   // key index aligned with this query (ALiBi distance origin)
+    const FragOff<DH> fo = make_frag_off<DH>(lane);
+    const RowCtx rc = make_row_ctx(lo_i, hi_i, uni_i, my_pos, p.scale, slope);
+    const TileRange tr = make_tile_range(lo_i, hi_i);
+    const bool has_alibi = p.alibi_slopes != nullptr;
+    const float dscale = uni_i ? 0.f : 1.f;      // dq pass: a uniform row's probabilities do not depend on q or k
     float m_i = NEG_BIG, l_i = 0.f, lse_i = 0.f, delta_i = 0.f;
     const size_t stat_idx = ((size_t)batch * p.heads + h) * p.Lq + my_row;
     if (BWD) {
@@ -228,10 +382,9 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) d += of_bf16_to_f32((bf16_t)dof[ks][e]) * of_bf16_to_f32((bf16_t)o8[e]);
         }
-        d += of_shfl_xor(d, 16);
-        d += of_shfl_xor(d, 32);
+        d = of_rows_sum(d);
         delta_i = d;
-        lse_i = my_row < p.Lq ? p.lse[stat_idx] : __builtin_inff();
+        lse_i = my_row < p.Lq ? p.lse[stat_idx] * LOG2E : __builtin_inff();      // log2 domain, like the scores
         if (g == 0 && my_row < p.Lq) p.delta[stat_idx] = d;
     }
     f32x4 acc[NDT];
@@ -264,76 +417,30 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
         for (int t = 0; t < 4; ++t) {
             s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) s[t] = of_mfma(frag_n<DH>(k_n, t * 16, ks, lane), qf[ks], s[t]);
+            for (int ks = 0; ks < NKS; ++ks) s[t] = of_mfma(frag_n2<DH>(k_n, fo.n[ks], t * 16), qf[ks], s[t]);
         }
-        // masked scores
-        float mb = NEG_BIG;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = (int)key0 + t * 16 + g * 4 + r;
-                const bool valid = j >= lo_i && j < hi_i;
-                float sv = uni_i ? 0.f : s[t][r] * p.scale + slope * (float)(j - my_pos);
-                sv = valid ? sv : NEG_BIG;
-                s[t][r] = sv;
-                mb = sv > mb ? sv : mb;
-            }
+        const float mb = score_block_any(s, rc, tr, (int)key0, 64, g, has_alibi);
         if (!BWD) {
-            float o16 = of_shfl_xor(mb, 16);
-            mb = o16 > mb ? o16 : mb;
-            float o32 = of_shfl_xor(mb, 32);
-            mb = o32 > mb ? o32 : mb;
-            const float m_new = mb > m_i ? mb : m_i;
-            const float alpha = of_exp(m_i - m_new);
-            float rs = 0.f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = s[t][r] > 0.5f * NEG_BIG ? of_exp(s[t][r] - m_new) : 0.f;
-                    s[t][r] = pv;
-                    rs += pv;
-                }
-            rs += of_shfl_xor(rs, 16);
-            rs += of_shfl_xor(rs, 32);
-            l_i = l_i * alpha + rs;
-            m_i = m_new;
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                acc[dt][0] *= alpha;
-                acc[dt][1] *= alpha;
-                acc[dt][2] *= alpha;
-                acc[dt][3] *= alpha;
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const s16x8 pf = pack8(s[2 * s2], s[2 * s2 + 1]);
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt)
-                    acc[dt] = of_mfma(frag_t<DH, SAFE>(v_img, s2 * 32, dt * 16, lane), pf, acc[dt]);
-            }
+            softmax_pv<DH, SAFE, 4>(s, mb, v_img, fo, lane, acc, m_i, l_i);
         } else {
             f32x4 dp[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) dp[t] = of_mfma(frag_n<DH>(v_img, t * 16, ks, lane), dof[ks], dp[t]);
+                for (int ks = 0; ks < NKS; ++ks) dp[t] = of_mfma(frag_n2<DH>(v_img, fo.n[ks], t * 16), dof[ks], dp[t]);
             }
+            // masked scores are NEG_BIG: exp2(NEG_BIG - lse) = 0 (lse = +inf marks rows without any visible key)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = s[t][r] > 0.5f * NEG_BIG ? of_exp(s[t][r] - lse_i) : 0.f;
-                    dp[t][r] = uni_i ? 0.f : pv * (dp[t][r] - delta_i);
-                }
+                for (int r = 0; r < 4; ++r) dp[t][r] = of_exp2(s[t][r] - lse_i) * (dp[t][r] - delta_i) * dscale;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const s16x8 dsf = pack8(dp[2 * s2], dp[2 * s2 + 1]);
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt)
-                    acc[dt] = of_mfma(frag_t<DH, SAFE>(k_t, s2 * 32, dt * 16, lane), dsf, acc[dt]);
+                    acc[dt] = of_mfma(frag_t2<DH, SAFE>(k_t, fo.t[dt], s2 * 32, dt * 16, lane), dsf, acc[dt]);
             }
         }
         of_sync();
@@ -348,7 +455,7 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
                            of_pack_bf16(acc[dt][2] * inv, acc[dt][3] * inv)};
                 *(u32x2*)(ob + dt * 16 + g * 4) = o;
             }
-            if (g == 0) p.lse[stat_idx] = l_i > 0.f ? m_i + of_log(l_i) : __builtin_inff();
+            if (g == 0) p.lse[stat_idx] = l_i > 0.f ? (m_i + of_log2(l_i)) * LN2 : __builtin_inff();
         } else {
             bf16_t* dqb = p.dq + ((size_t)batch * p.Lq + my_row) * p.lddq + hc;
 #pragma unroll
@@ -358,6 +465,156 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
                 *(u32x2*)(dqb + dt * 16 + g * 4) = o;
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward with K and V of one (batch, head) RESIDENT in LDS ("LDS-staged K/V tiles"): one workgroup per (batch, head)
+// instead of one per 64-query tile.  Every key block is fetched once per (batch, head) by LDS-DMA (global_load_lds, no
+// VGPR staging; the image swizzles of frag_n / frag_t are applied to the SOURCE address because the DMA destination is
+// lane-linear), all query tiles of the head then run against the resident images without a barrier: wave w owns the
+// 16-row tiles w, w+4, w+8, ...  Causal self-attention (Lq == Lk: the frozen MPT blocks) loads progressively -- the t-th
+// tile of every wave needs key blocks <= t, block t+1 is in flight while step t computes; everything else loads all blocks
+// up front (32-80 KB: two workgroups per CU overlap each other).  Same arithmetic, masks and statistics as
+// of_attn_q_kernel<DH, false>; eligible when the two images fit the CU's 160 KB.
+template <int DH, bool TR, int NW>
+OF_DEV void dma_block(const bf16_t* __restrict__ src, long ld, long row0, long nrows, int rows_blk, int col0, int wave, int lane,
+                      char* img) {
+    constexpr int RPK = DH == 128 ? 4 : 8;          // rows per 1-KiB DMA piece
+    constexpr int LPR = 64 / RPK;                   // lanes (16-byte units) per row
+    const int r = lane / LPR, qpos = lane % LPR;
+    for (int pc = wave; pc * RPK < rows_blk; pc += NW) {
+        const int row = pc * RPK + r;               // row inside the 64-row block image
+        long arow = row0 + row;
+        if (arow >= nrows) arow = nrows - 1;        // rows past the end: finite data, their scores are masked / P = 0
+        int unit;                                    // 16-byte source unit of the row that belongs at LDS position qpos
+        if (!TR) {
+            unit = qpos ^ (DH == 128 ? (row & 15) : ((row >> 1) & 7));
+        } else {
+            const int c = (qpos >> 1) ^ (DH == 128 ? (row & 7) : ((row >> 1) & 3));
+            unit = (c << 1) | (qpos & 1);
+        }
+        of_glds16(src + (size_t)arow * ld + col0 + unit * 8, img + pc * 1024);
+    }
+}
+
+template <int DH, int NW>      // NW waves per workgroup: 8 at head dim 128 (128 KB of images -> one workgroup per CU), else 4
+OF_GLOBAL void OF_BOUNDS(NW * 64, 2) of_attn_fwd_res_kernel(OfAttnArgs p) {
+    constexpr int NKS = DH / 32, NDT = DH / 16, IMG = 64 * DH * 2;
+    char* smem = of_smem();
+    const int tid = of_tid(), lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
+    const int h = of_bid_x();
+    const long batch = of_bid_y();
+    const int hc = h * DH;
+    const float slope = p.alibi_slopes ? p.alibi_slopes[h] : 0.f;
+    const bool has_alibi = p.alibi_slopes != nullptr;
+    const int lk32 = (p.Lk + 31) & ~31;
+    char* k_n = smem;
+    char* v_t = smem + (size_t)lk32 * DH * 2;
+    const int nkb = (p.Lk + 63) / 64, ntiles = (p.Lq + 15) / 16, nsteps = (ntiles + NW - 1) / NW;
+    constexpr int BPS = NW / 4;                       // key blocks a step of NW 16-row tiles can newly need (causal)
+    const bool progressive = p.causal && p.Lq == p.Lk;
+    const bf16_t* qb = p.q + (size_t)batch * p.Lq * p.ldq;
+    const bf16_t* kb_ptr = p.k + (size_t)batch * p.Lk * p.ldk;
+    const bf16_t* vb_ptr = p.v + (size_t)batch * p.Lk * p.ldv;
+    const FragOff<DH> fo = make_frag_off<DH>(lane);
+
+    auto issue = [&](int kb) OF_INLINE_LAMBDA {
+        const int rows_blk = lk32 - kb * 64 < 64 ? lk32 - kb * 64 : 64;
+        dma_block<DH, false, NW>(kb_ptr, p.ldk, (long)kb * 64, p.Lk, rows_blk, hc, wave, lane, k_n + (size_t)kb * IMG);
+        dma_block<DH, true, NW>(vb_ptr, p.ldv, (long)kb * 64, p.Lk, rows_blk, hc, wave, lane, v_t + (size_t)kb * IMG);
+    };
+    const int first = progressive ? (BPS < nkb ? BPS : nkb) : nkb;
+    for (int kb = 0; kb < first; ++kb) issue(kb);
+    s16x8 qf[NKS], qn[NKS];
+    {
+        const int row0 = wave * 16 + i16;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qn[ks] = gload_frag(qb, p.ldq, row0, p.Lq, hc + ks * 32 + g * 8);
+    }
+    of_wait_vm<0>();
+    of_sync();
+
+    u32x2 po[NDT];                 // previous tile's packed output, stored while the next tile computes
+    long po_row = -1;
+    for (int t = 0; t < nsteps; ++t) {
+        const bool more = progressive && (t + 1) * BPS < nkb;
+        if (more) {
+            for (int kb = (t + 1) * BPS; kb < (t + 2) * BPS && kb < nkb; ++kb) issue(kb);
+        }
+        if (po_row >= 0) {
+            bf16_t* ob = p.o + ((size_t)batch * p.Lq + po_row) * p.ldo + hc;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) *(u32x2*)(ob + dt * 16 + g * 4) = po[dt];
+            po_row = -1;
+        }
+        const int ti = t * NW + wave;
+        if (ti < ntiles) {     // wave-uniform
+            const int my_row = ti * 16 + i16;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) qf[ks] = qn[ks];
+            if (ti + NW < ntiles) {
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) qn[ks] = gload_frag(qb, p.ldq, my_row + NW * 16, p.Lq, hc + ks * 32 + g * 8);
+            }
+            const Window w = row_window(p, batch, my_row);
+            int rlo = w.hi > w.lo ? w.lo : 0x7fffffff, rhi = w.hi > w.lo ? w.hi : 0;
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) {
+                const int olo = of_shfl_xor_i(rlo, m), ohi = of_shfl_xor_i(rhi, m);
+                rlo = olo < rlo ? olo : rlo;
+                rhi = ohi > rhi ? ohi : rhi;
+            }
+            const int kb_lo = of_uniform(rhi > rlo ? rlo / 64 : 0), kb_hi = of_uniform(rhi > rlo ? (rhi + 63) / 64 : 0);
+            const RowCtx rc = make_row_ctx(w.lo, w.hi, w.uni, my_row + (p.Lk - p.Lq), p.scale, slope);
+            const TileRange tr = make_tile_range(w.lo, w.hi);
+            float m_i = NEG_BIG, l_i = 0.f;
+            f32x4 acc[NDT];
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int kb = kb_lo; kb < kb_hi; ++kb) {
+                const int key0 = kb * 64;
+                const char* kimg = k_n + (size_t)kb * IMG;
+                const char* vimg = v_t + (size_t)kb * IMG;
+                f32x4 s[4];
+                if (lk32 - key0 >= 64) {         // workgroup-uniform: a full block of four 16-key sub-tiles
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        s[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ks = 0; ks < NKS; ++ks) s[tt] = of_mfma(frag_n2<DH>(kimg, fo.n[ks], tt * 16), qf[ks], s[tt]);
+                    }
+                    const float mb = score_block_any(s, rc, tr, key0, 64, g, has_alibi);
+                    softmax_pv<DH, false, 4>(s, mb, vimg, fo, lane, acc, m_i, l_i);
+                } else {                          // 32-row tail block of the images
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) s[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                        for (int ks = 0; ks < NKS; ++ks) s[tt] = of_mfma(frag_n2<DH>(kimg, fo.n[ks], tt * 16), qf[ks], s[tt]);
+                    const float mb = score_block_any(s, rc, tr, key0, 32, g, has_alibi);
+                    softmax_pv<DH, false, 2>(s, mb, vimg, fo, lane, acc, m_i, l_i);
+                }
+            }
+            if (my_row < p.Lq) {
+                const float inv = l_i > 0.f ? 1.0f / l_i : 0.f;
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt)
+                    po[dt] = u32x2{of_pack_bf16(acc[dt][0] * inv, acc[dt][1] * inv), of_pack_bf16(acc[dt][2] * inv, acc[dt][3] * inv)};
+                po_row = my_row;
+                if (g == 0) p.lse[((size_t)batch * p.heads + h) * p.Lq + my_row] = l_i > 0.f ? (m_i + of_log2(l_i)) * LN2 : __builtin_inff();
+            }
+        }
+        if (more) {            // workgroup-uniform
+            of_wait_vm<0>();
+            of_sync();
+        }
+    }
+    if (po_row >= 0) {
+        bf16_t* ob = p.o + ((size_t)batch * p.Lq + po_row) * p.ldo + hc;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) *(u32x2*)(ob + dt * 16 + g * 4) = po[dt];
     }
 }
 
@@ -372,8 +629,9 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_dkv_kernel(OfAttnArgs p) {
     char* q_t = smem + 2 * IMG;
     char* do_t = smem + 3 * IMG;
     int* s_win = (int*)(smem + 4 * IMG);        // [64][3]
-    float* s_stat = (float*)(s_win + 64 * 3);   // [64][2] lse, delta
-    int* s_flag = (int*)(s_stat + 128);
+    float* s_lse = (float*)(s_win + 64 * 3);    // [64] row log-sum-exp in the log2 domain, [64] delta
+    float* s_delta = s_lse + 64;
+    int* s_flag = (int*)(s_lse + 128);          // [0] some row sees some key of this block  [1] every row sees every key
     const int tid = of_tid(), lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
     const int kblk = of_bid_y(), h = of_bid_x();     // head fastest: see of_attn_q_kernel
     const long batch = of_bid_z();
@@ -381,6 +639,8 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_dkv_kernel(OfAttnArgs p) {
     const float slope = p.alibi_slopes ? p.alibi_slopes[h] : 0.f;
     const int key_lo = kblk * 64, key_hi = key_lo + 64;
     const int my_key = key_lo + wave * 16 + i16;
+    const FragOff<DH> fo = make_frag_off<DH>(lane);
+    const float scale2 = p.scale * LOG2E, slope2 = slope * LOG2E;
 
     const bf16_t* kb_ptr = p.k + (size_t)batch * p.Lk * p.ldk;
     const bf16_t* vb_ptr = p.v + (size_t)batch * p.Lk * p.ldv;
@@ -399,15 +659,21 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_dkv_kernel(OfAttnArgs p) {
         accv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int nqt = (p.Lq + 63) / 64;
+    // causal: query i sees keys < i + 1 + Lk - Lq, so query tiles that end at or before key_lo - (Lk - Lq) never see this block
+    int qt_lo = 0;
+    if (p.causal) {
+        qt_lo = (key_lo - (p.Lk - p.Lq)) / 64;
+        qt_lo = qt_lo < 0 ? 0 : (qt_lo > nqt ? nqt : qt_lo);
+    }
     // head dim 64: Q / dO tiles are software-pipelined through registers like K / V in the q kernel (at head dim 128
     // the 32 extra VGPRs would spill: that instantiation loads synchronously)
-    constexpr bool PREFETCH = DH == 64;
+    constexpr bool PREFETCH = DH == 64 || !SAFE;
     u32x4 rq[DH / 32], rdo[DH / 32];
-    if (PREFETCH) {
-        tile_g2r<DH>(qb, p.ldq, 0, p.Lq, hc, tid, rq);
-        tile_g2r<DH>(dob, p.lddo, 0, p.Lq, hc, tid, rdo);
+    if (PREFETCH && qt_lo < nqt) {
+        tile_g2r<DH>(qb, p.ldq, (long)qt_lo * 64, p.Lq, hc, tid, rq);
+        tile_g2r<DH>(dob, p.lddo, (long)qt_lo * 64, p.Lq, hc, tid, rdo);
     }
-    for (int qt = 0; qt < nqt; ++qt) {
+    for (int qt = qt_lo; qt < nqt; ++qt) {
         const int q0 = qt * 64;
         if (tid < 64) {
             Window w = row_window(p, batch, q0 + tid);
@@ -416,15 +682,22 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_dkv_kernel(OfAttnArgs p) {
             s_win[tid * 3 + 2] = w.uni;
             const int row = q0 + tid;
             const size_t si = ((size_t)batch * p.heads + h) * p.Lq + row;
-            s_stat[tid * 2 + 0] = row < p.Lq ? p.lse[si] : __builtin_inff();
-            s_stat[tid * 2 + 1] = row < p.Lq ? p.delta[si] : 0.f;
+            s_lse[tid] = row < p.Lq ? p.lse[si] * LOG2E : __builtin_inff();
+            s_delta[tid] = row < p.Lq ? p.delta[si] : 0.f;
             int hit = (w.hi > w.lo && w.lo < key_hi && w.hi > key_lo) ? 1 : 0;
+            int all = (w.hi > w.lo && !w.uni && w.lo <= key_lo && w.hi >= key_hi) ? 1 : 0;   // this row sees the whole key block
 #pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) hit |= of_shfl_xor_i(hit, m);
-            if (tid == 0) s_flag[0] = hit;
+            for (int m = 32; m >= 1; m >>= 1) {
+                hit |= of_shfl_xor_i(hit, m);
+                all &= of_shfl_xor_i(all, m);
+            }
+            if (tid == 0) {
+                s_flag[0] = hit;
+                s_flag[1] = all;
+            }
         }
         of_sync();
-        const int hit = s_flag[0];
+        const int hit = of_uniform(s_flag[0]), all_visible = of_uniform(s_flag[1]);
         if (PREFETCH) {
             if (hit) {
                 tile_r2s<DH>(rq, tid, q_n, q_t);
@@ -452,27 +725,38 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_dkv_kernel(OfAttnArgs p) {
                     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
-                        s = of_mfma(frag_n<DH>(q_n, t * 16, ks, lane), kf[ks], s);
-                        dp = of_mfma(frag_n<DH>(do_n, t * 16, ks, lane), vf[ks], dp);
+                        s = of_mfma(frag_n2<DH>(q_n, fo.n[ks], t * 16), kf[ks], s);
+                        dp = of_mfma(frag_n2<DH>(do_n, fo.n[ks], t * 16), vf[ks], dp);
                     }
+                    // log2-domain score of (query q0 + 16 t + 4 g + r, key my_key); lse / delta of the four rows in one read each
+                    const f32x4 l4 = *(const f32x4*)(s_lse + t * 16 + g * 4), d4 = *(const f32x4*)(s_delta + t * 16 + g * 4);
+                    const float bg = slope2 * (float)(my_key - (q0 + t * 16 + g * 4 + p.Lk - p.Lq));
+                    if (all_visible) {       // workgroup-uniform: no window test, no uniform rows
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int qr = t * 16 + g * 4 + r;
-                        const int lo = s_win[qr * 3 + 0], hi = s_win[qr * 3 + 1], uni = s_win[qr * 3 + 2];
-                        const float lse = s_stat[qr * 2 + 0], delta = s_stat[qr * 2 + 1];
-                        const bool valid = my_key >= lo && my_key < hi;
-                        const float sv = uni ? 0.f : s[r] * p.scale + slope * (float)(my_key - (q0 + qr + p.Lk - p.Lq));
-                        const float pv = valid ? of_exp(sv - lse) : 0.f;
-                        pm[tt][r] = pv;
-                        ds[tt][r] = uni ? 0.f : pv * (dp[r] - delta);
+                        for (int r = 0; r < 4; ++r) {
+                            const float pv = of_exp2(s[r] * scale2 + (bg - slope2 * (float)r) - l4[r]);
+                            pm[tt][r] = pv;
+                            ds[tt][r] = pv * (dp[r] - d4[r]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int qr = t * 16 + g * 4 + r;
+                            const int lo = s_win[qr * 3 + 0], hi = s_win[qr * 3 + 1], uni = s_win[qr * 3 + 2];
+                            const bool valid = my_key >= lo && my_key < hi;
+                            const float sv = uni ? 0.f : s[r] * scale2 + (bg - slope2 * (float)r);
+                            const float pv = valid ? of_exp2(sv - l4[r]) : 0.f;
+                            pm[tt][r] = pv;
+                            ds[tt][r] = uni ? 0.f : pv * (dp[r] - d4[r]);
+                        }
                     }
                 }
                 const s16x8 pf = pack8(pm[0], pm[1]);
                 const s16x8 dsf = pack8(ds[0], ds[1]);
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) {
-                    accv[dt] = of_mfma(frag_t<DH, SAFE>(do_t, s2 * 32, dt * 16, lane), pf, accv[dt]);
-                    acck[dt] = of_mfma(frag_t<DH, SAFE>(q_t, s2 * 32, dt * 16, lane), dsf, acck[dt]);
+                    accv[dt] = of_mfma(frag_t2<DH, SAFE>(do_t, fo.t[dt], s2 * 32, dt * 16, lane), pf, accv[dt]);
+                    acck[dt] = of_mfma(frag_t2<DH, SAFE>(q_t, fo.t[dt], s2 * 32, dt * 16, lane), dsf, acck[dt]);
                 }
             }
         }
@@ -541,11 +825,28 @@ int check(const OfAttnArgs& a, bool bwd) {
 }  // namespace
 
 namespace {
+// LDS bytes of the resident-K/V forward, or 0 when this launch stays on the tiled kernel
+template <int DH>
+size_t resident_smem(const OfAttnArgs& a) {
+    if (a.safe != 0) return 0;                                   // safe = 1: scalar-LDS path, 2: tiled kernel (both of_attn_q_kernel)
+    const size_t need = (size_t)((a.Lk + 31) & ~31) * DH * 2 * 2;
+    if (need > 160 * 1024) return 0;
+    // Measured (profiles/r02_attention_*): the resident form wins where a (batch, head) has >= 4 query tiles re-reading >= 4
+    // key blocks (CLIP ViT 257 x 257: 64 vs 72 us) and ties on the frozen MPT blocks (256 x 256, head dim 128); the gated
+    // cross-attention (128 keys) and Perceiver (64 queries) cores stay on the tiled kernel (11 vs 14 us, 13 vs 16 us).
+    if (a.Lq < 256 || a.Lk < 256) return 0;
+    if ((long)a.batch * a.heads < 64) return 0;                   // few heads: the tiled grid has more workgroups
+    return need;
+}
 template <int DH>
 int launch_fwd(const OfAttnArgs& a, of_stream_t s) {
+    if (const size_t res = resident_smem<DH>(a)) {
+        const of_dim3 grid{(unsigned)a.heads, (unsigned)a.batch, 1};
+        return of_launch(of_attn_fwd_res_kernel<DH, (DH == 128 ? 8 : 4)>, grid, DH == 128 ? 512 : 256, res, s, a);
+    }
     of_dim3 grid{(unsigned)a.heads, (unsigned)((a.Lq + 63) / 64), (unsigned)a.batch};
     const size_t smem = 2 * (64 * DH * 2) + 196 * sizeof(int);
-    if (a.safe) return of_launch(of_attn_q_kernel<DH, false, true>, grid, 256, smem, s, a);
+    if (a.safe == 1) return of_launch(of_attn_q_kernel<DH, false, true>, grid, 256, smem, s, a);
     return of_launch(of_attn_q_kernel<DH, false, false>, grid, 256, smem, s, a);
 }
 template <int DH>
@@ -553,12 +854,12 @@ int launch_bwd(const OfAttnArgs& a, of_stream_t s) {
     constexpr int IMG = 64 * DH * 2;
     of_dim3 gq{(unsigned)a.heads, (unsigned)((a.Lq + 63) / 64), (unsigned)a.batch};
     const size_t smem_q = 3 * IMG + 196 * sizeof(int);
-    int rc = a.safe ? of_launch(of_attn_q_kernel<DH, true, true>, gq, 256, smem_q, s, a)
+    int rc = a.safe == 1 ? of_launch(of_attn_q_kernel<DH, true, true>, gq, 256, smem_q, s, a)
                     : of_launch(of_attn_q_kernel<DH, true, false>, gq, 256, smem_q, s, a);
     if (rc) return rc;
     of_dim3 gk{(unsigned)a.heads, (unsigned)((a.Lk + 63) / 64), (unsigned)a.batch};
     const size_t smem_k = 4 * IMG + 64 * 3 * sizeof(int) + 128 * sizeof(float) + 16;
-    return a.safe ? of_launch(of_attn_dkv_kernel<DH, true>, gk, 256, smem_k, s, a)
+    return a.safe == 1 ? of_launch(of_attn_dkv_kernel<DH, true>, gk, 256, smem_k, s, a)
                   : of_launch(of_attn_dkv_kernel<DH, false>, gk, 256, smem_k, s, a);
 }
 }  // namespace

@@ -111,6 +111,36 @@ OF_DEV int of_shfl_xor_i(int v, int m) { return __shfl_xor(v, m, 64); }
 OF_DEV float of_shfl(float v, int src) { return __shfl(v, src, 64); }
 OF_DEV void of_atomic_add(float* p, float v) { atomicAdd(p, v); }
 OF_DEV float of_exp(float x) { return __expf(x); }
+// bare v_exp_f32 / v_log_f32 (base 2, no denormal fix-up sequence): softmax in the log2 domain
+OF_DEV float of_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+OF_DEV float of_log2(float x) { return __builtin_amdgcn_logf(x); }
+OF_DEV float of_max(float a, float b) { return __builtin_fmaxf(a, b); }      // v_max_f32 (a ?: b keeps NaN order: cmp + cndmask)
+// Reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) without the LDS round trips of
+// ds_bpermute: v_permlane16_swap / v_permlane32_swap (gfx950) exchange rows between two registers inside the VALU.
+// Inline asm: given the same value in both operands the builtin forms are folded away by the compiler (it treats the swap as
+// lane-wise pure); the s_nop covers the VALU-write -> permlane-read hazard the compiler would otherwise pad.
+OF_DEV void of_swap_rows16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+OF_DEV void of_swap_rows32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+OF_DEV float of_rows_max(float x) {
+    float a = x, b = x;
+    of_swap_rows16(a, b);        // a = rows {0,0,2,2}, b = rows {1,1,3,3} of x
+    x = __builtin_fmaxf(a, b);
+    a = x;
+    b = x;
+    of_swap_rows32(a, b);        // a = lower half twice, b = upper half twice
+    return __builtin_fmaxf(a, b);
+}
+OF_DEV float of_rows_sum(float x) {
+    float a = x, b = x;
+    of_swap_rows16(a, b);
+    x = a + b;
+    a = x;
+    b = x;
+    of_swap_rows32(a, b);
+    return a + b;
+}
+// true if the predicate holds in ANY lane of the wave (the result is wave-uniform: scalar branch)
+OF_DEV bool of_wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 // 1-ulp hardware reciprocal (v_rcp_f32) instead of the ~12-instruction IEEE division sequence
 OF_DEV float of_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 typedef __bf16 of_bf16x2n __attribute__((ext_vector_type(2)));

@@ -247,6 +247,22 @@ OF_DEV int of_shfl_xor_i(int v, int m) {
     memcpy(&v, &f, 4);
     return v;
 }
+OF_DEV bool of_wave_any(bool p) {
+    int v = p ? 1 : 0;
+    for (int m = 32; m >= 1; m >>= 1) v |= of_shfl_xor_i(v, m);
+    return v != 0;
+}
+OF_DEV float of_rows_max(float x) {
+    x = fmaxf(x, of_shfl_xor(x, 16));
+    return fmaxf(x, of_shfl_xor(x, 32));
+}
+OF_DEV float of_rows_sum(float x) {
+    x += of_shfl_xor(x, 16);
+    return x + of_shfl_xor(x, 32);
+}
+OF_DEV float of_exp2(float x) { return exp2f(x); }
+OF_DEV float of_log2(float x) { return log2f(x); }
+OF_DEV float of_max(float a, float b) { return fmaxf(a, b); }
 OF_DEV void of_atomic_add(float* p, float v) {
     std::atomic<unsigned>* a = (std::atomic<unsigned>*)p;
     unsigned old = a->load();

@@ -51,7 +51,7 @@ def _check(q, k, v, heads, tt=None, n=0, T=0, only_imm=1, safe=0, tol=2e-2):
     return res
 
 
-@pytest.mark.parametrize("safe", [0, 1])
+@pytest.mark.parametrize("safe", [0, 1, 2])     # 0: resident-K/V forward; 1: tiled kernels, scalar-LDS path; 2: tiled kernels
 def test_perceiver_shape(safe):
     # 2 media, 2 heads, 64 latent queries, 96 keys (tail block half empty)
     q, k, v = _r((2, 64, 128), 1), _r((2, 96, 128), 2), _r((2, 96, 128), 3)
@@ -62,6 +62,23 @@ def test_perceiver_fused_kv_view_and_ragged_queries():
     kv = _r((1, 80, 256), 4)          # [k | v] fused, 2 heads
     q = _r((1, 40, 128), 5)           # Lq not a multiple of 16
     _check(q, kv[..., :128], kv[..., 128:], 2)
+
+
+@pytest.mark.parametrize("dh", [64, 128])
+def test_self_attention_vit_like_ragged(dh):
+    """Non-causal self-attention with L = 4 blocks + 1 token (CLIP's 257 = 256 patches + class token, scaled down): the
+    resident forward keeps a 32-row tail block and skips its empty sub-tiles; must equal the tiled kernel bit for bit."""
+    heads, B, L = 2, 2, 81
+    q, k, v = _r((B, L, heads * dh), 41), _r((B, L, heads * dh), 42), _r((B, L, heads * dh), 43)
+    outs = []
+    for safe in (0, 2):
+        o = torch.full_like(q, float("nan"))
+        lse = torch.full((B, heads, L), float("nan"))
+        H.attn_fwd(H.attn_args(q, k, v, o, lse, heads=heads, safe=safe, head_dim=dh))
+        outs.append((o, lse))
+    ref = dense_attention(q.double(), k.double(), v.double(), heads, head_dim=dh)
+    assert (outs[0][0].double() - ref).abs().max() <= 2e-2 * ref.abs().max()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 CASES = {
@@ -104,7 +121,7 @@ def test_text_time_kernel():
     assert torch.equal(tt2.long(), ml.sum(-1, keepdim=True).expand(-1, 7))
 
 
-@pytest.mark.parametrize("dh,safe", [(128, 0), (128, 1), (64, 0)])
+@pytest.mark.parametrize("dh,safe", [(128, 0), (128, 1), (128, 2), (64, 0), (64, 2)])
 @pytest.mark.parametrize("Lq,Lk", [(96, 96), (40, 104)])
 def test_causal_alibi_self_attention(dh, safe, Lq, Lk):
     """Causal self-attention with ALiBi (the frozen MPT blocks): head dim 128 and 64, ragged lengths, Lq < Lk

@@ -103,7 +103,8 @@ def main():
     ms = timeit(lambda: ops.attn_fwd(qkv[:, :1024], qkv[:, 1024:2048], qkv[:, 2048:], ov, lsev, batch=Nv, Lq=Sv, Lk=Sv, heads=Hv))
     qv, kv_, vv = (qkv[:, i * 1024:(i + 1) * 1024].view(Nv, Sv, Hv, 64).transpose(1, 2) for i in range(3))
     ms_t = timeit(lambda: torch.nn.functional.scaled_dot_product_attention(qv, kv_, vv))
-    print(json.dumps(dict(kernel="vit_attn_fwd", ms=round(ms, 4), torch_sdpa_ms=round(ms_t, 4))), flush=True)
+    ms_tiled = timeit(lambda: ops.attn_fwd(qkv[:, :1024], qkv[:, 1024:2048], qkv[:, 2048:], ov, lsev, batch=Nv, Lq=Sv, Lk=Sv, heads=Hv, safe=2))
+    print(json.dumps(dict(kernel="vit_attn_fwd", ms=round(ms, 4), tiled_ms=round(ms_tiled, 4), torch_sdpa_ms=round(ms_t, 4))), flush=True)
     # attention cores
     B_, L, T, n, H = 32, 256, 2, 64, 8
     q = torch.randn(B_ * L, H * 64, device=dev).to(torch.bfloat16)
@@ -117,7 +118,8 @@ def main():
     ops.text_time(ml, tt, L, False)
     kw = dict(batch=B_, Lq=L, Lk=T * n, heads=H, text_time=tt, n_per_media=n, T_img=T)
     ms = timeit(lambda: ops.attn_fwd(q, kv[:, :512], kv[:, 512:], o, lse, **kw))
-    print(json.dumps(dict(kernel="xattn_core_fwd", ms=round(ms, 4), gflop_restricted=round(4 * B_ * H * L * 64 * 64 / 1e9, 2))), flush=True)
+    ms_tiled = timeit(lambda: ops.attn_fwd(q, kv[:, :512], kv[:, 512:], o, lse, safe=2, **kw))
+    print(json.dumps(dict(kernel="xattn_core_fwd", ms=round(ms, 4), tiled_ms=round(ms_tiled, 4), gflop_restricted=round(4 * B_ * H * L * 64 * 64 / 1e9, 2))), flush=True)
     do = torch.randn_like(q)
     dq, dkv = torch.empty_like(q), torch.empty_like(kv)
     delta = torch.empty(B_, H, L, device=dev)
@@ -130,7 +132,8 @@ def main():
     lse = torch.empty(N, H, 64, device=dev)
     kw = dict(batch=N, Lq=64, Lk=320, heads=H)
     ms = timeit(lambda: ops.attn_fwd(q, kv[:, :512], kv[:, 512:], o, lse, **kw))
-    print(json.dumps(dict(kernel="perceiver_core_fwd", ms=round(ms, 4), gflop=round(4 * N * H * 64 * 320 * 64 / 1e9, 2))), flush=True)
+    ms_tiled = timeit(lambda: ops.attn_fwd(q, kv[:, :512], kv[:, 512:], o, lse, safe=2, **kw))
+    print(json.dumps(dict(kernel="perceiver_core_fwd", ms=round(ms, 4), tiled_ms=round(ms_tiled, 4), gflop=round(4 * N * H * 64 * 320 * 64 / 1e9, 2))), flush=True)
     do = torch.randn_like(q)
     dq, dkv = torch.empty_like(q), torch.empty_like(kv)
     delta = torch.empty(N, H, 64, device=dev)
@@ -148,7 +151,9 @@ def main():
     kw = dict(batch=Bm, Lq=Lm, Lk=Lm, heads=Hm, scale=dh ** -0.5, head_dim=dh, causal=True, alibi_slopes=slopes)
     ms = timeit(lambda: ops.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, **kw))
     gf = 4.0 * Bm * Hm * Lm * Lm * dh / 2 / 1e9
-    print(json.dumps(dict(kernel="mpt_causal_alibi_attn_fwd", ms=round(ms, 4), tflops=round(gf / ms, 1))), flush=True)
+    ms_tiled = timeit(lambda: ops.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, safe=2, **kw))
+    print(json.dumps(dict(kernel="mpt_causal_alibi_attn_fwd", ms=round(ms, 4), tiled_ms=round(ms_tiled, 4), tflops=round(gf / ms, 1),
+                          GBps=round(4 * Bm * Lm * d * 2 / ms / 1e6, 1))), flush=True)
     do = torch.randn_like(o)
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(Bm, Hm, Lm, device=dev)
