@@ -198,11 +198,24 @@ OF_DEV unsigned of_pack_bf16(float lo, float hi) {
     return (unsigned)of_f32_to_bf16(lo) | ((unsigned)of_f32_to_bf16(hi) << 16);
 }
 #endif
+#ifndef OF_HOST_EMU
+// Sum over the 64 lanes, result in every lane, entirely inside the VALU: four DPP adds give every 16-lane row its total
+// (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror), two permlane swaps add the four rows.  __shfl_xor would
+// make each of the six steps a ds_bpermute round trip through the LDS pipeline (~100+ cycles of latency apiece).
+OF_DEV float of_wave_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));
+    return of_rows_sum(v);
+}
+#else
 OF_DEV float of_wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += of_shfl_xor(v, m);
     return v;
 }
+#endif
 // erf-GELU (nn.GELU() default, reference helpers.py:20) for the GEMM epilogues.  erf by Abramowitz-Stegun 7.1.26
 // (|error| <= 1.5e-7, far below the bf16 rounding of the stored result) so that one exp + one rcp + 6 fma replace
 // the ~40-instruction libm erff; the same exp(-a^2/2) also yields the Gaussian term of the derivative.
