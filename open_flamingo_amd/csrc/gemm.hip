@@ -106,10 +106,7 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_gemm_kernel(OfGemmArgs p) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // Two staging register sets: the global loads of k-tile kt+2 are issued before k-tile kt is multiplied and land in LDS
-    // one iteration later (k-tile kt+1 travels in the other set).  With one set (prefetch distance 1) a load had a single
-    // k-tile of MFMAs (~0.25 us) to cover ~1-2 us of memory latency: the small projections ran at 1.4 us per k-tile.
-    u32x4 ra0[4], rb0[4], ra1[4], rb1[4];
+    u32x4 ra[4], rb[4];
     // split-K (p.ksplit > 1, OF_EPI_ACC_F32 only): slice of_bid_y() owns k-tiles [kt0, kt0 + nk) and adds its partial
     // sums into C with fp32 atomics (the launcher has zeroed C when beta == 0)
     const int nk_all = (p.K + BK - 1) / BK;
@@ -117,22 +114,18 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_gemm_kernel(OfGemmArgs p) {
     const int kt0 = of_bid_y() * per;
     const int nk = (nk_all - kt0 < per ? nk_all - kt0 : per);
     if (nk <= 0) return;
-    g2r<AT>(p.A, p.lda, m0, p.M, kt0 * BK, p.K, tid, ra0);
-    g2r<BT>(p.B, p.ldb, n0, p.N, kt0 * BK, p.K, tid, rb0);
-    if (nk > 1) {
-        g2r<AT>(p.A, p.lda, m0, p.M, (kt0 + 1) * BK, p.K, tid, ra1);
-        g2r<BT>(p.B, p.ldb, n0, p.N, (kt0 + 1) * BK, p.K, tid, rb1);
-    }
-    r2s<AT>(smem, tid, ra0);
-    r2s<BT>(smem + TILE_BYTES, tid, rb0);
+    g2r<AT>(p.A, p.lda, m0, p.M, kt0 * BK, p.K, tid, ra);
+    g2r<BT>(p.B, p.ldb, n0, p.N, kt0 * BK, p.K, tid, rb);
+    r2s<AT>(smem, tid, ra);
+    r2s<BT>(smem + TILE_BYTES, tid, rb);
     of_sync();
-    // one k-tile: (rxa, rxb) hold k-tile kt+1 (loaded one iteration ago), (rya, ryb) are free and receive k-tile kt+2
-    auto ktile = [&](int kt, u32x4 (&rxa)[4], u32x4 (&rxb)[4], u32x4 (&rya)[4], u32x4 (&ryb)[4]) OF_INLINE_LAMBDA {
+    for (int kt = 0; kt < nk; ++kt) {
         const char* ta = smem + (kt & 1) * 2 * TILE_BYTES;
         const char* tb = ta + TILE_BYTES;
-        if (kt + 2 < nk) {
-            g2r<AT>(p.A, p.lda, m0, p.M, (kt0 + kt + 2) * BK, p.K, tid, rya);
-            g2r<BT>(p.B, p.ldb, n0, p.N, (kt0 + kt + 2) * BK, p.K, tid, ryb);
+        const bool more = kt + 1 < nk;
+        if (more) {
+            g2r<AT>(p.A, p.lda, m0, p.M, (kt0 + kt + 1) * BK, p.K, tid, ra);
+            g2r<BT>(p.B, p.ldb, n0, p.N, (kt0 + kt + 1) * BK, p.K, tid, rb);
         }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -147,16 +140,12 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_gemm_kernel(OfGemmArgs p) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = of_mfma(fb[nt], fa[mt], acc[mt][nt]);
         }
-        if (kt + 1 < nk) {
+        if (more) {
             char* na = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
-            r2s<AT>(na, tid, rxa);
-            r2s<BT>(na + TILE_BYTES, tid, rxb);
+            r2s<AT>(na, tid, ra);
+            r2s<BT>(na + TILE_BYTES, tid, rb);
         }
         of_sync();
-    };
-    for (int kt = 0; kt < nk; kt += 2) {
-        ktile(kt, ra1, rb1, ra0, rb0);
-        if (kt + 1 < nk) ktile(kt + 1, ra0, rb0, ra1, rb1);
     }
 
     // ---------------------------------------------------------------- epilogue
