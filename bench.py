@@ -156,6 +156,9 @@ def main():
                     help="form the dense (vocab x d) embedding gradient and mask it down to the two trained rows, as the "
                          "reference does (train_utils.py:174-196); default: train/sparse_rows.py forms just those two rows "
                          "(identical values, no dense lookup scatter / tied-head weight-gradient GEMM)")
+    ap.add_argument("--vendor-gemm-table", default="tuned", choices=["tuned", "default"],
+                    help="kernel selection of the frozen towers' vendor-library GEMMs: the committed TunableOp table "
+                         "(open_flamingo_amd/train/tuned/, tuning off at run time) or the libraries' default heuristics")
     ap.add_argument("--gemm-report", default=None, help="write a per-(layout,epilogue,shape) GEMM time table (JSON lines)")
     args = ap.parse_args()
     if args.gpus > 1 and not any(k in os.environ for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK")):
@@ -177,6 +180,7 @@ def main():
                                         fused_lm_blocks=args.lm_blocks == "fused" and not args.frozen_fp32,
                                         fused_vision=False if (args.vision == "modules" or args.frozen_fp32) else args.vision)
     model.train()
+    n_tuned = towers.use_tuned_vendor_gemms() if args.vendor_gemm_table == "tuned" else 0
     args.sparse_embedding_rows = not args.dense_embedding_rows and not args.torch_optimizer
     if args.sparse_embedding_rows:
         from open_flamingo_amd.train import sparse_rows
@@ -289,6 +293,7 @@ def main():
                           "frozen_vision_tower": args.vision if not args.frozen_fp32 else "modules", "frozen_lm_blocks": args.lm_blocks if not args.frozen_fp32 else "modules",
                           "frozen_lm_attention": args.lm_attention, "frozen_tower_layernorm": args.tower_layernorm,
                           "lm_loss": args.lm_loss,
+                          "vendor_gemm_table": f"TunableOp table, {n_tuned} shapes, tuning off" if n_tuned else "library defaults",
                           "grad_wire_dtype": "bf16" if args.wire_bf16 else "fp32",
                           "embedding_row_gradient": "sparse taps" if args.sparse_embedding_rows else "dense, masked"},
                "loss": None if loss is None else round(float(loss), 4)}

@@ -384,6 +384,31 @@ def hold_frozen_linears_in_bf16(model):
     return n
 
 
+def use_tuned_vendor_gemms(table=None):
+    """The frozen towers' plain GEMMs stay on the vendor libraries (hipBLASLt / rocBLAS through torch.mm); their default
+    kernel heuristics are not the fastest choice for every shape of the step.  This loads a PyTorch TunableOp table --
+    per-shape kernel selections measured once on an MI355X with tools/gpu_tunableop.sh and committed under train/tuned/ --
+    with tuning itself switched off (no measurement at run time, shapes outside the table keep the default kernel).  The
+    table is only honoured when its validator lines (PyTorch / HIP / hipBLASLt / rocBLAS versions, gfx950) match the
+    running libraries.  Returns the number of table entries, 0 when TunableOp is unavailable."""
+    import os
+    try:
+        import torch.cuda.tunable as tun
+    except ImportError:
+        return 0
+    if table is None:
+        table = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "tunableop_gfx950_of3b_cfg2.csv")
+    if not os.path.exists(table) or not torch.cuda.is_available():
+        return 0
+    tun.enable(True)
+    tun.tuning_enable(False)
+    ok = tun.read_file(table)
+    if not ok:
+        tun.enable(False)
+        return 0
+    return len(tun.get_results())
+
+
 def build_flamingo(family: str = "OF-3B", device="cuda", seed: int = 0, gates: float = 0.5, vision_kw=None,
                    freeze_lm_embeddings: bool = False, verbose: bool = False, frozen_bf16: bool = False,
                    fused_lm_attention=True, tower_layernorm="eager", lm_loss="hf", fused_lm_blocks=False, fused_vision=False):

@@ -127,3 +127,16 @@ def test_laion_label_rule_and_single_process_embedding_mask():
     step.train_step(model, None, opt, b_mmc4, info, batch_laion=b_laion, amp=False)
     moved = ((emb.detach() - before).abs().sum(-1) > 0).nonzero().flatten().tolist()
     assert set(moved) <= {info["media_token_id"], info["eoc_token_id"]} and moved, moved
+
+
+def test_tuned_vendor_gemm_table_is_inert_without_a_gpu():
+    """train/towers.py::use_tuned_vendor_gemms: the committed TunableOp table names gfx950 + the library versions it was
+    measured with; on a machine without an AMD GPU the call does nothing (no TunableOp state is touched)."""
+    import csv
+    from open_flamingo_amd.train import towers
+    assert towers.use_tuned_vendor_gemms() == 0
+    path = os.path.join(ROOT, "open_flamingo_amd", "train", "tuned", "tunableop_gfx950_of3b_cfg2.csv")
+    rows = list(csv.reader(open(path)))
+    validators = {r[1]: r[2] for r in rows if r[0] == "Validator"}
+    assert validators["GCN_ARCH_NAME"].startswith("gfx950") and "HIPBLASLT_VERSION" in validators
+    assert sum(r[0].startswith("Gemm") for r in rows) >= 10
