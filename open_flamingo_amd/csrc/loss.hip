@@ -56,6 +56,7 @@ OF_DEV void ld_vec(const void* base, int f32, long idx, float (&x)[8]) {     // 
     }
 }
 
+template <bool F32IN>      // logits dtype as a template parameter: the per-vector loops unroll over a compile-time width
 OF_GLOBAL void OF_BOUNDS(256, 2) of_ce_fwd_kernel(CeArgs a) {
     float* red = (float*)of_smem();
     const int tid = of_tid(), lane = tid & 63, wave = tid >> 6;
@@ -68,26 +69,41 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_ce_fwd_kernel(CeArgs a) {
         const int nvec = (a.V - head) / vw;
         if (tid < head) lse_merge(m, s, ld_elem(a.logits, a.f32, base + tid), 1.0f);
         for (int j = head + nvec * vw + tid; j < a.V; j += 256) lse_merge(m, s, ld_elem(a.logits, a.f32, base + j), 1.0f);
+        // body: four 16-byte vectors in flight per lane; per element one v_max, then exp(x - mx) as ONE fma + bare v_exp_f32
+        // (exp2 of x * log2 e - mx * log2 e)
+        constexpr float LOG2E = 1.4426950408889634f;
+        constexpr int VW = F32IN ? 4 : 8;
+        auto fold = [&](const float (&x)[8], float& mx) OF_INLINE_LAMBDA {
+#pragma unroll
+            for (int e = 0; e < VW; ++e) mx = of_max(mx, x[e]);
+        };
+        auto sum_exp = [&](const float (&x)[8], float nb) OF_INLINE_LAMBDA -> float {
+            float p = 0.f;
+#pragma unroll
+            for (int e = 0; e < VW; ++e) p += of_exp2(x[e] * LOG2E + nb);
+            return p;
+        };
         int v = tid;
-        for (; v + 256 < nvec; v += 512) {            // two vectors in flight per lane
-            float x[8], y[8];
-            ld_vec(a.logits, a.f32, base + head + (long)v * vw, x);
-            ld_vec(a.logits, a.f32, base + head + (long)(v + 256) * vw, y);
-            float mx = x[0];
-            for (int e = 1; e < vw; ++e) mx = x[e] > mx ? x[e] : mx;
-            for (int e = 0; e < vw; ++e) mx = y[e] > mx ? y[e] : mx;
-            float part = 0.f;
-            for (int e = 0; e < vw; ++e) part += of_exp(x[e] - mx) + of_exp(y[e] - mx);
-            lse_merge(m, s, mx, part);
+        for (; v + 768 < nvec; v += 1024) {
+            float x0[8], x1[8], x2[8], x3[8];
+            ld_vec(a.logits, F32IN, base + head + (long)v * vw, x0);
+            ld_vec(a.logits, F32IN, base + head + (long)(v + 256) * vw, x1);
+            ld_vec(a.logits, F32IN, base + head + (long)(v + 512) * vw, x2);
+            ld_vec(a.logits, F32IN, base + head + (long)(v + 768) * vw, x3);
+            float mx = x0[0];
+            fold(x0, mx);
+            fold(x1, mx);
+            fold(x2, mx);
+            fold(x3, mx);
+            const float nb = -mx * LOG2E;
+            lse_merge(m, s, mx, (sum_exp(x0, nb) + sum_exp(x1, nb)) + (sum_exp(x2, nb) + sum_exp(x3, nb)));
         }
         for (; v < nvec; v += 256) {
             float x[8];
-            ld_vec(a.logits, a.f32, base + head + (long)v * vw, x);
+            ld_vec(a.logits, F32IN, base + head + (long)v * vw, x);
             float mx = x[0];
-            for (int e = 1; e < vw; ++e) mx = x[e] > mx ? x[e] : mx;
-            float part = 0.f;
-            for (int e = 0; e < vw; ++e) part += of_exp(x[e] - mx);
-            lse_merge(m, s, mx, part);
+            fold(x, mx);
+            lse_merge(m, s, mx, sum_exp(x, -mx * LOG2E));
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
@@ -111,6 +127,7 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_ce_fwd_kernel(CeArgs a) {
     }
 }
 
+template <bool F32IN>
 OF_GLOBAL void OF_BOUNDS(256, 2) of_ce_bwd_kernel(CeArgs a) {
     const int tid = of_tid();
     const float g = *a.gscale;
@@ -134,15 +151,33 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_ce_bwd_kernel(CeArgs a) {
         const int body_end = head + nvec * vw;
         if (tid < head) one(tid);
         for (int j = body_end + tid; j < a.V; j += 256) one(j);
-        for (int v = tid; v < nvec; v += 256) {
-            const int j0 = head + v * vw;
+        // body: d = g * exp(x - lse) as one fma + bare v_exp_f32 + one multiply per element, two vectors in flight per lane; the
+        // "- [j == label]" term is applied by the lane whose vector holds the label (a wave-divergent branch taken once per row)
+        constexpr float LOG2E = 1.4426950408889634f;
+        const float nb = -lse * LOG2E, gz = valid ? g : 0.f;
+        const int lab32 = valid ? (int)lab : -1;
+        auto body = [&](int v) OF_INLINE_LAMBDA {
+            constexpr int VW = F32IN ? 4 : 8;
+            const int j0 = head + v * VW;
             float x[8], d[8];
-            ld_vec(a.logits, a.f32, base + j0, x);
-            for (int e = 0; e < vw; ++e) d[e] = valid ? g * (of_exp(x[e] - lse) - (j0 + e == lab ? 1.0f : 0.0f)) : 0.f;
-            if (a.f32) *(f32x4*)((float*)a.dlogits + obase + j0) = f32x4{d[0], d[1], d[2], d[3]};
+            ld_vec(a.logits, F32IN, base + j0, x);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) d[e] = gz * of_exp2(x[e] * LOG2E + nb);
+            if ((unsigned)(lab32 - j0) < (unsigned)VW) {
+#pragma unroll
+                for (int e = 0; e < VW; ++e)
+                    if (j0 + e == lab32) d[e] -= gz;
+            }
+            if (F32IN) *(f32x4*)((float*)a.dlogits + obase + j0) = f32x4{d[0], d[1], d[2], d[3]};
             else *(u32x4*)((bf16_t*)a.dlogits + obase + j0) =
                 u32x4{of_pack_bf16(d[0], d[1]), of_pack_bf16(d[2], d[3]), of_pack_bf16(d[4], d[5]), of_pack_bf16(d[6], d[7])};
+        };
+        int v = tid;
+        for (; v + 256 < nvec; v += 512) {
+            body(v);
+            body(v + 256);
         }
+        for (; v < nvec; v += 256) body(v);
     }
 }
 
@@ -155,7 +190,8 @@ extern "C" int of_ce_fwd(const void* logits, int logits_f32, long ld, const long
     CeArgs a{};
     a.logits = logits; a.ld = ld; a.f32 = logits_f32; a.rows = rows; a.V = vocab;
     a.labels = labels; a.ignore_index = ignore_index; a.lse = lse; a.loss = loss_rows;
-    return of_launch(of_ce_fwd_kernel, of_dim3{(unsigned)grid_for(rows), 1, 1}, 256, 64, (of_stream_t)stream, a);
+    if (logits_f32) return of_launch(of_ce_fwd_kernel<true>, of_dim3{(unsigned)grid_for(rows), 1, 1}, 256, 64, (of_stream_t)stream, a);
+    return of_launch(of_ce_fwd_kernel<false>, of_dim3{(unsigned)grid_for(rows), 1, 1}, 256, 64, (of_stream_t)stream, a);
 }
 
 extern "C" int of_ce_bwd(const void* logits, int logits_f32, long ld, const long long* labels, long long ignore_index,
@@ -165,5 +201,6 @@ extern "C" int of_ce_bwd(const void* logits, int logits_f32, long ld, const long
     a.logits = logits; a.ld = ld; a.f32 = logits_f32; a.rows = rows; a.V = vocab;
     a.labels = labels; a.ignore_index = ignore_index; a.lse = const_cast<float*>(lse);
     a.gscale = gscale; a.dlogits = dlogits; a.ldd = ldd;
-    return of_launch(of_ce_bwd_kernel, of_dim3{(unsigned)grid_for(rows), 1, 1}, 256, 0, (of_stream_t)stream, a);
+    if (logits_f32) return of_launch(of_ce_bwd_kernel<true>, of_dim3{(unsigned)grid_for(rows), 1, 1}, 256, 0, (of_stream_t)stream, a);
+    return of_launch(of_ce_bwd_kernel<false>, of_dim3{(unsigned)grid_for(rows), 1, 1}, 256, 0, (of_stream_t)stream, a);
 }

@@ -95,6 +95,17 @@ def main():
     ms = timeit(lambda: ops.sumsq_partial(g, parts))
     print(json.dumps(dict(kernel="sumsq_partial (one gated-block bucket)", n=g.numel(), ms=round(ms, 4), GBps=round(g.numel() * 4 / ms / 1e6, 1))), flush=True)
     del g
+    # causal-LM loss at cfg-2: 8192 rows x 50435 logits (odd vocabulary: rows start at 2-byte alignment)
+    lg = torch.randn(8192, 50435, device=dev).to(torch.bfloat16)
+    lab = torch.randint(0, 50435, (8192,), device=dev)
+    lse_, lr_ = torch.empty(8192, device=dev), torch.empty(8192, device=dev)
+    ms = timeit(lambda: ops.ce_fwd(lg, lab, lse_, lr_), iters=10)
+    print(json.dumps(dict(kernel="ce_fwd", ms=round(ms, 4), GBps=round(lg.numel() * 2 / ms / 1e6, 1))), flush=True)
+    dl = torch.empty_like(lg)
+    gs = torch.full((1,), 1.0 / 8192, device=dev)
+    ms = timeit(lambda: ops.ce_bwd(lg, lab, lse_, gs, dl), iters=10)
+    print(json.dumps(dict(kernel="ce_bwd", ms=round(ms, 4), GBps=round(lg.numel() * 4 / ms / 1e6, 1))), flush=True)
+    del lg, dl
     # CLIP ViT-L/14 self-attention at cfg-2: 64 images x 16 heads x 257 tokens, head dim 64, fused q|k|v buffer
     Nv, Hv, Sv = 64, 16, 257
     qkv = torch.randn(Nv * Sv, 3 * 1024, device=dev).to(torch.bfloat16)
