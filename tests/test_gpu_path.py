@@ -94,6 +94,45 @@ def test_fused_step_epilogue_matches_torch_optimizer():
         assert (p0[k] - p1[k]).norm().item() <= 0.05 * travelled + 1e-7, (k, (p0[k] - p1[k]).norm().item(), travelled)
 
 
+def test_checkpoint_round_trip_with_the_fused_step_epilogue_on_gpu(tmp_path):
+    """SURVEY 8f N4 on the device: train two steps with the product modules + FlatAdamW, write the reference-format
+    checkpoint, resume into a differently initialised model (once with FlatAdamW, once with torch AdamW -- the file holds a
+    torch.optim.AdamW state dict) and take one more step: both must land where the uninterrupted run lands."""
+    from open_flamingo_amd.train import checkpoint, step, synthetic, towers
+    from open_flamingo_amd.train.reducer import GradReducer
+
+    def build(seed):
+        model, info = towers.build_flamingo("OF-tiny", device="cuda", seed=seed, gates=0.5)
+        model.train()
+        red = GradReducer(model, embedding_rows=[info["media_token_id"], info["eoc_token_id"]])
+        return model, info, red
+
+    def trainable(model):
+        return {k: v.detach().float().cpu().clone() for k, v in model.named_parameters() if v.requires_grad}
+
+    model, info, red = build(0)
+    opt = step.build_optimizer(model, lr=1e-3, reducer=red)
+    assert hasattr(opt, "reducer")
+    batch = synthetic.make_batch(2, 2, 24, info, "cuda", seed=5)
+    for _ in range(2):
+        step.train_step(model, red, opt, batch, info)
+    path = checkpoint.save_checkpoint(model, opt, None, 0, str(tmp_path / "run"))
+    step.train_step(model, red, opt, batch, info)
+    want = trainable(model)
+    frozen_lm = {k: v for k, v in model.lang_encoder.state_dict().items() if "gated_cross_attn" not in k}
+    for fused in (True, False):
+        fresh, _, red2 = build(1)
+        fresh.lang_encoder.load_state_dict(frozen_lm, strict=False)           # the frozen towers are "pretrained" weights
+        fresh.vision_encoder.load_state_dict(model.vision_encoder.state_dict())
+        opt2 = step.build_optimizer(fresh, lr=1e-3, reducer=red2 if fused else None)
+        assert checkpoint.load_checkpoint(path, fresh, opt2, None) == 1
+        step.train_step(fresh, red2, opt2, batch, info)
+        got = trainable(fresh)
+        for k in want:
+            scale = want[k].abs().max().item() + 1e-12
+            assert (got[k] - want[k]).abs().max().item() <= 2e-3 * scale + 2.5e-3, (fused, k)     # one Adam step = lr per element
+
+
 def test_step_epilogue_leaves_weight_gradients_for_the_backward_to_overwrite():
     """FlatAdamW does not clear the gradients of the nn.Linear weights (the next backward's dW GEMM overwrites them,
     beta = 0) but does clear everything its kernels add into; a step without a backward in between must not re-apply
