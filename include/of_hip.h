@@ -75,7 +75,7 @@ typedef struct OfGemmArgs {
                           skinny kernel; tile-aligned shapes that fill the chip -> a 256x256 big-tile kernel; otherwise the
                           general 128x128 kernel, split along K when the output is small).  Non-zero values force one
                           correct kernel so tests can compare kernels with each other: 1 = general kernel, slow scalar-LDS
-                          transposed-fragment path; 2 = general kernel; 4 = 8-wave ping-pong big-tile kernel; 6 / 7 = 4-wave
+                          transposed-fragment path; 2 = general kernel; 3 = general kernel with 128 x 64 tiles; 4 = 8-wave ping-pong big-tile kernel; 6 / 7 = 4-wave
                           big-tile kernel (register-staged / LDS-DMA operands); 8..15 = general kernel with 2^(safe-8) K
                           slices.  Every value the product library accepts gives correct results; anything else returns
                           OF_E_ARG (timing ablations live in tools/libofhip_tools.so, built with -DOF_TOOLS_BUILD, never

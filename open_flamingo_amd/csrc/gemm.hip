@@ -19,7 +19,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BM = 128, BN = 128, BK = 64;      // BN: the wide tile (of_gemm_kernel's NTW = 4); the narrow one is 64
 constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB for either image
 constexpr int SMEM_BYTES = 4 * TILE_BYTES;
 
@@ -30,10 +30,12 @@ OF_DEV int swz_t(int krow, int col) {  // byte offset of element (krow, col) in 
 }
 
 // ---- global -> registers (4 x 16 B per thread per operand), zero-filled out of range
-template <bool TR>
+// EXT = tile extent of the operand (rows of a K-contiguous operand / columns of a K-strided one): 128, or 64 for the B
+// operand of the 128 x 64 tile -- the images keep their 128-wide pitch, the narrow tile fills half of them
+template <bool TR, int EXT>
 OF_DEV void g2r(const bf16_t* __restrict__ base, int ld, int row0, int rows, int k0, int K, int tid, u32x4 (&r)[4]) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < EXT / 32; ++c) {
         int id = c * 256 + tid;
         u32x4 v = {0u, 0u, 0u, 0u};
         if (!TR) {
@@ -41,23 +43,23 @@ OF_DEV void g2r(const bf16_t* __restrict__ base, int ld, int row0, int rows, int
             int gr = row0 + row, gk = k0 + slot * 8;
             if (gr < rows && gk < K) v = *(const u32x4*)(base + (size_t)gr * ld + gk);
         } else {
-            int krow = id >> 4, cs = id & 15;
+            int krow = id / (EXT / 8), cs = id % (EXT / 8);
             int gk = k0 + krow, gc = row0 + cs * 8;
             if (gk < K && gc < rows) v = *(const u32x4*)(base + (size_t)gk * ld + gc);
         }
         r[c] = v;
     }
 }
-template <bool TR>
+template <bool TR, int EXT>
 OF_DEV void r2s(char* tile, int tid, const u32x4 (&r)[4]) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < EXT / 32; ++c) {
         int id = c * 256 + tid;
         int off;
         if (!TR) {
             off = swz_n(id >> 3, id & 7);
         } else {
-            int krow = id >> 4, cs = id & 15;
+            int krow = id / (EXT / 8), cs = id % (EXT / 8);
             off = swz_t(krow, cs * 8);
         }
         *(u32x4*)(tile + off) = r[c];
@@ -89,8 +91,13 @@ OF_DEV s16x8 frag(const char* tile, int row_base, int kk, int lane) {
     }
 }
 
-template <bool AT, bool BT, int EPI, bool SAFE>
+// NTW = 16-column fragments per wave along N: 4 -> the 128 x 128 tile, 2 -> a 128 x 64 tile.  The narrow tile is for launches
+// whose 128 x 128 grid would leave at most one 4-wave workgroup per CU (to_q, the dX of to_out, the Perceiver's 1024-wide
+// projections: 128-256 tiles): a k-tile there costs its LDS write -> barrier -> read -> MFMA chain with nothing else resident
+// to cover it; twice the workgroups overlap each other.
+template <bool AT, bool BT, int EPI, bool SAFE, int NTW = 4>
 OF_GLOBAL void OF_BOUNDS(256, 2) of_gemm_kernel(OfGemmArgs p) {
+    constexpr int BN = NTW * 32;
     char* smem = of_smem();
     const int tid = of_tid(), lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i16 = lane & 15;
@@ -100,11 +107,11 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_gemm_kernel(OfGemmArgs p) {
     ofg::tile_coords(of_bid_x(), of_gdim_x(), tiles_m, tiles_n, pm, pn);
     const int m0 = pm * BM, n0 = pn * BN;
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][NTW];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NTW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     u32x4 ra[4], rb[4];
     // split-K (p.ksplit > 1, OF_EPI_ACC_F32 only): slice of_bid_y() owns k-tiles [kt0, kt0 + nk) and adds its partial
@@ -114,36 +121,35 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_gemm_kernel(OfGemmArgs p) {
     const int kt0 = of_bid_y() * per;
     const int nk = (nk_all - kt0 < per ? nk_all - kt0 : per);
     if (nk <= 0) return;
-    g2r<AT>(p.A, p.lda, m0, p.M, kt0 * BK, p.K, tid, ra);
-    g2r<BT>(p.B, p.ldb, n0, p.N, kt0 * BK, p.K, tid, rb);
-    r2s<AT>(smem, tid, ra);
-    r2s<BT>(smem + TILE_BYTES, tid, rb);
+    g2r<AT, BM>(p.A, p.lda, m0, p.M, kt0 * BK, p.K, tid, ra);
+    g2r<BT, BN>(p.B, p.ldb, n0, p.N, kt0 * BK, p.K, tid, rb);
+    r2s<AT, BM>(smem, tid, ra);
+    r2s<BT, BN>(smem + TILE_BYTES, tid, rb);
     of_sync();
     for (int kt = 0; kt < nk; ++kt) {
         const char* ta = smem + (kt & 1) * 2 * TILE_BYTES;
         const char* tb = ta + TILE_BYTES;
         const bool more = kt + 1 < nk;
         if (more) {
-            g2r<AT>(p.A, p.lda, m0, p.M, (kt0 + kt + 1) * BK, p.K, tid, ra);
-            g2r<BT>(p.B, p.ldb, n0, p.N, (kt0 + kt + 1) * BK, p.K, tid, rb);
+            g2r<AT, BM>(p.A, p.lda, m0, p.M, (kt0 + kt + 1) * BK, p.K, tid, ra);
+            g2r<BT, BN>(p.B, p.ldb, n0, p.N, (kt0 + kt + 1) * BK, p.K, tid, rb);
         }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            s16x8 fa[4], fb[4];
+            s16x8 fa[4], fb[NTW];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                fa[t] = frag<AT, SAFE>(ta, wr * 64 + t * 16, kk, lane);
-                fb[t] = frag<BT, SAFE>(tb, wc * 64 + t * 16, kk, lane);
-            }
+            for (int t = 0; t < 4; ++t) fa[t] = frag<AT, SAFE>(ta, wr * 64 + t * 16, kk, lane);
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) fb[t] = frag<BT, SAFE>(tb, wc * (NTW * 16) + t * 16, kk, lane);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = of_mfma(fb[nt], fa[mt], acc[mt][nt]);
+                for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = of_mfma(fb[nt], fa[mt], acc[mt][nt]);
         }
         if (more) {
             char* na = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
-            r2s<AT>(na, tid, ra);
-            r2s<BT>(na + TILE_BYTES, tid, rb);
+            r2s<AT, BM>(na, tid, ra);
+            r2s<BT, BN>(na + TILE_BYTES, tid, rb);
         }
         of_sync();
     }
@@ -158,8 +164,8 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_gemm_kernel(OfGemmArgs p) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int m = m0 + wr * 64 + mt * 16 + i16, n = n0 + wc * 64 + nt * 16 + g * 4;
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int m = m0 + wr * 64 + mt * 16 + i16, n = n0 + wc * (NTW * 16) + nt * 16 + g * 4;
                 if (m < p.M && n < p.N) {
                     if (slab) {   // this slice's partial tile, combined by of_splitk_reduce_kernel in slice order
                         *(f32x4*)(slab + (size_t)m * p.N + n) =
@@ -176,8 +182,8 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_gemm_kernel(OfGemmArgs p) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-            ofg::epilogue_frag<EPI>(p, acc[mt][nt], m0 + wr * 64 + mt * 16 + i16, n0 + wc * 64 + nt * 16 + g * 4, gv, sc, dot);
+        for (int nt = 0; nt < NTW; ++nt)
+            ofg::epilogue_frag<EPI>(p, acc[mt][nt], m0 + wr * 64 + mt * 16 + i16, n0 + wc * (NTW * 16) + nt * 16 + g * 4, gv, sc, dot);
     ofg::epilogue_finish<EPI>(p, gv, dot, lane, wave, 4, (float*)smem);   // the K loop ended with a workgroup barrier
 }
 
@@ -203,31 +209,32 @@ OF_GLOBAL void of_splitk_reduce_kernel(OfGemmArgs p) {
 }
 
 template <bool AT, bool BT, int EPI>
-int launch_layout(const OfGemmArgs& a, of_dim3 grid, of_stream_t s) {
+int launch_layout(const OfGemmArgs& a, of_dim3 grid, of_stream_t s, bool narrow) {
     if (a.safe == 1 && (AT || BT)) return of_launch(of_gemm_kernel<AT, BT, EPI, true>, grid, 256, SMEM_BYTES, s, a);
+    if (narrow) return of_launch(of_gemm_kernel<AT, BT, EPI, false, 2>, grid, 256, SMEM_BYTES, s, a);
     return of_launch(of_gemm_kernel<AT, BT, EPI, false>, grid, 256, SMEM_BYTES, s, a);
 }
 // Only the (layout, epilogue) pairs the hot path uses are instantiated (see DESIGN.md kernel table).
-int dispatch(const OfGemmArgs& a, of_dim3 grid, of_stream_t s) {
+int dispatch(const OfGemmArgs& a, of_dim3 grid, of_stream_t s, bool narrow = false) {
     const int layout = a.a_trans * 2 + a.b_trans;
     if (layout == 0) {  // y = x W^T
         switch (a.epi) {
-            case OF_EPI_STORE_BF16: return launch_layout<false, false, OF_EPI_STORE_BF16>(a, grid, s);
-            case OF_EPI_GELU: return launch_layout<false, false, OF_EPI_GELU>(a, grid, s);
-            case OF_EPI_GATE_RESID: return launch_layout<false, false, OF_EPI_GATE_RESID>(a, grid, s);
-            case OF_EPI_ACC_F32: return launch_layout<false, false, OF_EPI_ACC_F32>(a, grid, s);
+            case OF_EPI_STORE_BF16: return launch_layout<false, false, OF_EPI_STORE_BF16>(a, grid, s, narrow);
+            case OF_EPI_GELU: return launch_layout<false, false, OF_EPI_GELU>(a, grid, s, narrow);
+            case OF_EPI_GATE_RESID: return launch_layout<false, false, OF_EPI_GATE_RESID>(a, grid, s, narrow);
+            case OF_EPI_ACC_F32: return launch_layout<false, false, OF_EPI_ACC_F32>(a, grid, s, narrow);
         }
     } else if (layout == 1) {  // dX = dY W
         switch (a.epi) {
-            case OF_EPI_STORE_BF16: return launch_layout<false, true, OF_EPI_STORE_BF16>(a, grid, s);
-            case OF_EPI_DGELU_DOT: return launch_layout<false, true, OF_EPI_DGELU_DOT>(a, grid, s);
-            case OF_EPI_SCALE_DOT: return launch_layout<false, true, OF_EPI_SCALE_DOT>(a, grid, s);
-            case OF_EPI_ACC_F32: return launch_layout<false, true, OF_EPI_ACC_F32>(a, grid, s);
+            case OF_EPI_STORE_BF16: return launch_layout<false, true, OF_EPI_STORE_BF16>(a, grid, s, narrow);
+            case OF_EPI_DGELU_DOT: return launch_layout<false, true, OF_EPI_DGELU_DOT>(a, grid, s, narrow);
+            case OF_EPI_SCALE_DOT: return launch_layout<false, true, OF_EPI_SCALE_DOT>(a, grid, s, narrow);
+            case OF_EPI_ACC_F32: return launch_layout<false, true, OF_EPI_ACC_F32>(a, grid, s, narrow);
         }
     } else if (layout == 3) {  // dW = dY^T X
         switch (a.epi) {
-            case OF_EPI_STORE_BF16: return launch_layout<true, true, OF_EPI_STORE_BF16>(a, grid, s);
-            case OF_EPI_ACC_F32: return launch_layout<true, true, OF_EPI_ACC_F32>(a, grid, s);
+            case OF_EPI_STORE_BF16: return launch_layout<true, true, OF_EPI_STORE_BF16>(a, grid, s, narrow);
+            case OF_EPI_ACC_F32: return launch_layout<true, true, OF_EPI_ACC_F32>(a, grid, s, narrow);
         }
     }
     return OF_E_SHAPE;
@@ -355,6 +362,11 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
     if ((a.safe == 0 && pp_ok) || pp_forced) {   // 4 = force the ping-pong kernel whenever the shape is eligible
         const int rc = of_gemm_pp_try(a, s);   // 256x256 ping-pong LDS-DMA kernel for tile-aligned shapes
         if (rc != OF_E_SHAPE) return rc;
+    }
+    // 128 x 64 tiles when the 128 x 128 grid leaves at most one workgroup per CU (safe = 3 forces them: self-check)
+    if ((a.safe == 0 && (long)tiles_m * tiles_n <= 256 && a.N > 64) || a.safe == 3) {
+        grid.x = (unsigned)(tiles_m * ((a.N + 63) / 64));
+        return dispatch(b, grid, s, true);
     }
     return dispatch(b, grid, s);
 }

@@ -95,6 +95,20 @@ def test_gemm_dot_epilogues():
         assert abs(float(dot) - float(wdot)) <= 1e-3 * abs(float(wdot)) + 1e-2
 
 
+@pytest.mark.parametrize("at,bt", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(136, 192, 128), (256, 72, 64), (128, 320, 200)])
+def test_gemm_narrow_tiles_match_wide_tiles(at, bt, M, N, K):
+    """128 x 64 tiles (safe = 3; of_gemm's own choice for grids of <= 256 wide tiles) vs 128 x 128 tiles (safe = 2): the same
+    products and k order per output element -> identical fp32 results; ragged M / N / K included."""
+    A = _rand((K, M) if at else (M, K), 51)
+    B = _rand((K, N) if bt else (N, K), 52)
+    o_n, o_w = torch.zeros(M, N), torch.zeros(M, N)
+    H.gemm(A, B, a_trans=at, b_trans=bt, epi=abi.EPI_ACC_F32, C_out=o_n, safe=3)
+    H.gemm(A, B, a_trans=at, b_trans=bt, epi=abi.EPI_ACC_F32, C_out=o_w, safe=2)
+    assert torch.equal(o_n, o_w)
+    np.testing.assert_allclose(o_n.double().numpy(), _ref(A, B, at, bt).numpy(), rtol=1e-5, atol=1e-4)
+
+
 BIG_TILE = [4, 6, 7]   # OfGemmArgs.safe: 4 = 8-wave ping-pong LDS-DMA kernel, 6 / 7 = 4-wave 128x128-per-wave kernel (register staged / LDS-DMA)
 
 
