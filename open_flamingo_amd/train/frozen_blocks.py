@@ -47,25 +47,23 @@ def _zero_bias(norm):
     return b
 
 
-_WT_CACHE = {}      # id(weight) -> (weight, version, W^T contiguous): frozen weights never change, so their transposes are made once
+def _transposed(mod, name, w):
+    """W^T of a frozen nn.Linear weight as its own contiguous bf16 matrix, cached on the owning module (rebuilt if the weight
+    is replaced or written).  The backward of a frozen Linear is dX = dY W: as torch.mm(dY, W) the vendor library sees an
+    'NN' product whose B operand is strided along K, as torch.mm(dY, (W^T)^T) the same 'NT' product the forward layers use --
+    129 vs 197 us for the 8192 x 2048 x 8192 dX of up_proj (train/tuned/).  Costs one extra bf16 copy of the frozen block
+    weights (2.4 GB at MPT-1B), made once: the weights never change."""
+    key = (w.data_ptr(), w._version, tuple(w.shape))
+    cache = mod.__dict__.setdefault("_of_wt", {})
+    hit = cache.get(name)
+    if hit is None or hit[0] != key:
+        hit = cache[name] = (key, w.detach().t().contiguous())
+    return hit[1]
 
 
-def _transposed(w):
-    """W^T as its own contiguous bf16 matrix.  The backward of a frozen Linear is dX = dY W: as torch.mm(dY, W) the vendor
-    library sees an 'NN' product whose B operand is strided along K, as torch.mm(dY, (W^T)^T) the same 'NT' product the
-    forward layers use -- measured 129 vs 197 us for the 8192 x 2048 x 8192 dX of up_proj (profiles/, TunableOp table).
-    Costs one extra bf16 copy of the frozen block weights (2.4 GB at MPT-1B)."""
-    hit = _WT_CACHE.get(id(w))
-    if hit is None or hit[0] is not w or hit[1] != w._version:
-        hit = _WT_CACHE[id(w)] = (w, w._version, w.detach().t().contiguous())
-    return hit[2]
-
-
-def _mm_dx(dy, w):
-    """dX = dY W for a frozen nn.Linear weight W (out, in)."""
-    if _DX_PRETRANSPOSED:
-        return torch.mm(dy, _transposed(w).t())
-    return torch.mm(dy, w)
+def _mm_dx(dy, w, wt):
+    """dX = dY W for a frozen nn.Linear weight W (out, in); wt = its cached transpose or None."""
+    return torch.mm(dy, wt.t()) if wt is not None else torch.mm(dy, w)
 
 
 class _FrozenMptBlockFn(torch.autograd.Function):
@@ -73,7 +71,7 @@ class _FrozenMptBlockFn(torch.autograd.Function):
     with frozen weights.  x: (B, L, d) fp32 residual stream; returns the new stream (fp32)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, Wqkv, Wo, Wup, Wdown, slopes, kv_len, heads, head_dim, scale):
+    def forward(ctx, x, w1, b1, w2, b2, Wqkv, Wo, Wup, Wdown, slopes, kv_len, heads, head_dim, scale, wts):
         ops = _ops()
         B, L, d = x.shape
         rows = B * L
@@ -99,35 +97,36 @@ class _FrozenMptBlockFn(torch.autograd.Function):
         u = torch.mm(torch.nn.functional.gelu(h), Wdown.t())
         y = torch.add(x1, u)                                         # fp32 stream + bf16 branch -> fp32
         ctx.save_for_backward(x2, st1, qkv, o, lse, x1, st2, h, w1, w2, Wqkv, Wo, Wup, Wdown, slopes, kv_len)
-        ctx.kw, ctx.shape = kw, (B, L, d)
+        ctx.kw, ctx.shape, ctx.wts = kw, (B, L, d), wts      # wts: (Wqkv^T, Wo^T, Wup^T, Wdown^T) or None: frozen, not autograd inputs
         return y.view(B, L, d)
 
     @staticmethod
     def backward(ctx, dy):
         ops = _ops()
         x2, st1, qkv, o, lse, x1, st2, h, w1, w2, Wqkv, Wo, Wup, Wdown, slopes, kv_len = ctx.saved_tensors
+        tq, to, tu, td = ctx.wts if ctx.wts is not None else (None, None, None, None)
         B, L, d = ctx.shape
         rows = B * L
         dev = dy.device
         dy2 = dy.reshape(rows, d)
         if dy2.dtype != F32 or not dy2.is_contiguous():
             dy2 = dy2.to(F32).contiguous()
-        dact = _mm_dx(ops.to_bf16(dy2), Wdown)                       # (rows, 4d)
+        dact = _mm_dx(ops.to_bf16(dy2), Wdown, td)                   # (rows, 4d)
         dh = torch.ops.aten.gelu_backward(dact, h, approximate="none")
         del dact
-        dm = _mm_dx(dh, Wup)                                         # (rows, d)
+        dm = _mm_dx(dh, Wup, tu)                                     # (rows, d)
         del dh
         dx1 = torch.empty(rows, d, dtype=F32, device=dev)
         dx1b = torch.empty(rows, d, dtype=BF16, device=dev)
         ops.ln_bwd(dm, x1, st2, w2, resid=dy2, dx=dx1, dx_bf16=dx1b)  # dx1 = dy + norm_2'(dm), plus its bf16 operand copy
-        do = _mm_dx(dx1b, Wo)
+        do = _mm_dx(dx1b, Wo, to)
         dqkv = torch.empty_like(qkv)
         delta = torch.empty(B, ctx.kw["heads"], L, dtype=F32, device=dev)
         ops.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, do, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
                      delta, **ctx.kw)
-        da = _mm_dx(dqkv, Wqkv)                                      # (rows, d)
+        da = _mm_dx(dqkv, Wqkv, tq)                                  # (rows, d)
         ops.ln_bwd(da, x2, st1, w1, resid=dx1, dx=dx1)               # in place: dx = dx1 + norm_1'(da)
-        return (dx1.view(B, L, d),) + (None,) * 13
+        return (dx1.view(B, L, d),) + (None,) * 14
 
 
 def _frozen_bf16(*linears):
@@ -153,9 +152,13 @@ def _mpt_block_fused_forward(self, hidden_states, position_bias, attention_mask,
                                       use_cache=use_cache, output_attentions=output_attentions, **kwargs)
     from .towers import _alibi_slopes_and_lens
     slopes, lens = _alibi_slopes_and_lens(position_bias, attention_mask, x.shape[1])
+    wts = None
+    if _DX_PRETRANSPOSED and torch.is_grad_enabled() and x.requires_grad:
+        wts = (_transposed(attn, "Wqkv", attn.Wqkv.weight), _transposed(attn, "out_proj", attn.out_proj.weight),
+               _transposed(ffn, "up_proj", ffn.up_proj.weight), _transposed(ffn, "down_proj", ffn.down_proj.weight))
     y = _FrozenMptBlockFn.apply(x, self.norm_1.weight, _zero_bias(self.norm_1), self.norm_2.weight, _zero_bias(self.norm_2),
                                 attn.Wqkv.weight, attn.out_proj.weight, ffn.up_proj.weight, ffn.down_proj.weight,
-                                slopes, lens, attn.n_heads, attn.head_dim, float(attn.softmax_scale))
+                                slopes, lens, attn.n_heads, attn.head_dim, float(attn.softmax_scale), wts)
     return y, None
 
 
