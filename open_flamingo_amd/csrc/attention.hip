@@ -23,6 +23,13 @@
 //     S tile    = Q(16 q x 64 d) . K^T            -> lane holds key l&15, queries 4g+r
 //     dV^T     += dO^T . P ; dK^T += Q^T . dS     (dO^T / Q^T via transpose read)
 // Two backward passes instead of atomics: deterministic, and the recomputed S is ~1% of the path FLOPs.
+//
+// What bounds these kernels is VALU issue, not MFMA, LDS or HBM (rocprofv3 --pmc, profiles/r02_final_*attention*_pmc.txt):
+// a 16-query x 64-key step is 16-32 MFMAs but, even after the diet below, ~200 VALU instructions (16 of them quarter-rate
+// v_exp_f32).  Hence: fragment-read addresses computed once per lane (FragOff), hardware bf16 packing, scores in the log2
+// domain, an unmasked path for key blocks every row of a tile sees completely, row reductions by permlane swaps, scalar
+// block loops.  For self-attention with >= 4 query tiles over >= 4 key blocks of_attn_fwd_res_kernel keeps K and V of a
+// (batch, head) resident in LDS (LDS-DMA, one workgroup per head); everything else runs one workgroup per 64-query tile.
 #include "of_platform.h"
 #include "../../include/of_hip.h"
 

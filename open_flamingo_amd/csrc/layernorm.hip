@@ -2,8 +2,10 @@
 // Replaces aten::native_layer_norm (+backward) under nn.LayerNorm in open_flamingo/src/helpers.py:18,
 // 33-34,105,152.  HBM-bound: one wave per row, 16-byte vector accesses, fp32 statistics.  The forward
 // writes the bf16 GEMM operand directly (optionally into a strided destination so the Perceiver's
-// cat(LN(x), LN(latents)) of helpers.py:53 is never materialised by a copy); the backward fuses the
-// residual-stream add, the bf16 operand copy of the result, and the dw/db column reductions.
+// cat(LN(x), LN(latents)) of helpers.py:53 is never materialised by a copy; optionally after adding a bf16 branch
+// output to the stream: of_layernorm_fwd_add); the backward fuses the residual-stream add, the bf16 operand copy
+// of the result, and the dw/db column reductions -- as one wave per row, or for wide rows with dw/db one WORKGROUP
+// per row (of_ln_bwd_wg_kernel: 16 instead of 64 accumulator registers per lane, twice the waves per SIMD).
 #include "of_platform.h"
 #include "../../include/of_hip.h"
 
