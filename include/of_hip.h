@@ -171,8 +171,8 @@ typedef struct OfAttnArgs {
     float* delta;             /* (batch,H,Lq) fp32 scratch: rowsum(dO*O), written by the dq pass */
     int safe;                 /* DEBUG / SELF-CHECK ONLY -- production callers pass 0 (auto: forward with K and V of a (batch, head)
                                  resident in LDS where that pays, else one workgroup per 64-query tile).  1 = tiled kernels with the
-                                 scalar-LDS transposed-fragment path, 2 = tiled kernels: every value gives correct results, tests
-                                 compare the forms with each other. */
+                                 scalar-LDS transposed-fragment path, 2 = tiled kernels, 3 = resident-K/V forward whenever the two
+                                 images fit 160 KB: every value gives correct results, tests compare the forms with each other. */
     /* causal self-attention with ALiBi (the frozen MPT blocks); all zero/NULL for the two hot-path uses */
     int head_dim;             /* 0 or 64: 64;  128 */
     int causal;               /* 1: query i sees keys [0, i + 1 + Lk - Lq); text_time must be NULL */

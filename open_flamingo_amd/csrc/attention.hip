@@ -835,11 +835,12 @@ namespace {
 // LDS bytes of the resident-K/V forward, or 0 when this launch stays on the tiled kernel
 template <int DH>
 size_t resident_smem(const OfAttnArgs& a) {
-    if (a.safe != 0) return 0;                                   // safe = 1: scalar-LDS path, 2: tiled kernel (both of_attn_q_kernel)
+    if (a.safe != 0 && a.safe != 3) return 0;                    // safe = 1: scalar-LDS path, 2: tiled kernel (both of_attn_q_kernel)
     const size_t need = (size_t)((a.Lk + 31) & ~31) * DH * 2 * 2;
     if (need > 160 * 1024) return 0;
-    // Measured (profiles/r02_attention_*): the resident form wins where a (batch, head) has >= 4 query tiles re-reading >= 4
-    // key blocks (CLIP ViT 257 x 257: 64 vs 72 us) and ties on the frozen MPT blocks (256 x 256, head dim 128); the gated
+    if (a.safe == 3) return need;                                // self-check: the resident form whenever the images fit
+    // Measured (profiles/r02_final_*): the resident form wins where a (batch, head) has >= 4 query tiles re-reading >= 4
+    // key blocks (CLIP ViT 257 x 257: 65 vs 71 us) and ties on the frozen MPT blocks (256 x 256, head dim 128); the gated
     // cross-attention (128 keys) and Perceiver (64 queries) cores stay on the tiled kernel (11 vs 14 us, 13 vs 16 us).
     if (a.Lq < 256 || a.Lk < 256) return 0;
     if ((long)a.batch * a.heads < 64) return 0;                   // few heads: the tiled grid has more workgroups

@@ -51,7 +51,7 @@ def _check(q, k, v, heads, tt=None, n=0, T=0, only_imm=1, safe=0, tol=2e-2):
     return res
 
 
-@pytest.mark.parametrize("safe", [0, 1, 2])     # 0: resident-K/V forward; 1: tiled kernels, scalar-LDS path; 2: tiled kernels
+@pytest.mark.parametrize("safe", [0, 1, 2, 3])  # 0: of_attn's own choice; 1: tiled kernels, scalar-LDS path; 2: tiled kernels; 3: resident-K/V forward
 def test_perceiver_shape(safe):
     # 2 media, 2 heads, 64 latent queries, 96 keys (tail block half empty)
     q, k, v = _r((2, 64, 128), 1), _r((2, 96, 128), 2), _r((2, 96, 128), 3)
@@ -71,7 +71,7 @@ def test_self_attention_vit_like_ragged(dh):
     heads, B, L = 2, 2, 81
     q, k, v = _r((B, L, heads * dh), 41), _r((B, L, heads * dh), 42), _r((B, L, heads * dh), 43)
     outs = []
-    for safe in (0, 2):
+    for safe in (3, 2):
         o = torch.full_like(q, float("nan"))
         lse = torch.full((B, heads, L), float("nan"))
         H.attn_fwd(H.attn_args(q, k, v, o, lse, heads=heads, safe=safe, head_dim=dh))
@@ -79,6 +79,26 @@ def test_self_attention_vit_like_ragged(dh):
     ref = dense_attention(q.double(), k.double(), v.double(), heads, head_dim=dh)
     assert (outs[0][0].double() - ref).abs().max() <= 2e-2 * ref.abs().max()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_resident_forward_progressive_causal_loading():
+    """Causal self-attention with Lq == Lk = 4 key blocks + a ragged tail at head dim 128 (8 waves: two key blocks become
+    visible per step) and head dim 64 (4 waves: one per step): the resident forward's progressive LDS-DMA schedule must
+    reproduce the tiled kernel bit for bit, with and without right padding."""
+    for dh, L in ((128, 300), (64, 272)):
+        heads, B = 2, 2
+        q, k, v = _r((B, L, heads * dh), 61), _r((B, L, heads * dh), 62), _r((B, L, heads * dh), 63)
+        slopes = torch.tensor([0.25, 0.03125])
+        outs = []
+        for safe in (3, 2):
+            o = torch.full_like(q, float("nan"))
+            lse = torch.full((B, heads, L), float("nan"))
+            H.attn_fwd(H.attn_args(q, k, v, o, lse, heads=heads, safe=safe, head_dim=dh, causal=1, alibi_slopes=slopes))
+            outs.append((o, lse))
+        assert torch.isfinite(outs[0][0].float()).all()
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        ref = dense_attention(q.double(), k.double(), v.double(), heads, head_dim=dh, causal=True, alibi_slopes=slopes)
+        assert (outs[0][0].double() - ref).abs().max() <= 2e-2 * ref.abs().max()
 
 
 CASES = {
@@ -121,7 +141,7 @@ def test_text_time_kernel():
     assert torch.equal(tt2.long(), ml.sum(-1, keepdim=True).expand(-1, 7))
 
 
-@pytest.mark.parametrize("dh,safe", [(128, 0), (128, 1), (128, 2), (64, 0), (64, 2)])
+@pytest.mark.parametrize("dh,safe", [(128, 0), (128, 1), (128, 3), (64, 0), (64, 3)])
 @pytest.mark.parametrize("Lq,Lk", [(96, 96), (40, 104)])
 def test_causal_alibi_self_attention(dh, safe, Lq, Lk):
     """Causal self-attention with ALiBi (the frozen MPT blocks): head dim 128 and 64, ragged lengths, Lq < Lk

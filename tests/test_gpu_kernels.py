@@ -136,6 +136,34 @@ def _attn_case(ops, q, k, v, heads, tt=None, n=0, T=0, only_imm=True, safe=0):
     return o2.reshape(q.shape), lse, res
 
 
+@pytest.mark.parametrize("dh,heads,B,L,causal", [(128, 16, 8, 256, True), (64, 16, 8, 257, False), (64, 4, 3, 300, True)])
+def test_resident_forward_matches_tiled_forward_at_tower_shapes(ops, dh, heads, B, L, causal):
+    """of_attn_fwd's resident-K/V form (of_attn_fwd_res_kernel: LDS-DMA, progressive loading for causal self-attention, a
+    32-row tail block) at the shapes it is selected for -- frozen MPT blocks (256 x 256, head dim 128, causal + ALiBi) and the
+    CLIP tower (257 x 257, head dim 64) -- against the tiled kernel (bit for bit) and a dense fp32 softmax."""
+    d = heads * dh
+    qkv = _r((B * L, 3 * d), 71)
+    slopes = torch.tensor([2.0 ** (-8.0 * (i + 1) / heads) for i in range(heads)], device="cuda") if causal else None
+    outs = []
+    for safe in (0, 3, 2):
+        o = torch.full((B * L, d), float("nan"), device="cuda", dtype=torch.bfloat16)
+        lse = torch.full((B, heads, L), float("nan"), device="cuda")
+        ops.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, batch=B, Lq=L, Lk=L, heads=heads, scale=dh ** -0.5,
+                     head_dim=dh, causal=causal, alibi_slopes=slopes, safe=safe)
+        outs.append((o, lse))
+    for o, lse in outs[:2]:
+        assert torch.equal(o, outs[2][0]) and torch.equal(lse, outs[2][1])
+    q, k, v = (qkv[:, i * d:(i + 1) * d].float().view(B, L, heads, dh).transpose(1, 2) for i in range(3))
+    s = q @ k.transpose(-1, -2) * dh ** -0.5
+    if causal:
+        pos = torch.arange(L, device="cuda")
+        s = s + slopes.view(1, heads, 1, 1) * (pos.view(1, 1, 1, L) - pos.view(1, 1, L, 1))
+        s = s.masked_fill(pos.view(1, 1, 1, L) > pos.view(1, 1, L, 1), float("-inf"))
+    want = (s.softmax(-1) @ v).transpose(1, 2).reshape(B * L, d)
+    assert _rel(outs[0][0], want) < 1e-2
+    assert torch.allclose(outs[0][1], s.logsumexp(-1), atol=2e-3, rtol=1e-4)
+
+
 @pytest.mark.parametrize("safe", [0, 1])
 def test_attention_perceiver_shape(ops, safe):
     kv = _r((4, 320, 2 * 512), 11)
