@@ -411,7 +411,7 @@ def use_tuned_vendor_gemms(table=None):
 
 def build_flamingo(family: str = "OF-3B", device="cuda", seed: int = 0, gates: float = 0.5, vision_kw=None,
                    freeze_lm_embeddings: bool = False, verbose: bool = False, frozen_bf16: bool = False,
-                   fused_lm_attention=True, tower_layernorm="eager", lm_loss="hf", fused_lm_blocks=False, fused_vision=False):
+                   fused_lm_attention=True, tower_layernorm="eager", lm_loss="hf", fused_lm_blocks=False, fused_vision=False, perceiver_depth=None):
     """Random-init Flamingo of the given family, assembled through the factory path, gates set to ``gates``
     (their init value 0 makes the hot path an exact no-op with zero weight gradients -- SURVEY.md section 7)."""
     from ..src.factory import assemble_flamingo
@@ -427,6 +427,10 @@ def build_flamingo(family: str = "OF-3B", device="cuda", seed: int = 0, gates: f
         model = assemble_flamingo(vision, lm, eoc_id, media_id, vis_dim=vis_dim, cross_attn_every_n_layers=f["every"],
                                   decoder_layers_attr_name=attr, freeze_lm_embeddings=freeze_lm_embeddings,
                                   verbose=verbose)
+        if perceiver_depth is not None:    # tests: a shallower Perceiver than the reference's fixed depth 6 (flamingo.py:74)
+            from ..src.helpers import PerceiverResampler
+            model.perceiver = PerceiverResampler(dim=vis_dim, depth=perceiver_depth)
+            model.perceiver.requires_grad_(True)
     if frozen_bf16:
         hold_frozen_linears_in_bf16(model)
     if tower_layernorm == "libofhip":      # the element-wise pieces of the frozen towers on libofhip

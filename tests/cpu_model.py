@@ -7,7 +7,7 @@ from open_flamingo_amd.train import towers
 
 
 def swap_in_oracle(model):
-    per = O.OraclePerceiverResampler(dim=model.vis_dim)
+    per = O.OraclePerceiverResampler(dim=model.vis_dim, depth=len(model.perceiver.layers))
     per.load_state_dict(model.perceiver.state_dict(), strict=True)
     per.requires_grad_(True)
     model.perceiver = per

@@ -33,7 +33,10 @@ def _rel(a, b):
 
 
 def _tiny(seed=0):
-    model, info = towers.build_flamingo("OF-tiny", device="cpu", seed=seed, gates=0.5, fused_lm_attention=False)
+    # 56-pixel images = 16 patch tokens per image and a 2-layer Perceiver: the kernels run on the host emulator, the
+    # reference's 256 patches / depth 6 would only repeat the same code paths (minutes instead of seconds)
+    model, info = towers.build_flamingo("OF-tiny", device="cpu", seed=seed, gates=0.5, fused_lm_attention=False,
+                                        vision_kw=dict(width=64, layers=2, heads=2, patch=14, image=56), perceiver_depth=2)
     model.train()
     return model, info
 
@@ -87,7 +90,7 @@ def test_gradients_accumulate_in_place_into_reducer_buckets(on_emulator):
             for b in red.buckets:
                 for p in b["params"]:
                     p._of_on_grad = (lambda q, f=p._of_on_grad: (fired.append(q), f(q))[1])
-        for b in (synthetic.make_batch(2, 1, 16, info, "cpu", seed=6), synthetic.make_batch(2, 2, 24, info, "cpu", seed=5)):
+        for b in (synthetic.make_batch(2, 1, 16, info, "cpu", seed=6, image_size=56), synthetic.make_batch(2, 2, 24, info, "cpu", seed=5, image_size=56)):
             step.forward_loss(model, b, info, amp=False).backward()
         if red is not None:
             n_params = sum(len(b["params"]) for b in red.buckets)
@@ -114,7 +117,7 @@ def test_train_step_with_product_modules_tracks_oracle_modules(on_emulator):
             swap_in_oracle(model)
         red = GradReducer(model, embedding_rows=[info["media_token_id"], info["eoc_token_id"]])
         opt = FlatAdamW(red, lr=1e-3, ops=H.emu_ops()) if product else step.build_optimizer(model, lr=1e-3)
-        batch = batch or synthetic.make_batch(2, 2, 24, info, "cpu", seed=5)
+        batch = batch or synthetic.make_batch(2, 2, 24, info, "cpu", seed=5, image_size=56)
         init = {k: p.detach().clone() for k, p in model.named_parameters() if p.requires_grad}
         losses = [float(step.train_step(model, red, opt, batch, info, amp=False)) for _ in range(2)]
         runs.append((losses, init, {k: p.detach().clone() for k, p in model.named_parameters() if p.requires_grad}))
@@ -201,8 +204,8 @@ def test_step_epilogue_leaves_weight_gradients_for_the_backward_to_overwrite(on_
     model, info = _tiny()
     red = GradReducer(model, embedding_rows=[info["media_token_id"], info["eoc_token_id"]])
     opt = FlatAdamW(red, lr=1e-3, ops=H.emu_ops())
-    b1 = synthetic.make_batch(2, 1, 16, info, "cpu", seed=6)
-    b2 = synthetic.make_batch(2, 2, 24, info, "cpu", seed=5)
+    b1 = synthetic.make_batch(2, 1, 16, info, "cpu", seed=6, image_size=56)
+    b2 = synthetic.make_batch(2, 2, 24, info, "cpu", seed=5, image_size=56)
     step.train_step(model, red, opt, b2, info, amp=False)
     mats = [p for b in red.buckets for p in b["overwritable"]]
     small = [p for b in red.buckets for p in b["params"] if all(p is not q for q in b["overwritable"])]
@@ -236,10 +239,10 @@ def test_grouped_media_projections_match_per_block_projections(on_emulator, monk
     results = []
     for grouped in (False, True):
         model, info = towers.build_flamingo("OF-tiny", device="cpu", seed=0, gates=0.5, fused_lm_attention=False,
-                                            vision_kw=dict(width=256, layers=1, heads=2, patch=14, image=224))
+                                            vision_kw=dict(width=256, layers=1, heads=2, patch=14, image=56), perceiver_depth=2)
         model.train()
         model.group_media_projections = grouped
-        batch = synthetic.make_batch(2, 2, 24, info, "cpu", seed=5)
+        batch = synthetic.make_batch(2, 2, 24, info, "cpu", seed=5, image_size=56)
         calls = []
         orig = Ops.gemm_grouped
         monkeypatch.setattr(Ops, "gemm_grouped", lambda self, *a, **kw: (calls.append(kw["kind"]), orig(self, *a, **kw))[1])
