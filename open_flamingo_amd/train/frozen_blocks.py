@@ -129,6 +129,71 @@ class _FrozenMptBlockFn(torch.autograd.Function):
         return (dx1.view(B, L, d),) + (None,) * 14
 
 
+class _LiteMask:
+    """Stand-in for the (B, 1, L, L) boolean mask HF's MptModel.forward builds for its blocks.  transformers' eager-mask
+    builder synchronises the host once per LM forward (a device scalar made with torch.tensor, an `if mask.all()`): the
+    host then sits idle until the GPU has drained everything enqueued so far -- 58 of the 108 ms of host time per step
+    were that wait (tools/host_profile.py), and a step whose host cannot run ahead of the GPU is at the mercy of the
+    box's CPU load.  The fused blocks only need the per-sequence key counts; a block that falls back to its HF forward
+    asks for the real mask (full())."""
+
+    def __init__(self, am, B, L, device):
+        self.am, self.B, self.L, self.device = am, B, L, device
+        self._lens = None
+        self._slopes = None
+        self._full = None
+
+    def to(self, *a, **kw):          # MptModel.forward: create_causal_mask(...).to(torch.bool)
+        return self
+
+    def lens(self):
+        if self.am is None:
+            return None
+        if self._lens is None:       # right padding (train/data.py pads on the right): real keys per sequence
+            self._lens = self.am.ne(0).sum(-1).to(torch.int32).contiguous()
+        return self._lens
+
+    def slopes(self, position_bias):
+        if self._slopes is None or self._slopes[0] is not position_bias:
+            pb = position_bias[:, 0, :].float()
+            self._slopes = (position_bias, (pb[:, -1] - pb[:, -2]).contiguous())
+        return self._slopes[1]
+
+    def full(self):
+        """HF's boolean mask (True = masked): causal, plus the padded keys."""
+        if self._full is None:
+            i = torch.arange(self.L, device=self.device)
+            m = (i[None, :] > i[:, None])[None, None].expand(self.B, 1, self.L, self.L)
+            if self.am is not None:
+                m = m | self.am.eq(0)[:, None, None, :]
+            self._full = m.contiguous()
+        return self._full
+
+
+_orig_create_causal_mask = None
+
+
+def _install_lite_mask():
+    """Route transformers' mask builder (the name MptModel.forward resolves in its module) through _LiteMask for language
+    models that opted in (config._of_lite_mask, set by use_fused_frozen_mpt_blocks); every other call is untouched."""
+    global _orig_create_causal_mask
+    from transformers.models.mpt import modeling_mpt
+    if _orig_create_causal_mask is not None or not hasattr(modeling_mpt, "create_causal_mask"):
+        return
+    _orig_create_causal_mask = modeling_mpt.create_causal_mask
+
+    def create_causal_mask(config=None, inputs_embeds=None, attention_mask=None, past_key_values=None, **kw):
+        lite = (getattr(config, "_of_lite_mask", False) and past_key_values is None and not kw and inputs_embeds is not None
+                and inputs_embeds.dim() == 3
+                and (attention_mask is None or (attention_mask.dim() == 2 and attention_mask.shape == inputs_embeds.shape[:2])))
+        if not lite:
+            return _orig_create_causal_mask(config=config, inputs_embeds=inputs_embeds, attention_mask=attention_mask,
+                                            past_key_values=past_key_values, **kw)
+        return _LiteMask(attention_mask, inputs_embeds.shape[0], inputs_embeds.shape[1], inputs_embeds.device)
+
+    modeling_mpt.create_causal_mask = create_causal_mask
+
+
 def _frozen_bf16(*linears):
     return all(lin.bias is None and lin.weight.dtype == BF16 and not lin.weight.requires_grad for lin in linears)
 
@@ -147,11 +212,15 @@ def _mpt_block_fused_forward(self, hidden_states, position_bias, attention_mask,
           and isinstance(ffn.act, nn.GELU) and ffn.act.approximate == "none"
           and (getattr(self, "_of_allow_cpu", False)
                or (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == BF16)))
+    lite = attention_mask if isinstance(attention_mask, _LiteMask) else None
     if not ok:
-        return self._of_eager_forward(hidden_states, position_bias, attention_mask, layer_past=layer_past,
-                                      use_cache=use_cache, output_attentions=output_attentions, **kwargs)
-    from .towers import _alibi_slopes_and_lens
-    slopes, lens = _alibi_slopes_and_lens(position_bias, attention_mask, x.shape[1])
+        return self._of_eager_forward(hidden_states, position_bias, lite.full() if lite is not None else attention_mask,
+                                      layer_past=layer_past, use_cache=use_cache, output_attentions=output_attentions, **kwargs)
+    if lite is not None:
+        slopes, lens = lite.slopes(position_bias), lite.lens()
+    else:
+        from .towers import _alibi_slopes_and_lens
+        slopes, lens = _alibi_slopes_and_lens(position_bias, attention_mask, x.shape[1])
     wts = None
     if _DX_PRETRANSPOSED and torch.is_grad_enabled() and x.requires_grad:
         wts = (_transposed(attn, "Wqkv", attn.Wqkv.weight), _transposed(attn, "out_proj", attn.out_proj.weight),
@@ -174,6 +243,9 @@ def use_fused_frozen_mpt_blocks(lm, allow_cpu=False):
                 mod.forward = types.MethodType(_mpt_block_fused_forward, mod)
             mod._of_allow_cpu = bool(allow_cpu)
             n += 1
+    if n and getattr(lm, "config", None) is not None:
+        _install_lite_mask()
+        lm.config._of_lite_mask = True
     return n
 
 

@@ -103,6 +103,12 @@ def test_fused_frozen_mpt_block_matches_hf_eager(on_emulator, d, heads):
     assert len(calls) == 2, "the fused path must have been taken by both blocks"
     assert _rel(got_o, ref_o) < 2e-2, _rel(got_o, ref_o)
     assert _rel(got_g, ref_g) < 3e-2, _rel(got_g, ref_g)
+    # a call the fused form does not cover inside a forward that got the light-weight mask (output_attentions): the blocks ask
+    # the stand-in for HF's full boolean mask and run their own forward -- same logits as the unpatched model
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        out = lm(inputs_embeds=lm.get_input_embeddings()(ids), attention_mask=am, use_cache=False, output_attentions=True)
+    assert out.attentions is not None and len(out.attentions) == 2
+    assert _rel(out.logits.float() * am.bool()[..., None], ref_o) < 2e-2
     # a call the fused form does not cover (KV cache) goes through the module's own forward
     with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
         out = lm(input_ids=ids[:1, :5], use_cache=True)
