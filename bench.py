@@ -159,6 +159,10 @@ def main():
     ap.add_argument("--vendor-gemm-table", default="tuned", choices=["tuned", "default"],
                     help="kernel selection of the frozen towers' vendor-library GEMMs: the committed TunableOp table "
                          "(open_flamingo_amd/train/tuned/, tuning off at run time) or the libraries' default heuristics")
+    ap.add_argument("--nan-check", default="device", choices=["device", "host"],
+                    help="the reference's skip-the-step-on-NaN-loss (train_utils.py:161-169): decided on the device by the fused step "
+                         "epilogue (non-finite global gradient norm: no update, on every rank alike, no host sync), or with the "
+                         "reference's host-side torch.isnan(loss)")
     ap.add_argument("--gemm-report", default=None, help="write a per-(layout,epilogue,shape) GEMM time table (JSON lines)")
     args = ap.parse_args()
     if args.gpus > 1 and not any(k in os.environ for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK")):
@@ -191,6 +195,7 @@ def main():
     opt = step.build_optimizer(model, reducer=None if args.torch_optimizer else reducer)
     batch = synthetic.make_batch(args.batch, args.T, args.L, info, device, seed=1 + rank)
     ops = Ops.default()
+    nan_check = "device" if (args.nan_check == "device" and not args.torch_optimizer) else True
 
     def sync():
         if world > 1:
@@ -204,7 +209,7 @@ def main():
     for w in range(args.warmup):
         if not args.no_roofline and w == args.warmup - 1:
             ops.gemm_timing = []
-        loss = step.train_step(model, reducer, opt, batch, info)
+        loss = step.train_step(model, reducer, opt, batch, info, nan_check=nan_check)
     sync()
     if not args.no_roofline and args.warmup > 0:
         survey, ops.gemm_timing = ops.gemm_timing, None
@@ -221,7 +226,7 @@ def main():
     reducer.time_waits = world > 1          # two HIP events per step around the compute stream's wait for RCCL
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step.train_step(model, reducer, opt, batch, info)
+        loss = step.train_step(model, reducer, opt, batch, info, nan_check=nan_check)
     sync()
     elapsed = time.perf_counter() - t0
     overlap = reducer.overlap_stats()
@@ -292,7 +297,7 @@ def main():
                           "frozen_tower_weights": "fp32 (re-cast by autocast)" if args.frozen_fp32 else "bf16 copies held",
                           "frozen_vision_tower": args.vision if not args.frozen_fp32 else "modules", "frozen_lm_blocks": args.lm_blocks if not args.frozen_fp32 else "modules",
                           "frozen_lm_attention": args.lm_attention, "frozen_tower_layernorm": args.tower_layernorm,
-                          "lm_loss": args.lm_loss,
+                          "lm_loss": args.lm_loss, "nan_check": "device (step epilogue)" if nan_check == "device" else "host (torch.isnan(loss))",
                           "vendor_gemm_table": f"TunableOp table, {n_tuned} shapes, tuning off" if n_tuned else "library defaults",
                           "grad_wire_dtype": "bf16" if args.wire_bf16 else "fp32",
                           "embedding_row_gradient": "sparse taps" if args.sparse_embedding_rows else "dense, masked"},

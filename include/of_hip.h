@@ -223,7 +223,9 @@ int of_add(const void* a, const void* b, void* out, int f32, long n, void* strea
  *   of_adamw_clip:  the effective gradient is grad_scale * g (grad_scale = 1/world_size when g holds the all-reduced SUM);
  *                   coef = min(1, max_norm / (grad_scale * sqrt(*sumsq) + 1e-6)) (max_norm <= 0: no clipping);
  *                   torch.optim.AdamW update with gradient coef * grad_scale * g at 1-based `step`; p_bf16 (optional) receives the bf16 copy of the new
- *                   parameters; zero_grad != 0 clears g in the same pass.  No host synchronisation. */
+ *                   parameters; zero_grad != 0 clears g in the same pass.  A non-finite *sumsq (NaN / Inf anywhere in the
+ *                   gradients) skips the update -- p, m, v, p_bf16 untouched, g still cleared if asked: the reference's skip-on-NaN
+ *                   (train_utils.py:161-169) decided on the device, identically on every rank.  No host synchronisation. */
 #define OF_SUMSQ_PARTS 512
 int of_sumsq_partial(const float* g, long n, float* partials, void* stream);
 int of_sumsq_finish(const float* partials, long count, float* acc, void* stream);

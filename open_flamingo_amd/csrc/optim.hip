@@ -85,6 +85,20 @@ OF_GLOBAL void of_adamw_kernel(OptArgs a) {
     // gradients arrive as SUMS over ranks: grad_scale = 1/world turns them into the average DDP would have produced;
     // *acc is the squared norm of the unscaled buffers
     const float norm = sqrtf(*a.acc) * a.grad_scale;
+    // A non-finite global norm (a NaN / Inf anywhere in the gradients, e.g. from a NaN loss) skips the update on every rank
+    // alike -- they all read the same all-reduced norm: the device-side form of the reference's "if torch.isnan(loss): skip
+    // the step" (train_utils.py:161-169) without its host synchronisation and without the deadlock a one-rank host decision
+    // would cause under a collective.  Parameters, moments and bf16 copies stay untouched; gradients this pass would have
+    // cleared are still cleared.
+    if (!(norm < 3.0e38f)) {
+        if (a.zero_grad) {
+            const long nvz = a.n >> 2, strz = (long)of_gdim_x() * 256;
+            for (long i = (long)of_bid_x() * 256 + of_tid(); i < nvz; i += strz) *(f32x4*)(a.g + i * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (of_bid_x() == 0)
+                for (long i = (nvz << 2) + of_tid(); i < a.n; i += 256) a.g[i] = 0.f;
+        }
+        return;
+    }
     float coef = a.max_norm > 0.f ? a.max_norm / (norm + 1e-6f) : 1.0f;
     coef = (coef < 1.0f ? coef : 1.0f) * a.grad_scale;
     const float step_size = a.lr / a.bc1, inv_sqrt_bc2 = 1.0f / sqrtf(a.bc2), decay = 1.0f - a.lr * a.wd;

@@ -65,7 +65,12 @@ def train_step(model, reducer, optimizer, batch_mmc4, info, batch_laion=None, lo
                loss_multiplier_mmc4=1.0, clip_norm=1.0, amp=True, nan_check=True, lr_scheduler=None,
                mask_embedding_rows=True):
     """Returns the (detached) MMC4 loss tensor, or None if the step was skipped because the loss was NaN.
-    reducer=None is the single-process form of the reference loop (embedding-gradient mask applied in place)."""
+    reducer=None is the single-process form of the reference loop (embedding-gradient mask applied in place).
+    nan_check: True = the reference's host-side ``torch.isnan(loss)`` (train_utils.py:161-169: one host sync per step, and under
+    data parallelism a NaN on one rank alone leaves the others waiting in their collectives); "device" = no host sync -- the
+    backward runs, the NaN reaches every rank through the all-reduce, and the fused step epilogue (of_adamw_clip) skips the
+    update on a non-finite global norm, on all ranks alike (needs the FlatAdamW optimizer; the returned loss is then NaN
+    instead of None, and FlatAdamW's step counter still advances); False = no check."""
     fused = hasattr(optimizer, "reducer")         # FlatAdamW: clip + AdamW + zero_grad in two device passes
     params = None if fused else [p for g in optimizer.param_groups for p in g["params"]]
     if batch_laion is not None:
@@ -73,7 +78,9 @@ def train_step(model, reducer, optimizer, batch_mmc4, info, batch_laion=None, lo
             loss_l = forward_loss(model, batch_laion, info, amp, kind="laion")
             (loss_l * loss_multiplier_laion).backward()
     loss = forward_loss(model, batch_mmc4, info, amp)
-    if nan_check and torch.isnan(loss):          # train_utils.py:161-169 (host sync, as in the reference)
+    if nan_check == "device":
+        assert fused, "nan_check='device' relies on the fused step epilogue (FlatAdamW)"
+    elif nan_check and torch.isnan(loss):          # train_utils.py:161-169 (host sync, as in the reference)
         if reducer is not None:
             reducer.zero_grad()
         else:

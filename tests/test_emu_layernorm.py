@@ -144,6 +144,38 @@ def test_step_epilogue_matches_torch_adamw_with_clipping():
             assert torch.equal(b16, p.to(torch.bfloat16))
 
 
+def test_step_epilogue_skips_the_update_on_a_non_finite_gradient_norm():
+    """The device-side form of the reference's skip-on-NaN (train_utils.py:161-169): a NaN or Inf anywhere in the gradients makes
+    the global norm non-finite and of_adamw_clip leaves parameters, moments and bf16 copies of EVERY buffer untouched (they all
+    read the same norm), while still clearing the gradients it was asked to clear; the next finite step updates normally."""
+    ops = H.emu_ops()
+    g = torch.Generator().manual_seed(4)
+    sizes = [1027, 4096]
+    ps = [torch.randn(n, generator=g) for n in sizes]
+    ms = [torch.rand(n, generator=g) * 0.1 for n in sizes]
+    vs = [torch.rand(n, generator=g) * 0.1 for n in sizes]
+    bf = [p.to(torch.bfloat16) for p in ps]
+    for bad in (float("nan"), float("inf")):
+        before = [(p.clone(), m.clone(), v.clone(), b.clone()) for p, m, v, b in zip(ps, ms, vs, bf)]
+        grads = [torch.randn(n, generator=g) for n in sizes]
+        grads[1][77] = bad                                  # one bad element in ONE buffer
+        acc = torch.zeros(1)
+        ops.sumsq(grads, acc)
+        assert not torch.isfinite(acc).all()
+        for p, gb, m, v, b16, zero in zip(ps, grads, ms, vs, bf, (True, False)):
+            ops.adamw_clip(p, gb, m, v, acc, step=3, lr=1e-2, weight_decay=0.1, max_norm=1.0, p_bf16=b16, zero_grad=zero)
+        for (p0, m0, v0, b0), p, m, v, b16 in zip(before, ps, ms, vs, bf):
+            assert torch.equal(p, p0) and torch.equal(m, m0) and torch.equal(v, v0) and torch.equal(b16, b0)
+        assert float(grads[0].abs().max()) == 0.0           # cleared as asked
+        assert not torch.isfinite(grads[1]).all()           # left for the next backward to overwrite
+    grads = [torch.randn(n, generator=g) * 0.01 for n in sizes]
+    acc = torch.zeros(1)
+    ops.sumsq(grads, acc)
+    p0 = ps[0].clone()
+    ops.adamw_clip(ps[0], grads[0], ms[0], vs[0], acc, step=4, lr=1e-2, weight_decay=0.1, max_norm=1.0, p_bf16=bf[0], zero_grad=True)
+    assert not torch.equal(ps[0], p0) and torch.isfinite(ps[0]).all()
+
+
 def test_quick_gelu():
     L = H.lib()
     x = (torch.randn(1003, generator=torch.Generator().manual_seed(2)) * 3).to(torch.bfloat16)

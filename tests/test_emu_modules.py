@@ -229,6 +229,32 @@ def test_step_epilogue_leaves_weight_gradients_for_the_backward_to_overwrite(on_
         assert torch.allclose(opt._moments_of(p)[0], 0.9 * m0, rtol=1e-5, atol=1e-12)
 
 
+def test_nan_loss_skips_the_step_on_the_device(on_emulator, monkeypatch):
+    """train_step(nan_check="device"): no host-side isnan; a NaN loss makes every gradient NaN, the fused step epilogue sees a
+    non-finite global norm and leaves every trainable parameter (and AdamW moment) as it was -- the reference's skip
+    (train_utils.py:161-169) without its host sync; the following finite step trains normally."""
+    model, info = _tiny()
+    red = GradReducer(model, embedding_rows=[info["media_token_id"], info["eoc_token_id"]])
+    opt = FlatAdamW(red, lr=1e-3, ops=H.emu_ops())
+    batch = synthetic.make_batch(2, 2, 24, info, "cpu", seed=5, image_size=56)
+    step.train_step(model, red, opt, batch, info, amp=False, nan_check="device")
+    snap = {k: p.detach().clone() for k, p in model.named_parameters() if p.requires_grad}
+    moments = [b["m"].clone() for b in red.buckets]
+    real = step.forward_loss
+    monkeypatch.setattr(step, "forward_loss", lambda *a, **kw: real(*a, **kw) * float("nan"))
+    loss = step.train_step(model, red, opt, batch, info, amp=False, nan_check="device")
+    monkeypatch.setattr(step, "forward_loss", real)
+    assert loss is not None and torch.isnan(loss)
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            assert torch.equal(p.detach(), snap[k]), k
+    assert all(torch.equal(b["m"], m0) for b, m0 in zip(red.buckets, moments))
+    loss = step.train_step(model, red, opt, batch, info, amp=False, nan_check="device")
+    assert torch.isfinite(loss)
+    moved = [k for k, p in model.named_parameters() if p.requires_grad and not torch.equal(p.detach(), snap[k])]
+    assert len(moved) > 10 and all(torch.isfinite(p).all() for p in model.parameters())
+
+
 def test_grouped_media_projections_match_per_block_projections(on_emulator, monkeypatch):
     """with Flamingo.group_media_projections the to_kv of every gated block runs as ONE grouped GEMM
     right after the Perceiver and the media gradient of all blocks as ONE K-grouped GEMM; loss and every gradient must
