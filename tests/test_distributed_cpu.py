@@ -159,7 +159,21 @@ def _worker_product_modules(rank, world, port, q):
     dist.all_gather(gathered, chk)
     same = all(torch.equal(gathered[0], g) for g in gathered)
     fresh = all(p._of_grad_fresh for b in red.buckets for p in b["overwritable"])
-    q.put((rank, losses, same, per_step, len(red.buckets), fresh, bucket_err))
+    # a NaN loss on rank 0 ALONE, decided on the device (nan_check="device"): no rank leaves the collectives, the NaN reaches
+    # both through the all-reduce, both step epilogues skip -- parameters unchanged and still identical on both ranks
+    before = torch.cat([p.detach().flatten() for p in model.parameters() if p.requires_grad]).clone()
+    real = step.forward_loss
+    if rank == 0:
+        step.forward_loss = lambda *a, **kw: real(*a, **kw) * float("nan")
+    nan_loss = step.train_step(model, red, opt, b_mmc4, info, amp=False, nan_check="device")
+    step.forward_loss = real
+    after = torch.cat([p.detach().flatten() for p in model.parameters() if p.requires_grad])
+    skipped = torch.equal(before, after) and bool(torch.isnan(nan_loss)) == (rank == 0)
+    chk2 = after[::97].double().contiguous()
+    gathered2 = [torch.zeros_like(chk2) for _ in range(world)]
+    dist.all_gather(gathered2, chk2)
+    skipped = skipped and all(torch.equal(gathered2[0], g) for g in gathered2)
+    q.put((rank, losses, same, per_step, len(red.buckets), fresh, bucket_err, skipped))
     dist.destroy_process_group()
 
 
@@ -175,7 +189,8 @@ def test_product_modules_world2_inplace_buckets_and_per_layer_exchange():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, losses, same, per_step, nb, fresh, bucket_err in res:
+    for rank, losses, same, per_step, nb, fresh, bucket_err, skipped in res:
+        assert skipped, f"rank {rank}: a NaN loss on rank 0 must skip the update on every rank (device-side check)"
         assert bucket_err < 1e-5, f"rank {rank}: exchanged buckets differ from the mean of the local buckets ({bucket_err})"
         assert same, f"rank {rank}: replicas diverged"
         assert all(l == l for l in losses)
