@@ -234,7 +234,9 @@ def _mpt_block_fused_forward(self, hidden_states, position_bias, attention_mask,
 def use_fused_frozen_mpt_blocks(lm, allow_cpu=False):
     """Route every HF MptBlock of ``lm`` through _FrozenMptBlockFn when its weights are frozen bf16 copies (see
     towers.hold_frozen_linears_in_bf16) and the call is a plain training / scoring forward; the module keeps its class,
-    parameters and state-dict keys.  ``allow_cpu``: tests only (the host-emulator build of the kernels)."""
+    parameters and state-dict keys.  Batches must be unpadded or RIGHT-padded (train/data.py pads on the right; the kernels
+    take the number of real keys per sequence): left-padded prompts belong to generate(), whose KV cache sends every block
+    through its own HF forward anyway.  ``allow_cpu``: tests only (the host-emulator build of the kernels)."""
     n = 0
     for mod in lm.modules():
         if type(mod).__name__ == "MptBlock":
