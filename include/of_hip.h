@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OF_ABI_VERSION 5
+#define OF_ABI_VERSION 6
 #define OF_E_ARG (-1)      /* null pointer / negative size */
 #define OF_E_SHAPE (-2)    /* shape not supported by the kernels (see each function) */
 #define OF_E_ALIGN (-3)    /* pointer or leading dimension not 16-byte aligned */
@@ -209,6 +209,12 @@ int of_reduce_rows_strided(const void* src, int src_f32, long rows, int dim, lon
 /* y = x * sigmoid(1.702 x), bf16 -> bf16: the "quick GELU" of the frozen CLIP tower's MLP (HF runs it as
  * three element-wise passes).  Forward only: the vision tower runs under no_grad (flamingo.py:194-195). */
 int of_quick_gelu(const uint16_t* x, uint16_t* y, long n, void* stream);
+/* Element-wise pieces of a frozen MPT block's MLP and residual stream (HF MptMLP: up_proj -> nn.GELU(exact) ->
+ * down_proj -> + residual), bf16 in / out like the eager chain under autocast:
+ *   of_gelu_fwd: y = gelu_erf(x);   of_gelu_bwd: dx = dy * gelu_erf'(x);   of_add_bf16: out(fp32) = x(fp32) + y(bf16). */
+int of_gelu_fwd(const uint16_t* x, uint16_t* y, long n, void* stream);
+int of_gelu_bwd(const uint16_t* dy, const uint16_t* x, uint16_t* dx, long n, void* stream);
+int of_add_bf16(const float* x, const uint16_t* y, float* out, long n, void* stream);
 /* out(T) = a(T) + b(T) */
 int of_add(const void* a, const void* b, void* out, int f32, long n, void* stream);
 

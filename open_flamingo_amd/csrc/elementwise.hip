@@ -69,6 +69,53 @@ OF_GLOBAL void of_quick_gelu_kernel(EwArgs a) {
         }
     }
 }
+// erf-GELU of a frozen tower's MLP (HF MptMLP: nn.GELU(approximate="none") between up_proj and down_proj), bf16 -> bf16, and
+// its backward dx = dy * gelu'(x); MODE 0: y = gelu(a); 1: out = b * gelu'(a) (a = pre-activation, b = upstream gradient);
+// 2: out(fp32) = a(fp32) + b(bf16) -- the fp32 residual stream plus a bf16 branch output.  8 elements per lane.
+template <int MODE>
+OF_GLOBAL void of_ew8_kernel(EwArgs a) {
+    const long nv = a.n >> 3;
+    const long stride = (long)of_gdim_x() * 256;
+    auto unpack = [](const u32x4 r, float (&v)[8]) OF_INLINE_LAMBDA {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] = of_bf16_to_f32((bf16_t)(r[e] & 0xffff));
+            v[2 * e + 1] = of_bf16_to_f32((bf16_t)(r[e] >> 16));
+        }
+    };
+    for (long i = (long)of_bid_x() * 256 + of_tid(); i < nv; i += stride) {
+        float x[8], y[8];
+        if (MODE == 2) {
+            const f32x4 x0 = *(const f32x4*)((const float*)a.a + i * 8), x1 = *(const f32x4*)((const float*)a.a + i * 8 + 4);
+            unpack(*(const u32x4*)((const bf16_t*)a.b + i * 8), y);
+            *(f32x4*)((float*)a.out + i * 8) = f32x4{x0[0] + y[0], x0[1] + y[1], x0[2] + y[2], x0[3] + y[3]};
+            *(f32x4*)((float*)a.out + i * 8 + 4) = f32x4{x1[0] + y[4], x1[1] + y[5], x1[2] + y[6], x1[3] + y[7]};
+            continue;
+        }
+        unpack(*(const u32x4*)((const bf16_t*)a.a + i * 8), x);
+        if (MODE == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = of_gelu(x[e]);
+        } else {
+            unpack(*(const u32x4*)((const bf16_t*)a.b + i * 8), y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] *= of_dgelu(x[e]);
+        }
+        *(u32x4*)((bf16_t*)a.out + i * 8) = u32x4{of_pack_bf16(y[0], y[1]), of_pack_bf16(y[2], y[3]), of_pack_bf16(y[4], y[5]),
+                                                 of_pack_bf16(y[6], y[7])};
+    }
+    if (of_bid_x() == 0) {
+        for (long i = (nv << 3) + of_tid(); i < a.n; i += 256) {
+            if (MODE == 2) {
+                ((float*)a.out)[i] = ((const float*)a.a)[i] + of_bf16_to_f32(((const bf16_t*)a.b)[i]);
+            } else {
+                const float x = of_bf16_to_f32(((const bf16_t*)a.a)[i]);
+                const float y = MODE == 0 ? of_gelu(x) : of_bf16_to_f32(((const bf16_t*)a.b)[i]) * of_dgelu(x);
+                ((bf16_t*)a.out)[i] = of_f32_to_bf16(y);
+            }
+        }
+    }
+}
 OF_GLOBAL void of_add_kernel(EwArgs a) {
     const long stride = (long)of_gdim_x() * 256;
     if (a.f32) {
@@ -218,6 +265,27 @@ extern "C" int of_reduce_rows_strided(const void* src, int src_f32, long rows, i
                      (of_stream_t)stream, a);
 }
 
+extern "C" int of_gelu_fwd(const uint16_t* x, uint16_t* y, long n, void* stream) {
+    if (!x || !y || n <= 0) return OF_E_ARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return OF_E_ALIGN;
+    EwArgs a{};
+    a.a = x; a.out = y; a.n = n;
+    return of_launch(of_ew8_kernel<0>, of_dim3{grid_for(n >> 3), 1, 1}, 256, 0, (of_stream_t)stream, a);
+}
+extern "C" int of_gelu_bwd(const uint16_t* dy, const uint16_t* x, uint16_t* dx, long n, void* stream) {
+    if (!dy || !x || !dx || n <= 0) return OF_E_ARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)dx & 15)) return OF_E_ALIGN;
+    EwArgs a{};
+    a.a = x; a.b = dy; a.out = dx; a.n = n;
+    return of_launch(of_ew8_kernel<1>, of_dim3{grid_for(n >> 3), 1, 1}, 256, 0, (of_stream_t)stream, a);
+}
+extern "C" int of_add_bf16(const float* x, const uint16_t* y, float* out, long n, void* stream) {
+    if (!x || !y || !out || n <= 0) return OF_E_ARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)out & 15)) return OF_E_ALIGN;
+    EwArgs a{};
+    a.a = x; a.b = y; a.out = out; a.n = n;
+    return of_launch(of_ew8_kernel<2>, of_dim3{grid_for(n >> 3), 1, 1}, 256, 0, (of_stream_t)stream, a);
+}
 extern "C" int of_quick_gelu(const uint16_t* x, uint16_t* y, long n, void* stream) {
     if (!x || !y || n <= 0) return OF_E_ARG;
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return OF_E_ALIGN;

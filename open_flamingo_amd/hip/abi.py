@@ -5,7 +5,7 @@ Pure declarations: nothing here loads a library.  ``open_flamingo_amd.hip.lib`` 
 """
 import ctypes as C
 
-OF_ABI_VERSION = 5
+OF_ABI_VERSION = 6
 OF_SUMSQ_PARTS = 512
 EPI_STORE_BF16, EPI_GELU, EPI_GATE_RESID, EPI_DGELU_DOT, EPI_SCALE_DOT, EPI_ACC_F32 = range(6)
 
@@ -71,6 +71,9 @@ PROTOTYPES = {
     "of_reduce_rows": (C.c_int, [vp, C.c_int, C.c_long, C.c_int, vp, C.c_int, vp]),
     "of_add": (C.c_int, [vp, vp, vp, C.c_int, C.c_long, vp]),
     "of_quick_gelu": (C.c_int, [vp, vp, C.c_long, vp]),
+    "of_gelu_fwd": (C.c_int, [vp, vp, C.c_long, vp]),
+    "of_gelu_bwd": (C.c_int, [vp, vp, vp, C.c_long, vp]),
+    "of_add_bf16": (C.c_int, [vp, vp, vp, C.c_long, vp]),
     "of_sumsq_partial": (C.c_int, [vp, C.c_long, vp, vp]),
     "of_sumsq_finish": (C.c_int, [vp, C.c_long, vp, vp]),
     "of_adamw_clip": (C.c_int, [vp, vp, vp, vp, vp, C.c_long, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,

@@ -319,6 +319,26 @@ class Ops:
         self._chk(self.lib.of_quick_gelu(x.data_ptr(), out.data_ptr(), x.numel(), self._stream()), "of_quick_gelu")
         return out
 
+    def gelu_fwd(self, x, out=None):
+        assert x.dtype == BF16 and x.is_contiguous()
+        out = torch.empty_like(x) if out is None else out
+        self._chk(self.lib.of_gelu_fwd(x.data_ptr(), out.data_ptr(), x.numel(), self._stream()), "of_gelu_fwd")
+        return out
+
+    def gelu_bwd(self, dy, x, out=None):
+        """dy * gelu'(x); ``out`` may be ``dy`` (in place)."""
+        assert x.dtype == BF16 and dy.dtype == BF16 and x.is_contiguous() and dy.is_contiguous() and dy.shape == x.shape
+        out = torch.empty_like(x) if out is None else out
+        self._chk(self.lib.of_gelu_bwd(dy.data_ptr(), x.data_ptr(), out.data_ptr(), x.numel(), self._stream()), "of_gelu_bwd")
+        return out
+
+    def add_bf16(self, a, b, out=None):
+        """fp32 stream + bf16 branch output -> fp32."""
+        assert a.dtype == F32 and b.dtype == BF16 and a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+        out = torch.empty_like(a) if out is None else out
+        self._chk(self.lib.of_add_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), self._stream()), "of_add_bf16")
+        return out
+
     def add(self, a, b, out):
         assert a.dtype == b.dtype == out.dtype and a.is_contiguous() and b.is_contiguous() and out.is_contiguous()
         self._chk(self.lib.of_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), _is_f32(a), a.numel(), self._stream()),

@@ -94,8 +94,8 @@ class _FrozenMptBlockFn(torch.autograd.Function):
         st2 = torch.empty(rows, 2, dtype=F32, device=dev)
         ops.ln_fwd_add(x2, t, x1, w2, b2, m, st2)                    # x1 = x + attn branch;  m = norm_2(x1)
         h = torch.mm(m, Wup.t())
-        u = torch.mm(torch.nn.functional.gelu(h), Wdown.t())
-        y = torch.add(x1, u)                                         # fp32 stream + bf16 branch -> fp32
+        u = torch.mm(ops.gelu_fwd(h), Wdown.t())
+        y = ops.add_bf16(x1, u)                                      # fp32 stream + bf16 branch -> fp32
         ctx.save_for_backward(x2, st1, qkv, o, lse, x1, st2, h, w1, w2, Wqkv, Wo, Wup, Wdown, slopes, kv_len)
         ctx.kw, ctx.shape, ctx.wts = kw, (B, L, d), wts      # wts: (Wqkv^T, Wo^T, Wup^T, Wdown^T) or None: frozen, not autograd inputs
         return y.view(B, L, d)
@@ -112,7 +112,7 @@ class _FrozenMptBlockFn(torch.autograd.Function):
         if dy2.dtype != F32 or not dy2.is_contiguous():
             dy2 = dy2.to(F32).contiguous()
         dact = _mm_dx(ops.to_bf16(dy2), Wdown, td)                   # (rows, 4d)
-        dh = torch.ops.aten.gelu_backward(dact, h, approximate="none")
+        dh = ops.gelu_bwd(dact, h, out=dact)                         # in place: dact * gelu'(h)
         del dact
         dm = _mm_dx(dh, Wup, tu)                                     # (rows, d)
         del dh

@@ -176,6 +176,26 @@ def test_step_epilogue_skips_the_update_on_a_non_finite_gradient_norm():
     assert not torch.equal(ps[0], p0) and torch.isfinite(ps[0]).all()
 
 
+def test_gelu_and_mixed_add_helpers_of_the_frozen_mlp():
+    """of_gelu_fwd / of_gelu_bwd / of_add_bf16 (frozen MPT MLP) vs torch on the same bf16 inputs; odd length
+    (vector body + scalar tail); of_gelu_bwd in place."""
+    ops = H.emu_ops()
+    g = torch.Generator().manual_seed(8)
+    n = 8 * 300 + 5
+    x = (torch.randn(n, generator=g) * 2).to(torch.bfloat16)
+    dy = torch.randn(n, generator=g).to(torch.bfloat16)
+    y = ops.gelu_fwd(x)
+    np.testing.assert_allclose(y.float().numpy(), torch.nn.functional.gelu(x.float()).numpy(), rtol=1e-2, atol=1e-2)
+    want = torch.ops.aten.gelu_backward(dy.float(), x.float(), approximate="none")
+    buf = dy.clone()
+    out = ops.gelu_bwd(buf, x, out=buf)
+    assert out.data_ptr() == buf.data_ptr()
+    np.testing.assert_allclose(out.float().numpy(), want.numpy(), rtol=1e-2, atol=1e-2)
+    a = torch.randn(n, generator=g)
+    s = ops.add_bf16(a, dy)
+    assert torch.equal(s, a + dy.float())
+
+
 def test_quick_gelu():
     L = H.lib()
     x = (torch.randn(1003, generator=torch.Generator().manual_seed(2)) * 3).to(torch.bfloat16)
