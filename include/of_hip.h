@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OF_ABI_VERSION 6
+#define OF_ABI_VERSION 7
 #define OF_E_ARG (-1)      /* null pointer / negative size */
 #define OF_E_SHAPE (-2)    /* shape not supported by the kernels (see each function) */
 #define OF_E_ALIGN (-3)    /* pointer or leading dimension not 16-byte aligned */
@@ -69,13 +69,16 @@ typedef struct OfGemmArgs {
     int ldaux;
     const float* gate; /* device pointer to the raw gate parameter, or NULL */
     float alpha, beta;
-    float* dot_out;    /* device scalar accumulated atomically, or NULL */
+    float* dot_out;    /* *_DOT epilogues: device scalar the gate-gradient sum is ADDED to, or NULL.  Deterministic: every workgroup
+                          writes one partial to `workspace` (of_gemm_workspace_bytes(args) bytes, required: OF_E_WORKSPACE
+                          otherwise) and a second one-workgroup launch adds the partials in a fixed order -- no fp atomics */
     int io_f32;        /* OF_EPI_GATE_RESID: 1 = fp32 stream, 0 = bf16 stream */
     int safe;          /* DEBUG / SELF-CHECK ONLY -- production callers pass 0 (auto: M <= 16 untransposed -> weight-streaming
                           skinny kernel; tile-aligned shapes that fill the chip -> a 256x256 big-tile kernel; otherwise the
                           general 128x128 kernel, split along K when the output is small).  Non-zero values force one
                           correct kernel so tests can compare kernels with each other: 1 = general kernel, slow scalar-LDS
-                          transposed-fragment path; 2 = general kernel; 3 = general kernel with 128 x 64 tiles; 4 = 8-wave ping-pong big-tile kernel; 6 / 7 = 4-wave
+                          transposed-fragment path; 2 = general kernel; 3 = general kernel with 128 x 64 tiles; 4 = 8-wave ping-pong big-tile kernel;
+                          5 = 8-wave LDS-DMA 128x128 kernel; 6 / 7 = 4-wave
                           big-tile kernel (register-staged / LDS-DMA operands); 8..15 = general kernel with 2^(safe-8) K
                           slices.  Every value the product library accepts gives correct results; anything else returns
                           OF_E_ARG (timing ablations live in tools/libofhip_tools.so, built with -DOF_TOOLS_BUILD, never
@@ -99,7 +102,8 @@ typedef struct OfGemmArgs {
 } OfGemmArgs;
 
 int of_gemm(const OfGemmArgs* args, void* stream);
-/* Bytes of workspace of_gemm would use for these arguments (0 when the launch is not split along K). */
+/* Bytes of workspace of_gemm would use for these arguments: split-K slabs (optional, see `workspace`), the per-workgroup
+ * partials of a *_DOT launch with dot_out (required), else 0. */
 size_t of_gemm_workspace_bytes(const OfGemmArgs* args);
 
 /* ---------------------------------------------------------------------------------------------------

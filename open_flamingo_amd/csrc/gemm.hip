@@ -184,7 +184,7 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_gemm_kernel(OfGemmArgs p) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
             ofg::epilogue_frag<EPI>(p, acc[mt][nt], m0 + wr * 64 + mt * 16 + i16, n0 + wc * (NTW * 16) + nt * 16 + g * 4, gv, sc, dot);
-    ofg::epilogue_finish<EPI>(p, gv, dot, lane, wave, 4, (float*)smem);   // the K loop ended with a workgroup barrier
+    ofg::epilogue_finish<EPI>(p, dot, lane, wave, 4, (float*)smem, of_bid_x());   // the K loop ended with a workgroup barrier
 }
 
 // C = beta * C + sum over slices of slab[s]  (fixed slice order: deterministic)
@@ -208,11 +208,39 @@ OF_GLOBAL void of_splitk_reduce_kernel(OfGemmArgs p) {
     }
 }
 
+// *dot_out += (1 - tanh(gate)^2) * (partials[0] + ... + partials[n-1]), one workgroup, fixed order (ofg::epilogue_finish)
+struct OfDotFinishArgs {
+    const float* partials;
+    int n;
+    const float* gate;
+    float* dot_out;
+};
+OF_GLOBAL void of_dot_finish_kernel(OfDotFinishArgs a) {
+    float* red = (float*)of_smem();
+    const int tid = of_tid();
+    float s = 0.f;
+    for (int i = tid; i < a.n; i += 256) s += a.partials[i];
+    red[tid] = s;
+    of_sync();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if (tid < w) red[tid] += red[tid + w];
+        of_sync();
+    }
+    if (tid == 0) {
+        float gv = 1.0f;
+        if (a.gate) gv = of_tanh(*a.gate);
+        *a.dot_out += (1.0f - gv * gv) * red[0];
+    }
+}
+
 template <bool AT, bool BT, int EPI>
 int launch_layout(const OfGemmArgs& a, of_dim3 grid, of_stream_t s, bool narrow) {
-    if (a.safe == 1 && (AT || BT)) return of_launch(of_gemm_kernel<AT, BT, EPI, true>, grid, 256, SMEM_BYTES, s, a);
-    if (narrow) return of_launch(of_gemm_kernel<AT, BT, EPI, false, 2>, grid, 256, SMEM_BYTES, s, a);
-    return of_launch(of_gemm_kernel<AT, BT, EPI, false>, grid, 256, SMEM_BYTES, s, a);
+    int rc;
+    if (a.safe == 1 && (AT || BT)) rc = of_launch(of_gemm_kernel<AT, BT, EPI, true>, grid, 256, SMEM_BYTES, s, a);
+    else if (narrow) rc = of_launch(of_gemm_kernel<AT, BT, EPI, false, 2>, grid, 256, SMEM_BYTES, s, a);
+    else rc = of_launch(of_gemm_kernel<AT, BT, EPI, false>, grid, 256, SMEM_BYTES, s, a);
+    if (rc || !of_gemm_has_dot(a)) return rc;
+    return of_gemm_dot_finish(a, (int)(grid.x * grid.y), s);
 }
 // Only the (layout, epilogue) pairs the hot path uses are instantiated (see DESIGN.md kernel table).
 int dispatch(const OfGemmArgs& a, of_dim3 grid, of_stream_t s, bool narrow = false) {
@@ -254,15 +282,25 @@ int pick_ksplit(const OfGemmArgs& a, bool with_workspace) {
     int split = 1;
     // with slabs a slice costs one coalesced fp32 store + read of the tile (cheap): go to two workgroups per CU;
     // with atomics (~4 M fp32 atomics per 1 M outputs and slice) stop at one
-    const long target = with_workspace ? 512 : 256;
+    // (the 8-wave LDS-DMA kernel that takes tile-aligned slab launches holds one workgroup per CU: stop at 256 there)
+    const bool mid = !(a.M % 128) && !(a.N % 128) && !(a.K % 64) && a.safe == 0;
+    const long target = with_workspace ? (mid ? 256 : 512) : 256;
     while (split < 16 && t128 * split < target && a.K / (split * 2) >= 512) split *= 2;
     if (forced) split = 1 << (a.safe - 8);
     return split;
 }
 }  // namespace
 
+int of_gemm_dot_finish(const OfGemmArgs& a, int nslots, of_stream_t s) {
+    OfDotFinishArgs f{(const float*)a.workspace, nslots, a.gate, a.dot_out};
+    return of_launch(of_dot_finish_kernel, of_dim3{1, 1, 1}, 256, 256 * sizeof(float), s, f);
+}
+// slots of per-workgroup gate-gradient partials a *_DOT launch with dot_out may use: the finest tiling any kernel picks
+static size_t dot_slots(const OfGemmArgs& a) { return (size_t)((a.M + 127) / 128) * ((a.N + 63) / 64); }
+
 extern "C" size_t of_gemm_workspace_bytes(const OfGemmArgs* args) {
     if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return 0;
+    if (of_gemm_has_dot(*args)) return dot_slots(*args) * sizeof(float);
     if (of_gemm_is_skinny(*args)) return 0;
     const int split = pick_ksplit(*args, true);
     return split > 1 ? (size_t)split * args->M * args->N * sizeof(float) : 0;
@@ -300,6 +338,8 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
     if ((a.epi == OF_EPI_GATE_RESID || a.epi == OF_EPI_DGELU_DOT || a.epi == OF_EPI_SCALE_DOT) &&
         (!a.aux || (a.ldaux & 3) || ((uintptr_t)a.aux & 15)))
         return OF_E_ARG;
+    if (of_gemm_has_dot(a) && (!a.workspace || a.workspace_bytes < dot_slots(a) * sizeof(float) || ((uintptr_t)a.workspace & 3)))
+        return OF_E_WORKSPACE;      // the gate gradient is reduced from per-workgroup partials: no atomic fallback
     of_stream_t s = (of_stream_t)stream;
     if (of_gemm_is_skinny(a)) {                    // a handful of rows (decode step): stream the weights, no tiles
         const int rc = of_gemm_skinny_try(a, s);
@@ -314,6 +354,7 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
     // K (K = tokens) are additionally split along K until every CU has work.
     const long tiles256 = (long)(a.M / 256) * (a.N / 256);
     const bool pp_ok = !(a.M % 256) && !(a.N % 256) && !(a.K % 64) && tiles256 >= 192;
+    const bool mid_ok = !(a.M % 128) && !(a.N % 128) && !(a.K % 64);      // the 8-wave LDS-DMA 128x128 kernel (gemm_mid.hip)
     {
         int split = pick_ksplit(a, true);
         const bool slabs = split > 1 && a.workspace && a.workspace_bytes >= (size_t)split * a.M * a.N * sizeof(float) &&
@@ -323,7 +364,9 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
             b.ksplit = split;
             grid.y = (unsigned)split;
             if (slabs) {
-                int rc = dispatch(b, grid, s);
+                int rc = OF_E_SHAPE;
+                if (mid_ok && a.safe == 0) rc = of_gemm_mid_try(b, s);
+                if (rc == OF_E_SHAPE) rc = dispatch(b, grid, s);
                 if (rc) return rc;
                 long blocks = (((long)a.M * a.N >> 2) + 255) / 256;
                 if (blocks > 2048) blocks = 2048;
@@ -343,13 +386,13 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
     }
 #ifdef OF_TOOLS_BUILD      // tools/libofhip_tools.so only: timing ablations and A/B variants (some wrong by design)
     if (a.safe >= 70 && a.safe <= 73) return of_gemm_w4_try(a, s);
+    if (a.safe == 55) return of_gemm_pp_try(a, s);
     if (a.safe >= 32) return of_gemm_w4_ablate(a, a.safe - 32, s);
     if (a.safe >= 16) return of_gemm_pp_ablate(a, a.safe - 16, s);
-    const bool pp_forced = a.safe == 4 || a.safe == 5;
 #else
-    if (a.safe >= 16 || a.safe == 5) return OF_E_ARG;
-    const bool pp_forced = a.safe == 4;
+    if (a.safe >= 16) return OF_E_ARG;
 #endif
+    const bool pp_forced = a.safe == 4;
     // Big-tile selection (measured on MI355X, random operands, profiles/r02_gemm_big_tile_ab.jsonl): both operands
     // K-contiguous (NT: y = x W^T) -> the 4-wave LDS-DMA kernel (+4..6 % over the ping-pong kernel); a K-strided operand
     // (NN: dX = dY W, TN: dW = dY^T X) -> the 8-wave ping-pong kernel (the 4-wave DMA schedule loses 15-25 % there).
@@ -361,6 +404,11 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
     }
     if ((a.safe == 0 && pp_ok) || pp_forced) {   // 4 = force the ping-pong kernel whenever the shape is eligible
         const int rc = of_gemm_pp_try(a, s);   // 256x256 ping-pong LDS-DMA kernel for tile-aligned shapes
+        if (rc != OF_E_SHAPE) return rc;
+    }
+    // tile-aligned shapes that do not fill the chip with 256x256 tiles: the 8-wave LDS-DMA 128x128 kernel (5 forces it)
+    if ((a.safe == 0 || a.safe == 5) && mid_ok) {
+        const int rc = of_gemm_mid_try(b, s);
         if (rc != OF_E_SHAPE) return rc;
     }
     // 128 x 64 tiles when the 128 x 128 grid leaves at most one workgroup per CU (safe = 3 forces them: self-check)

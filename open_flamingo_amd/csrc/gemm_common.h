@@ -178,11 +178,92 @@ OF_DEV void epilogue_row8(const OfGemmArgs& p, const float (&a)[8], int m, int n
     }
 }
 
-// Gate-gradient reduction of the *_DOT epilogues: one fp32 atomic per WORKGROUP (wave sums meet in LDS first).  All
-// launches of a step add into the same scalar, and same-address device atomics serialise at ~12 ns each: one per wave
-// cost 0.1 ms on a 1024-tile GEMM.  `red` = nwaves floats of LDS nobody else touches any more; every wave must call.
+// One 32(M) x 64(N) accumulator group of a wave -- two 32x32 MFMA fragments side by side -- leaves through the wave's private
+// LDS patch (32 rows x 64 fp32, row pitch 272 B) so that a lane ends up with 8 consecutive n of one row: aux loads and
+// output stores are 16-byte, 8 lanes cover a full 128-byte (bf16) / 256-byte (fp32) row segment.  Shared by the three
+// tiled DMA kernels (gemm_pp.hip, gemm_w4.hip, gemm_mid.hip).
+constexpr int PATCH_PITCH = 64 * 4 + 16;
+constexpr int PATCH_BYTES = 32 * PATCH_PITCH;
 template <int EPI>
-OF_DEV void epilogue_finish(const OfGemmArgs& p, float gv, float dot, int lane, int wave, int nwaves, float* red) {
+constexpr bool epi_has_aux() { return EPI == OF_EPI_GATE_RESID || EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT; }
+// the four aux row segments (residual / saved activation) this lane needs for the group at (m_base, n_base)
+template <int EPI>
+OF_DEV void epilogue_group_aux(const OfGemmArgs& p, int m_base, int n_base, int lane, AuxPre (&pre)[4]) {
+    if (!epi_has_aux<EPI>()) return;
+    const int rd_row = lane >> 3, rd_col = (lane & 7) * 8;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) pre[it] = epilogue_aux_load<EPI>(p, m_base + it * 8 + rd_row, n_base + rd_col);
+}
+// a0 / a1: the fragments of columns [0, 32) / [32, 64) of the group.  `pre` = epilogue_group_aux of the SAME group, requested
+// a whole group earlier by the callers (software pipelining: a group's aux latency hides behind the previous group's
+// transposition, math and stores; the first group's is requested before the K loop where registers allow).
+// The four row passes are unrolled with a scheduling fence between them: without the fence the compiler interleaves the four
+// copies of the erf-GELU math of the *_DOT epilogues on top of the live accumulators and spills.
+template <int EPI>
+OF_DEV void epilogue_group(const OfGemmArgs& p, const f32x16& a0, const f32x16& a1, char* patch, int m_base, int n_base, int lane,
+                           float gv, float sc, float& dot, const AuxPre (&pre)[4]) {
+    const int wr_off = (lane & 31) * PATCH_PITCH + (lane >> 5) * 16;
+    const int rd_row = lane >> 3, rd_col = (lane & 7) * 8;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        *(f32x4*)(patch + wr_off + (q * 8) * 4) = f32x4{a0[4 * q], a0[4 * q + 1], a0[4 * q + 2], a0[4 * q + 3]};
+        *(f32x4*)(patch + wr_off + (32 + q * 8) * 4) = f32x4{a1[4 * q], a1[4 * q + 1], a1[4 * q + 2], a1[4 * q + 3]};
+    }
+    of_wave_sync();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + rd_row;
+        const f32x4 v0 = *(const f32x4*)(patch + r * PATCH_PITCH + rd_col * 4), v1 = *(const f32x4*)(patch + r * PATCH_PITCH + rd_col * 4 + 16);
+        const float a8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        epilogue_row8<EPI>(p, a8, m_base + r, n_base + rd_col, gv, sc, dot, epi_has_aux<EPI>() ? &pre[it] : nullptr);
+        if (EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT || EPI == OF_EPI_GELU) of_sched_fence();
+    }
+    of_wave_sync();
+}
+
+// *_DOT epilogues in the big-tile kernels: the saved bf16 activation of a group travels global -> LDS by DMA instead of through
+// registers (the erf-GELU math on top of the live accumulators leaves none: register prefetch spilled to scratch).  A group's
+// aux tile = 32 rows x 128 B = four 1-KiB pieces; piece `it`, lane l holds row it*8 + (l>>3), bytes (l&7)*16.. -- exactly the
+// vector lane l needs in row pass `it`, so the read is base + it*1024 + lane*16 (conflict-free).  Completion is the CALLER's
+// job: s_waitcnt vmcnt(n) with n = vector-memory operations issued after these four (vmcnt retires in order on gfx950).
+constexpr int AUX_LDS_BYTES = 4096;
+OF_DEV void epilogue_group_aux_dma(const OfGemmArgs& p, int m_base, int n_base, int lane, char* lds_dst) {
+    const bf16_t* src = (const bf16_t*)p.aux + (size_t)(m_base + (lane >> 3)) * p.ldaux + n_base + (lane & 7) * 8;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) of_glds16(src + (size_t)it * 8 * p.ldaux, lds_dst + it * 1024);
+}
+// as epilogue_group with the aux tile in LDS (aux_lds, landed); row passes in a ROLLED loop (one copy of the math)
+template <int EPI>
+OF_DEV void epilogue_group_auxlds(const OfGemmArgs& p, const f32x16& a0, const f32x16& a1, char* patch, const char* aux_lds, int m_base,
+                                  int n_base, int lane, float gv, float sc, float& dot) {
+    static_assert(EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT, "bf16 aux epilogues only");
+    const int wr_off = (lane & 31) * PATCH_PITCH + (lane >> 5) * 16;
+    const int rd_row = lane >> 3, rd_col = (lane & 7) * 8;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        *(f32x4*)(patch + wr_off + (q * 8) * 4) = f32x4{a0[4 * q], a0[4 * q + 1], a0[4 * q + 2], a0[4 * q + 3]};
+        *(f32x4*)(patch + wr_off + (32 + q * 8) * 4) = f32x4{a1[4 * q], a1[4 * q + 1], a1[4 * q + 2], a1[4 * q + 3]};
+    }
+    of_wave_sync();
+#pragma unroll 1
+    for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + rd_row;
+        const f32x4 v0 = *(const f32x4*)(patch + r * PATCH_PITCH + rd_col * 4), v1 = *(const f32x4*)(patch + r * PATCH_PITCH + rd_col * 4 + 16);
+        AuxPre pre;
+        pre.lo = *(const u32x4*)(aux_lds + it * 1024 + lane * 16);
+        const float a8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        epilogue_row8<EPI>(p, a8, m_base + r, n_base + rd_col, gv, sc, dot, &pre);
+    }
+    of_wave_sync();
+}
+
+// Gate-gradient reduction of the *_DOT epilogues, deterministic: every workgroup writes ONE partial sum (wave sums meet in
+// LDS first, fixed order) to its own slot of the caller's workspace; of_dot_finish_kernel (one workgroup, launched behind the
+// GEMM by dot_finish below) adds the slots in a fixed order and accumulates (1 - tanh(gate)^2) * total into *dot_out.
+// No floating-point atomics: the same operands give the same gate gradient on every run and every rank.
+// `red` = nwaves floats of LDS nobody else touches any more; every wave must call.
+template <int EPI>
+OF_DEV void epilogue_finish(const OfGemmArgs& p, float dot, int lane, int wave, int nwaves, float* red, int slot) {
     if (EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) {
         if (p.dot_out) {
             dot = of_wave_sum(dot);
@@ -191,7 +272,7 @@ OF_DEV void epilogue_finish(const OfGemmArgs& p, float gv, float dot, int lane, 
             if (wave == 0 && lane == 0) {
                 float s = 0.f;
                 for (int w = 0; w < nwaves; ++w) s += red[w];
-                of_atomic_add(p.dot_out, (1.0f - gv * gv) * s);
+                ((float*)p.workspace)[slot] = s;
             }
         }
     }
@@ -199,6 +280,13 @@ OF_DEV void epilogue_finish(const OfGemmArgs& p, float gv, float dot, int lane, 
 
 }  // namespace ofg
 
+// implemented in gemm.hip: the second launch of a *_DOT GEMM with dot_out (see epilogue_finish); nslots = workgroups of the GEMM
+int of_gemm_dot_finish(const OfGemmArgs& a, int nslots, of_stream_t s);
+inline bool of_gemm_has_dot(const OfGemmArgs& a) {
+    return (a.epi == OF_EPI_DGELU_DOT || a.epi == OF_EPI_SCALE_DOT) && a.dot_out;
+}
+// implemented in gemm_mid.hip (8 waves, 128x128 tile, 4-slot LDS-DMA ring); OF_E_SHAPE when not eligible
+int of_gemm_mid_try(const OfGemmArgs& a, of_stream_t s);
 // implemented in gemm_skinny.hip: M <= 16 rows (decode step), HBM-bound weight streaming; OF_E_SHAPE when not eligible
 int of_gemm_skinny_try(const OfGemmArgs& a, of_stream_t s);
 inline bool of_gemm_is_skinny(const OfGemmArgs& a) {

@@ -49,7 +49,7 @@ using namespace oft;
 // hold the issuing wave) and are stored to the same LDS addresses (ds_write_b128) at the START of the wave's next load
 // segment, i.e. two wall segments later -- exactly when the DMA version's vmcnt(4) declares them landed, so every
 // reader/writer pair below keeps its barrier (the writes only happen LATER than a DMA issue would overwrite).
-// VAR: 0 = LDS-DMA (product), 1 = register staging (measured A/B, safe = 5)
+// VAR: 0 = LDS-DMA (product), 1 = register staging (measured A/B, tools build: safe = 55)
 template <bool AT, bool BT, int EPI, int ABL = 0, int VAR = 0>
 OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
     constexpr bool RS = VAR == 1;
@@ -210,6 +210,12 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
     of_barrier_raw();
     if (wm == 1) of_barrier_raw();   // stagger: G1 runs one segment behind G0
     if (ABL & 64) t_prev = of_cycles();
+    // epilogue operand of this wave's first 32 x 64 group: requested here, lands during the K loop -- in registers (16 / 32),
+    // or, for the *_DOT epilogues, by DMA in the 32 KiB of LDS behind the ring (no registers at all)
+    constexpr bool AUXL = EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT;
+    ofg::AuxPre pre0[4];
+    if (AUXL) ofg::epilogue_group_aux_dma(p, m0 + wm * 128, n0 + wn * 64, lane, smem + SMEM_PP + wave * ofg::AUX_LDS_BYTES);
+    else ofg::epilogue_group_aux<EPI>(p, m0 + wm * 128, n0 + wn * 64, lane, pre0);
 
     // Stage p lives in slot p&1.  Reader/writer pairs (T = wall segment, see header):
     //   B rows 0-127 of p+1   written G0 T0(p), landed+published end of T2(p); first read T0(p+1).
@@ -260,69 +266,56 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
     if (wm == 0) of_barrier_raw();   // balances G1's stagger barrier
 
     // ---------------------------------------------------------------- epilogue, staged through LDS
-    // The ring is idle now (every wave's last fragment read and DMA wait are behind its last barrier).  Each wave
-    // transposes its accumulators through a private 32-row x 64-column fp32 patch (row pitch 272 B) so that a lane ends
-    // up with 8 consecutive n of one row: aux loads and output stores are 16-byte, 8 lanes cover a full row segment
-    // (the row-per-lane MFMA layout would store 16-byte fragments of 32 different rows per instruction).
+    // The ring is idle now (every wave's last fragment read and DMA wait are behind its last barrier).  Each wave sends its
+    // four 32 x 64 accumulator groups through a private LDS patch (ofg::epilogue_group).  The aux row segments of group g + 1
+    // are requested before group g is processed; group 0's were requested before the K loop (pre0).
     float gv = 1.0f;
     if (p.gate) gv = of_tanh(*p.gate);
     const float sc = gv * p.alpha;
     float dot = 0.f;
-    constexpr int PITCH = 64 * 4 + 16;
-    char* patch = smem + wave * (32 * PITCH);
-    const int wr_off = (lane & 31) * PITCH + (lane >> 5) * 16;
-    const int rd_row = lane >> 3, rd_col = (lane & 7) * 8;
-    constexpr bool HAS_AUX = EPI == OF_EPI_GATE_RESID || EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT;
+    char* patch = smem + wave * ofg::PATCH_BYTES;
+    if constexpr (AUXL) {
+        // aux tiles alternate between two 4-KiB buffers per wave: E behind the ring (group 0 landed there during the K loop: its
+        // last wait was vmcnt(0)) and R inside the idle ring.  vmcnt is counted by hand: a group issues 4 stores.
+        char* bufE = smem + SMEM_PP + wave * ofg::AUX_LDS_BYTES;
+        char* bufR = smem + 8 * ofg::PATCH_BYTES + 256 + wave * ofg::AUX_LDS_BYTES;
+        of_wait_vm<0>();
+        ofg::epilogue_group_aux_dma(p, m0 + wm * 128 + 32, n0 + wn * 64, lane, bufR);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        // The aux row segments (residual / saved activation) are requested ahead of their use so that their global latency
-        // overlaps the LDS transposition and the previous row group's math.  Cheap epilogues: all four up front, loop
-        // unrolled.  *_DOT epilogues: the loop stays rolled (four interleaved copies of the erf-GELU math on top of the live
-        // accumulators spilled to scratch) and the next group's segment is requested one iteration ahead.
-        constexpr bool ROLLED = EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT;
-        ofg::AuxPre pre[4];
-        if (HAS_AUX) {
-#pragma unroll
-            for (int it = 0; it < (ROLLED ? 1 : 4); ++it) pre[it] = ofg::epilogue_aux_load<EPI>(p, m0 + wm * 128 + mt * 32 + it * 8 + rd_row, n0 + wn * 64 + rd_col);
+        for (int mt = 0; mt < 4; ++mt) {
+            // the next group's tile goes where the previous group's was (its reads are consumed: their stores are issued)
+            if (mt >= 1 && mt < 3) ofg::epilogue_group_aux_dma(p, m0 + wm * 128 + (mt + 1) * 32, n0 + wn * 64, lane, (mt & 1) ? bufE : bufR);
+            if (mt == 1 || mt == 2) of_wait_vm<8>();        // newer than this group's pieces: 4 stores + the next group's 4 pieces
+            if (mt == 3) of_wait_vm<4>();                   // ... 4 stores
+            ofg::epilogue_group_auxlds<EPI>(p, acc[mt][0], acc[mt][1], patch, (mt & 1) ? bufR : bufE, m0 + wm * 128 + mt * 32, n0 + wn * 64, lane, gv,
+                                            sc, dot);
         }
+    } else {
+        ofg::AuxPre pre[2][4];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int it = 0; it < 4; ++it) pre[0][it] = pre0[it];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *(f32x4*)(patch + wr_off + (nt * 32 + q * 8) * 4) =
-                    f32x4{acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
-        of_wave_sync();
-        if (ROLLED) {
-#pragma unroll 1
-            for (int it = 0; it < 4; ++it) {
-                const int r = it * 8 + rd_row;
-                const ofg::AuxPre cur = pre[0];
-                if (it < 3) pre[0] = ofg::epilogue_aux_load<EPI>(p, m0 + wm * 128 + mt * 32 + r + 8, n0 + wn * 64 + rd_col);
-                const f32x4 v0 = *(const f32x4*)(patch + r * PITCH + rd_col * 4), v1 = *(const f32x4*)(patch + r * PITCH + rd_col * 4 + 16);
-                const float a8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                ofg::epilogue_row8<EPI>(p, a8, m0 + wm * 128 + mt * 32 + r, n0 + wn * 64 + rd_col, gv, sc, dot, &cur);
-            }
-        } else {
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int r = it * 8 + rd_row;
-                const f32x4 v0 = *(const f32x4*)(patch + r * PITCH + rd_col * 4), v1 = *(const f32x4*)(patch + r * PITCH + rd_col * 4 + 16);
-                const float a8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                ofg::epilogue_row8<EPI>(p, a8, m0 + wm * 128 + mt * 32 + r, n0 + wn * 64 + rd_col, gv, sc, dot, HAS_AUX ? &pre[it] : nullptr);
-            }
+        for (int mt = 0; mt < 4; ++mt) {
+            if (mt < 3) ofg::epilogue_group_aux<EPI>(p, m0 + wm * 128 + (mt + 1) * 32, n0 + wn * 64, lane, pre[(mt + 1) & 1]);
+            ofg::epilogue_group<EPI>(p, acc[mt][0], acc[mt][1], patch, m0 + wm * 128 + mt * 32, n0 + wn * 64, lane, gv, sc, dot, pre[mt & 1]);
         }
-        of_wave_sync();
     }
-    ofg::epilogue_finish<EPI>(p, gv, dot, lane, wave, 8, (float*)(smem + 8 * 32 * PITCH));
+    ofg::epilogue_finish<EPI>(p, dot, lane, wave, 8, (float*)(smem + 8 * ofg::PATCH_BYTES), of_bid_x());
 }
 
 template <bool AT, bool BT, int EPI>
 int launch_pp(const OfGemmArgs& a, of_stream_t s) {
     of_dim3 grid{(unsigned)((a.M / TM) * (a.N / TN)), 1, 1};
+    // *_DOT epilogues: + 4 KiB per wave behind the ring for the first group's aux tile (160 KiB in all)
+    constexpr int smem_bytes = SMEM_PP + ((EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) ? 8 * ofg::AUX_LDS_BYTES : 0);
+    int rc;
 #ifdef OF_TOOLS_BUILD
-    if (a.safe == 5) return of_launch(of_gemm_pp_kernel<AT, BT, EPI, 0, 1>, grid, 512, SMEM_PP, s, a);
+    if (a.safe == 55) rc = of_launch(of_gemm_pp_kernel<AT, BT, EPI, 0, 1>, grid, 512, smem_bytes, s, a);
+    else
 #endif
-    return of_launch(of_gemm_pp_kernel<AT, BT, EPI>, grid, 512, SMEM_PP, s, a);
+        rc = of_launch(of_gemm_pp_kernel<AT, BT, EPI>, grid, 512, smem_bytes, s, a);
+    if (rc || !of_gemm_has_dot(a)) return rc;
+    return of_gemm_dot_finish(a, (int)grid.x, s);
 }
 
 #ifdef OF_TOOLS_BUILD

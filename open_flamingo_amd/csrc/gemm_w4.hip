@@ -120,6 +120,8 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
         return -1;
     };
 
+    constexpr bool AUXL = EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT;
+    if (AUXL) ofg::epilogue_group_aux_dma(p, m0 + wm * 128, n0 + wn * 128, lane, smem + SMEM_W4 + wave * ofg::AUX_LDS_BYTES);
     s16x8 fa[2][4], fb[2][4];     // [register buffer][32-row fragment]
     // one operand fragment of k-step ks16 (16 deep) of a stage: slot order = the order the next phase's MFMAs need them
     // (fb0 fa0 fb1 fb2 fb3 fa1 fa2 fa3), one per MFMA gap
@@ -231,76 +233,63 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
     of_barrier_raw();          // the last stage's k-step-3 fragments were read before its barrier: LDS is idle from here
 
     // ---------------------------------------------------------------- epilogue, staged through LDS (as gemm_pp.hip)
-    // Each wave transposes its accumulators through a private 32-row x 64-column fp32 patch (row pitch 272 B) so that a
-    // lane ends up with 8 consecutive n of one row: aux loads and output stores are 16-byte, 8 lanes per row segment.
+    // Each wave sends its eight 32 x 64 accumulator groups through a private LDS patch (ofg::epilogue_group); the aux row
+    // segments of group g + 1 are requested before group g is processed (group 0's right here: this kernel has no registers
+    // to spare across the K loop).
     float gv = 1.0f;
     if (p.gate) gv = of_tanh(*p.gate);
     const float sc = gv * p.alpha;
     float dot = 0.f;
-    constexpr int PITCH = 64 * 4 + 16;
-    char* patch = smem + wave * (32 * PITCH);
-    const int wr_off = (lane & 31) * PITCH + (lane >> 5) * 16;
-    const int rd_row = lane >> 3, rd_col = (lane & 7) * 8;
-    constexpr bool HAS_AUX = EPI == OF_EPI_GATE_RESID || EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT;
+    char* patch = smem + wave * ofg::PATCH_BYTES;
+    if constexpr (AUXL) {
+        // *_DOT epilogues: aux tiles by DMA, alternating between two 4-KiB buffers per wave -- E behind the ring (group 0 was
+        // requested before the K loop) and R inside the idle ring; vmcnt counted by hand (a group issues 4 stores): gemm_pp.hip
+        char* bufE = smem + SMEM_W4 + wave * ofg::AUX_LDS_BYTES;
+        char* bufR = smem + 4 * ofg::PATCH_BYTES + 256 + wave * ofg::AUX_LDS_BYTES;
+        of_wait_vm<0>();
+        ofg::epilogue_group_aux_dma(p, m0 + wm * 128, n0 + wn * 128 + 64, lane, bufR);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+        for (int g = 0; g < 8; ++g) {
+            const int mt = g >> 1, np = g & 1;
+            if (g >= 1 && g < 7) ofg::epilogue_group_aux_dma(p, m0 + wm * 128 + ((g + 1) >> 1) * 32, n0 + wn * 128 + ((g + 1) & 1) * 64, lane, (g & 1) ? bufE : bufR);
+            if (g >= 1 && g < 7) of_wait_vm<8>();
+            if (g == 7) of_wait_vm<4>();
+            ofg::epilogue_group_auxlds<EPI>(p, acc[mt][np * 2], acc[mt][np * 2 + 1], patch, (g & 1) ? bufR : bufE, m0 + wm * 128 + mt * 32,
+                                            n0 + wn * 128 + np * 64, lane, gv, sc, dot);
+        }
+    } else {
+        ofg::AuxPre pre[2][4];
+        ofg::epilogue_group_aux<EPI>(p, m0 + wm * 128, n0 + wn * 128, lane, pre[0]);
 #pragma unroll
-        for (int np = 0; np < 2; ++np) {
-            // The aux row segments (residual / saved activation) are requested ahead of their use so that their global latency
-            // overlaps the LDS transposition and the previous row group's math.  Cheap epilogues: all four up front, loop
-            // unrolled.  *_DOT epilogues: the loop stays rolled (four interleaved copies of the erf-GELU math on top of the live
-            // accumulators spilled to scratch) and the next group's segment is requested one iteration ahead.
-            constexpr bool ROLLED = EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT;
-            ofg::AuxPre pre[4];
-            if (HAS_AUX) {
-#pragma unroll
-                for (int it = 0; it < (ROLLED ? 1 : 4); ++it) pre[it] = ofg::epilogue_aux_load<EPI>(p, m0 + wm * 128 + mt * 32 + it * 8 + rd_row, n0 + wn * 128 + np * 64 + rd_col);
-            }
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *(f32x4*)(patch + wr_off + (nt * 32 + q * 8) * 4) =
-                        f32x4{acc[mt][np * 2 + nt][4 * q], acc[mt][np * 2 + nt][4 * q + 1], acc[mt][np * 2 + nt][4 * q + 2],
-                              acc[mt][np * 2 + nt][4 * q + 3]};
-            of_wave_sync();
-            if (ROLLED) {
-#pragma unroll 1
-                for (int it = 0; it < 4; ++it) {
-                    const int r = it * 8 + rd_row;
-                    const ofg::AuxPre cur = pre[0];
-                    if (it < 3) pre[0] = ofg::epilogue_aux_load<EPI>(p, m0 + wm * 128 + mt * 32 + r + 8, n0 + wn * 128 + np * 64 + rd_col);
-                    const f32x4 v0 = *(const f32x4*)(patch + r * PITCH + rd_col * 4), v1 = *(const f32x4*)(patch + r * PITCH + rd_col * 4 + 16);
-                    const float a8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    ofg::epilogue_row8<EPI>(p, a8, m0 + wm * 128 + mt * 32 + r, n0 + wn * 128 + np * 64 + rd_col, gv, sc, dot, &cur);
-                }
-            } else {
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int r = it * 8 + rd_row;
-                    const f32x4 v0 = *(const f32x4*)(patch + r * PITCH + rd_col * 4), v1 = *(const f32x4*)(patch + r * PITCH + rd_col * 4 + 16);
-                    const float a8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    ofg::epilogue_row8<EPI>(p, a8, m0 + wm * 128 + mt * 32 + r, n0 + wn * 128 + np * 64 + rd_col, gv, sc, dot, HAS_AUX ? &pre[it] : nullptr);
-                }
-            }
-            of_wave_sync();
+        for (int g = 0; g < 8; ++g) {
+            const int mt = g >> 1, np = g & 1;
+            if (g < 7) ofg::epilogue_group_aux<EPI>(p, m0 + wm * 128 + ((g + 1) >> 1) * 32, n0 + wn * 128 + ((g + 1) & 1) * 64, lane, pre[(g + 1) & 1]);
+            ofg::epilogue_group<EPI>(p, acc[mt][np * 2], acc[mt][np * 2 + 1], patch, m0 + wm * 128 + mt * 32, n0 + wn * 128 + np * 64, lane, gv, sc,
+                                     dot, pre[g & 1]);
         }
     }
-    ofg::epilogue_finish<EPI>(p, gv, dot, lane, wave, 4, (float*)(smem + 4 * 32 * PITCH));
+    ofg::epilogue_finish<EPI>(p, dot, lane, wave, 4, (float*)(smem + 4 * ofg::PATCH_BYTES), of_bid_x());
 }
 
 template <bool AT, bool BT, int EPI>
 int launch_w4(const OfGemmArgs& a, of_stream_t s) {
     of_dim3 grid{(unsigned)((a.M / TM) * (a.N / TN)), 1, 1};
+    constexpr int smem_bytes = SMEM_W4 + ((EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) ? 4 * ofg::AUX_LDS_BYTES : 0);
     // product DMA placement = 2 (A in phase 3, B in phase 0, odd / even waves in odd / even gaps): +1..3 % over the
     // unstaggered form on MI355X (profiles/r02_gemm_big_tile_ab.jsonl)
-    if (a.safe == 7) return of_launch(of_gemm_w4_kernel<AT, BT, EPI, 0, true, 2>, grid, 256, SMEM_W4, s, a);
+    if (a.safe == 7) return of_launch(of_gemm_w4_kernel<AT, BT, EPI, 0, true, 2>, grid, 256, smem_bytes, s, a);
 #ifdef OF_TOOLS_BUILD       // DMA placement A/B (tools/bench_gemm_w4b.py)
-    if (a.safe == 70) return of_launch(of_gemm_w4_kernel<AT, BT, EPI, 0, true, 0>, grid, 256, SMEM_W4, s, a);
-    if (a.safe == 71) return of_launch(of_gemm_w4_kernel<AT, BT, EPI, 0, true, 1>, grid, 256, SMEM_W4, s, a);
-    if (a.safe == 73) return of_launch(of_gemm_w4_kernel<AT, BT, EPI, 0, true, 3>, grid, 256, SMEM_W4, s, a);
+    if (a.safe == 70) return of_launch(of_gemm_w4_kernel<AT, BT, EPI, 0, true, 0>, grid, 256, smem_bytes, s, a);
+    if (a.safe == 71) return of_launch(of_gemm_w4_kernel<AT, BT, EPI, 0, true, 1>, grid, 256, smem_bytes, s, a);
+    if (a.safe == 73) return of_launch(of_gemm_w4_kernel<AT, BT, EPI, 0, true, 3>, grid, 256, smem_bytes, s, a);
 #endif
-    return of_launch(of_gemm_w4_kernel<AT, BT, EPI>, grid, 256, SMEM_W4, s, a);
+    return of_launch(of_gemm_w4_kernel<AT, BT, EPI>, grid, 256, smem_bytes, s, a);
+}
+template <bool AT, bool BT, int EPI>
+int launch_w4_dot(const OfGemmArgs& a, of_stream_t s) {
+    const int rc = launch_w4<AT, BT, EPI>(a, s);
+    if (rc || !of_gemm_has_dot(a)) return rc;
+    return of_gemm_dot_finish(a, (a.M / TM) * (a.N / TN), s);
 }
 #ifdef OF_TOOLS_BUILD
 template <int ABL>
@@ -346,8 +335,8 @@ int of_gemm_w4_try(const OfGemmArgs& a, of_stream_t s) {
     } else if (layout == 1) {
         switch (a.epi) {
             case OF_EPI_STORE_BF16: return launch_w4<false, true, OF_EPI_STORE_BF16>(a, s);
-            case OF_EPI_DGELU_DOT: return launch_w4<false, true, OF_EPI_DGELU_DOT>(a, s);
-            case OF_EPI_SCALE_DOT: return launch_w4<false, true, OF_EPI_SCALE_DOT>(a, s);
+            case OF_EPI_DGELU_DOT: return launch_w4_dot<false, true, OF_EPI_DGELU_DOT>(a, s);
+            case OF_EPI_SCALE_DOT: return launch_w4_dot<false, true, OF_EPI_SCALE_DOT>(a, s);
             case OF_EPI_ACC_F32: return launch_w4<false, true, OF_EPI_ACC_F32>(a, s);
         }
     } else if (layout == 3) {

@@ -93,7 +93,9 @@ class Ops:
         else:
             assert out.dtype == BF16
         a.safe = safe
-        if epi == abi.EPI_ACC_F32:      # split-K scratch (fp32 slabs); one grow-only buffer, reused in stream order
+        # scratch: split-K fp32 slabs (EPI_ACC_F32) or the per-workgroup gate-gradient partials of a *_DOT launch (summed in
+        # a fixed order by a second launch: deterministic); one grow-only buffer, reused in stream order
+        if epi == abi.EPI_ACC_F32 or dot is not None:
             need = self.lib.of_gemm_workspace_bytes(C.byref(a))
             if need:
                 ws = self.__dict__.get("_gemm_ws")

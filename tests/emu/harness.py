@@ -51,6 +51,8 @@ def gemm(A, B, *, a_trans=0, b_trans=0, epi=abi.EPI_STORE_BF16, C_out=None, C2=N
     a.alpha, a.beta = alpha, beta
     a.dot_out = dot_out.data_ptr() if dot_out is not None else None
     a.io_f32, a.safe = io_f32, safe
+    if workspace is None and dot_out is not None:      # per-workgroup gate-gradient partials (deterministic finish)
+        workspace = torch.empty(max(1, lib().of_gemm_workspace_bytes(C.byref(a)) // 4))
     if workspace is not None:
         a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     rc = lib().of_gemm(C.byref(a), None)

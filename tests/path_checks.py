@@ -8,8 +8,8 @@ Used with the emulator Ops on CPU (tests/test_emu_path.py) and with the real lib
 * ``check_xattn_8c`` / ``check_perceiver_8c``: the criterion SURVEY.md 8c states, against the plain **fp32** oracle:
   forward error (relative L2 and max-abs) <= 2 x the error the reference itself makes under ``autocast(bfloat16)``
   on the same inputs (the oracle IS the reference's arithmetic, pinned by tests/golden; run under torch.autocast
-  on the GPU it reproduces the reference's own cast points), every gradient by relative L2 <= 2e-2 (a scalar gate
-  gradient, a cancelling sum over the whole tensor, may instead stay within 2 x the autocast reference's own error)."""
+  on the GPU it reproduces the reference's own cast points), every gradient -- the scalar gate gradients included -- by
+  relative L2 <= 2e-2, on a loss that keeps the gate gradients well conditioned (``conditioned_upstream``)."""
 import torch
 
 from oracle import flamingo_oracle as O
@@ -160,17 +160,14 @@ def _oracle_run(m, inputs, w, autocast, **fw):
     return y.detach().float(), g
 
 
-def judge_8c(hip, ref32, refac, *, grad_tol=2e-2, factor=2.0, floor=1e-6, scalar_tol=2e-2):
+def judge_8c(hip, ref32, refac, *, grad_tol=2e-2, factor=2.0, floor=1e-6):
     """hip / ref32 / refac: (y, grads) triples.  Returns (report, failures).  refac may be None (no autocast
     reference available, e.g. on CPU): then only the gradient rule and a 1e-2 forward rel-L2 bound are applied.
-    scalar_tol: bound for the (1,)-shaped gate gradients -- sums of B*L*d signed terms whose relative error is set by
-    how much they cancel, not by the kernels: 2e-2 at model sizes (millions of terms); the toy-size callers pass 5e-2
-    (a few thousand terms: the reference's own autocast run lands anywhere in 0.2-3 % there, seed by seed)."""
+    ONE rule per quantity: forward error <= factor x the reference's own autocast error (rel-L2 and max-abs); every gradient --
+    tensors and the (1,)-shaped gate gradients alike -- by relative L2 <= grad_tol.  The gate gradients are sums of B*L*d
+    signed terms; the callers make them well conditioned (a loss whose upstream gradient is correlated with the block's output,
+    see check_xattn_8c) instead of this function granting cancelling sums an escape hatch."""
     rep, bad = {}, {}
-    # (1,)-shaped gate gradients are sums of B*L*d signed terms: how much they cancel differs between the two gates of
-    # one block by orders of magnitude, so each is also allowed an ABSOLUTE error of grad_tol x the larger gate gradient
-    scalars = [float(v.abs().max()) for v in ref32[1].values() if v.numel() == 1]
-    scalar_abs = grad_tol * max(scalars) if scalars else 0.0
     y, y32 = hip[0], ref32[0]
     e_l2, e_mx = rel_l2(y, y32), max_abs(y, y32)
     if refac is not None:
@@ -187,19 +184,22 @@ def judge_8c(hip, ref32, refac, *, grad_tol=2e-2, factor=2.0, floor=1e-6, scalar
             continue
         e = rel_l2(hip[1][k], g32)
         ent = dict(hip_rel_l2=e)
-        ok = e <= (scalar_tol if g32.numel() == 1 else grad_tol)
         if refac is not None:
-            a = rel_l2(refac[1][k], g32)
-            ent["autocast_rel_l2"] = a
-            if g32.numel() == 1:           # gate gradients: whole-tensor sums that cancel
-                ok = ok or e <= factor * a + floor
-        if g32.numel() == 1:
-            ok = ok or max_abs(hip[1][k], g32) <= scalar_abs
+            ent["autocast_rel_l2"] = rel_l2(refac[1][k], g32)
         rep["d" + k] = ent
-        if not ok:
+        if not e <= grad_tol:
             bad["d" + k] = ent
     return rep, bad
 
+
+def conditioned_upstream(m, ins, w, **fw):
+    """Upstream gradient for the 8c checks of a gated block: w + y32 (y32 = the fp32 oracle's output, detached).  With a
+    purely random w the two gate gradients <w, branch_out> are sums of millions of signed terms that cancel to ~1/sqrt(N) of
+    their term mass, so their RELATIVE error measures the cancellation, not the kernels; adding the output makes each contain
+    tanh(gate) * |branch_out|^2 (no cancellation) while every other gradient still sees a dense random direction."""
+    with torch.no_grad():
+        y32 = m(*ins, **fw).float()
+    return w + y32
 
 def hip_xattn(ops, m, x, media, media_locs, w, *, heads, only_immediate=True, stream_dtype=torch.float32, dev="cuda"):
     """The HIP path of one gated block on the oracle module's parameters.  Returns (y, grads) keyed like _oracle_run."""
@@ -260,10 +260,11 @@ def check_xattn_8c(ops, dev, *, B=2, L=40, T=2, n=16, heads=2, d=64, Dv=48, medi
     w = torch.randn(B, L, d, generator=g)
     ins = (x.to(oracle_dev), media.to(oracle_dev))
     fw = dict(media_locations=media_locs.to(oracle_dev))
-    ref32 = _oracle_run(m, ins, w.to(oracle_dev), False, **fw)
-    refac = _oracle_run(m, ins, w.to(oracle_dev), True, **fw) if oracle_dev != "cpu" else None
-    hip = hip_xattn(ops, m, x, media, media_locs, w, heads=heads, only_immediate=only_immediate, dev=dev)
-    rep, bad = judge_8c(hip, ref32, refac, scalar_tol=5e-2 if x.numel() < (1 << 16) else 2e-2)
+    w = conditioned_upstream(m, ins, w.to(oracle_dev), **fw)
+    ref32 = _oracle_run(m, ins, w, False, **fw)
+    refac = _oracle_run(m, ins, w, True, **fw) if oracle_dev != "cpu" else None
+    hip = hip_xattn(ops, m, x, media, media_locs, w.cpu(), heads=heads, only_immediate=only_immediate, dev=dev)
+    rep, bad = judge_8c(hip, ref32, refac)
     assert not bad, f"SURVEY 8c tolerance failures: {bad}\nall: {rep}"
     return rep
 

@@ -129,6 +129,88 @@ def test_gemm_pingpong_matches_general_kernel(at, bt, M, N, K, big):
     np.testing.assert_allclose(o_fast.numpy(), o_gen.numpy(), rtol=1e-6, atol=1e-5)
 
 
+@pytest.mark.parametrize("at,bt", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 320), (384, 128, 576)])
+def test_gemm_mid_kernel_matches_general_kernel(at, bt, M, N, K):
+    """The 8-wave LDS-DMA 128x128 kernel (safe = 5; of_gemm's own choice for tile-aligned shapes that do not fill the chip with
+    256x256 tiles) vs the general kernel (safe = 2) and fp64.  K = 64 / 320 / 576: one stage (no steady state), five and nine
+    stages (the four-slot ring wraps once / twice; every vmcnt tail case)."""
+    A = _rand((K, M) if at else (M, K), 31)
+    B = _rand((K, N) if bt else (N, K), 32)
+    ref = _ref(A, B, at, bt)
+    o_mid, o_gen = torch.zeros(M, N), torch.zeros(M, N)
+    H.gemm(A, B, a_trans=at, b_trans=bt, epi=abi.EPI_ACC_F32, C_out=o_mid, safe=5)
+    H.gemm(A, B, a_trans=at, b_trans=bt, epi=abi.EPI_ACC_F32, C_out=o_gen, safe=2)
+    np.testing.assert_allclose(o_mid.double().numpy(), ref.numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(o_mid.numpy(), o_gen.numpy(), rtol=1e-6, atol=5e-5)      # k order inside a 64-deep stage differs
+    ob = torch.zeros(M, N, dtype=torch.bfloat16)
+    H.gemm(A, B, a_trans=at, b_trans=bt, epi=abi.EPI_STORE_BF16, C_out=ob, safe=5, alpha=0.5)
+    np.testing.assert_allclose(ob.double().numpy(), 0.5 * ref.numpy(), rtol=1e-2, atol=2e-2)
+
+
+def test_gemm_mid_kernel_epilogues_and_auto_selection():
+    M, N, K = 256, 128, 192
+    A, B = _rand((M, K), 33), _rand((N, K), 34) * 0.1
+    acc = _ref(A, B, 0, 0)
+    gate = torch.tensor([0.37])
+    g = float(torch.tanh(gate))
+    for safe in (5, 0):           # forced, and of_gemm's own selection (2 tiles: not big-tile eligible -> the same kernel)
+        b_out, a_out = torch.zeros(M, N, dtype=torch.bfloat16), torch.zeros(M, N, dtype=torch.bfloat16)
+        H.gemm(A, B, epi=abi.EPI_GELU, C_out=b_out, C2=a_out, safe=safe)
+        np.testing.assert_allclose(a_out.double().numpy(), acc.numpy(), rtol=1e-2, atol=1e-2)
+        np.testing.assert_allclose(b_out.double().numpy(), torch.nn.functional.gelu(acc).numpy(), rtol=1e-2, atol=1e-2)
+        res = torch.randn(M, N)
+        out = torch.zeros(M, N)
+        H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=out, aux=res, gate=gate, io_f32=1, safe=safe)
+        np.testing.assert_allclose(out.double().numpy(), (res.double() + g * acc).numpy(), rtol=1e-5, atol=1e-4)
+        resb, outb = res.to(torch.bfloat16), torch.zeros(M, N, dtype=torch.bfloat16)
+        H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=outb, aux=resb, gate=gate, io_f32=0, safe=safe)
+        np.testing.assert_allclose(outb.double().numpy(), (resb.double() + g * acc).numpy(), rtol=1e-2, atol=2e-2)
+        c = torch.randn(M, N)
+        c0 = c.clone()
+        H.gemm(A, B, epi=abi.EPI_ACC_F32, C_out=c, alpha=0.5, beta=1.0, gate=gate, safe=safe)
+        np.testing.assert_allclose(c.double().numpy(), (c0.double() + 0.5 * g * acc).numpy(), rtol=1e-5, atol=1e-4)
+        W = _rand((K, N), 35) * 0.2
+        acc2 = A.double() @ W.double()
+        aux = _rand((M, N), 36)
+        for epi in (abi.EPI_DGELU_DOT, abi.EPI_SCALE_DOT):
+            o = torch.zeros(M, N, dtype=torch.bfloat16)
+            dot = torch.full((1,), 3.0)                       # accumulates into what the scalar held
+            H.gemm(A, W, b_trans=1, epi=epi, C_out=o, aux=aux, gate=gate, dot_out=dot, safe=safe)
+            x = aux.double()
+            if epi == abi.EPI_DGELU_DOT:
+                xx = x.clone().requires_grad_(True)
+                torch.nn.functional.gelu(xx).sum().backward()
+                want, wdot = g * acc2 * xx.grad, (1 - g * g) * (torch.nn.functional.gelu(x) * acc2).sum()
+            else:
+                want, wdot = g * acc2, (1 - g * g) * (x * acc2).sum()
+            np.testing.assert_allclose(o.double().numpy(), want.numpy(), rtol=1e-2, atol=2e-2)
+            assert abs(float(dot) - 3.0 - float(wdot)) <= 1e-3 * abs(float(wdot)) + 1e-2
+
+
+@pytest.mark.parametrize("safe", [2, 4, 5, 6, 7])
+def test_gate_gradient_dot_is_deterministic_and_needs_its_workspace(safe):
+    """The *_DOT epilogues reduce the gate gradient from per-workgroup partials in a fixed order (no floating-point atomics):
+    repeated launches give the same BITS whatever order the workgroups ran in (the emulator runs them on parallel host threads);
+    without the partials workspace the call is refused instead of falling back to atomics."""
+    M, N, K = 512, 512, 128
+    A, W, aux = _rand((M, K), 41), _rand((K, N), 42) * 0.2, _rand((M, N), 43)
+    gate = torch.tensor([0.3])
+    vals = []
+    for _ in range(3):
+        o, dot = torch.zeros(M, N, dtype=torch.bfloat16), torch.zeros(1)
+        H.gemm(A, W, b_trans=1, epi=abi.EPI_DGELU_DOT, C_out=o, aux=aux, gate=gate, dot_out=dot, safe=safe)
+        vals.append(dot.clone())
+    assert torch.equal(vals[0], vals[1]) and torch.equal(vals[0], vals[2]) and float(vals[0]) != 0.0
+    a = abi.OfGemmArgs()
+    a.A, a.B, a.M, a.N, a.K, a.lda, a.ldb, a.b_trans, a.epi = A.data_ptr(), W.data_ptr(), M, N, K, K, N, 1, abi.EPI_DGELU_DOT
+    o, dot = torch.zeros(M, N, dtype=torch.bfloat16), torch.zeros(1)
+    a.C, a.ldc, a.aux, a.ldaux, a.gate, a.dot_out, a.safe = o.data_ptr(), N, aux.data_ptr(), N, gate.data_ptr(), dot.data_ptr(), safe
+    import ctypes
+    assert H.lib().of_gemm(ctypes.byref(a), None) == -4     # OF_E_WORKSPACE
+    assert H.lib().of_gemm_workspace_bytes(ctypes.byref(a)) >= 4 * (M // 128) * (N // 64)
+
+
 def test_gemm_split_k():
     """Weight-gradient layout with a small output and deep K: of_gemm splits K and accumulates with fp32 atomics."""
     M, N, K = 128, 256, 2048
