@@ -186,6 +186,27 @@ def test_attention_masked_cases(ops, only_imm):
         assert (o[zero] == 0).all()
 
 
+@pytest.mark.parametrize("L", [256, 2048])
+def test_attention_five_image_windows_at_cfg5_shapes(ops, L):
+    """BASELINE config 5's cross-attention core (B = 8, T = 5, n = 64: Lk = 320; L = 256 and the long-context 2048) with the
+    mask quirks at five images -- text_time > T (every key masked: uniform rows), text_time == 0 (zero rows), unused images,
+    consecutive <image> tokens -- element-wise against the fp64 dense restatement of helpers.py:192-231
+    (tests/attn_reference.py), forward and all three gradients."""
+    from tests.test_gpu_path import _t5_media_locations
+    B, T, n, heads = 8, 5, 64, 8
+    ml = _t5_media_locations(B, L)
+    tt = ml.cumsum(-1)
+    assert int(tt.max()) > T and bool((tt == 0).any()) and int(tt[3].max()) == 2
+    q, k, v = _r((B, L, heads * 64), 61), _r((B, T * n, heads * 64), 62), _r((B, T * n, heads * 64), 63)
+    o, lse, res = _attn_case(ops, q, k, v, heads, tt, n, T, True)
+    print(res)
+    assert (o[(tt == 0).cuda()] == 0).all()
+    # uniform rows: the plain mean of ALL T*n values (helpers.py:218-221 with every key at -finfo.max)
+    uni = (tt > T).cuda()
+    want = v.float().view(B, T * n, heads * 64).mean(1, keepdim=True).expand(B, L, heads * 64)
+    assert torch.allclose(o.float()[uni], want[uni], atol=2e-2, rtol=2e-2)
+
+
 @pytest.mark.parametrize("x_f32", [1, 0])
 def test_layernorm(ops, x_f32):
     rows, dim = 1000, 2048
@@ -232,6 +253,91 @@ def test_gemm_pingpong_race_screen(ops, ta, tb, big):
             got = torch.full((M, N), float("nan"), device="cuda")
             ops.gemm(A, B, got, ta=ta, tb=tb, epi=abi.EPI_ACC_F32, safe=big)
             assert torch.equal(got, want), f"{(M, N, K)} iteration {it}: max diff {(got - want).abs().max().item()}"
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
+def test_gemm_mid_kernel_race_screen(ops, ta, tb):
+    """The 8-wave LDS-DMA 128x128 kernel (safe = 5; four-slot ring ordered by counted vmcnt + one barrier per stage): the CPU
+    emulator cannot see a race.  Screen on hardware: 1..128 stages, single-tile to multi-wave grids, repeated launches, results
+    bit-identical to the general kernel's up to the k order inside a stage (compared in fp32 with a summation-order tolerance)
+    and identical across repeats."""
+    torch.manual_seed(0)
+    for (M, N, K) in [(128, 128, 64), (128, 256, 128), (256, 128, 192), (384, 256, 256), (8192, 512, 2048), (2048, 512, 8192),
+                      (4096, 1024, 4096), (1024, 1024, 4096), (20480, 1024, 1024)]:
+        A = _r((K, M) if ta else (M, K), M + K)
+        B = _r((K, N) if tb else (N, K), N + K)
+        want = torch.zeros(M, N, device="cuda")
+        ops.gemm(A, B, want, ta=ta, tb=tb, epi=abi.EPI_ACC_F32, safe=2)
+        first = None
+        for it in range(5):
+            got = torch.full((M, N), float("nan"), device="cuda")
+            ops.gemm(A, B, got, ta=ta, tb=tb, epi=abi.EPI_ACC_F32, safe=5)
+            assert _rel(got, want) < 1e-5, f"{(M, N, K)} iteration {it}: rel {_rel(got, want)}"
+            first = got if first is None else first
+            assert torch.equal(got, first), f"{(M, N, K)} iteration {it}: not repeatable"
+
+
+def test_gemm_mid_kernel_epilogues_at_projection_shapes(ops):
+    """Every (layout, epilogue) the hot path sends to the 128x128 LDS-DMA kernel, at the gated blocks' projection shapes and
+    through of_gemm's OWN selection (safe = 0): to_q, to_out + gate + residual (fp32 stream), dX of to_out with the gate-gradient
+    dot, dX of to_q, the four weight gradients (split along K, slabs), the Perceiver FFN's GELU / DGELU launches at N = 4096 rows
+    -- element-wise against fp32 products of the same bf16 operands."""
+    rows, d, inner = 8192, 2048, 512
+    gate = torch.tensor([0.41], device="cuda")
+    g = float(torch.tanh(gate))
+    x, Wq = _r((rows, d), 71), _r((inner, d), 72, 0.03)
+    q = torch.zeros(rows, inner, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(x, Wq, q)
+    assert _rel(q, x.float() @ Wq.float().t()) < 1e-2
+    o, Wo, res = _r((rows, inner), 73), _r((d, inner), 74, 0.05), torch.randn(rows, d, device="cuda")
+    y = torch.zeros(rows, d, device="cuda")
+    ops.gemm(o, Wo, y, epi=abi.EPI_GATE_RESID, aux=res, gate=gate)
+    want = res + g * (o.float() @ Wo.float().t())
+    assert _rel(y, want) < 2e-4 and float((y - want).abs().max()) < 2e-3
+    dy = _r((rows, d), 75)
+    dO, dot = torch.zeros(rows, inner, device="cuda", dtype=torch.bfloat16), torch.zeros(1, device="cuda")
+    ops.gemm(dy, Wo, dO, tb=True, epi=abi.EPI_SCALE_DOT, aux=o, gate=gate, dot=dot)
+    acc = dy.float() @ Wo.float()
+    assert _rel(dO, g * acc) < 1e-2
+    wdot = (1 - g * g) * (o.double() * acc.double()).sum()
+    assert abs(float(dot) - float(wdot)) <= 1e-3 * abs(float(wdot)) + 1e-1
+    dq = _r((rows, inner), 76)
+    dxn = torch.zeros(rows, d, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(dq, Wq, dxn, tb=True)
+    assert _rel(dxn, dq.float() @ Wq.float()) < 1e-2
+    for A_, B_, shape in ((dy, o, (d, inner)), (dq, x, (inner, d))):            # dW = dY^T X, K = 8192 tokens
+        c0 = torch.randn(*shape, device="cuda")
+        got = c0.clone()
+        ops.gemm(A_, B_, got, ta=True, tb=True, epi=abi.EPI_ACC_F32, beta=1.0)
+        assert _rel(got, c0 + A_.float().t() @ B_.float()) < 2e-4
+        got2 = torch.full(shape, float("nan"), device="cuda")
+        ops.gemm(A_, B_, got2, ta=True, tb=True, epi=abi.EPI_ACC_F32, beta=0.0)
+        assert _rel(got2, A_.float().t() @ B_.float()) < 2e-4
+    # Perceiver FFN (4096 latent rows): up + GELU with both outputs, dgelu_dot without a gate
+    u, W1 = _r((4096, 1024), 77), _r((4096, 1024), 78, 0.05)
+    a_out = torch.zeros(4096, 4096, device="cuda", dtype=torch.bfloat16)
+    b_out = torch.zeros_like(a_out)
+    ops.gemm(u, W1, b_out, epi=abi.EPI_GELU, out2=a_out)
+    acc = u.float() @ W1.float().t()
+    assert _rel(a_out, acc) < 1e-2 and _rel(b_out, torch.nn.functional.gelu(acc)) < 1e-2
+
+
+@pytest.mark.parametrize("M,N,K,safe", [(8192, 8192, 2048, 0), (8192, 512, 2048, 0), (4096, 4096, 1024, 0), (8192, 8192, 2048, 7)])
+def test_gate_gradient_dot_is_bit_reproducible(ops, M, N, K, safe):
+    """The gate gradient of the *_DOT epilogues (per-workgroup partials + ordered finish, no fp32 atomics): ten launches, one
+    bit pattern -- at the benchmark's DGELU_DOT shape (1024 workgroups) and the projection shapes."""
+    A, W, aux = _r((M, K), 81), _r((K, N), 82, 0.05), _r((M, N), 83)
+    gate = torch.tensor([0.5], device="cuda")
+    vals = []
+    for _ in range(10):
+        o, dot = torch.empty(M, N, device="cuda", dtype=torch.bfloat16), torch.zeros(1, device="cuda")
+        ops.gemm(A, W, o, tb=True, epi=abi.EPI_DGELU_DOT, aux=aux, gate=gate, dot=dot, safe=safe)
+        vals.append(dot.clone())
+    assert all(torch.equal(v, vals[0]) for v in vals), [float(v) for v in vals]
+    acc = (A.float() @ W.float()).double()
+    g = float(torch.tanh(gate))
+    wdot = (1 - g * g) * (torch.nn.functional.gelu(aux.double()) * acc).sum()
+    assert abs(float(vals[0]) - float(wdot)) <= 2e-3 * abs(float(wdot)) + 1.0
 
 
 @pytest.mark.parametrize("beta", [0.0, 1.0])

@@ -594,6 +594,72 @@ def test_cfg2_full_batch_parity_with_nonzero_gates(ops):
         assert PC.rel_l2(gp["in0"][s:s + 1], g32["in0"]) < 2e-2
 
 
+def _t5_media_locations(B, L, T=5):
+    """<image> positions for a T = 5 batch (BASELINE config 5's B = 8): regular chunks, rows before the first image (zero rows),
+    MORE <image> tokens than images (text_time > T: uniform rows), FEWER than T, consecutive tokens, one at the last position."""
+    ml = torch.zeros(B, L, dtype=torch.bool)
+    step = L // T
+    for b in range(B):
+        ml[b, [min(L - 1, (b % 3) + k * step) for k in range(T)]] = True
+    ml[1 % B] = False
+    ml[1 % B, [17 + k * (step - 5) for k in range(T)]] = True                 # 17 rows before the first image
+    ml[2 % B, [3 + k * (L // 8) for k in range(7)]] = True                     # 7+ tokens for 5 images
+    ml[3 % B] = False
+    ml[3 % B, [0, L // 2]] = True                                              # 2 of 5 images used
+    ml[4 % B] = False
+    ml[4 % B, [3, 4, 5, L // 2, L - 1]] = True                                 # consecutive, and at the last position
+    return ml
+
+
+def test_cfg4_full_batch_parity_d2560(ops):
+    """BASELINE config 4 (OF-4B: RedPajama-3B width d = 2560) at the batch it is BENCHMARKED on -- B = 32, T = 2, L = 256: the
+    320-tile big-tile launches (M = 8192, N = 2560), the 10240-wide FFN, CPL = 5 LayerNorm -- y, dx, dmedia and every parameter
+    gradient of the whole batch against the fp32 oracle by the SURVEY 8c rule."""
+    rep = PC.check_xattn_8c(ops, "cuda", B=32, L=256, T=2, n=64, heads=8, d=2560, Dv=1024, seed=41, gates=(0.5, 0.5),
+                            oracle_dev="cuda")
+    print(_fmt(rep))
+
+
+@pytest.mark.parametrize("L", [256, 2048])
+def test_cfg5_full_batch_parity_d4096_T5(ops, L):
+    """BASELINE config 5 (OF-9B: MPT-7B width d = 4096) at the batches it is BENCHMARKED on -- B = 8, T = 5, L = 256 and the
+    long-context L = 2048: Lk = 320 cross-attention windows, masks with five images incl. text_time > T (uniform rows), rows
+    before the first image (zero rows), unused images; the 128-tile launches of B*L = 2048 rows and the big-tile launches of
+    B*L = 16384 rows -- whole batch against the fp32 oracle by the SURVEY 8c rule."""
+    ml = _t5_media_locations(8, L)
+    rep = PC.check_xattn_8c(ops, "cuda", B=8, L=L, T=5, n=64, heads=8, d=4096, Dv=1024, seed=51, gates=(0.5, 0.5),
+                            media_locs=ml, oracle_dev="cuda")
+    print(_fmt(rep))
+    if L == 256:
+        rep = PC.check_perceiver_8c(ops, "cuda", b=8, T=5, Fv=256, n=64, heads=8, D=1024, depth=6, seed=52, oracle_dev="cuda")
+        print(_fmt(rep))
+
+
+def test_cfg45_grouped_media_projections_at_benchmarked_shapes(ops):
+    """The grouped launches of configs 4 / 5 at their benchmarked sizes, against per-block launches of the same kernels'
+    general form: 16-way to_kv of (B*T*n = 4096, 1024) media rows (OF-4B: 16 gated blocks) and 8-way at 2560 rows (OF-9B:
+    B = 8, T = 5), plus the K-grouped media-gradient GEMM with 16 / 8 groups."""
+    torch.manual_seed(0)
+    for rows, nblk in ((4096, 16), (2560, 8)):
+        media = torch.randn(rows, 1024, device="cuda").to(torch.bfloat16)
+        Ws = [(torch.randn(1024, 1024, device="cuda") * 0.03).to(torch.bfloat16) for _ in range(nblk)]
+        table = torch.tensor([w.data_ptr() for w in Ws], dtype=torch.int64, device="cuda")
+        kv = torch.full((rows, nblk * 1024), float("nan"), device="cuda", dtype=torch.bfloat16)
+        ops.gemm_grouped(media, Ws, table, kv, kind=1)
+        for i in (0, nblk // 2, nblk - 1):
+            want = torch.zeros(rows, 1024, device="cuda", dtype=torch.bfloat16)
+            ops.gemm(media, Ws[i], want, safe=2)
+            assert PC.rel_err(kv[:, i * 1024:(i + 1) * 1024], want) < 4e-3, (rows, nblk, i)
+        dkv = (torch.randn(rows, nblk * 1024, device="cuda") * 0.1).to(torch.bfloat16)
+        dmedia = torch.full((rows, 1024), float("nan"), device="cuda")
+        from open_flamingo_amd.hip import abi
+        ops.gemm_grouped(dkv, Ws, table, dmedia, kind=2, epi=abi.EPI_ACC_F32)
+        want = torch.zeros(rows, 1024, device="cuda")
+        for i in range(nblk):
+            ops.gemm(dkv[:, i * 1024:(i + 1) * 1024], Ws[i], want, tb=True, epi=abi.EPI_ACC_F32, beta=1.0, safe=2)
+        assert PC.rel_l2(dmedia, want) < 1e-4, (rows, nblk, PC.rel_l2(dmedia, want))
+
+
 def _summ(t):
     import numpy as np
     t = t.detach().double().flatten().cpu()
@@ -653,10 +719,17 @@ def test_hip_path_against_reference_goldens_at_of3b_size(ops, golden_dir):
             _close_to_reference_summary(gp[k], z["gradsum." + k], name + " " + k, 2e-2)
 
 
-def _rccl_rank(rank, world, port, q):
+def _rccl_rank(rank, world, port, q, same_device=False):
     import os
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      LOCAL_RANK=str(0 if same_device else rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if same_device:
+        # two ranks on ONE GPU: RCCL refuses two ranks of a host on one device ("Duplicate GPU detected"), so each rank
+        # claims its own host id and the ranks talk through RCCL's socket transport over the loopback interface -- the
+        # collective kernels, the side-stream launches, finish() and the replica bookkeeping are the multi-GPU ones, only the
+        # wire is not xGMI
+        os.environ.update(NCCL_HOSTID=f"of-one-gpu-rank{rank}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1",
+                          NCCL_NET_GDR_LEVEL="0", NCCL_SHM_DISABLE="1", NCCL_P2P_DISABLE="1")
     import torch.distributed as dist
     from open_flamingo_amd.train import distributed, step, synthetic, towers
     from open_flamingo_amd.train.reducer import GradReducer
@@ -699,6 +772,40 @@ def test_two_gpu_rccl_train_step_keeps_replicas_identical():
         assert same, f"rank {rank}: replicas diverged"
         assert all(l == l for l in losses)
         assert stats["collectives_per_step"] >= 3 and stats["exposed_wait_ms_per_step"] is not None
+
+
+def test_two_rank_rccl_train_step_on_one_gpu_over_loopback():
+    """The 2-rank RCCL path on a ONE-GPU box (every box of the pool has one GPU): two processes, both on device 0,
+    RCCL's socket transport over `lo` (see _rccl_rank).  Executes on hardware what the 2-GPU test executes: NCCL-backend
+    process group, per-bucket all-reduces launched from the backward on the side stream, finish() ordering, the fused step
+    epilogue with grad_scale = 1/world -- replicas must be bit-identical after three steps on different per-rank batches."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_rank, args=(r, 2, port, q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=420) for _ in procs]
+    except Exception:
+        for p in procs:                      # never leave a rank spinning on the GPU
+            if p.is_alive():
+                p.kill()
+        raise
+    for p in procs:
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+        assert p.exitcode == 0
+    for rank, losses, same, stats in res:
+        assert same, f"rank {rank}: replicas diverged"
+        assert all(l == l for l in losses)
+        assert stats["collectives_per_step"] >= 3 and stats["exposed_wait_ms_per_step"] is not None
+    assert res[0][1] != res[1][1], "the ranks trained on different batches"
 
 
 @pytest.mark.timeout(900, method="thread")
