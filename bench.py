@@ -35,70 +35,88 @@ LAYOUT_NAMES = {(0, 0): "NT(y=xW^T)", (0, 1): "NN(dX=dY W)", (1, 1): "TN(dW=dY^T
 MFMA_PEAK_TFLOPS = 2500.0   # bf16 dense, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(family_info, threads, T=2, L=256):
-    """The oracle (CPU restatement of reference helpers.py, fp32, all host cores) on a bounded sample of the SAME
-    workload shapes: hot path only -- PerceiverResampler + gated cross-attention blocks, forward + backward -- at the
-    benchmark's per-sequence shapes (T images, L text tokens, OF-3B widths) for B=2 sequences; 6 of the blocks are timed
-    and scaled to all of them.  The frozen towers are not part of the sample (they are not part of the path)."""
+def _oracle_hot_path(d, nblk, seed=0):
     from oracle import flamingo_oracle as O
-    torch.set_num_threads(threads)
-    d, nblk = family_info["d"], family_info["layers"] // family_info["every"]
-    B = 2
-    g = torch.Generator().manual_seed(0)
+    torch.manual_seed(seed)
     per = O.OraclePerceiverResampler(dim=1024)
-    sample_blocks = min(6, nblk)
-    blocks = [O.OracleGatedCrossAttentionBlock(dim=d, dim_visual=1024) for _ in range(sample_blocks)]
+    blocks = [O.OracleGatedCrossAttentionBlock(dim=d, dim_visual=1024) for _ in range(nblk)]
     for b in blocks:
         with torch.no_grad():
             b.attn_gate.fill_(0.5)
             b.ff_gate.fill_(0.5)
+    return per, blocks
+
+
+def _oracle_time(per, blocks, B, T, L, d, reps, warm, backward):
+    """median seconds of `reps` runs after `warm` warm-ups: (forward, forward + backward) of Perceiver + the given blocks"""
+    import statistics
+    g = torch.Generator().manual_seed(1)
     feats = torch.randn(B, T, 1, 256, 1024, generator=g)
     x0 = torch.randn(B, L, d, generator=g)
     ml = torch.zeros(B, L, dtype=torch.bool)
     for t in range(T):
         ml[:, t * (L // T)] = True
-
-    def one():
+    fwd, both = [], []
+    for i in range(warm + reps):
         t0 = time.perf_counter()
-        vis = per(feats)
+        with torch.set_grad_enabled(backward):
+            y = x0.clone().requires_grad_(backward)
+            vis = per(feats)
+            for b in blocks:
+                y = b(y, vis, media_locations=ml)
         t1 = time.perf_counter()
-        x = x0.clone().requires_grad_(True)
-        y = x
-        for b in blocks:
-            y = b(y, vis, media_locations=ml)
+        if backward:
+            y.square().mean().backward()
+            for m in [per] + blocks:
+                m.zero_grad(set_to_none=True)
         t2 = time.perf_counter()
-        y.square().mean().backward()
-        t3 = time.perf_counter()
-        for m in [per] + blocks:
-            m.zero_grad(set_to_none=True)
-        return t1 - t0, t2 - t1, t3 - t2
-
-    one()
-    ts = [one() for _ in range(2)]
-    t_per = min(t[0] for t in ts)
-    t_blk_f = min(t[1] for t in ts)
-    t_bwd = min(t[2] for t in ts)
-    # backward covers perceiver + sample blocks; scale the block share (fwd-proportional) to all blocks
-    share = t_blk_f / (t_blk_f + t_per)
-    total = t_per + t_blk_f * nblk / sample_blocks + t_bwd * (share * nblk / sample_blocks + (1 - share))
-    return {"value": round(B * T / total, 3), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"hot path only (PerceiverResampler + {nblk} gated xattn blocks, fwd+bwd), fp32 oracle, B={B} T={T} "
-                      f"L={L} (the benchmark's per-sequence shapes); timed Perceiver + {sample_blocks} blocks x2 after 1 warm-up, "
-                      f"scaled to {nblk} blocks; {total * 1e3:.0f} ms per {B * T} images"}
+        if i >= warm:
+            fwd.append(t1 - t0)
+            both.append(t2 - t0)
+    return statistics.median(fwd), statistics.median(both)
 
 
-def pmc_traffic(key):
+def cpu_baseline(family_info, threads, T=2, L=256):
+    """The reference's CPU path for the hot path, timed on this box's host cores.  What runs is the oracle
+    (oracle/flamingo_oracle.py: the reference's helpers.py arithmetic restated line by line in plain PyTorch fp32 and PINNED
+    to the real reference by tests/golden -- /root/reference does not exist on the GPU box), kind = "port".
+      * primary figure = BASELINE.json configs[0]: B = 1, T = 2 images, L = 32 text tokens, fp32, the WHOLE hot path
+        (PerceiverResampler + every gated block of the family, no extrapolation): forward, and forward + backward; median of 5
+        after 2 warm-ups;
+      * second figure = the benchmark's own per-sequence shapes (T images, L tokens) for B = 2, forward + backward, median of 3
+        after 1 warm-up.
+    The frozen towers are not part of the path and not part of the sample."""
+    torch.set_num_threads(threads)
+    d, nblk = family_info["d"], family_info["layers"] // family_info["every"]
+    per, blocks = _oracle_hot_path(d, nblk)
+    f1, fb1 = _oracle_time(per, blocks, 1, 2, 32, d, reps=5, warm=2, backward=True)
+    f1_ng, _ = _oracle_time(per, blocks, 1, 2, 32, d, reps=5, warm=2, backward=False)
+    _, fb2 = _oracle_time(per, blocks, 2, T, L, d, reps=3, warm=1, backward=True)
+    return {"value": round(2 / fb1, 3), "unit": "images/s", "cores": threads, "kind": "port",
+            "pinning": "oracle = line-by-line restatement of reference helpers.py, pinned to the real reference by tests/golden "
+                       "(tests/golden/make_golden.py ran /root/reference; tests/test_oracle_golden.py replays it)",
+            "sample": f"BASELINE config 1: B=1 T=2 L=32 fp32, whole hot path (PerceiverResampler + all {nblk} gated xattn blocks at "
+                      f"d={d}), forward + backward, median of 5 after 2 warm-ups: {fb1 * 1e3:.0f} ms per 2 images "
+                      f"(forward {f1 * 1e3:.0f} ms; forward under no_grad {f1_ng * 1e3:.0f} ms)",
+            "config1_forward_ms": round(f1_ng * 1e3, 1), "config1_forward_backward_ms": round(fb1 * 1e3, 1),
+            "bench_shape_sample": {"value": round(2 * T / fb2, 3), "unit": "images/s",
+                                   "sample": f"B=2 T={T} L={L} (the benchmark's per-sequence shapes), whole hot path forward + "
+                                             f"backward, median of 3 after 1 warm-up: {fb2 * 1e3:.0f} ms per {2 * T} images"}}
+
+
+def pmc_traffic(key, shape):
     """HBM-side bytes per launch of the dominant kernel.  PMC counters cannot be collected inside a timed run (rocprofv3
     --pmc serialises kernels and needs separate passes per counter group), so the live line quotes the committed PMC
-    passes of the same kernel symbol and launch shape (profiles/pmc_traffic.json, refreshed with tools/gpu_pmc_traffic.sh)
-    and says so; null when that file has no entry for the kernel."""
+    passes of the SAME kernel, epilogue and launch shape (profiles/pmc_traffic.json: keys "ta tb epi kernel M N K") and says
+    so; null when there is no pass on record for exactly that launch."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    name = " ".join(str(k) for k in (int(key[0]), int(key[1]), int(key[2]), key[3], *shape))
     try:
         with open(path) as f:
             table = json.load(f)
-        ent = table["kernels"][" ".join(str(int(k)) for k in key)]
+        ent = table["kernels"][name]
     except (OSError, KeyError, ValueError):
-        return None, "no PMC pass on record for this kernel (profiles/pmc_traffic.json)"
+        return None, f"no PMC pass on record for this launch ({name}; profiles/pmc_traffic.json)"
     return ent["fetch_bytes"] + ent["write_bytes"], (
         f"bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE; fetches include "
         f"Infinity-Cache hits), not collected in this run: {ent['launch']}; algorithmic bytes {ent['algorithmic_bytes']}; "
@@ -250,8 +268,7 @@ def main():
             r[2] += 1
         with open(args.gemm_report, "w") as f:
             for (key, shape), (fl, ms, n) in sorted(per.items(), key=lambda kv: -kv[1][1]):
-                f.write(json.dumps({"layout": LAYOUT_NAMES[key[:2]], "epi": EPI_NAMES[key[2]],
-                                    "kernel": (("w4dma256" if key[:2] == (0, 0) else "pingpong256") if key[3] else "general128"),
+                f.write(json.dumps({"layout": LAYOUT_NAMES[key[:2]], "epi": EPI_NAMES[key[2]], "kernel": key[3],
                                     "MNK": list(shape),
                                     "launches_per_step": n, "ms_per_step": round(ms, 3),
                                     "avg_ms": round(ms / n, 4), "tflops": round(fl / ms / 1e9, 1)}) + "\n")
@@ -264,8 +281,14 @@ def main():
             gsum[2] += 1
         key = max(groups, key=lambda k: groups[k][1])
         fl, ms, n = groups[key]
-        big = "of_gemm_w4_kernel" if key[:2] == (0, 0) else "of_gemm_pp_kernel"      # of_gemm's big-tile choice per layout
-        sym = (big if key[3] else "of_gemm_kernel") + f"<{str(bool(key[0])).lower()}, {str(bool(key[1])).lower()}, {key[2]}, ...>"
+        sym = {"w4dma256": "of_gemm_w4_kernel", "pingpong256": "of_gemm_pp_kernel", "mid128": "of_gemm_mid_kernel",
+               "general128": "of_gemm_kernel", "skinny": "of_gemm_skinny_kernel"}[key[3]]
+        sym += f"<{str(bool(key[0])).lower()}, {str(bool(key[1])).lower()}, {key[2]}, ...>"
+        shapes = {}
+        for k2, _, shape, _, _ in timing:
+            if k2 == key:
+                shapes[shape] = shapes.get(shape, 0) + 1
+        top_shape = max(shapes, key=shapes.get)
         if survey:      # every of_gemm launch of the last warm-up step
             all_fl = sum(f for _, f, _, _, _ in survey) * args.steps
             all_ms = sum(e0.elapsed_time(e1) for _, _, _, e0, e1 in survey) * args.steps
@@ -273,10 +296,11 @@ def main():
             all_fl = sum(v[0] for v in groups.values())
             all_ms = sum(v[1] for v in groups.values())
         ach = fl / ms / 1e9
-        traffic, traffic_note = pmc_traffic(key)
+        traffic, traffic_note = pmc_traffic(key, top_shape)
         roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "kernel": f"{sym}  = of_gemm {LAYOUT_NAMES[key[:2]]}, epilogue {EPI_NAMES[key[2]]}",
+                    "shapes_MNK": {"x".join(map(str, sh)): c // args.steps for sh, c in shapes.items()},
                     "launches_per_step": n // args.steps, "avg_launch_ms": round(ms / n, 4),
                     "gflop_per_launch": round(fl / n / 1e9, 2),
                     "all_gemm_tflops": round(all_fl / all_ms / 1e9, 1),

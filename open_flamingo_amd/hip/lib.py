@@ -13,8 +13,8 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: libofhip.so needs 
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# OF_LIBOFHIP_PATH: A/B measurements of two builds on one box (tools/); the product never sets it
-LIB_PATH = os.environ.get("OF_LIBOFHIP_PATH") or os.path.join(os.path.dirname(_HERE), "csrc", "libofhip.so")
+# the ONE library the package ever loads: no environment override (A/B tooling under tools/ opens other builds itself)
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libofhip.so")
 _lib = None
 
 

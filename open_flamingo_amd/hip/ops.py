@@ -33,7 +33,7 @@ class Ops:
         self.lib = lib
         self._stream_fn = stream_fn
         self.gemm_timing = None   # bench.py sets this to a list to collect (key, flops, start_evt, end_evt) per launch
-        self.gemm_timing_only = None   # optional set of (ta, tb, epi) keys: only those launches are bracketed by events
+        self.gemm_timing_only = None   # optional set of (ta, tb, epi, kernel label) keys: only those launches are bracketed by events
 
     _default = None
 
@@ -57,10 +57,16 @@ class Ops:
 
     # ------------------------------------------------------------------ GEMM
     @staticmethod
-    def takes_pingpong_kernel(M, N, K):
-        """Mirror of of_gemm's kernel selection (csrc/gemm.hip): which HIP kernel symbol a launch ends up in -- only
-        used to label timing records (bench.py's roofline names ONE kernel so that it can be checked against rocprofv3)."""
-        return M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and (M // 256) * (N // 256) >= 192
+    def kernel_label(M, N, K, ta, tb):
+        """Mirror of of_gemm's kernel selection (csrc/gemm.hip): which HIP kernel a launch ends up in -- only used to label
+        timing records (bench.py's roofline names ONE kernel so that it can be checked against rocprofv3)."""
+        if M <= 16 and not ta and not tb:
+            return "skinny"
+        if M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and (M // 256) * (N // 256) >= 192:
+            return "w4dma256" if (not ta and not tb) else "pingpong256"
+        if M % 128 == 0 and N % 128 == 0 and K % 64 == 0:
+            return "mid128"
+        return "general128"
 
     def gemm(self, A, B, out, *, ta=False, tb=False, epi=abi.EPI_STORE_BF16, out2=None, aux=None, gate=None,
              alpha=1.0, beta=0.0, dot=None, safe=0):
@@ -103,16 +109,15 @@ class Ops:
                     ws = torch.empty((need + 3) // 4, dtype=F32, device=out.device)
                     self._gemm_ws = ws
                 a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
-        if self.gemm_timing is not None and (self.gemm_timing_only is None or
-                                             (int(ta), int(tb), epi, self.takes_pingpong_kernel(M, N, K))
-                                             in self.gemm_timing_only):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            self._chk(self.lib.of_gemm(C.byref(a), self._stream()), "of_gemm")
-            e1.record()
-            self.gemm_timing.append(((int(ta), int(tb), epi, self.takes_pingpong_kernel(M, N, K)), 2.0 * M * N * K,
-                                     (M, N, K), e0, e1))
-            return out
+        if self.gemm_timing is not None:
+            key = (int(ta), int(tb), epi, self.kernel_label(M, N, K, ta, tb))
+            if self.gemm_timing_only is None or key in self.gemm_timing_only:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self._chk(self.lib.of_gemm(C.byref(a), self._stream()), "of_gemm")
+                e1.record()
+                self.gemm_timing.append((key, 2.0 * M * N * K, (M, N, K), e0, e1))
+                return out
         self._chk(self.lib.of_gemm(C.byref(a), self._stream()), "of_gemm")
         return out
 
