@@ -235,20 +235,26 @@ int of_add(const void* a, const void* b, void* out, int f32, long n, void* strea
  *                   torch.optim.AdamW update with gradient coef * grad_scale * g at 1-based `step`; p_bf16 (optional) receives the bf16 copy of the new
  *                   parameters; zero_grad != 0 clears g in the same pass.  A non-finite *sumsq (NaN / Inf anywhere in the
  *                   gradients) skips the update -- p, m, v, p_bf16 untouched, g still cleared if asked: the reference's skip-on-NaN
- *                   (train_utils.py:161-169) decided on the device, identically on every rank.  No host synchronisation. */
+ *                   (train_utils.py:161-169) decided on the device, identically on every rank.  No host synchronisation.
+ *                   applied_steps (optional device int): Adam's bias correction then uses *applied_steps instead of `step`;
+ *   of_step_advance: *applied_steps += 1 iff *sumsq is finite -- launched once per optimizer step between of_sumsq_finish and
+ *                   the of_adamw_clip launches, so the count of APPLIED updates lives on the device and a skipped (NaN) step
+ *                   does not advance the bias correction (the reference `continue`s before optimizer.step()). */
 #define OF_SUMSQ_PARTS 512
 int of_sumsq_partial(const float* g, long n, float* partials, void* stream);
 int of_sumsq_finish(const float* partials, long count, float* acc, void* stream);
 int of_adamw_clip(float* p, float* g, float* m, float* v, uint16_t* p_bf16, long n, const float* sumsq,
                   float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
-                  int step, int zero_grad, void* stream);
+                  int step, int zero_grad, const int* applied_steps, void* stream);
+int of_step_advance(const float* sumsq, int* applied_steps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Token-level cross entropy of the causal-LM loss (the reference's Flamingo.forward passes `labels` to the HF language
  * model, open_flamingo/src/flamingo.py:112-121; transformers computes logits.float() -> log_softmax -> nll, mean over
  * labels != ignore_index).  logits: rows x vocab (bf16, or fp32 when logits_f32), row stride ld elements, any 2-byte
  * alignment; labels: rows int64 (already shifted by the caller).
- *   of_ce_fwd: lse[row] = log sum_j exp(logit[row][j]) (fp32); loss_rows[row] = lse - logit[row][label], 0 for ignored rows
+ *   of_ce_fwd: lse[row] = log sum_j exp(logit[row][j]) (fp32); loss_rows[row] = lse - logit[row][label], 0 for ignored rows,
+ *              NaN for a label outside [0, vocab) that is not ignore_index (a caller bug: surfaces as a NaN loss)
  *   of_ce_bwd: dlogits[row][j] = *gscale * (exp(logit - lse[row]) - [j == label]) in the logits' dtype, 0 for ignored rows
  *              (*gscale = upstream gradient / number of valid rows, a device scalar: no host sync)
  */

@@ -120,8 +120,10 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_ce_fwd_kernel(CeArgs a) {
             for (int w = 1; w < 4; ++w) lse_merge(M, S, red[w * 2], red[w * 2 + 1]);
             const float lse = M + of_log(S);
             a.lse[row] = lse;
-            const bool valid = lab != a.ignore_index && lab >= 0 && lab < a.V;
-            a.loss[row] = valid ? lse - ld_elem(a.logits, a.f32, base + lab) : 0.f;
+            // a label outside [0, V) that is not the ignore index is a caller bug (F.cross_entropy raises a device assert):
+            // poison the row's loss so that it surfaces as a NaN loss instead of silently lowering the mean
+            const bool in_range = lab >= 0 && lab < a.V;
+            a.loss[row] = lab == a.ignore_index ? 0.f : (in_range ? lse - ld_elem(a.logits, a.f32, base + lab) : __builtin_nanf(""));
         }
         of_sync();
     }

@@ -22,6 +22,7 @@ struct OptArgs {
     float* acc;            // sum of squares (device scalar); of_sumsq_partial: the OF_SUMSQ_PARTS partial slots
     float max_norm, lr, beta1, beta2, eps, wd, bc1, bc2, grad_scale;
     int zero_grad;
+    int* applied;          // device counter of APPLIED updates (of_step_advance), or NULL: bias correction from the host's step
 };
 
 constexpr int OPT_GRID_CAP = 4096;
@@ -101,7 +102,13 @@ OF_GLOBAL void of_adamw_kernel(OptArgs a) {
     }
     float coef = a.max_norm > 0.f ? a.max_norm / (norm + 1e-6f) : 1.0f;
     coef = (coef < 1.0f ? coef : 1.0f) * a.grad_scale;
-    const float step_size = a.lr / a.bc1, inv_sqrt_bc2 = 1.0f / sqrtf(a.bc2), decay = 1.0f - a.lr * a.wd;
+    float bc1 = a.bc1, bc2 = a.bc2;
+    if (a.applied) {       // Adam's step = updates actually applied (a skipped NaN step does not advance the bias correction)
+        const float t = (float)*a.applied;
+        bc1 = 1.0f - powf(a.beta1, t);
+        bc2 = 1.0f - powf(a.beta2, t);
+    }
+    const float step_size = a.lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2), decay = 1.0f - a.lr * a.wd;
     const long nv = a.n >> 2;
     const long stride = (long)of_gdim_x() * 256;
     for (long i = (long)of_bid_x() * 256 + of_tid(); i < nv; i += stride) {
@@ -128,6 +135,11 @@ OF_GLOBAL void of_adamw_kernel(OptArgs a) {
             if (a.zero_grad) a.g[i] = 0.f;
         }
     }
+}
+
+// one thread: the device-side "optimizer step happened" counter
+OF_GLOBAL void of_step_advance_kernel(OptArgs a) {
+    if (of_tid() == 0 && of_bid_x() == 0 && sqrtf(*a.acc) < 3.0e38f) *a.applied += 1;
 }
 
 unsigned opt_grid(long n) {
@@ -157,17 +169,25 @@ extern "C" int of_sumsq_finish(const float* partials, long count, float* acc, vo
     return of_launch(of_sumsq_finish_kernel, of_dim3{1, 1, 1}, 256, 4 * sizeof(float), (of_stream_t)stream, a);
 }
 
+extern "C" int of_step_advance(const float* sumsq, int* applied_steps, void* stream) {
+    if (!sumsq || !applied_steps) return OF_E_ARG;
+    OptArgs a{};
+    a.acc = const_cast<float*>(sumsq); a.applied = applied_steps;
+    return of_launch(of_step_advance_kernel, of_dim3{1, 1, 1}, 64, 0, (of_stream_t)stream, a);
+}
+
 extern "C" int of_adamw_clip(float* p, float* g, float* m, float* v, uint16_t* p_bf16, long n, const float* sumsq,
                              float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
-                             float grad_scale, int step, int zero_grad, void* stream) {
-    if (!p || !g || !m || !v || !sumsq || n <= 0 || step <= 0) return OF_E_ARG;
+                             float grad_scale, int step, int zero_grad, const int* applied_steps, void* stream) {
+    if (!p || !g || !m || !v || !sumsq || n <= 0 || (step <= 0 && !applied_steps)) return OF_E_ARG;
     if (((uintptr_t)p & 15) || ((uintptr_t)g & 15) || ((uintptr_t)m & 15) || ((uintptr_t)v & 15) || ((uintptr_t)p_bf16 & 7))
         return OF_E_ALIGN;
     OptArgs a{};
     a.p = p; a.g = g; a.m = m; a.v = v; a.p_bf16 = p_bf16; a.n = n; a.acc = const_cast<float*>(sumsq);
     a.grad_scale = grad_scale; a.max_norm = max_norm; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
-    a.bc1 = 1.0f - powf(beta1, (float)step);
-    a.bc2 = 1.0f - powf(beta2, (float)step);
+    a.bc1 = 1.0f - powf(beta1, (float)(step > 0 ? step : 1));
+    a.bc2 = 1.0f - powf(beta2, (float)(step > 0 ? step : 1));
     a.zero_grad = zero_grad;
+    a.applied = const_cast<int*>(applied_steps);
     return of_launch(of_adamw_kernel, of_dim3{opt_grid(n), 1, 1}, 256, 0, (of_stream_t)stream, a);
 }

@@ -298,13 +298,19 @@ class Ops:
         self.sumsq_finish(scratch[:len(bufs) * self.SUMSQ_PARTS], acc)
         return scratch
 
+    def step_advance(self, sumsq, applied):
+        """applied[0] += 1 iff the global gradient norm is finite (the update will be applied): Adam's step count on the device."""
+        assert applied.dtype == torch.int32 and sumsq.dtype == F32
+        self._chk(self.lib.of_step_advance(sumsq.data_ptr(), applied.data_ptr(), self._stream()), "of_step_advance")
+
     def adamw_clip(self, p, g, m, v, sumsq, *, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=1.0,
-                   p_bf16=None, zero_grad=True, grad_scale=1.0):
+                   p_bf16=None, zero_grad=True, grad_scale=1.0, applied=None):
+        """applied: optional device int32 count of applied updates (step_advance) that replaces ``step`` in the bias correction."""
         n = p.numel()
         assert all(t.dtype == F32 and t.is_contiguous() and t.numel() == n for t in (p, g, m, v))
         self._chk(self.lib.of_adamw_clip(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(p_bf16), n,
                                          sumsq.data_ptr(), max_norm, lr, betas[0], betas[1], eps, weight_decay,
-                                         grad_scale, step, int(zero_grad), self._stream()), "of_adamw_clip")
+                                         grad_scale, step, int(zero_grad), _p(applied), self._stream()), "of_adamw_clip")
 
     # ------------------------------------------------------------------ causal-LM loss
     def ce_fwd(self, logits, labels, lse, loss_rows, ignore_index=-100):

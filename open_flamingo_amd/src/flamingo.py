@@ -50,7 +50,8 @@ class Flamingo(nn.Module):
         with torch.no_grad():
             tokens = self.vision_encoder(vision_x.flatten(0, 2))[1]           # (b*T*F, patches, vis_dim)
         latents = self.perceiver(tokens.unflatten(0, (batch, n_media, n_frames)))
-        if self.group_media_projections and torch.is_grad_enabled():
+        # (not while media are being cached: several forwards may then run over the same latents, each with its own graph)
+        if self.group_media_projections and torch.is_grad_enabled() and not self.lang_encoder._use_cached_vision_x:
             # every gated block applies its own to_kv to this one tensor: one grouped GEMM for all of them
             from . import helpers
             helpers.group_media_projections(list(self.lang_encoder.gated_cross_attn_layers), latents)

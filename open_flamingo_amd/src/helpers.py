@@ -121,6 +121,12 @@ def _grad_sinks(names, params):
             if getattr(p, "_of_grad_fresh", False):      # not cleared by the step epilogue: this backward overwrites it
                 fresh.add(k)
                 p._of_grad_fresh = False
+        elif getattr(p, "_of_grad_fresh", False):
+            # marked "stale content, overwrite me" but not usable as a sink (its .grad was replaced or is not the plain fp32
+            # view any more): autograd's AccumulateGrad would ADD the fresh gradient to the previous step's -- clear it first
+            if p.grad is not None:
+                p.grad.zero_()
+            p._of_grad_fresh = False
     return sinks, fresh
 
 
@@ -517,12 +523,16 @@ class _GroupedMediaKVFn(torch.autograd.Function):
         grp = ctx.grp
         if not ctx.needs_input_grad[1] or grp.dkv_all is None:
             return None, None
-        assert len(grp.written) == len(grp.blocks), "a gated block of the group did not run its backward"
+        for i in range(len(grp.blocks)):       # a block whose output the loss does not reach never wrote its columns: zero
+            if i not in grp.written:
+                grp.dkv_all[:, i * grp.E:(i + 1) * grp.E].zero_()
         ops = Ops.default()
         from ..hip.abi import EPI_ACC_F32
         dmedia = torch.empty(grp.kv_all.shape[0], ctx.mshape[-1], dtype=F32, device=grp.kv_all.device)
         ops.gemm_grouped(grp.dkv_all, grp.Ws, grp.table, dmedia, kind=2, epi=EPI_ACC_F32)
-        grp.kv_all = grp.dkv_all = None
+        # dkv_all is re-made by the next backward (retain_graph / a second grad-enabled forward over cached media); kv_all
+        # lives as long as the group does (dropped with the conditioning or when newer groups push it out)
+        grp.dkv_all = None
         return None, (dmedia if ctx.mdtype == F32 else ops.to_bf16(dmedia)).view(ctx.mshape)
 
 

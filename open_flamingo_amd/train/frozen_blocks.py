@@ -213,6 +213,14 @@ def _mpt_block_fused_forward(self, hidden_states, position_bias, attention_mask,
           and (getattr(self, "_of_allow_cpu", False)
                or (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == BF16)))
     lite = attention_mask if isinstance(attention_mask, _LiteMask) else None
+    # The kernels take the NUMBER of real keys per sequence: correct for unpadded and RIGHT-padded batches only.  Training
+    # batches are right-padded by contract (reference train/data.py sets tokenizer.padding_side = "right"); the reference's
+    # eval wrapper LEFT-pads its prompts (eval/models/open_flamingo.py:57), so outside training a masked forward keeps HF's own
+    # block forward with the real mask unless the caller vouches for right padding (use_fused_frozen_mpt_blocks(...,
+    # assume_right_padding=True)).
+    masked = (lite.am is not None) if lite is not None else (attention_mask is not None)
+    if masked and not (self.training or getattr(self, "_of_assume_right_padding", False)):
+        ok = False
     if not ok:
         return self._of_eager_forward(hidden_states, position_bias, lite.full() if lite is not None else attention_mask,
                                       layer_past=layer_past, use_cache=use_cache, output_attentions=output_attentions, **kwargs)
@@ -231,12 +239,20 @@ def _mpt_block_fused_forward(self, hidden_states, position_bias, attention_mask,
     return y, None
 
 
-def use_fused_frozen_mpt_blocks(lm, allow_cpu=False):
+def right_padded(attention_mask):
+    """True when every row of a (B, L) attention mask is a prefix of ones (host-synchronising debug / test helper)."""
+    am = attention_mask.ne(0)
+    return bool((am[:, 1:] <= am[:, :-1]).all())
+
+
+def use_fused_frozen_mpt_blocks(lm, allow_cpu=False, assume_right_padding=False):
     """Route every HF MptBlock of ``lm`` through _FrozenMptBlockFn when its weights are frozen bf16 copies (see
     towers.hold_frozen_linears_in_bf16) and the call is a plain training / scoring forward; the module keeps its class,
-    parameters and state-dict keys.  Batches must be unpadded or RIGHT-padded (train/data.py pads on the right; the kernels
-    take the number of real keys per sequence): left-padded prompts belong to generate(), whose KV cache sends every block
-    through its own HF forward anyway.  ``allow_cpu``: tests only (the host-emulator build of the kernels)."""
+    parameters and state-dict keys.  The kernels take the number of real keys per sequence, i.e. batches must be unpadded or
+    RIGHT-padded: in training mode that is the data pipeline's contract (reference train/data.py); in eval mode a forward
+    WITH an attention mask takes the fused path only with ``assume_right_padding=True`` (the reference's eval wrapper
+    left-pads: eval/models/open_flamingo.py:57) and otherwise runs HF's block forward on the real mask.
+    ``allow_cpu``: tests only (the host-emulator build of the kernels)."""
     n = 0
     for mod in lm.modules():
         if type(mod).__name__ == "MptBlock":
@@ -244,6 +260,7 @@ def use_fused_frozen_mpt_blocks(lm, allow_cpu=False):
                 mod._of_eager_forward = mod.forward
                 mod.forward = types.MethodType(_mpt_block_fused_forward, mod)
             mod._of_allow_cpu = bool(allow_cpu)
+            mod._of_assume_right_padding = bool(assume_right_padding)
             n += 1
     if n and getattr(lm, "config", None) is not None:
         _install_lite_mask()

@@ -58,6 +58,7 @@ class FlatAdamW(torch.optim.Optimizer):
             self.param_groups = [have.get(True, dict(groups[0], betas=tuple(betas), eps=eps)),
                                  have.get(False, dict(groups[1], betas=tuple(betas), eps=eps))]
         self._sumsq = None
+        self._applied = None          # device int32: updates applied so far (NaN-skipped steps do not count)
         self.refresh_bf16()
         model = reducer.module
         for mod in [model.perceiver] + [b for b in model.lang_encoder.gated_cross_attn_layers if b is not None]:
@@ -89,6 +90,9 @@ class FlatAdamW(torch.optim.Optimizer):
     # ------------------------------------------------------------------ optimizer API subset used by train_step
     @torch.no_grad()
     def step(self, closure=None):
+        """NOTE for code that reads gradients: after step() the ``.grad`` of the nn.Linear weights is UNDEFINED (it still
+        holds the all-reduced SUM of the step just applied, left for the next backward's dW GEMM to overwrite); read
+        gradients between backward and step(), or call ``reducer.zero_grad()`` first."""
         assert closure is None, "FlatAdamW does not re-evaluate the model"
         ops = self._ops()
         self.step_count += 1
@@ -114,6 +118,12 @@ class FlatAdamW(torch.optim.Optimizer):
         # bits from the same all-reduced buffers, so the clip coefficient cannot differ between replicas
         self._parts = ops.sumsq([b["flat"] for b in self.reducer.buckets] + ([g_rows] if g_rows is not None else []),
                                 self._sumsq, getattr(self, "_parts", None))
+        # Adam's step = the number of updates actually APPLIED, counted on the device: a step skipped for a non-finite norm
+        # (the reference `continue`s before optimizer.step(), train_utils.py:161-169) does not advance the bias correction.
+        # (step_count, the host's count of step() calls, only seeds the counter and names checkpoints' "step" after a sync.)
+        if self._applied is None:
+            self._applied = torch.full((1,), self.step_count - 1, dtype=torch.int32, device=dev)
+        ops.step_advance(self._sumsq, self._applied)
         for b, lr in ((b, self.param_groups[0 if b["wd"] else 1]["lr"]) for b in self.reducer.buckets):
             # front part: small vectors whose kernels ADD into the gradient -> cleared here; back part: weight matrices
             # the next backward overwrites (their "fresh" mark makes its dW GEMM run with beta = 0): no zero pass, and no
@@ -123,7 +133,8 @@ class FlatAdamW(torch.optim.Optimizer):
                 if hi > lo:
                     ops.adamw_clip(b["flat_p"][lo:hi], b["flat"][lo:hi], b["m"][lo:hi], b["v"][lo:hi], self._sumsq,
                                    step=self.step_count, lr=lr, betas=self.betas, eps=self.eps, weight_decay=b["wd"],
-                                   max_norm=self.max_norm, p_bf16=b["flat_bf16"][lo:hi], zero_grad=zero, grad_scale=gs)
+                                   max_norm=self.max_norm, p_bf16=b["flat_bf16"][lo:hi], zero_grad=zero, grad_scale=gs,
+                                   applied=self._applied)
             for p in b.get("overwritable", ()):
                 p._of_grad_fresh = True
         if g_rows is not None:
@@ -131,7 +142,7 @@ class FlatAdamW(torch.optim.Optimizer):
             p_rows = self.embedding.data.index_select(0, e["rows"]).contiguous()
             ops.adamw_clip(p_rows, g_rows, e["m"], e["v"], self._sumsq, step=self.step_count,
                            lr=self.param_groups[1]["lr"], betas=self.betas, eps=self.eps, weight_decay=0.0,
-                           max_norm=self.max_norm, zero_grad=False, grad_scale=gs)
+                           max_norm=self.max_norm, zero_grad=False, grad_scale=gs, applied=self._applied)
             self.embedding.data.index_copy_(0, e["rows"], p_rows)
             self.embedding.grad = None
             if sparse is not None:
@@ -165,6 +176,7 @@ class FlatAdamW(torch.optim.Optimizer):
         """A ``torch.optim.AdamW`` state dict (what train_utils.py:354 saves), so a run can move between the fused
         step epilogue, ``torch.optim.AdamW`` and the reference's own training script at any checkpoint."""
         with_wd, without = self._reference_order()
+        applied = self.applied_steps()
         state, idx = {}, 0
         for p in with_wd + without:
             mom = self._moments_of(p)
@@ -174,8 +186,8 @@ class FlatAdamW(torch.optim.Optimizer):
                 v.index_copy_(0, self._emb["rows"], self._emb["v"])
             else:
                 m, v = mom[0].clone(), mom[1].clone()
-            if self.step_count > 0:
-                state[idx] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m, "exp_avg_sq": v}
+            if applied > 0:
+                state[idx] = {"step": torch.tensor(float(applied)), "exp_avg": m, "exp_avg_sq": v}
             idx += 1
         groups = []
         start = 0
@@ -211,6 +223,7 @@ class FlatAdamW(torch.optim.Optimizer):
         if len(steps) > 1:
             raise ValueError(f"parameters at different step counts {sorted(steps)}: not an AdamW run of this model")
         self.step_count = steps.pop() if steps else 0
+        self._applied = None          # re-seeded from step_count by the next step()
         for g, saved in zip(self.param_groups, sd["param_groups"]):
             for k, val in saved.items():
                 if k not in ("params", "weight_decay", "betas", "eps") and k in g:
@@ -218,6 +231,10 @@ class FlatAdamW(torch.optim.Optimizer):
             if "initial_lr" in saved:
                 g["initial_lr"] = saved["initial_lr"]
         self.refresh_bf16()
+
+    def applied_steps(self):
+        """Updates applied so far (host int; synchronises): step() calls minus the ones skipped for a non-finite norm."""
+        return self.step_count if self._applied is None else int(self._applied.item())
 
     def grad_norm(self):
         """Global gradient norm of the last step() (device scalar tensor, pre-clip)."""

@@ -177,8 +177,11 @@ def _mpt_attention_fused_forward(self, hidden_states, position_bias, past_key_va
                                       attention_mask=attention_mask, **kwargs)
     b, l = hidden_states.shape[:2]
     qkv = self.Wqkv(hidden_states)
+    # the libofhip kernel takes key COUNTS (unpadded / right-padded batches: the training contract, reference train/data.py);
+    # outside training a masked forward may be left-padded (reference eval wrapper) and takes the SDPA form with the real mask
     if (getattr(self, "_of_attention_kernel", "sdpa") == "libofhip" and qkv.is_cuda and qkv.dtype == torch.bfloat16
-            and self.head_dim in (64, 128) and position_bias.shape[-1] >= 2):
+            and self.head_dim in (64, 128) and position_bias.shape[-1] >= 2
+            and (attention_mask is None or self.training or getattr(self, "_of_assume_right_padding", False))):
         slopes, lens = _alibi_slopes_and_lens(position_bias, attention_mask, l)
         ctx = _CausalAlibiAttention.apply(qkv.contiguous(), slopes, lens, self.n_heads, self.head_dim,
                                           float(self.softmax_scale))

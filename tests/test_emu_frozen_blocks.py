@@ -115,6 +115,52 @@ def test_fused_frozen_mpt_block_matches_hf_eager(on_emulator, d, heads):
     assert out.past_key_values is not None
 
 
+def test_left_padded_eval_forward_keeps_hf_masking(on_emulator):
+    """the fused blocks collapse the attention mask to a per-sequence key COUNT, which is only right for
+    right-padded batches.  The reference's eval wrapper LEFT-pads (eval/models/open_flamingo.py:57): an eval-mode masked
+    forward must therefore NOT take the fused path (same logits as the unpatched model on the real positions), unless the
+    caller vouches for right padding; training mode keeps the fused path (right padding is the data pipeline's contract)."""
+    from transformers import MptConfig, MptForCausalLM
+    torch.manual_seed(0)
+    lm = MptForCausalLM(MptConfig(d_model=128, n_heads=2, n_layers=2, vocab_size=128, max_seq_len=64))
+    lm.requires_grad_(False)
+    for mod in lm.modules():
+        if isinstance(mod, torch.nn.Linear) and mod is not lm.get_output_embeddings():
+            mod.weight.data = mod.weight.data.to(torch.bfloat16)
+    lm.eval()
+    ids = torch.randint(0, 128, (3, 24))
+    left = torch.ones(3, 24, dtype=torch.long)
+    left[1, :9] = 0
+    left[2, :17] = 0
+    right = left.flip(1)
+    assert not frozen_blocks.right_padded(left) and frozen_blocks.right_padded(right)
+
+    def logits(am):
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+            return lm(input_ids=ids, attention_mask=am, use_cache=False).logits.float() * am.bool()[..., None]
+
+    ref_left, ref_right = logits(left), logits(right)
+    calls = []
+    orig = frozen_blocks._FrozenMptBlockFn.apply
+    frozen_blocks._FrozenMptBlockFn.apply = staticmethod(lambda *a: (calls.append(1), orig(*a))[1])
+    try:
+        frozen_blocks.use_fused_frozen_mpt_blocks(lm, allow_cpu=True)
+        got = logits(left)
+        assert calls == [] and _rel(got, ref_left) < 1e-6, "eval + mask: HF's own block forward on the real mask"
+        assert _rel(logits(right), ref_right) < 1e-6 and calls == []
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):     # no mask at all: nothing to get wrong
+            lm(input_ids=ids, use_cache=False)
+        assert len(calls) == 2
+        calls.clear()
+        frozen_blocks.use_fused_frozen_mpt_blocks(lm, allow_cpu=True, assume_right_padding=True)
+        assert _rel(logits(right), ref_right) < 2e-2 and len(calls) == 2
+        calls.clear()
+        lm.train()                                                              # training: right padding by contract
+        assert _rel(logits(right), ref_right) < 2e-2 and len(calls) == 2
+    finally:
+        frozen_blocks._FrozenMptBlockFn.apply = orig
+
+
 @pytest.mark.parametrize("attention", ["libofhip", "sdpa"])
 def test_fused_clip_tower_matches_hf_modules(on_emulator, attention):
     """The frozen CLIP tower's fused forward (one q|k|v GEMM, residual adds inside the LayerNorm passes, last add folded into

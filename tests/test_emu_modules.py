@@ -249,8 +249,13 @@ def test_nan_loss_skips_the_step_on_the_device(on_emulator, monkeypatch):
         if p.requires_grad:
             assert torch.equal(p.detach(), snap[k]), k
     assert all(torch.equal(b["m"], m0) for b, m0 in zip(red.buckets, moments))
+    # Adam's step is counted on the device and only for applied updates: the skipped step does not advance the bias
+    # correction (the reference `continue`s before optimizer.step()), and a checkpoint records the applied count
+    assert opt.step_count == 2 and opt.applied_steps() == 1
     loss = step.train_step(model, red, opt, batch, info, amp=False, nan_check="device")
     assert torch.isfinite(loss)
+    assert opt.step_count == 3 and opt.applied_steps() == 2
+    assert {float(st["step"]) for st in opt.state_dict()["state"].values()} == {2.0}
     moved = [k for k, p in model.named_parameters() if p.requires_grad and not torch.equal(p.detach(), snap[k])]
     assert len(moved) > 10 and all(torch.isfinite(p).all() for p in model.parameters())
 
