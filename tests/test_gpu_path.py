@@ -790,7 +790,7 @@ def test_two_rank_rccl_train_step_on_one_gpu_over_loopback():
     for p in procs:
         p.start()
     try:
-        res = [q.get(timeout=420) for _ in procs]
+        res = [q.get(timeout=240) for _ in procs]
     except Exception:
         for p in procs:                      # never leave a rank spinning on the GPU
             if p.is_alive():
