@@ -78,27 +78,55 @@ OF_DEV void of_wave_sync() { __builtin_amdgcn_wave_barrier(); }
 OF_DEV s16x4 of_lds_tr(const void* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
-// LDS-DMA: 16 bytes per lane from a per-lane global address straight into LDS at (wave-uniform base + lane*16).
-// Asynchronous: completion is tracked only by this wave's vmcnt (of_wait_vm) + a barrier for other waves.
+// ---- LDS-DMA (global -> LDS without a VGPR round trip), issued by INLINE ASM on purpose.
+// Through the builtins (__builtin_amdgcn_global_load_lds / raw_ptr_buffer_load_lds) hipcc's waitcnt pass knows that LDS-DMA
+// writes are pending and puts `s_waitcnt vmcnt(0)` in front of every later LDS read it cannot prove disjoint -- in practice in
+// front of every ds_read_b64_tr_b16 (the transposed-fragment reads of K-strided GEMM operands and of the attention kernels):
+// the whole ring drains once per stage, which is what made every DMA kernel with a K-strided operand 15-50 % slower than its
+// K-contiguous twin (round 3: cross-compiled ISA of of_gemm_mid_kernel<false,true,..>, a vmcnt(0) the source never asked for).
+// Ordering between a DMA and the reads of its data is this code's job anyway (the issuing wave's of_wait_vm<N> + a barrier for
+// the other waves); as inline asm the compiler neither tracks nor "protects" it.  Its own vmcnt bookkeeping for ordinary
+// loads stays correct: vmcnt retires in order, so untracked operations only make its waits conservative.
+// M0 = LDS destination of the wave (base + lane*16 is applied by the hardware); s_nop 0 = the M0-write -> LDS-DMA hazard.
+OF_DEV unsigned of_lds_u32(const void* p) { return (unsigned)(size_t)((__attribute__((address_space(3))) const char*)p); }
+#ifndef OF_DMA_VIA_BUILTIN
+OF_DEV void of_glds16(const void* gsrc, void* lds_wave_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(of_lds_u32(lds_wave_base))) : "memory");
+}
+#else       // tools/ab builds only: the builtin form, for same-box A/B of the effect described above
 OF_DEV void of_glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+#endif
 // Buffer-descriptor loads: wave-uniform 128-bit descriptor (base pointer in SGPRs) + per-lane 32-bit byte offset +
 // scalar byte offset -- no 64-bit per-lane address arithmetic.  `base` must be provably wave-uniform (kernel arguments /
 // blockIdx-derived), or hipcc wraps every load in a waterfall loop.
-typedef __amdgpu_buffer_rsrc_t of_buf_t;
+struct of_buf_t {
+    __amdgpu_buffer_rsrc_t r;      // for the builtin register loads
+    u32x4 w;                       // the same descriptor as four dwords, for the inline-asm LDS-DMA
+};
 OF_DEV of_buf_t of_buf_make(const void* base) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xffffffff, 0x00020000);
+    const unsigned long long a = (unsigned long long)base;
+    return of_buf_t{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xffffffff, 0x00020000),
+                    u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, 0xffffffffu, 0x00020000u}};
 }
 OF_DEV u32x4 of_buf_load16(of_buf_t b, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(b, (int)voff, (int)soff, 0));
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)voff, (int)soff, 0));
 }
 // LDS-DMA through a buffer descriptor: 16 bytes per lane straight into LDS at (wave-uniform base + lane*16); completion is
 // tracked only by the issuing wave's vmcnt (+ a barrier for other waves), like of_glds16
+#ifndef OF_DMA_VIA_BUILTIN
 OF_DEV void of_buf_load16_lds(of_buf_t b, unsigned voff, unsigned soff, void* lds_wave_base) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(b, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(b.w), "s"(soff),
+                 "s"(__builtin_amdgcn_readfirstlane(of_lds_u32(lds_wave_base)))
+                 : "memory");
 }
+#else
+OF_DEV void of_buf_load16_lds(of_buf_t b, unsigned voff, unsigned soff, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+}
+#endif
 template <int N>
 OF_DEV void of_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

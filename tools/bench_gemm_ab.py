@@ -80,19 +80,31 @@ def timed(fn, iters):
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    fam = sys.argv[sys.argv.index("--family") + 1] if "--family" in sys.argv else "OF-3B"
-    old = load(args[0] if args else os.path.join(HERE, "ab", "libofhip_r02.so"))
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("old", nargs="?", default=os.path.join(HERE, "ab", "libofhip_r02.so"))
+    ap.add_argument("--family", default="OF-3B")
+    ap.add_argument("--builtin", default=os.path.join(HERE, "ab", "libofhip_builtin_dma.so"),
+                    help="same sources as the product library built with -DOF_DMA_VIA_BUILTIN (tools/build_ab_variant.sh)")
+    a = ap.parse_args()
+    fam = a.family
+    old = load(a.old)
+    builtin = load(a.builtin) if os.path.exists(a.builtin) else None
     new = Ops.default()
     for name, M, N, K, ta, tb, epi in family_shapes(fam):
         A, B, C, kw = make(M, N, K, ta, tb, epi)
         arms = {"old": lambda: old.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, **kw),
                 "new": lambda: new.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, **kw)}
+        if builtin is not None:
+            arms["builtin_dma"] = lambda: builtin.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, **kw)
         big_ok = M % 256 == 0 and N % 256 == 0 and K % 64 == 0
         mid_ok = M % 128 == 0 and N % 128 == 0 and K % 64 == 0
         if big_ok and mid_ok:     # both tilings possible: force each on the new build
             arms["new_mid128"] = lambda: new.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=5, **kw)
-            arms["new_big256"] = lambda: new.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=(7 if not ta and not tb else 4), **kw)
+            arms["new_pp256"] = lambda: new.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=4, **kw)
+            arms["new_w4dma256"] = lambda: new.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=7, **kw)
+            if builtin is not None:
+                arms["builtin_w4dma256"] = lambda: builtin.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=7, **kw)
         best = {k: 1e9 for k in arms}
         for k, fn in arms.items():
             for _ in range(3):
