@@ -274,7 +274,7 @@ namespace {
 // K slices for a weight-gradient GEMM with a small output and a deep K (see of_gemm); 1 = not split
 int pick_ksplit(const OfGemmArgs& a, bool with_workspace) {
     const long tiles256 = (long)(a.M / 256) * (a.N / 256);
-    const bool pp_ok = !(a.M % 256) && !(a.N % 256) && !(a.K % 64) && tiles256 >= 192;
+    const bool pp_ok = !(a.M % 256) && !(a.N % 256) && !(a.K % 64) && tiles256 >= 128;
     const bool forced = a.safe >= 8 && a.safe < 16;          // 8 + log2(split): tuning aid (tools/bench_splitk.py)
     if (!(forced || (a.safe == 0 && !pp_ok)) || a.epi != OF_EPI_ACC_F32) return 1;
     if (!with_workspace && !(a.beta == 1.f || (a.beta == 0.f && a.ldc == a.N))) return 1;
@@ -349,11 +349,13 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
     of_dim3 grid{(unsigned)(tiles_m * tiles_n), 1, 1};
     OfGemmArgs b = a;
     b.ksplit = 1;
-    // Kernel selection (safe == 0).  The 256x256 ping-pong kernel needs >= ~3/4 of the 256 CUs' worth of tiles to pay;
-    // below that the 128x128 kernel gives 4x the workgroups, and weight-gradient GEMMs with a small output and a deep
-    // K (K = tokens) are additionally split along K until every CU has work.
+    // Kernel selection (safe == 0).  The 256x256 kernels need >= half of the 256 CUs' worth of tiles to pay (OF-9B's B*L =
+    // 2048-row launches, 128 tiles with K = 16384, run 9-14 % faster on half the chip with the big tile than on all of it with
+    // 128x128 tiles -- twice the operand bytes per FLOP; same-box A/B profiles/r03b_gemm_ab_OF-9B.jsonl); below that the
+    // 128x128 kernels give 4x the workgroups, and weight-gradient GEMMs with a small output and a deep K (K = tokens) are
+    // additionally split along K until every CU has work.
     const long tiles256 = (long)(a.M / 256) * (a.N / 256);
-    const bool pp_ok = !(a.M % 256) && !(a.N % 256) && !(a.K % 64) && tiles256 >= 192;
+    const bool pp_ok = !(a.M % 256) && !(a.N % 256) && !(a.K % 64) && tiles256 >= 128;
     const bool mid_ok = !(a.M % 128) && !(a.N % 128) && !(a.K % 64);      // the 8-wave LDS-DMA 128x128 kernel (gemm_mid.hip)
     {
         int split = pick_ksplit(a, true);
@@ -393,10 +395,13 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
     if (a.safe >= 16) return OF_E_ARG;
 #endif
     const bool pp_forced = a.safe == 4;
-    // Big-tile selection (measured on MI355X, random operands, profiles/r02_gemm_big_tile_ab.jsonl): both operands
-    // K-contiguous (NT: y = x W^T) -> the 4-wave LDS-DMA kernel (+4..6 % over the ping-pong kernel); a K-strided operand
-    // (NN: dX = dY W, TN: dW = dY^T X) -> the 8-wave ping-pong kernel (the 4-wave DMA schedule loses 15-25 % there).
-    if (a.safe == 0 && pp_ok && !a.a_trans && !a.b_trans) {
+    // Big-tile selection (measured on MI355X, random operands, same box: profiles/r03b_gemm_ab_*.jsonl): every layout -> the
+    // 4-wave LDS-DMA kernel.  Round 2 sent layouts with a K-strided operand (NN: dX = dY W, TN: dW = dY^T X) to the 8-wave
+    // ping-pong kernel because the 4-wave DMA schedule lost 15-25 % there -- that was hipcc draining the DMA ring in front of
+    // every transposed-fragment read (of_platform.h); with the DMA issued by inline asm the 4-wave kernel is 3-9 % ahead on
+    // those layouts too (NN 8192x2048x8192: 206 vs 221 us; TN: 215 vs 228 us).  The ping-pong kernel keeps the K-grouped B
+    // launches (gemm_grouped) and safe = 4.
+    if (a.safe == 0 && pp_ok) {
         OfGemmArgs w = a;
         w.safe = 7;
         const int rc = of_gemm_w4_try(w, s);

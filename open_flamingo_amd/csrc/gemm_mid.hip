@@ -66,9 +66,9 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_mid_kernel(OfGemmArgs p) {
     unsigned sA = (unsigned)kt0 * stepA, sB = (unsigned)kt0 * stepB;      // stage the next issue() fetches
     auto issue = [&](char* slot) OF_INLINE_LAMBDA {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) of_buf_load16_lds(gA, offA[j], sA, slot + (j * 8 + wave) * 1024);
+        for (int j = 0; j < 2; ++j) of_buf_load16_lds<AT || BT>(gA, offA[j], sA, slot + (j * 8 + wave) * 1024);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) of_buf_load16_lds(gB, offB[j], sB, slot + MID_OPER + (j * 8 + wave) * 1024);
+        for (int j = 0; j < 2; ++j) of_buf_load16_lds<AT || BT>(gB, offB[j], sB, slot + MID_OPER + (j * 8 + wave) * 1024);
         sA += stepA;
         sB += stepB;
     };

@@ -101,7 +101,7 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (RS) stg[j] = *(const u32x4*)srcA[j];
-            else of_glds16(srcA[j], slot + offA + j * 4096);
+            else of_glds16<false>(srcA[j], slot + offA + j * 4096);
             srcA[j] += stepA;
         }
         if (RS) stg_dst = slot + offA;
@@ -115,7 +115,7 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (RS) stg[j] = *(const u32x4*)srcB[j];
-            else of_glds16(srcB[j], slot + offB + j * 4096);
+            else of_glds16<false>(srcB[j], slot + offB + j * 4096);
             srcB[j] += stepB;
         }
         if (RS) stg_dst = slot + offB;

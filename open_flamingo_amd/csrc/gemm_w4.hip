@@ -108,8 +108,8 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
         const int op = j >> 3, hf = (j >> 2) & 1, jj = j & 3;
         char* dst = slot + op * OPER_BYTES + hf * HALF_BYTES + jj * 4096 + wave * 1024;
         if (ABL & 2) return;
-        if (op == 0) of_buf_load16_lds(gA, offA[hf][jj], sA + (ahead ? stepA : 0u), dst);
-        else of_buf_load16_lds(gB, offB[hf][jj], sB + (ahead ? stepB : 0u), dst);
+        if (op == 0) of_buf_load16_lds<AT || BT>(gA, offA[hf][jj], sA + (ahead ? stepA : 0u), dst);
+        else of_buf_load16_lds<AT || BT>(gB, offB[hf][jj], sB + (ahead ? stepB : 0u), dst);
     };
     const int par = wave & 1;
     // piece issued in gap i of window phase w (0 = phase 3 of the previous iteration, 1 = phase 0, 2 = phase 1), or -1

@@ -89,16 +89,21 @@ OF_DEV s16x4 of_lds_tr(const void* p) {
 // loads stays correct: vmcnt retires in order, so untracked operations only make its waits conservative.
 // M0 = LDS destination of the wave (base + lane*16 is applied by the hardware); s_nop 0 = the M0-write -> LDS-DMA hazard.
 OF_DEV unsigned of_lds_u32(const void* p) { return (unsigned)(size_t)((__attribute__((address_space(3))) const char*)p); }
+// Kernels WITHOUT transposed-fragment reads (both operands K-contiguous) keep the builtin form: nothing there triggers the
+// extra wait and the compiler schedules the M0 set-up better than the asm's fixed s_mov + s_nop (same-box: 1-2 % faster,
+// profiles/r03b_gemm_ab_*.jsonl); `TRSAFE = true` selects the inline-asm form.  -DOF_DMA_VIA_BUILTIN (tools/ab builds only)
+// forces the builtin everywhere, for A/B of the effect.
+template <bool TRSAFE = true>
+OF_DEV void of_glds16(const void* gsrc, void* lds_wave_base) {
 #ifndef OF_DMA_VIA_BUILTIN
-OF_DEV void of_glds16(const void* gsrc, void* lds_wave_base) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(of_lds_u32(lds_wave_base))) : "memory");
-}
-#else       // tools/ab builds only: the builtin form, for same-box A/B of the effect described above
-OF_DEV void of_glds16(const void* gsrc, void* lds_wave_base) {
+    if (TRSAFE) {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(of_lds_u32(lds_wave_base))) : "memory");
+        return;
+    }
+#endif
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
-#endif
 // Buffer-descriptor loads: wave-uniform 128-bit descriptor (base pointer in SGPRs) + per-lane 32-bit byte offset +
 // scalar byte offset -- no 64-bit per-lane address arithmetic.  `base` must be provably wave-uniform (kernel arguments /
 // blockIdx-derived), or hipcc wraps every load in a waterfall loop.
@@ -116,17 +121,18 @@ OF_DEV u32x4 of_buf_load16(of_buf_t b, unsigned voff, unsigned soff) {
 }
 // LDS-DMA through a buffer descriptor: 16 bytes per lane straight into LDS at (wave-uniform base + lane*16); completion is
 // tracked only by the issuing wave's vmcnt (+ a barrier for other waves), like of_glds16
+template <bool TRSAFE = true>
+OF_DEV void of_buf_load16_lds(of_buf_t b, unsigned voff, unsigned soff, void* lds_wave_base) {
 #ifndef OF_DMA_VIA_BUILTIN
-OF_DEV void of_buf_load16_lds(of_buf_t b, unsigned voff, unsigned soff, void* lds_wave_base) {
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(b.w), "s"(soff),
-                 "s"(__builtin_amdgcn_readfirstlane(of_lds_u32(lds_wave_base)))
-                 : "memory");
-}
-#else
-OF_DEV void of_buf_load16_lds(of_buf_t b, unsigned voff, unsigned soff, void* lds_wave_base) {
+    if (TRSAFE) {
+        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(b.w), "s"(soff),
+                     "s"(__builtin_amdgcn_readfirstlane(of_lds_u32(lds_wave_base)))
+                     : "memory");
+        return;
+    }
+#endif
     __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
 }
-#endif
 template <int N>
 OF_DEV void of_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

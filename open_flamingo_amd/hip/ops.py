@@ -62,8 +62,8 @@ class Ops:
         timing records (bench.py's roofline names ONE kernel so that it can be checked against rocprofv3)."""
         if M <= 16 and not ta and not tb:
             return "skinny"
-        if M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and (M // 256) * (N // 256) >= 192:
-            return "w4dma256" if (not ta and not tb) else "pingpong256"
+        if M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and (M // 256) * (N // 256) >= 128:
+            return "w4dma256"
         if M % 128 == 0 and N % 128 == 0 and K % 64 == 0:
             return "mid128"
         return "general128"

@@ -214,6 +214,7 @@ OF_DEV s16x4 of_lds_tr(const void* p) {
     return r;
 }
 // LDS-DMA executes synchronously here: layout (lane -> LDS address) is emulated, asynchrony is not.
+template <bool TRSAFE = true>
 OF_DEV void of_glds16(const void* gsrc, void* lds_wave_base) {
     memcpy((char*)lds_wave_base + 16 * (of_emu::g_blk->cur & 63), gsrc, 16);
 }
@@ -225,6 +226,7 @@ struct of_buf_t {
 };
 OF_DEV of_buf_t of_buf_make(const void* base) { return of_buf_t{(const char*)base}; }
 OF_DEV u32x4 of_buf_load16(of_buf_t b, unsigned voff, unsigned soff) { return *(const u32x4*)(b.base + voff + soff); }
+template <bool TRSAFE = true>
 OF_DEV void of_buf_load16_lds(of_buf_t b, unsigned voff, unsigned soff, void* lds_wave_base) {
     *(u32x4*)((char*)lds_wave_base + (of_emu::g_blk->cur & 63) * 16) = *(const u32x4*)(b.base + voff + soff);
 }

@@ -400,7 +400,7 @@ def test_big_tile_gemm_fused_epilogues_at_benchmark_shapes(ops, safe):
     gate = torch.tensor([0.37], device="cuda")
     g = float(torch.tanh(gate))
     rows, d, hid, inner = 8192, 2048, 8192, 512
-    assert Ops.kernel_label(rows, hid, d, False, False) == "w4dma256" and Ops.kernel_label(rows, d, hid, False, True) == "pingpong256"
+    assert Ops.kernel_label(rows, hid, d, False, False) == "w4dma256" and Ops.kernel_label(rows, d, hid, False, True) == "w4dma256"
     # ---- up-projection + erf-GELU, two outputs (pre-activation kept for the backward): NT 8192 x 8192 x 2048
     u, W1 = _r((rows, d), 41), _r((hid, d), 42, d ** -0.5)
     acc = u.float() @ W1.float().t()

@@ -79,11 +79,48 @@ def timed(fn, iters):
     return s.elapsed_time(e) / iters
 
 
+def ladder(ops):
+    """Where a K = 2048 FFN launch's time goes beyond its main loop: the same GEMM with increasingly expensive epilogues."""
+    E = abi
+    M = N = 8192
+    K = 2048
+    for ta, tb, steps in ((0, 0, (("store_bf16", E.EPI_STORE_BF16, {}), ("gelu (one output)", E.EPI_GELU, {"no_out2": True}),
+                                  ("gelu + pre-activation", E.EPI_GELU, {}), ("acc_f32 beta0", E.EPI_ACC_F32, {}))),
+                          (0, 1, (("store_bf16", E.EPI_STORE_BF16, {}), ("scale_dot (aux + dot)", E.EPI_SCALE_DOT, {}),
+                                  ("dgelu_dot", E.EPI_DGELU_DOT, {}), ("dgelu_dot no dot", E.EPI_DGELU_DOT, {"no_dot": True})))):
+        for name, epi, opt in steps:
+            A, B, C, kw = make(M, N, K, ta, tb, epi)
+            if opt.get("no_out2"):
+                kw.pop("out2")
+            if opt.get("no_dot"):
+                kw.pop("dot")
+            rec = dict(ladder="NT NN".split()[tb], epilogue=name, MNK=[M, N, K])
+            for label, safe in (("w4dma256", 7), ("pp256", 4)):
+                fn = lambda: ops.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=safe, **kw)
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                ms = min(timed(fn, 10) for _ in range(4))
+                rec[label + "_ms"] = round(ms, 4)
+                rec[label + "_tflops"] = round(2.0 * M * N * K / ms / 1e9, 1)
+            print(json.dumps(rec), flush=True)
+    # K sweep at M = N = 8192, plain store: per-tile fixed cost = intercept / 4 tiles per CU
+    for K in (512, 1024, 2048, 4096, 8192):
+        A, B, C, kw = make(M, N, K, 0, 0, E.EPI_STORE_BF16)
+        fn = lambda: ops.gemm(A, B, C, epi=E.EPI_STORE_BF16, safe=7)
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        print(json.dumps(dict(ksweep="NT store_bf16 w4dma256", MNK=[M, N, K], ms=round(min(timed(fn, 10) for _ in range(4)), 4))), flush=True)
+
+
 def main():
     import argparse
     ap = argparse.ArgumentParser()
     ap.add_argument("old", nargs="?", default=os.path.join(HERE, "ab", "libofhip_r02.so"))
     ap.add_argument("--family", default="OF-3B")
+    ap.add_argument("--ladder", action="store_true", help="epilogue ladder on the K = 2048 FFN shapes instead of the family table")
+    ap.add_argument("--only-big", action="store_true", help="only shapes with >= 128 big tiles")
     ap.add_argument("--builtin", default=os.path.join(HERE, "ab", "libofhip_builtin_dma.so"),
                     help="same sources as the product library built with -DOF_DMA_VIA_BUILTIN (tools/build_ab_variant.sh)")
     a = ap.parse_args()
@@ -91,7 +128,15 @@ def main():
     old = load(a.old)
     builtin = load(a.builtin) if os.path.exists(a.builtin) else None
     new = Ops.default()
+    if a.ladder:
+        return ladder(new)
+    tools = None
+    tl = os.path.join(HERE, "libofhip_tools.so")
+    if os.path.exists(tl):
+        tools = load(tl)
     for name, M, N, K, ta, tb, epi in family_shapes(fam):
+        if a.only_big and not (M % 256 == 0 and N % 256 == 0 and (M // 256) * (N // 256) >= 128):
+            continue
         A, B, C, kw = make(M, N, K, ta, tb, epi)
         arms = {"old": lambda: old.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, **kw),
                 "new": lambda: new.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, **kw)}
@@ -105,6 +150,9 @@ def main():
             arms["new_w4dma256"] = lambda: new.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=7, **kw)
             if builtin is not None:
                 arms["builtin_w4dma256"] = lambda: builtin.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=7, **kw)
+        if tools is not None and big_ok and (M // 256) * (N // 256) >= 128:       # DMA placement variants of the 4-wave kernel
+            for code, tag in ((70, "dpl0"), (71, "dpl1"), (73, "dpl3")):
+                arms["tools_w4_" + tag] = (lambda c: (lambda: tools.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=c, **kw)))(code)
         best = {k: 1e9 for k in arms}
         for k, fn in arms.items():
             for _ in range(3):
