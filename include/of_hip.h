@@ -219,6 +219,18 @@ int of_quick_gelu(const uint16_t* x, uint16_t* y, long n, void* stream);
 int of_gelu_fwd(const uint16_t* x, uint16_t* y, long n, void* stream);
 int of_gelu_bwd(const uint16_t* dy, const uint16_t* x, uint16_t* dx, long n, void* stream);
 int of_add_bf16(const float* x, const uint16_t* y, float* out, long n, void* stream);
+/* Frozen GPT-NeoX blocks (OF-4B = RedPajama-INCITE-3B; HF GPTNeoXAttention.forward): rotary embedding +
+ * head padding in one pass.  qkv: [rows][heads * 3 * head_size] bf16 in HF's per-head [q_h | k_h | v_h] layout (row stride
+ * ldqkv); cos / sin: [L][rot_dims] fp32 (HF's position_embeddings of one sequence; position = row % L); q, k, v: three
+ * [rows][heads * head_pad] bf16 matrices (row stride ldo), every head zero-padded from head_size to head_pad columns so that the
+ * attention kernels' head sizes (64 / 128) cover head size 80; the first rot_dims columns of q and k are rotated
+ * (apply_rotary_pos_emb).  inverse = 1 is the gradient's way back: q, k, v hold padded dq, dk, dv and qkv receives d(qkv).
+ * of_head_repack: dst[row][h * dst_hs + c] = c < src_hs ? src[row][h * src_hs + c] : 0 -- pads or trims every head (the
+ * attention output back to head_size columns in front of the dense projection, its gradient forward to head_pad). */
+int of_rotary_neox(uint16_t* qkv, long ldqkv, const float* cos, const float* sin, long L, uint16_t* q, uint16_t* k, uint16_t* v,
+                   long ldo, long rows, int heads, int head_size, int rot_dims, int head_pad, int inverse, void* stream);
+int of_head_repack(const uint16_t* src, long lds, uint16_t* dst, long ldd, long rows, int heads, int src_head_size,
+                   int dst_head_size, void* stream);
 /* out(T) = a(T) + b(T) */
 int of_add(const void* a, const void* b, void* out, int f32, long n, void* stream);
 

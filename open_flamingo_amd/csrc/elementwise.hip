@@ -206,6 +206,75 @@ unsigned grid_for(long work_items) {
     return (unsigned)b;
 }
 
+
+// ---- frozen GPT-NeoX blocks (SURVEY.md 8f N1, OF-4B = RedPajama-INCITE-3B: 32 heads x head size 80, rotary embedding)
+// HF GPTNeoXAttention lays the fused projection out per head as [q_h | k_h | v_h] (3 * hs columns) and rotates the first
+// `rot` columns of q_h and k_h:  out[j] = x[j] cos[j] - x[j + rot/2] sin[j],  out[j + rot/2] = x[j + rot/2] cos[j + rot/2] +
+// x[j] sin[j + rot/2]  (apply_rotary_pos_emb / rotate_half; cos = cat(freqs, freqs).cos()).  The attention kernels exist for head
+// sizes 64 and 128, so the same pass writes q, k, v as three [rows][heads * pad] matrices with every head zero-padded to `pad`
+// columns (80 -> 128: zero key / value columns change neither the scores nor the used output columns).
+// INVERSE: the gradient's way back -- padded dq, dk, dv -> d(qkv) in the projection's layout, rotation transposed.
+struct RotArgs {
+    bf16_t* qkv; long ldqkv;
+    const float* cos; const float* sin;      // [L][rot] fp32, position = row % L
+    long L;
+    bf16_t* q; bf16_t* k; bf16_t* v; long ldo;
+    long rows; int heads, hs, rot, pad;
+};
+template <bool INVERSE>
+OF_GLOBAL void of_rotary_neox_kernel(RotArgs a) {
+    const int half = a.rot >> 1;
+    const long per_row = (long)a.heads * a.pad;
+    const long total = a.rows * per_row;
+    const long stride = (long)of_gdim_x() * 256;
+    for (long i = (long)of_bid_x() * 256 + of_tid(); i < total; i += stride) {
+        const long row = i / per_row;
+        const int rem = (int)(i - row * per_row);
+        const int h = rem / a.pad, c = rem - h * a.pad;
+        const long po = row * a.ldo + (long)h * a.pad + c;
+        if (c >= a.hs) {
+            if (!INVERSE) a.q[po] = a.k[po] = a.v[po] = 0;
+            continue;
+        }
+        bf16_t* src = a.qkv + row * a.ldqkv + (long)h * 3 * a.hs;
+        if (c >= a.rot) {                   // pass-through columns
+            if (!INVERSE) { a.q[po] = src[c]; a.k[po] = src[a.hs + c]; a.v[po] = src[2 * a.hs + c]; }
+            else { src[c] = a.q[po]; src[a.hs + c] = a.k[po]; src[2 * a.hs + c] = a.v[po]; }
+            continue;
+        }
+        const long pos = row % a.L;
+        const int pc = c < half ? c + half : c - half;          // rotate_half partner
+        const float cs = a.cos[pos * a.rot + c];
+        if (!INVERSE) {
+            const float sn = a.sin[pos * a.rot + c] * (c < half ? -1.0f : 1.0f);
+            a.q[po] = of_f32_to_bf16(of_bf16_to_f32(src[c]) * cs + of_bf16_to_f32(src[pc]) * sn);
+            a.k[po] = of_f32_to_bf16(of_bf16_to_f32(src[a.hs + c]) * cs + of_bf16_to_f32(src[a.hs + pc]) * sn);
+            a.v[po] = src[2 * a.hs + c];
+        } else {                            // transpose: d x[c] = g[c] cos[c] + g[pc] * (sign of the PARTNER's row) sin[pc]
+            const float sn = a.sin[pos * a.rot + pc] * (pc < half ? -1.0f : 1.0f);
+            const long pp = po - c + pc;
+            src[c] = of_f32_to_bf16(of_bf16_to_f32(a.q[po]) * cs + of_bf16_to_f32(a.q[pp]) * sn);
+            src[a.hs + c] = of_f32_to_bf16(of_bf16_to_f32(a.k[po]) * cs + of_bf16_to_f32(a.k[pp]) * sn);
+            src[2 * a.hs + c] = a.v[po];
+        }
+    }
+}
+// dst[row][h * dhs + c] = c < shs ? src[row][h * shs + c] : 0   for c < dhs: pads (dhs > shs) or trims (dhs < shs) every head
+struct RepackArgs {
+    const bf16_t* src; long lds; bf16_t* dst; long ldd;
+    long rows; int heads, shs, dhs;
+};
+OF_GLOBAL void of_head_repack_kernel(RepackArgs a) {
+    const long per_row = (long)a.heads * a.dhs;
+    const long total = a.rows * per_row;
+    const long stride = (long)of_gdim_x() * 256;
+    for (long i = (long)of_bid_x() * 256 + of_tid(); i < total; i += stride) {
+        const long row = i / per_row;
+        const int rem = (int)(i - row * per_row);
+        const int h = rem / a.dhs, c = rem - h * a.dhs;
+        a.dst[row * a.ldd + rem] = c < a.shs ? a.src[row * a.lds + (long)h * a.shs + c] : (bf16_t)0;
+    }
+}
 }  // namespace
 
 extern "C" int of_cast_f32_to_bf16(const float* x, uint16_t* y, long n, void* stream) {
@@ -292,4 +361,23 @@ extern "C" int of_quick_gelu(const uint16_t* x, uint16_t* y, long n, void* strea
     EwArgs a{};
     a.a = x; a.out = y; a.n = n;
     return of_launch(of_quick_gelu_kernel, of_dim3{grid_for(n >> 3), 1, 1}, 256, 0, (of_stream_t)stream, a);
+}
+
+extern "C" int of_rotary_neox(uint16_t* qkv, long ldqkv, const float* cos, const float* sin, long L, uint16_t* q, uint16_t* k,
+                              uint16_t* v, long ldo, long rows, int heads, int head_size, int rot_dims, int head_pad, int inverse,
+                              void* stream) {
+    if (!qkv || !cos || !sin || !q || !k || !v || rows <= 0 || L <= 0 || heads <= 0) return OF_E_ARG;
+    if (head_size <= 0 || head_pad < head_size || rot_dims < 0 || rot_dims > head_size || (rot_dims & 1)) return OF_E_SHAPE;
+    if (ldqkv < 3L * heads * head_size || ldo < (long)heads * head_pad) return OF_E_SHAPE;
+    RotArgs a{qkv, ldqkv, cos, sin, L, q, k, v, ldo, rows, heads, head_size, rot_dims, head_pad};
+    const of_dim3 grid{grid_for(rows * heads * head_pad / 4 + 1), 1, 1};
+    if (inverse) return of_launch(of_rotary_neox_kernel<true>, grid, 256, 0, (of_stream_t)stream, a);
+    return of_launch(of_rotary_neox_kernel<false>, grid, 256, 0, (of_stream_t)stream, a);
+}
+extern "C" int of_head_repack(const uint16_t* src, long lds, uint16_t* dst, long ldd, long rows, int heads, int src_head_size,
+                              int dst_head_size, void* stream) {
+    if (!src || !dst || rows <= 0 || heads <= 0 || src_head_size <= 0 || dst_head_size <= 0) return OF_E_ARG;
+    if (lds < (long)heads * src_head_size || ldd < (long)heads * dst_head_size) return OF_E_SHAPE;
+    RepackArgs a{src, lds, dst, ldd, rows, heads, src_head_size, dst_head_size};
+    return of_launch(of_head_repack_kernel, of_dim3{grid_for(rows * heads * dst_head_size / 4 + 1), 1, 1}, 256, 0, (of_stream_t)stream, a);
 }

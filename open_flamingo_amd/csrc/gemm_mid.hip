@@ -12,7 +12,9 @@
 //   * 8 waves = 4 (M) x 2 (N), a wave owns 32 x 64 = two 32x32x16 accumulators (32 registers): two waves per SIMD, so one
 //     wave's MFMAs run while its partner is held at the texture unit by a DMA issue;
 //   * ONE barrier per stage: iteration kt waits for its own four pieces of stage kt (vmcnt), the barrier publishes everybody's
-//     and retires stage kt-1's readers, whose slot then takes stage kt+3;
+//     and retires stage kt-1's readers, whose slot then takes stage kt+3 -- issued BEFORE the stage's MFMAs by waves 0-3 and
+//     AFTER them by waves 4-7 (the SIMD partners), so that a SIMD's matrix pipe has work while one of its waves queues at
+//     the texture unit;
 //   * split-K slices (grid.y, weight gradients with a deep K) write fp32 slabs that of_splitk_reduce_kernel combines in a fixed
 //     order, exactly like the general kernel.
 #include "gemm_tile256.h"
@@ -73,6 +75,7 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_mid_kernel(OfGemmArgs p) {
         sB += stepB;
     };
 
+    const bool late = wave >= 4;     // waves w and w + 4 share a SIMD (see the K loop)
     // epilogue operand of this wave's 32 x 64 group: requested here, lands during the K loop
     const bool sliced = EPI == OF_EPI_ACC_F32 && p.ksplit > 1;
     ofg::AuxPre pre[4];
@@ -91,7 +94,13 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_mid_kernel(OfGemmArgs p) {
         else of_wait_vm<0>();
         of_barrier_raw();            // everybody's pieces of stage kt landed; everybody finished reading stage kt - 1
         of_sched_fence();
-        if (kt + MID_PD < nk) issue(smem + ((kt + MID_PD) % MID_NS) * MID_STAGE);     // into the slot of stage kt - 1
+        // The refill of the slot this barrier freed (stage kt + 3 into the slot of stage kt - 1) may go before or after this
+        // stage's MFMAs -- either way it is ~3 stages ahead of its use.  A wave is HELD at the texture unit while its pieces
+        // are accepted (all 32 pieces of a stage queue there: ~1200 cycles), so the two waves of a SIMD take opposite orders:
+        // waves 0-3 refill first, waves 4-7 compute first -- one of the pair always has MFMAs to issue.
+        const bool refill = kt + MID_PD < nk;
+        char* refill_slot = smem + ((kt + MID_PD) % MID_NS) * MID_STAGE;
+        if (refill && !late) issue(refill_slot);
         const char* stage = smem + (kt % MID_NS) * MID_STAGE;
         s16x8 fa[4], fb[4][2];
 #pragma unroll
@@ -105,6 +114,8 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_mid_kernel(OfGemmArgs p) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) acc[t] = of_mfma32(fb[k16][t], fa[k16], acc[t]);
         of_wait_lgkm0();             // fragment reads done before the next barrier lets the slot be overwritten
+        of_sched_fence();
+        if (refill && late) issue(refill_slot);
     }
     of_barrier_raw();                // the ring is idle: every wave's last fragment read is behind this barrier
 

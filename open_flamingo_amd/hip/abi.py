@@ -79,6 +79,9 @@ PROTOTYPES = {
     "of_adamw_clip": (C.c_int, [vp, vp, vp, vp, vp, C.c_long, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_float, C.c_float, C.c_int, C.c_int, vp, vp]),
     "of_step_advance": (C.c_int, [vp, vp, vp]),
+    "of_rotary_neox": (C.c_int, [vp, C.c_long, vp, vp, C.c_long, vp, vp, vp, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, vp]),
+    "of_head_repack": (C.c_int, [vp, C.c_long, vp, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, vp]),
     "of_add_embs": (C.c_int, [vp, C.c_int, vp, C.c_long, C.c_int, vp, C.c_long, C.c_int, vp, C.c_long, C.c_int, vp]),
     "of_ce_fwd": (C.c_int, [vp, C.c_int, C.c_long, vp, C.c_longlong, C.c_long, C.c_int, vp, vp, vp]),
     "of_ce_bwd": (C.c_int, [vp, C.c_int, C.c_long, vp, C.c_longlong, C.c_long, C.c_int, vp, vp, vp, C.c_long, vp]),

@@ -352,6 +352,22 @@ class Ops:
         self._chk(self.lib.of_add_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), self._stream()), "of_add_bf16")
         return out
 
+    def rotary_neox(self, qkv, cos, sin, q, k, v, *, L, heads, head_size, rot_dims, head_pad, inverse=False):
+        """HF GPT-NeoX rotary embedding + per-head zero padding (forward: qkv -> q, k, v; inverse: padded dq, dk, dv -> d(qkv))."""
+        rows = qkv.shape[0]
+        assert qkv.dtype == BF16 and qkv.stride(1) == 1 and all(t.dtype == BF16 and t.stride(1) == 1 and t.stride(0) == q.stride(0)
+                                                              for t in (q, k, v))
+        assert cos.dtype == F32 and sin.dtype == F32 and cos.is_contiguous() and sin.is_contiguous() and cos.shape == (L, rot_dims)
+        self._chk(self.lib.of_rotary_neox(qkv.data_ptr(), qkv.stride(0), cos.data_ptr(), sin.data_ptr(), L, q.data_ptr(), k.data_ptr(),
+                                          v.data_ptr(), q.stride(0), rows, heads, head_size, rot_dims, head_pad, int(inverse),
+                                          self._stream()), "of_rotary_neox")
+
+    def head_repack(self, src, dst, *, heads, src_head_size, dst_head_size):
+        assert src.dtype == BF16 and dst.dtype == BF16 and src.stride(1) == 1 and dst.stride(1) == 1 and src.shape[0] == dst.shape[0]
+        self._chk(self.lib.of_head_repack(src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0), src.shape[0], heads,
+                                          src_head_size, dst_head_size, self._stream()), "of_head_repack")
+        return dst
+
     def add(self, a, b, out):
         assert a.dtype == b.dtype == out.dtype and a.is_contiguous() and b.is_contiguous() and out.is_contiguous()
         self._chk(self.lib.of_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), _is_f32(a), a.numel(), self._stream()),

@@ -137,11 +137,12 @@ class _LiteMask:
     box's CPU load.  The fused blocks only need the per-sequence key counts; a block that falls back to its HF forward
     asks for the real mask (full())."""
 
-    def __init__(self, am, B, L, device):
+    def __init__(self, am, B, L, device, build=None):
         self.am, self.B, self.L, self.device = am, B, L, device
         self._lens = None
         self._slopes = None
         self._full = None
+        self._build, self._hf = build, None      # transformers' own mask builder for this call (GPT-NeoX fallbacks)
 
     def to(self, *a, **kw):          # MptModel.forward: create_causal_mask(...).to(torch.bool)
         return self
@@ -170,7 +171,37 @@ class _LiteMask:
         return self._full
 
 
+    def hf_mask(self):
+        """What transformers' create_causal_mask would have handed the layers (built on demand: it synchronises the host)."""
+        if self._hf is None:
+            self._hf = (self._build(),)
+        return self._hf[0]
+
+
 _orig_create_causal_mask = None
+_orig_neox_create_causal_mask = None
+
+
+def _install_lite_mask_neox():
+    """As _install_lite_mask, for GPTNeoXModel.forward (which also passes position_ids: the default arange(L) of a cache-less
+    forward is what the fused blocks assume)."""
+    global _orig_neox_create_causal_mask
+    from transformers.models.gpt_neox import modeling_gpt_neox as mod
+    if _orig_neox_create_causal_mask is not None or not hasattr(mod, "create_causal_mask"):
+        return
+    _orig_neox_create_causal_mask = mod.create_causal_mask
+
+    def create_causal_mask(config=None, inputs_embeds=None, attention_mask=None, past_key_values=None, **kw):
+        orig = lambda: _orig_neox_create_causal_mask(config=config, inputs_embeds=inputs_embeds, attention_mask=attention_mask,
+                                                     past_key_values=past_key_values, **kw)
+        lite = (getattr(config, "_of_lite_mask", False) and past_key_values is None and set(kw) <= {"position_ids"}
+                and inputs_embeds is not None and inputs_embeds.dim() == 3
+                and (attention_mask is None or (attention_mask.dim() == 2 and attention_mask.shape == inputs_embeds.shape[:2])))
+        if not lite:
+            return orig()
+        return _LiteMask(attention_mask, inputs_embeds.shape[0], inputs_embeds.shape[1], inputs_embeds.device, build=orig)
+
+    mod.create_causal_mask = create_causal_mask
 
 
 def _install_lite_mask():
@@ -264,6 +295,170 @@ def use_fused_frozen_mpt_blocks(lm, allow_cpu=False, assume_right_padding=False)
             n += 1
     if n and getattr(lm, "config", None) is not None:
         _install_lite_mask()
+        lm.config._of_lite_mask = True
+    return n
+
+
+# ------------------------------------------------------------------------------------------------ frozen GPT-NeoX blocks (OF-4B)
+_NEOX_HEAD_PAD = {64: 64, 128: 128}
+
+
+def _neox_pad(head_size):
+    """Head size the attention kernels run at: 64 / 128 as they are, anything else <= 128 zero-padded to the next of the two
+    (RedPajama-INCITE-3B: 80 -> 128)."""
+    return 64 if head_size <= 64 else 128
+
+
+class _FrozenNeoXBlockFn(torch.autograd.Function):
+    """HF GPTNeoXLayer with frozen weights as ONE autograd node: input_layernorm -> query_key_value
+    (+ bias) -> rotary embedding -> causal attention -> dense (+ bias); post_attention_layernorm -> dense_h_to_4h (+ bias) ->
+    GELU -> dense_4h_to_h (+ bias); parallel residual (x + attn + mlp, both norms on x) or sequential (x1 = x + attn, mlp on
+    norm(x1)).  fp32 residual stream, bf16 GEMM operands / outputs, exact GELU on the bf16 pre-activation -- the eager chain's
+    arithmetic under amp_bf16.  Rotary + head padding is one libofhip pass (of_rotary_neox), attention runs on of_attn_fwd/bwd
+    (causal, per-sequence key counts), LayerNorms / residual adds as in the MPT block; plain GEMMs on the vendor library with
+    the bias in the GEMM (addmm).  Backward = the chain reversed, dX GEMMs only (against pre-transposed weights)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, Wqkv, bqkv, Wd, bd, Wup, bup, Wdown, bdown, cos, sin, kv_len, heads, hs, rot, parallel, wts):
+        ops = _ops()
+        B, L, d = x.shape
+        rows = B * L
+        dev = x.device
+        x2 = x.reshape(rows, d)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        pad = _neox_pad(hs)
+        a = torch.empty(rows, d, dtype=BF16, device=dev)
+        st1 = torch.empty(rows, 2, dtype=F32, device=dev)
+        ops.ln_fwd(x2, w1, b1, a, st1)
+        qkv = torch.addmm(bqkv, a, Wqkv.t())                             # (rows, heads * 3 * hs): [q_h | k_h | v_h] per head
+        qp = torch.empty(3, rows, heads * pad, dtype=BF16, device=dev)   # rotated + padded q, k, v
+        ops.rotary_neox(qkv, cos, sin, qp[0], qp[1], qp[2], L=L, heads=heads, head_size=hs, rot_dims=rot, head_pad=pad)
+        op = torch.empty(rows, heads * pad, dtype=BF16, device=dev)
+        lse = torch.empty(B, heads, L, dtype=F32, device=dev)
+        kw = dict(batch=B, Lq=L, Lk=L, heads=heads, scale=hs ** -0.5, head_dim=pad, causal=True, kv_len=kv_len)
+        ops.attn_fwd(qp[0], qp[1], qp[2], op, lse, **kw)
+        o = op if pad == hs else ops.head_repack(op, torch.empty(rows, d, dtype=BF16, device=dev), heads=heads, src_head_size=pad,
+                                                  dst_head_size=hs)
+        t = torch.addmm(bd, o, Wd.t())                                   # attention branch, bf16
+        m = torch.empty(rows, d, dtype=BF16, device=dev)
+        st2 = torch.empty(rows, 2, dtype=F32, device=dev)
+        if parallel:
+            ops.ln_fwd(x2, w2, b2, m, st2)
+            x1 = x2
+        else:
+            x1 = torch.empty(rows, d, dtype=F32, device=dev)
+            ops.ln_fwd_add(x2, t, x1, w2, b2, m, st2)                    # x1 = x + attn branch;  m = norm(x1)
+        h = torch.addmm(bup, m, Wup.t())
+        u = torch.addmm(bdown, ops.gelu_fwd(h), Wdown.t())
+        y = ops.add_bf16(x1, u)
+        if parallel:
+            ops.add_bf16(y, t, out=y)                                    # x + mlp + attn
+        ctx.save_for_backward(x2, st1, qp, op, lse, x1, st2, h, w1, w2, Wqkv, Wd, Wup, Wdown, cos, sin, kv_len)
+        ctx.kw, ctx.shape, ctx.wts, ctx.cfg = kw, (B, L, d), wts, (heads, hs, rot, pad, parallel)
+        return y.view(B, L, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ops = _ops()
+        x2, st1, qp, op, lse, x1, st2, h, w1, w2, Wqkv, Wd, Wup, Wdown, cos, sin, kv_len = ctx.saved_tensors
+        tq, td, tu, tdn = ctx.wts if ctx.wts is not None else (None, None, None, None)
+        heads, hs, rot, pad, parallel = ctx.cfg
+        B, L, d = ctx.shape
+        rows = B * L
+        dev = dy.device
+        dy2 = dy.reshape(rows, d)
+        if dy2.dtype != F32 or not dy2.is_contiguous():
+            dy2 = dy2.to(F32).contiguous()
+        dyb = ops.to_bf16(dy2)
+        dact = _mm_dx(dyb, Wdown, tdn)                                   # (rows, 4d)
+        dh = ops.gelu_bwd(dact, h, out=dact)
+        del dact
+        dm = _mm_dx(dh, Wup, tu)
+        del dh
+        dx1 = torch.empty(rows, d, dtype=F32, device=dev)
+        if parallel:
+            ops.ln_bwd(dm, x2, st2, w2, resid=dy2, dx=dx1)               # dy + norm_2'(dm): the stream's and the MLP branch's share
+            dtb = dyb                                                    # the attention branch sees dy itself
+        else:
+            dtb = torch.empty(rows, d, dtype=BF16, device=dev)
+            ops.ln_bwd(dm, x1, st2, w2, resid=dy2, dx=dx1, dx_bf16=dtb)  # dx1 = dy + norm_2'(dm) reaches x AND the attention branch
+        do = _mm_dx(dtb, Wd, td)                                         # (rows, d)
+        dop = do if pad == hs else ops.head_repack(do, torch.empty(rows, heads * pad, dtype=BF16, device=dev), heads=heads,
+                                                    src_head_size=hs, dst_head_size=pad)
+        dqp = torch.empty_like(qp)
+        delta = torch.empty(B, heads, L, dtype=F32, device=dev)
+        ops.attn_bwd(qp[0], qp[1], qp[2], op, lse, dop, dqp[0], dqp[1], dqp[2], delta, **ctx.kw)
+        dqkv = torch.empty(rows, heads * 3 * hs, dtype=BF16, device=dev)
+        ops.rotary_neox(dqkv, cos, sin, dqp[0], dqp[1], dqp[2], L=L, heads=heads, head_size=hs, rot_dims=rot, head_pad=pad, inverse=True)
+        da = _mm_dx(dqkv, Wqkv, tq)
+        ops.ln_bwd(da, x2, st1, w1, resid=dx1, dx=dx1)                   # in place: dx = dx1 + norm_1'(da)
+        return (dx1.view(B, L, d),) + (None,) * 20
+
+
+def _is_exact_gelu(act):
+    """nn.GELU() / transformers' GELUActivation in its default form: erf GELU through torch.nn.functional.gelu."""
+    if isinstance(act, nn.GELU):
+        return act.approximate == "none"
+    return type(act).__name__ == "GELUActivation" and getattr(act, "act", None) is nn.functional.gelu
+
+
+def _neox_layer_fused_forward(self, hidden_states, attention_mask=None, position_ids=None, use_cache=False, layer_past=None,
+                              position_embeddings=None, **kwargs):
+    at, mlp = self.attention, self.mlp
+    x = hidden_states
+    lite = attention_mask if isinstance(attention_mask, _LiteMask) else None
+    lins = (at.query_key_value, at.dense, mlp.dense_h_to_4h, mlp.dense_4h_to_h)
+    ok = (lite is not None and layer_past is None and not kwargs and position_embeddings is not None
+          and x.dim() == 3 and x.dtype == F32 and (x.is_cuda or getattr(self, "_of_allow_cpu", False))
+          and x.shape[-1] % 8 == 0 and x.shape[-1] <= 4096 and at.head_size <= 128 and at.head_size % 8 == 0
+          and at.rotary_ndims % 2 == 0 and float(getattr(at, "scaling", at.head_size ** -0.5)) == at.head_size ** -0.5
+          and not (self.training and (self.post_attention_dropout.p > 0.0 or self.post_mlp_dropout.p > 0.0 or at.attention_dropout > 0.0))
+          and all(lin.bias is not None and lin.weight.dtype == BF16 and lin.bias.dtype == BF16 and not lin.weight.requires_grad for lin in lins)
+          and all(n.weight.dtype == F32 and n.bias is not None and not n.weight.requires_grad and abs(n.eps - 1e-5) < 1e-12
+                  for n in (self.input_layernorm, self.post_attention_layernorm))
+          and _is_exact_gelu(mlp.act)
+          and (getattr(self, "_of_allow_cpu", False)
+               or (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == BF16)))
+    if ok and lite.am is not None and not (self.training or getattr(self, "_of_assume_right_padding", False)):
+        ok = False          # key counts = right padding only (see _mpt_block_fused_forward)
+    if ok:
+        cos, sin = position_embeddings
+        ok = cos.dim() == 3 and cos.shape[1] == x.shape[1] and cos.shape[2] == at.rotary_ndims
+    if not ok:
+        mask = lite.hf_mask() if lite is not None else attention_mask
+        return self._of_eager_forward(hidden_states, attention_mask=mask, position_ids=position_ids, use_cache=use_cache,
+                                      layer_past=layer_past, position_embeddings=position_embeddings, **kwargs)
+    cs = lite.__dict__.get("_cos_sin")
+    if cs is None or cs[0] is not cos:       # one fp32 [L][rot] table per LM forward (HF repeats it per batch row)
+        cs = lite.__dict__["_cos_sin"] = (cos, cos[0].float().contiguous(), sin[0].float().contiguous())
+    wts = None
+    if _DX_PRETRANSPOSED and torch.is_grad_enabled() and x.requires_grad:
+        wts = tuple(_transposed(mod, name, lin.weight) for mod, name, lin in
+                    ((at, "query_key_value", at.query_key_value), (at, "dense", at.dense),
+                     (mlp, "dense_h_to_4h", mlp.dense_h_to_4h), (mlp, "dense_4h_to_h", mlp.dense_4h_to_h)))
+    n1, n2 = self.input_layernorm, self.post_attention_layernorm
+    return _FrozenNeoXBlockFn.apply(x, n1.weight, n1.bias, n2.weight, n2.bias, at.query_key_value.weight, at.query_key_value.bias,
+                                    at.dense.weight, at.dense.bias, mlp.dense_h_to_4h.weight, mlp.dense_h_to_4h.bias,
+                                    mlp.dense_4h_to_h.weight, mlp.dense_4h_to_h.bias, cs[1], cs[2], lite.lens(),
+                                    at.config.num_attention_heads, at.head_size, at.rotary_ndims,
+                                    bool(self.use_parallel_residual), wts)
+
+
+def use_fused_frozen_neox_blocks(lm, allow_cpu=False, assume_right_padding=False):
+    """Route every HF GPTNeoXLayer of ``lm`` (OF-4B: RedPajama-INCITE-3B) through _FrozenNeoXBlockFn when its weights are
+    frozen bf16 copies and the call is a plain training / scoring forward; padding rules as use_fused_frozen_mpt_blocks."""
+    n = 0
+    for mod in lm.modules():
+        if type(mod).__name__ == "GPTNeoXLayer":
+            if not hasattr(mod, "_of_eager_forward"):
+                mod._of_eager_forward = mod.forward
+                mod.forward = types.MethodType(_neox_layer_fused_forward, mod)
+            mod._of_allow_cpu = bool(allow_cpu)
+            mod._of_assume_right_padding = bool(assume_right_padding)
+            n += 1
+    if n and getattr(lm, "config", None) is not None:
+        _install_lite_mask_neox()
         lm.config._of_lite_mask = True
     return n
 

@@ -366,8 +366,11 @@ def build_lang_encoder(family: str, extra_tokens: int = 3, max_seq_len: int = 20
             use_fused_attention_in_mpt(lm, kernel=fused_attention if isinstance(fused_attention, str) else "sdpa")
         return lm, "transformer.blocks"
     from transformers import GPTNeoXConfig, GPTNeoXForCausalLM
+    # RedPajama-INCITE-Base-3B-v1's published config (no network here to re-read it): rotary over the whole head (rotary_pct
+    # 1.0), sequential residual (use_parallel_residual false), head size 2560 / 32 = 80, biases on every Linear
     cfg = GPTNeoXConfig(hidden_size=f["d"], num_hidden_layers=f["layers"], num_attention_heads=f["heads"],
-                        intermediate_size=4 * f["d"], vocab_size=vocab, max_position_embeddings=max_seq_len)
+                        intermediate_size=4 * f["d"], vocab_size=vocab, max_position_embeddings=max_seq_len,
+                        rotary_pct=1.0, use_parallel_residual=False)
     return GPTNeoXForCausalLM(cfg), "gpt_neox.layers"
 
 
@@ -445,8 +448,9 @@ def build_flamingo(family: str = "OF-3B", device="cuda", seed: int = 0, gates: f
     if fused_vision:                       # the CLIP tower's encoder as one fused forward (train/frozen_blocks.py)
         model.vision_encoder.fused = fused_vision
     if fused_lm_blocks:                    # whole frozen MPT blocks as one autograd node each (train/frozen_blocks.py)
-        from .frozen_blocks import use_fused_frozen_mpt_blocks
+        from .frozen_blocks import use_fused_frozen_mpt_blocks, use_fused_frozen_neox_blocks
         use_fused_frozen_mpt_blocks(model.lang_encoder)
+        use_fused_frozen_neox_blocks(model.lang_encoder)     # OF-4B's GPT-NeoX layers (no-op for the MPT families)
     with torch.no_grad():
         for blk in model.lang_encoder.gated_cross_attn_layers:
             if blk is not None:

@@ -115,6 +115,65 @@ def test_fused_frozen_mpt_block_matches_hf_eager(on_emulator, d, heads):
     assert out.past_key_values is not None
 
 
+@pytest.mark.parametrize("parallel,rotary_pct,hs", [(True, 0.25, 80), (False, 1.0, 80), (True, 1.0, 64)])
+def test_fused_frozen_neox_block_matches_hf_eager(on_emulator, parallel, rotary_pct, hs):
+    """SURVEY 8f N1 for OF-4B: whole frozen GPT-NeoX layers (RedPajama-INCITE-3B's head size 80, zero-padded to 128 for the
+    attention kernels; rotary embedding + padding in one libofhip pass; parallel and sequential residual layouts; biases in the
+    GEMMs) as one autograd node each vs the HF modules' eager forward / autograd under autocast(bf16), right padding."""
+    from transformers import GPTNeoXConfig, GPTNeoXForCausalLM
+    torch.manual_seed(0)
+    cfg = GPTNeoXConfig(hidden_size=2 * hs, num_hidden_layers=2, num_attention_heads=2, intermediate_size=8 * hs, vocab_size=128,
+                        max_position_embeddings=64, rotary_pct=rotary_pct, use_parallel_residual=parallel,
+                        attn_implementation="eager")
+    lm = GPTNeoXForCausalLM(cfg)
+    lm.requires_grad_(False)
+    for mod in lm.modules():
+        if isinstance(mod, torch.nn.Linear) and mod is not lm.get_output_embeddings():
+            mod.weight.data = mod.weight.data.to(torch.bfloat16)
+            mod.bias.data = (torch.randn_like(mod.bias) * 0.1).to(torch.bfloat16)        # HF inits biases to 0: make them count
+    ids = torch.randint(0, 128, (3, 40))
+    am = torch.ones(3, 40, dtype=torch.long)
+    am[1, 30:] = 0
+    am[2, 17:] = 0
+
+    def run():
+        emb = lm.get_input_embeddings()(ids).detach().requires_grad_(True)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            out = lm(inputs_embeds=emb, attention_mask=am, use_cache=False).logits
+        valid = am.bool()[..., None]
+        (out.float() * valid).square().mean().backward()
+        return out.float().detach() * valid, emb.grad.detach() * valid
+
+    ref_o, ref_g = run()
+    assert frozen_blocks.use_fused_frozen_neox_blocks(lm, allow_cpu=True) == 2
+    calls = []
+    orig = frozen_blocks._FrozenNeoXBlockFn.apply
+    frozen_blocks._FrozenNeoXBlockFn.apply = staticmethod(lambda *a: (calls.append(1), orig(*a))[1])
+    try:
+        got_o, got_g = run()
+        assert len(calls) == 2, "the fused path must have been taken by both layers"
+        assert _rel(got_o, ref_o) < 2e-2, _rel(got_o, ref_o)
+        assert _rel(got_g, ref_g) < 3e-2, _rel(got_g, ref_g)
+        calls.clear()
+        lm.eval()                      # eval + mask: HF's own layer forward on HF's own mask (left padding must stay right)
+        left = am.flip(1)
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+            got = lm(input_ids=ids, attention_mask=left, use_cache=False).logits.float() * left.bool()[..., None]
+        assert calls == []
+    finally:
+        frozen_blocks._FrozenNeoXBlockFn.apply = orig
+    for mod in lm.modules():
+        if hasattr(mod, "_of_eager_forward"):
+            mod.forward = mod._of_eager_forward
+    lm.config._of_lite_mask = False
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        want = lm(input_ids=ids, attention_mask=left, use_cache=False).logits.float() * left.bool()[..., None]
+    assert _rel(got, want) < 1e-6
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):     # KV cache: the module's own forward
+        out = lm(input_ids=ids[:1, :5], use_cache=True)
+    assert out.past_key_values is not None
+
+
 def test_left_padded_eval_forward_keeps_hf_masking(on_emulator):
     """the fused blocks collapse the attention mask to a per-sequence key COUNT, which is only right for
     right-padded batches.  The reference's eval wrapper LEFT-pads (eval/models/open_flamingo.py:57): an eval-mode masked

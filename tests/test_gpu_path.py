@@ -245,6 +245,50 @@ def test_fused_frozen_mpt_block_matches_hf_eager(ops, d, heads):
     assert PC.rel_err(got_g, ref_g) < 5e-2, PC.rel_err(got_g, ref_g)
 
 
+@pytest.mark.parametrize("parallel,rotary_pct", [(False, 1.0), (True, 0.25)])
+def test_fused_frozen_neox_block_matches_hf_eager(ops, parallel, rotary_pct):
+    """SURVEY 8f N1 for OF-4B (RedPajama-INCITE-3B = GPT-NeoX, head size 80): whole frozen GPT-NeoX layers as one autograd node
+    each (rotary + head padding in one libofhip pass, attention on of_attn_fwd/bwd at the padded head size 128, LayerNorm /
+    residual passes, dX-only backward) vs the HF modules' eager forward / autograd under autocast(bf16), right padding."""
+    from transformers import GPTNeoXConfig, GPTNeoXForCausalLM
+    from open_flamingo_amd.train import frozen_blocks
+    torch.manual_seed(0)
+    cfg = GPTNeoXConfig(hidden_size=320, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1280, vocab_size=512,
+                        max_position_embeddings=256, rotary_pct=rotary_pct, use_parallel_residual=parallel,
+                        attn_implementation="eager")
+    lm = GPTNeoXForCausalLM(cfg).cuda()
+    lm.requires_grad_(False)
+    for mod in lm.modules():
+        if isinstance(mod, torch.nn.Linear) and mod is not lm.get_output_embeddings():
+            mod.weight.data = mod.weight.data.to(torch.bfloat16)
+            mod.bias.data = (torch.randn_like(mod.bias) * 0.1).to(torch.bfloat16)
+    ids = torch.randint(0, 512, (3, 80), device="cuda")
+    am = torch.ones(3, 80, dtype=torch.long, device="cuda")
+    am[1, 60:] = 0
+    am[2, 33:] = 0
+
+    def run():
+        emb = lm.get_input_embeddings()(ids).detach().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = lm(inputs_embeds=emb, attention_mask=am, use_cache=False).logits
+        valid = am.bool()[..., None]
+        (out.float() * valid).square().mean().backward()
+        return out.float().detach() * valid, emb.grad.detach() * valid
+
+    ref_o, ref_g = run()
+    assert frozen_blocks.use_fused_frozen_neox_blocks(lm) == 2
+    calls = []
+    orig = frozen_blocks._FrozenNeoXBlockFn.apply
+    frozen_blocks._FrozenNeoXBlockFn.apply = staticmethod(lambda *a: (calls.append(1), orig(*a))[1])
+    try:
+        got_o, got_g = run()
+    finally:
+        frozen_blocks._FrozenNeoXBlockFn.apply = orig
+    assert len(calls) == 2
+    assert PC.rel_err(got_o, ref_o) < 3e-2, PC.rel_err(got_o, ref_o)
+    assert PC.rel_err(got_g, ref_g) < 5e-2, PC.rel_err(got_g, ref_g)
+
+
 @pytest.mark.parametrize("attention", ["libofhip", "sdpa"])
 def test_fused_clip_tower_matches_hf_modules(ops, attention):
     """the frozen CLIP tower's fused forward vs the HF modules under autocast(bf16), ViT-L/14-like widths
