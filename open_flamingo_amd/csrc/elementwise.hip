@@ -275,6 +275,85 @@ OF_GLOBAL void of_head_repack_kernel(RepackArgs a) {
         a.dst[row * a.ldd + rem] = c < a.shs ? a.src[row * a.lds + (long)h * a.shs + c] : (bf16_t)0;
     }
 }
+
+// Vector forms (8 bf16 = 16 bytes per lane) for head sizes and half-rotations that are multiples of 8 -- OF-4B: hs 80, rot 80.
+OF_DEV void of_unpack8(const u32x4 r, float (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[2 * e] = of_bf16_to_f32((bf16_t)(r[e] & 0xffff));
+        v[2 * e + 1] = of_bf16_to_f32((bf16_t)(r[e] >> 16));
+    }
+}
+OF_DEV u32x4 of_pack8(const float (&v)[8]) {
+    return u32x4{of_pack_bf16(v[0], v[1]), of_pack_bf16(v[2], v[3]), of_pack_bf16(v[4], v[5]), of_pack_bf16(v[6], v[7])};
+}
+template <bool INVERSE>
+OF_GLOBAL void of_rotary_neox_vec_kernel(RotArgs a) {
+    const int half = a.rot >> 1, cpr = a.pad >> 3;              // 8-column chunks per padded head
+    const long per_row = (long)a.heads * cpr;
+    const long total = a.rows * per_row;
+    const long stride = (long)of_gdim_x() * 256;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    for (long i = (long)of_bid_x() * 256 + of_tid(); i < total; i += stride) {
+        const long row = i / per_row;
+        const int rem = (int)(i - row * per_row);
+        const int h = rem / cpr, c = (rem - h * cpr) << 3;
+        const long po = row * a.ldo + (long)h * a.pad + c;
+        if (c >= a.hs) {
+            if (!INVERSE) {
+                *(u32x4*)(a.q + po) = zero;
+                *(u32x4*)(a.k + po) = zero;
+                *(u32x4*)(a.v + po) = zero;
+            }
+            continue;
+        }
+        bf16_t* src = a.qkv + row * a.ldqkv + (long)h * 3 * a.hs;
+        if (!INVERSE) *(u32x4*)(a.v + po) = *(const u32x4*)(src + 2 * a.hs + c);
+        else *(u32x4*)(src + 2 * a.hs + c) = *(const u32x4*)(a.v + po);
+        if (c >= a.rot) {
+            if (!INVERSE) {
+                *(u32x4*)(a.q + po) = *(const u32x4*)(src + c);
+                *(u32x4*)(a.k + po) = *(const u32x4*)(src + a.hs + c);
+            } else {
+                *(u32x4*)(src + c) = *(const u32x4*)(a.q + po);
+                *(u32x4*)(src + a.hs + c) = *(const u32x4*)(a.k + po);
+            }
+            continue;
+        }
+        const long pos = row % a.L;
+        const int pc = c < half ? c + half : c - half;
+        const float* cs = a.cos + pos * a.rot + c;
+        // forward: out[c] = x[c] cos[c] + x[pc] * s(c) sin[c];  inverse: dx[c] = g[c] cos[c] + g[pc] * s(pc) sin[pc]
+        const float* sn = a.sin + pos * a.rot + (INVERSE ? pc : c);
+        const float sg = (INVERSE ? pc : c) < half ? -1.0f : 1.0f;
+        float x[8], y[8], o[8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const bf16_t* in = INVERSE ? (t == 0 ? a.q : a.k) : src + t * a.hs;
+            const long base = INVERSE ? po - c : 0;
+            of_unpack8(*(const u32x4*)(in + base + c), x);
+            of_unpack8(*(const u32x4*)(in + base + pc), y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = x[e] * cs[e] + y[e] * (sg * sn[e]);
+            if (!INVERSE) *(u32x4*)((t == 0 ? a.q : a.k) + po) = of_pack8(o);
+            else *(u32x4*)(src + t * a.hs + c) = of_pack8(o);
+        }
+    }
+}
+OF_GLOBAL void of_head_repack_vec_kernel(RepackArgs a) {
+    const int cpr = a.dhs >> 3;
+    const long per_row = (long)a.heads * cpr;
+    const long total = a.rows * per_row;
+    const long stride = (long)of_gdim_x() * 256;
+    for (long i = (long)of_bid_x() * 256 + of_tid(); i < total; i += stride) {
+        const long row = i / per_row;
+        const int rem = (int)(i - row * per_row);
+        const int h = rem / cpr, c = (rem - h * cpr) << 3;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (c < a.shs) v = *(const u32x4*)(a.src + row * a.lds + (long)h * a.shs + c);
+        *(u32x4*)(a.dst + row * a.ldd + (long)h * a.dhs + c) = v;
+    }
+}
 }  // namespace
 
 extern "C" int of_cast_f32_to_bf16(const float* x, uint16_t* y, long n, void* stream) {
@@ -370,6 +449,13 @@ extern "C" int of_rotary_neox(uint16_t* qkv, long ldqkv, const float* cos, const
     if (head_size <= 0 || head_pad < head_size || rot_dims < 0 || rot_dims > head_size || (rot_dims & 1)) return OF_E_SHAPE;
     if (ldqkv < 3L * heads * head_size || ldo < (long)heads * head_pad) return OF_E_SHAPE;
     RotArgs a{qkv, ldqkv, cos, sin, L, q, k, v, ldo, rows, heads, head_size, rot_dims, head_pad};
+    const bool vec = !(head_size & 7) && !(head_pad & 7) && !(rot_dims & 15) && !(ldqkv & 7) && !(ldo & 7) &&
+                     !(((uintptr_t)qkv | (uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15);
+    if (vec) {
+        const of_dim3 grid{grid_for(rows * heads * (head_pad >> 3) / 2 + 1), 1, 1};
+        if (inverse) return of_launch(of_rotary_neox_vec_kernel<true>, grid, 256, 0, (of_stream_t)stream, a);
+        return of_launch(of_rotary_neox_vec_kernel<false>, grid, 256, 0, (of_stream_t)stream, a);
+    }
     const of_dim3 grid{grid_for(rows * heads * head_pad / 4 + 1), 1, 1};
     if (inverse) return of_launch(of_rotary_neox_kernel<true>, grid, 256, 0, (of_stream_t)stream, a);
     return of_launch(of_rotary_neox_kernel<false>, grid, 256, 0, (of_stream_t)stream, a);
@@ -379,5 +465,24 @@ extern "C" int of_head_repack(const uint16_t* src, long lds, uint16_t* dst, long
     if (!src || !dst || rows <= 0 || heads <= 0 || src_head_size <= 0 || dst_head_size <= 0) return OF_E_ARG;
     if (lds < (long)heads * src_head_size || ldd < (long)heads * dst_head_size) return OF_E_SHAPE;
     RepackArgs a{src, lds, dst, ldd, rows, heads, src_head_size, dst_head_size};
+    if (!(src_head_size & 7) && !(dst_head_size & 7) && !(lds & 7) && !(ldd & 7) && !(((uintptr_t)src | (uintptr_t)dst) & 15))
+        return of_launch(of_head_repack_vec_kernel, of_dim3{grid_for(rows * heads * (dst_head_size >> 3) / 2 + 1), 1, 1}, 256, 0,
+                         (of_stream_t)stream, a);
     return of_launch(of_head_repack_kernel, of_dim3{grid_for(rows * heads * dst_head_size / 4 + 1), 1, 1}, 256, 0, (of_stream_t)stream, a);
 }
+
+#if defined(OF_TOOLS_BUILD) && !defined(OF_HOST_EMU)
+// tools/libofhip_tools.so only (tools/rehearse_contention.py): `nwg` one-wave workgroups that stay resident for `ticks` of the
+// 100-MHz wall clock doing nothing -- a stand-in for the CUs an RCCL collective occupies while the backward's GEMMs run.
+namespace {
+struct HoldArgs { long long ticks; };
+OF_GLOBAL void of_tools_hold_kernel(HoldArgs a) {
+    const long long t0 = (long long)wall_clock64();
+    while ((long long)wall_clock64() - t0 < a.ticks) __builtin_amdgcn_s_sleep(32);
+}
+}  // namespace
+extern "C" int of_tools_hold_cus(int nwg, long long ticks, void* stream) {
+    if (nwg <= 0 || ticks <= 0) return OF_E_ARG;
+    return of_launch(of_tools_hold_kernel, of_dim3{(unsigned)nwg, 1, 1}, 64, 0, (of_stream_t)stream, HoldArgs{ticks});
+}
+#endif

@@ -386,14 +386,7 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
         const int rc = of_gemm_w4_try(a, s);
         if (rc != OF_E_SHAPE) return rc;
     }
-#ifdef OF_TOOLS_BUILD      // tools/libofhip_tools.so only: timing ablations and A/B variants (some wrong by design)
-    if (a.safe >= 70 && a.safe <= 73) return of_gemm_w4_try(a, s);
-    if (a.safe == 55) return of_gemm_pp_try(a, s);
-    if (a.safe >= 32) return of_gemm_w4_ablate(a, a.safe - 32, s);
-    if (a.safe >= 16) return of_gemm_pp_ablate(a, a.safe - 16, s);
-#else
     if (a.safe >= 16) return OF_E_ARG;
-#endif
     const bool pp_forced = a.safe == 4;
     // Big-tile selection (measured on MI355X, random operands, same box: profiles/r03b_gemm_ab_*.jsonl): every layout -> the
     // 4-wave LDS-DMA kernel.  Round 2 sent layouts with a K-strided operand (NN: dX = dY W, TN: dW = dY^T X) to the 8-wave

@@ -295,9 +295,5 @@ inline bool of_gemm_is_skinny(const OfGemmArgs& a) {
 }
 // implemented in gemm_pp.hip; returns OF_E_SHAPE when the shape/layout is not eligible (caller falls back)
 int of_gemm_pp_try(const OfGemmArgs& a, of_stream_t s);
-#ifdef OF_TOOLS_BUILD
-int of_gemm_pp_ablate(const OfGemmArgs& a, int mask, of_stream_t s);
-int of_gemm_w4_ablate(const OfGemmArgs& a, int mask, of_stream_t s);
-#endif
 // implemented in gemm_w4.hip (4 waves x 128x128, register staged); same eligibility and return convention as of_gemm_pp_try
 int of_gemm_w4_try(const OfGemmArgs& a, of_stream_t s);

@@ -37,22 +37,8 @@
 namespace {
 using namespace oft;
 
-// ABL: timing-only ablation mask for tools/bench_gemm_ablate.py (results are wrong when != 0):
-//   1 = no DMA inside the K loop, 2 = no fragment reads, 4 = no MFMAs, 16 = no vmcnt waits (racy)
-//   128 = the MFMAs read constant operand registers; the fragment reads still happen (same LDS traffic) but nothing
-//        in flight reads the registers they overwrite: isolates the VGPR write-after-read interlock between a wave's
-//        queued MFMAs and its next segment's fragment reads
-//   64 = cycle stamps: every wave adds up, over the K loop, the shader cycles it spent in each part of its load and
-//        compute segments and writes 8 counters to p.C2 [(block * 8 + wave) * 8 ...] (results stay correct)
-//
-// RS = register staging instead of LDS-DMA: the same pieces travel global -> VGPR (global_load_dwordx4, which does not
-// hold the issuing wave) and are stored to the same LDS addresses (ds_write_b128) at the START of the wave's next load
-// segment, i.e. two wall segments later -- exactly when the DMA version's vmcnt(4) declares them landed, so every
-// reader/writer pair below keeps its barrier (the writes only happen LATER than a DMA issue would overwrite).
-// VAR: 0 = LDS-DMA (product), 1 = register staging (measured A/B, tools build: safe = 55)
-template <bool AT, bool BT, int EPI, int ABL = 0, int VAR = 0>
+template <bool AT, bool BT, int EPI>
 OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
-    constexpr bool RS = VAR == 1;
     char* smem = of_smem();
     const int tid = of_tid(), lane = tid & 63;
     const int wave = of_uniform(tid >> 6);
@@ -88,23 +74,12 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
     const int nd = p.K / DK;
     const int offA = hfA * HALF_BYTES + wn * 1024, offB = OPER_BYTES + hfB * HALF_BYTES + wn * 1024;
 
-    u32x4 stg[4];              // RS: the 4 pieces in flight
-    char* stg_dst = nullptr;   // RS: where they go (piece j at + j * 4096), nullptr = nothing pending
-    auto flush = [&]() {       // RS: store the pieces loaded in this wave's previous load segment
-        if (RS && stg_dst) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) *(u32x4*)(stg_dst + j * 4096 + lane * 16) = stg[j];
-            stg_dst = nullptr;
-        }
-    };
     auto issueA = [&](char* slot) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (RS) stg[j] = *(const u32x4*)srcA[j];
-            else of_glds16<false>(srcA[j], slot + offA + j * 4096);
+            of_glds16<false>(srcA[j], slot + offA + j * 4096);
             srcA[j] += stepA;
         }
-        if (RS) stg_dst = slot + offA;
     };
     auto issueB = [&](char* slot) {
         if (spg && b_stage && b_stage % spg == 0) {     // first stage of the next weight matrix: re-base the sources
@@ -114,32 +89,12 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
         ++b_stage;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (RS) stg[j] = *(const u32x4*)srcB[j];
-            else of_glds16<false>(srcB[j], slot + offB + j * 4096);
+            of_glds16<false>(srcB[j], slot + offB + j * 4096);
             srcB[j] += stepB;
-        }
-        if (RS) stg_dst = slot + offB;
-    };
-    unsigned tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;   // ABL & 64
-    auto lap = [&](int slot) {
-        if (ABL & 64) {
-            const unsigned now = of_cycles();
-            tm[slot] += now - t_prev;
-            t_prev = now;
         }
     };
     s16x8 fa[4][2], fb[2][2];
     auto load_frags = [&](const char* stage, int h, int gi) {
-        if (ABL & 2) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) fb[t][ks] = s16x8{(short)gi, 1, 2, 3, 4, 5, 6, (short)lane};
-#pragma unroll
-                for (int t = 0; t < 4; ++t) fa[t][ks] = s16x8{(short)lane, 1, 2, 3, 4, 5, 6, (short)gi};
-            }
-            return;
-        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -148,22 +103,8 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
             for (int t = 0; t < 4; ++t) fa[t][ks] = frag32<AT>(stage, wm * 128 + t * 32, h, ks, lane);
         }
     };
-    s16x8 cfa = {(short)lane, 1, 2, 3, 4, 5, 6, 7}, cfb = {7, 6, 5, 4, 3, 2, 1, (short)lane};   // ABL & 128
     auto compute = [&]() {
         of_sched_fence();
-        if (ABL & 128) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = of_mfma32(cfb, cfa, acc[mt][nt]);
-            return;
-        }
-        if (ABL & 4) {
-            acc[0][0][0] += __builtin_bit_cast(float, (int)fa[0][0][0] + fa[1][1][1] + fa[2][0][2] + fa[3][1][3] + fb[0][0][4] + fb[1][1][5]);
-            return;
-        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -173,43 +114,24 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
     };
     // end of a load segment: the 4 pieces issued two segments ago have landed (or everything, if nothing was issued now)
     auto publish = [&](bool issued) {
-        lap(1);                        // [1] DMA issue
-        if (!(ABL & 16) && !RS) {      // RS: loads target VGPRs and stay in flight across the barrier
-            if (issued) of_wait_vm<4>();
-            else of_wait_vm<0>();
-        }
-        lap(2);                        // [2] wait for the pieces issued two segments ago
-        of_wait_lgkm0();
-        if (ABL & 128) {               // the reads are real: keep their results alive up to here
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(fa[t][ks]));
-#pragma unroll
-                for (int t = 0; t < 2; ++t) asm volatile("" ::"v"(fb[t][ks]));
-            }
-        }
-        lap(3);                        // [3] wait for this segment's fragment reads
+        if (issued) of_wait_vm<4>();
+        else of_wait_vm<0>();
+        of_wait_lgkm0();               // this segment's fragment reads
         of_sched_fence();
         of_barrier_raw();
-        lap(4);                        // [4] barrier at the end of a load segment
     };
 
     // prologue: stage 0 complete for everybody (the 8 waves' duties cover all 64 chunks); G1 starts A rows 0-127 of stage 1
     issueB(smem);
-    flush();
     issueA(smem);
-    flush();
     if (wm == 1 && nd > 1) {
-        issueA(smem + STAGE_BYTES);     // RS: stays pending until G1's first load segment
-        if (!RS) of_wait_vm<4>();
-    } else if (!RS) {
+        issueA(smem + STAGE_BYTES);
+        of_wait_vm<4>();
+    } else {
         of_wait_vm<0>();
     }
-    if (RS) of_wait_lgkm0();
     of_barrier_raw();
     if (wm == 1) of_barrier_raw();   // stagger: G1 runs one segment behind G0
-    if (ABL & 64) t_prev = of_cycles();
     // epilogue operand of this wave's first 32 x 64 group: requested here, lands during the K loop -- in registers (16 / 32),
     // or, for the *_DOT epilogues, by DMA in the 32 KiB of LDS behind the ring (no registers at all)
     constexpr bool AUXL = EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT;
@@ -226,42 +148,26 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
     //   A rows 0-127 of p+2   written G1 T3(p), published end of T1(p+1); first read G0.L0(p+2) = T0(p+2).
     //                         overwrites A 0-127 of p (same slot), last read G0.L1(p) = T2(p), published by its barrier.
     for (int d = 0; d < nd; ++d) {
-        const bool dma = !(ABL & 1);
         const char* stage = smem + (d & 1) * STAGE_BYTES;
         char* other = smem + ((d + 1) & 1) * STAGE_BYTES;
         // ---- L0
-        flush();
-        const bool i0 = dma && d + 1 < nd;
-        if (RS && i0) issueB(other);
+        const bool i0 = d + 1 < nd;
         load_frags(stage, 0, d);
-        lap(0);                        // [0] fragment reads issued AND returned (the stamp waits lgkmcnt(0))
-        if (!RS && i0) issueB(other);
+        if (i0) issueB(other);
         publish(i0);
         // ---- C0
         compute();
-        lap(5);                        // [5] MFMA issue
         of_sched_fence();
         of_barrier_raw();
-        lap(6);                        // [6] barrier at the end of a compute segment
         // ---- L1
-        flush();
-        const bool i1 = dma && (wm == 0 ? d + 1 < nd : d + 2 < nd);
-        if (RS && i1) issueA(wm == 0 ? other : smem + (d & 1) * STAGE_BYTES);
+        const bool i1 = wm == 0 ? d + 1 < nd : d + 2 < nd;
         load_frags(stage, 1, d);
-        lap(0);
-        if (!RS && i1) issueA(wm == 0 ? other : smem + (d & 1) * STAGE_BYTES);
+        if (i1) issueA(wm == 0 ? other : smem + (d & 1) * STAGE_BYTES);
         publish(i1);
         // ---- C1
         compute();
-        lap(5);
         of_sched_fence();
         of_barrier_raw();
-        lap(6);
-    }
-    if ((ABL & 64) && p.C2 && lane == 0) {
-        unsigned* out = (unsigned*)p.C2 + ((size_t)of_bid_x() * 8 + wave) * 8;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) out[i] = tm[i];
     }
     if (wm == 0) of_barrier_raw();   // balances G1's stagger barrier
 
@@ -308,48 +214,11 @@ int launch_pp(const OfGemmArgs& a, of_stream_t s) {
     of_dim3 grid{(unsigned)((a.M / TM) * (a.N / TN)), 1, 1};
     // *_DOT epilogues: + 4 KiB per wave behind the ring for the first group's aux tile (160 KiB in all)
     constexpr int smem_bytes = SMEM_PP + ((EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) ? 8 * ofg::AUX_LDS_BYTES : 0);
-    int rc;
-#ifdef OF_TOOLS_BUILD
-    if (a.safe == 55) rc = of_launch(of_gemm_pp_kernel<AT, BT, EPI, 0, 1>, grid, 512, smem_bytes, s, a);
-    else
-#endif
-        rc = of_launch(of_gemm_pp_kernel<AT, BT, EPI>, grid, 512, smem_bytes, s, a);
+    const int rc = of_launch(of_gemm_pp_kernel<AT, BT, EPI>, grid, 512, smem_bytes, s, a);
     if (rc || !of_gemm_has_dot(a)) return rc;
     return of_gemm_dot_finish(a, (int)grid.x, s);
 }
-
-#ifdef OF_TOOLS_BUILD
-template <int ABL>
-int launch_abl(const OfGemmArgs& a, of_stream_t s) {
-    of_dim3 grid{(unsigned)((a.M / TM) * (a.N / TN)), 1, 1};
-    return of_launch(of_gemm_pp_kernel<false, false, OF_EPI_STORE_BF16, ABL>, grid, 512, SMEM_PP, s, a);
-}
-#endif
 }  // namespace
-
-#ifdef OF_TOOLS_BUILD
-// timing-only entry (NT layout, bf16 store): mask as documented at the kernel
-int of_gemm_pp_ablate(const OfGemmArgs& a, int mask, of_stream_t s) {
-    if ((a.M % TM) || (a.N % TN) || (a.K % DK) || a.a_trans || a.b_trans || a.epi != OF_EPI_STORE_BF16) return OF_E_SHAPE;
-    switch (mask) {
-        case 0: return launch_abl<0>(a, s);
-        case 1: return launch_abl<1>(a, s);
-        case 2: return launch_abl<2>(a, s);
-        case 3: return launch_abl<3>(a, s);
-        case 4: return launch_abl<4>(a, s);
-        case 5: return launch_abl<5>(a, s);
-        case 6: return launch_abl<6>(a, s);
-        case 16: return launch_abl<16>(a, s);
-        case 22: return launch_abl<22>(a, s);
-        case 38: return launch_abl<38>(a, s);
-        case 54: return launch_abl<54>(a, s);
-        case 18: return launch_abl<18>(a, s);
-        case 64: return launch_abl<64>(a, s);
-        case 128: return launch_abl<128>(a, s);
-    }
-    return OF_E_ARG;
-}
-#endif
 
 int of_gemm_pp_try(const OfGemmArgs& a, of_stream_t s) {
     if ((a.M % TM) || (a.N % TN) || (a.K % DK)) return OF_E_SHAPE;

@@ -27,17 +27,13 @@ using namespace oft;
 
 constexpr int SMEM_W4 = NSLOT * STAGE_BYTES;    // 128 KiB
 
-// ABL (tools/libofhip_tools.so only; results are wrong when != 0): timing ablations for tools/bench_w4_ablate.py
-//   1 = no staging writes, 2 = no global loads, 4 = no fragment reads in the K loop, 8 = no barrier,
-//   16 = no MFMAs (NOT meaningful: the compiler then shrinks the fragment reads), 32 = the source never advances along K
-//   (every stage re-reads stage 0: all loads hit L1/L2 -- separates memory latency from the cost of the load path itself)
-// DMA: operands travel global -> LDS directly (buffer_load ... lds, no VGPR round trip, no ds_write) instead of through
-//   staging registers.  A(d+2) is issued in phase 3 of iteration d (into the slot that barrier d just freed), B(d+1) in
-//   phase 0 of iteration d; one s_waitcnt vmcnt(0) in front of the stage's barrier covers both.
-// DPL (DMA variant): where the 16 pieces of a stage are issued inside their window (slot free after barrier d .. wait in
-//   front of barrier d+1): 0 = A in phase 3 gaps 8-15, B in phase 0 gaps 8-15; 1 = all 16 in phase 3; 2 = as 0 but waves
-//   of odd / even index use odd / even gaps of the whole phase (staggered); 3 = A in phase 3 gaps 8-15, B in phase 0 gaps 0-7
-template <bool AT, bool BT, int EPI, int ABL = 0, bool DMA = false, int DPL = 0>
+// DMA (product: safe = 7): operands travel global -> LDS directly (buffer_load ... lds, no VGPR round trip, no ds_write)
+//   instead of through staging registers (DMA = false, safe = 6: kept as the measured A/B partner and as a second
+//   implementation for the race screens).  A(d+2) is issued in phase 3 of iteration d (into the slot that barrier d just
+//   freed), B(d+1) in phase 0 of iteration d; one s_waitcnt vmcnt(0) in front of the stage's barrier covers both.  Inside
+//   those two phases waves of odd / even index use the odd / even MFMA gaps (half as many waves meet at the texture unit per
+//   gap: +1..3 % over the unstaggered placements, profiles/r02_gemm_big_tile_ab.jsonl, r03c_gemm_ab_OF-3B.jsonl).
+template <bool AT, bool BT, int EPI, bool DMA>
 OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
     char* smem = of_smem();
     const int tid = of_tid(), lane = tid & 63;
@@ -77,15 +73,14 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
             offA[hf][jj] = 2u * chunk_off<AT>(p.lda, hf, jj * 4 + wave, lane);
             offB[hf][jj] = 2u * chunk_off<BT>(p.ldb, hf, jj * 4 + wave, lane);
         }
-    const unsigned stepA = (ABL & 32) ? 0u : 2u * (AT ? (unsigned)DK * (unsigned)p.lda : (unsigned)DK);
-    const unsigned stepB = (ABL & 32) ? 0u : 2u * (BT ? (unsigned)DK * (unsigned)p.ldb : (unsigned)DK);
+    const unsigned stepA = 2u * (AT ? (unsigned)DK * (unsigned)p.lda : (unsigned)DK);
+    const unsigned stepB = 2u * (BT ? (unsigned)DK * (unsigned)p.ldb : (unsigned)DK);
     const int nd = p.K / DK;
     const int wdst = wave * 1024 + lane * 16;     // + op * OPER_BYTES + hf * HALF_BYTES + jj * 4096
 
     u32x4 stg[16];       // piece j = op * 8 + hf * 4 + jj
     auto load_piece = [&](int j) OF_INLINE_LAMBDA {
         const int op = j >> 3, hf = (j >> 2) & 1, jj = j & 3;
-        if (ABL & 2) return;
         if (op == 0) stg[j] = of_buf_load16(gA, offA[hf][jj], sA);
         else stg[j] = of_buf_load16(gB, offB[hf][jj], sB);
     };
@@ -95,10 +90,6 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
     };
     auto store_piece = [&](char* slot, int j) OF_INLINE_LAMBDA {
         const int op = j >> 3, hf = (j >> 2) & 1, jj = j & 3;
-        if (ABL & 1) {
-            asm volatile("" ::"v"(stg[j]));     // keep the load alive
-            return;
-        }
         *(u32x4*)(slot + op * OPER_BYTES + hf * HALF_BYTES + jj * 4096 + wdst) = stg[j];
     };
 
@@ -107,19 +98,10 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
     auto dma_piece = [&](char* slot, int j, int ahead) OF_INLINE_LAMBDA {
         const int op = j >> 3, hf = (j >> 2) & 1, jj = j & 3;
         char* dst = slot + op * OPER_BYTES + hf * HALF_BYTES + jj * 4096 + wave * 1024;
-        if (ABL & 2) return;
         if (op == 0) of_buf_load16_lds<AT || BT>(gA, offA[hf][jj], sA + (ahead ? stepA : 0u), dst);
         else of_buf_load16_lds<AT || BT>(gB, offB[hf][jj], sB + (ahead ? stepB : 0u), dst);
     };
     const int par = wave & 1;
-    // piece issued in gap i of window phase w (0 = phase 3 of the previous iteration, 1 = phase 0, 2 = phase 1), or -1
-    auto dma_at = [&](int w, int i) OF_INLINE_LAMBDA -> int {
-        if (DPL == 0) return (w == 0 && i >= 8) ? i - 8 : (w == 1 && i >= 8) ? i : -1;
-        if (DPL == 1) return w == 0 ? i : -1;
-        if (DPL == 3) return (w == 0 && i >= 8) ? i - 8 : (w == 1 && i < 8) ? 8 + i : -1;
-        return -1;
-    };
-
     constexpr bool AUXL = EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT;
     if (AUXL) ofg::epilogue_group_aux_dma(p, m0 + wm * 128, n0 + wn * 128, lane, smem + SMEM_W4 + wave * ofg::AUX_LDS_BYTES);
     s16x8 fa[2][4], fb[2][4];     // [register buffer][32-row fragment]
@@ -141,13 +123,8 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
         of_wait_vm<0>();
         if (nd > 1) {                      // what phase 3 of "iteration -1" would have issued for stage 1
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (DPL == 2) {
-                    if ((i & 1) == par) dma_piece(smem + STAGE_BYTES, i >> 1, 0);
-                } else if (dma_at(0, i) >= 0) {
-                    dma_piece(smem + STAGE_BYTES, dma_at(0, i), 0);
-                }
-            }
+            for (int i = 0; i < 16; ++i)
+                if ((i & 1) == par) dma_piece(smem + STAGE_BYTES, i >> 1, 0);
         }
     } else {
 #pragma unroll
@@ -166,8 +143,8 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) read_one(smem, 0, 0, i);
 
-    // The K loop, compiled once per wave parity for DPL == 2 (odd waves issue their DMA pieces in odd gaps, even waves in
-    // even gaps: half as many waves meet at the texture unit per gap) -- the parity is a compile-time constant inside.
+    // The K loop, compiled once per wave parity (odd waves issue their DMA pieces in odd gaps, even waves in even gaps: half as
+    // many waves meet at the texture unit per gap) -- the parity is a compile-time constant inside.
     auto main_loop = [&](auto parc) OF_INLINE_LAMBDA {
         constexpr int PARC = decltype(parc)::value;
         // One phase = the 16 MFMAs of one k-step (register buffer `buf`); every MFMA gap carries at most one LDS instruction:
@@ -181,25 +158,14 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
                          char* dma_slot, int win, bool dma_on) OF_INLINE_LAMBDA {
     #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                if (ABL & 16) {
-                    if (i == 0) acc[0][0][0] += __builtin_bit_cast(float, (int)fa[buf][0][0] + fa[buf][1][1] + fa[buf][2][2] + fa[buf][3][3] +
-                                                                              fb[buf][0][4] + fb[buf][1][5] + fb[buf][2][6] + fb[buf][3][7]);
-                } else {
-                    acc[i >> 2][i & 3] = of_mfma32(fb[buf][i & 3], fa[buf][i >> 2], acc[i >> 2][i & 3]);
-                }
+                acc[i >> 2][i & 3] = of_mfma32(fb[buf][i & 3], fa[buf][i >> 2], acc[i >> 2][i & 3]);
                 if (i < 8) {
-                    if (rd && !(ABL & 4)) read_one(rd_stage, rd_ks16, buf ^ 1, i);
+                    if (rd) read_one(rd_stage, rd_ks16, buf ^ 1, i);
                     if (!DMA && LD && ld0 >= 0) load_piece(ld0 + i);
                 } else if (!DMA && WR && wr0 >= 0) {
                     store_piece(nxt, wr0 + i - 8);
                 }
-                if (DMA && dma_on && win >= 0) {
-                    if (DPL == 2) {
-                        if (win < 2 && (i & 1) == PARC) dma_piece(dma_slot, win * 8 + (i >> 1), win == 0);
-                    } else if (dma_at(win, i) >= 0) {
-                        dma_piece(dma_slot, dma_at(win, i), win == 0);
-                    }
-                }
+                if (DMA && dma_on && win >= 0 && win < 2 && (i & 1) == PARC) dma_piece(dma_slot, win * 8 + (i >> 1), win == 0);
                 of_sched_fence();
             }
         };
@@ -211,7 +177,7 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
             if (!DMA && LD) next_stage_src();
             if (DMA) of_wait_vm<0>();      // own DMA pieces of stage d+1 have landed ...
             of_wait_lgkm0();       // own writes of stage d+1 and reads of this slot are done ...
-            if (!(ABL & 8)) of_barrier_raw();      // ... and so are everybody else's
+            of_barrier_raw();      // ... and so are everybody else's
             of_sched_fence();
             phase(1, nxt, 0, WR, nxt, -1, -1, false, false, cur, 0, LD);      // DMA: window phase 0 of stage d+2 -> cur (free since the barrier)
             if (DMA) {
@@ -228,7 +194,7 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
         }
         stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, false, false);
     };
-    if (DPL == 2 && par) main_loop(std::integral_constant<int, 1>{});
+    if (DMA && par) main_loop(std::integral_constant<int, 1>{});
     else main_loop(std::integral_constant<int, 0>{});
     of_barrier_raw();          // the last stage's k-step-3 fragments were read before its barrier: LDS is idle from here
 
@@ -274,16 +240,10 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
 template <bool AT, bool BT, int EPI>
 int launch_w4(const OfGemmArgs& a, of_stream_t s) {
     of_dim3 grid{(unsigned)((a.M / TM) * (a.N / TN)), 1, 1};
+    // *_DOT epilogues: + 4 KiB per wave behind the ring for the first group's aux tile
     constexpr int smem_bytes = SMEM_W4 + ((EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) ? 4 * ofg::AUX_LDS_BYTES : 0);
-    // product DMA placement = 2 (A in phase 3, B in phase 0, odd / even waves in odd / even gaps): +1..3 % over the
-    // unstaggered form on MI355X (profiles/r02_gemm_big_tile_ab.jsonl)
-    if (a.safe == 7) return of_launch(of_gemm_w4_kernel<AT, BT, EPI, 0, true, 2>, grid, 256, smem_bytes, s, a);
-#ifdef OF_TOOLS_BUILD       // DMA placement A/B (tools/bench_gemm_w4b.py)
-    if (a.safe == 70) return of_launch(of_gemm_w4_kernel<AT, BT, EPI, 0, true, 0>, grid, 256, smem_bytes, s, a);
-    if (a.safe == 71) return of_launch(of_gemm_w4_kernel<AT, BT, EPI, 0, true, 1>, grid, 256, smem_bytes, s, a);
-    if (a.safe == 73) return of_launch(of_gemm_w4_kernel<AT, BT, EPI, 0, true, 3>, grid, 256, smem_bytes, s, a);
-#endif
-    return of_launch(of_gemm_w4_kernel<AT, BT, EPI>, grid, 256, smem_bytes, s, a);
+    if (a.safe == 6) return of_launch(of_gemm_w4_kernel<AT, BT, EPI, false>, grid, 256, smem_bytes, s, a);   // register staged
+    return of_launch(of_gemm_w4_kernel<AT, BT, EPI, true>, grid, 256, smem_bytes, s, a);                        // LDS-DMA (product)
 }
 template <bool AT, bool BT, int EPI>
 int launch_w4_dot(const OfGemmArgs& a, of_stream_t s) {
@@ -291,36 +251,7 @@ int launch_w4_dot(const OfGemmArgs& a, of_stream_t s) {
     if (rc || !of_gemm_has_dot(a)) return rc;
     return of_gemm_dot_finish(a, (a.M / TM) * (a.N / TN), s);
 }
-#ifdef OF_TOOLS_BUILD
-template <int ABL>
-int launch_w4_abl(const OfGemmArgs& a, of_stream_t s) {
-    of_dim3 grid{(unsigned)((a.M / TM) * (a.N / TN)), 1, 1};
-    if (a.C2) return of_launch(of_gemm_w4_kernel<false, false, OF_EPI_STORE_BF16, ABL, true>, grid, 256, SMEM_W4, s, a);   // DMA variant
-    return of_launch(of_gemm_w4_kernel<false, false, OF_EPI_STORE_BF16, ABL>, grid, 256, SMEM_W4, s, a);
-}
-#endif
 }  // namespace
-
-#ifdef OF_TOOLS_BUILD
-// timing-only entry (NT layout, bf16 store): mask as documented at the kernel
-int of_gemm_w4_ablate(const OfGemmArgs& a, int mask, of_stream_t s) {
-    if ((a.M % TM) || (a.N % TN) || (a.K % DK) || a.a_trans || a.b_trans || a.epi != OF_EPI_STORE_BF16) return OF_E_SHAPE;
-    switch (mask) {
-        case 0: return launch_w4_abl<0>(a, s);
-        case 1: return launch_w4_abl<1>(a, s);
-        case 2: return launch_w4_abl<2>(a, s);
-        case 3: return launch_w4_abl<3>(a, s);
-        case 4: return launch_w4_abl<4>(a, s);
-        case 7: return launch_w4_abl<7>(a, s);
-        case 8: return launch_w4_abl<8>(a, s);
-        case 9: return launch_w4_abl<9>(a, s);
-        case 15: return launch_w4_abl<15>(a, s);
-        case 32: return launch_w4_abl<32>(a, s);
-        case 40: return launch_w4_abl<40>(a, s);
-    }
-    return OF_E_ARG;
-}
-#endif
 
 int of_gemm_w4_try(const OfGemmArgs& a, of_stream_t s) {
     if ((a.M % TM) || (a.N % TN) || (a.K % DK)) return OF_E_SHAPE;

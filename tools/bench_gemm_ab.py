@@ -130,10 +130,6 @@ def main():
     new = Ops.default()
     if a.ladder:
         return ladder(new)
-    tools = None
-    tl = os.path.join(HERE, "libofhip_tools.so")
-    if os.path.exists(tl):
-        tools = load(tl)
     for name, M, N, K, ta, tb, epi in family_shapes(fam):
         if a.only_big and not (M % 256 == 0 and N % 256 == 0 and (M // 256) * (N // 256) >= 128):
             continue
@@ -150,9 +146,6 @@ def main():
             arms["new_w4dma256"] = lambda: new.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=7, **kw)
             if builtin is not None:
                 arms["builtin_w4dma256"] = lambda: builtin.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=7, **kw)
-        if tools is not None and big_ok and (M // 256) * (N // 256) >= 128:       # DMA placement variants of the 4-wave kernel
-            for code, tag in ((70, "dpl0"), (71, "dpl1"), (73, "dpl3")):
-                arms["tools_w4_" + tag] = (lambda c: (lambda: tools.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=c, **kw)))(code)
         best = {k: 1e9 for k in arms}
         for k, fn in arms.items():
             for _ in range(3):

@@ -1,6 +1,7 @@
-"""Ops bound to tools/libofhip_tools.so: the same sources as the product library compiled with -DOF_TOOLS_BUILD, which
-adds the timing ablations / A-B variants of the GEMM kernels (OfGemmArgs.safe = 5, >= 16; several give wrong results by
-design).  PROFILING TOOLS ONLY -- the package (open_flamingo_amd.hip.lib) never loads this file."""
+"""Ops bound to tools/libofhip_tools.so: the same sources as the product library compiled with -DOF_TOOLS_BUILD, which only
+adds of_tools_hold_cus (tools/rehearse_contention.py).  The timing ablations of rounds 1-2 (loop parts switched off, DMA
+placements, register staging of the ping-pong kernel) were removed from the kernel sources in round 3 -- their results are in
+profiles/r01_* / r02_*.  PROFILING TOOLS ONLY -- the package (open_flamingo_amd.hip.lib) never loads this file."""
 import ctypes
 import os
 import sys
