@@ -181,6 +181,11 @@ def main():
                     help="the reference's skip-the-step-on-NaN-loss (train_utils.py:161-169): decided on the device by the fused step "
                          "epilogue (non-finite global gradient norm: no update, on every rank alike, no host sync), or with the "
                          "reference's host-side torch.isnan(loss)")
+    ap.add_argument("--laion-batch", type=int, default=0,
+                    help="also run the reference's LAION pass in every step (train_utils.py:94-118: B image-caption pairs, T = 1, "
+                         "32 text tokens, loss multiplier 0.2, its backward under no_sync) before the MMC4-style pass -- the two-pass "
+                         "step of the reference's training script (run_train.sh: batch_size_laion = 2 x batch_size_mmc4); BASELINE.json "
+                         "names only the MMC4-style batch, so the default (0) is the primary number")
     ap.add_argument("--gemm-report", default=None, help="write a per-(layout,epilogue,shape) GEMM time table (JSON lines)")
     args = ap.parse_args()
     if args.gpus > 1 and not any(k in os.environ for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK")):
@@ -212,6 +217,8 @@ def main():
     reducer.broadcast_parameters()
     opt = step.build_optimizer(model, reducer=None if args.torch_optimizer else reducer)
     batch = synthetic.make_batch(args.batch, args.T, args.L, info, device, seed=1 + rank)
+    laion = synthetic.make_batch(args.laion_batch, 1, 32, info, device, seed=101 + rank) if args.laion_batch > 0 else None
+    step_kw = dict(batch_laion=laion, loss_multiplier_laion=0.2) if laion is not None else {}
     ops = Ops.default()
     nan_check = "device" if (args.nan_check == "device" and not args.torch_optimizer) else True
 
@@ -227,7 +234,7 @@ def main():
     for w in range(args.warmup):
         if not args.no_roofline and w == args.warmup - 1:
             ops.gemm_timing = []
-        loss = step.train_step(model, reducer, opt, batch, info, nan_check=nan_check)
+        loss = step.train_step(model, reducer, opt, batch, info, nan_check=nan_check, **step_kw)
     sync()
     if not args.no_roofline and args.warmup > 0:
         survey, ops.gemm_timing = ops.gemm_timing, None
@@ -244,7 +251,7 @@ def main():
     reducer.time_waits = world > 1          # two HIP events per step around the compute stream's wait for RCCL
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step.train_step(model, reducer, opt, batch, info, nan_check=nan_check)
+        loss = step.train_step(model, reducer, opt, batch, info, nan_check=nan_check, **step_kw)
     sync()
     elapsed = time.perf_counter() - t0
     overlap = reducer.overlap_stats()
@@ -255,7 +262,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
-    images = args.batch * args.T * world
+    images = (args.batch * args.T + args.laion_batch) * world
     value = images * args.steps / elapsed
 
     roofline = None
@@ -324,7 +331,8 @@ def main():
                           "lm_loss": args.lm_loss, "nan_check": "device (step epilogue)" if nan_check == "device" else "host (torch.isnan(loss))",
                           "vendor_gemm_table": f"TunableOp table, {n_tuned} shapes, tuning off" if n_tuned else "library defaults",
                           "grad_wire_dtype": "bf16" if args.wire_bf16 else "fp32",
-                          "embedding_row_gradient": "sparse taps" if args.sparse_embedding_rows else "dense, masked"},
+                          "embedding_row_gradient": "sparse taps" if args.sparse_embedding_rows else "dense, masked",
+                          "laion_pass": (f"B={args.laion_batch} T=1 L=32, loss x0.2, same optimizer step" if args.laion_batch else "off")},
                "loss": None if loss is None else round(float(loss), 4)}
         out["overlap"] = {"allreduce_bytes_per_step_per_gpu": int(overlap["allreduce_bytes_per_step"]),
                           "collectives_per_step": overlap["collectives_per_step"], "wire_dtype": overlap["wire_dtype"],

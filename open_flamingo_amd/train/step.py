@@ -70,7 +70,10 @@ def train_step(model, reducer, optimizer, batch_mmc4, info, batch_laion=None, lo
     data parallelism a NaN on one rank alone leaves the others waiting in their collectives); "device" = no host sync -- the
     backward runs, the NaN reaches every rank through the all-reduce, and the fused step epilogue (of_adamw_clip) skips the
     update on a non-finite global norm, on all ranks alike (needs the FlatAdamW optimizer; the returned loss is then NaN
-    instead of None, and FlatAdamW's step counter still advances); False = no check."""
+    instead of None).  Adam's step count lives on the device and only counts applied updates, so a skipped step leaves the
+    bias correction where the reference's `continue` leaves it; a host-side ``lr_scheduler`` cannot see the skip without a
+    sync and does advance by one step per NaN batch -- the one remaining difference from the reference, bounded by the number
+    of NaN batches (use nan_check=True where that matters more than the sync); False = no check."""
     fused = hasattr(optimizer, "reducer")         # FlatAdamW: clip + AdamW + zero_grad in two device passes
     params = None if fused else [p for g in optimizer.param_groups for p in g["params"]]
     if batch_laion is not None:
