@@ -395,6 +395,31 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
     // those layouts too (NN 8192x2048x8192: 206 vs 221 us; TN: 215 vs 228 us).  The ping-pong kernel keeps the K-grouped B
     // launches (gemm_grouped) and safe = 4.
     if (a.safe == 0 && pp_ok) {
+        // Tile quantisation: a grid whose last round of 256x256 tiles would be under half full (OF-4B: M = 8192, N = 2560 ->
+        // 320 tiles = 1.25 rounds of 256 CUs, 790-870 TFLOP/s where full rounds reach 1250) is split along N into whole rounds
+        // of big tiles + a remainder strip on the 128x128 kernel (8192 x 512 -> 256 small tiles: one round).  Two launches on
+        // disjoint output columns; every epilogue is column-local, the gate-gradient partials of the two finish in order.
+        const int tm = a.M / 256, tn = a.N / 256;
+        int n1 = 0;
+        if (tiles256 > 256 && tiles256 % 256)
+            for (int n = tn - 1; n >= 1 && !n1; --n)
+                if (((long)tm * n) % 256 == 0) n1 = n;
+        if (n1 && (long)tm * (tn - n1) <= 128 && mid_ok) {
+            const long off = (long)n1 * 256;
+            const int c_bytes = a.epi == OF_EPI_ACC_F32 ? 4 : (a.epi == OF_EPI_GATE_RESID ? (a.io_f32 ? 4 : 2) : 2);
+            const int aux_bytes = a.epi == OF_EPI_GATE_RESID ? (a.io_f32 ? 4 : 2) : 2;
+            OfGemmArgs left = a, right = b;
+            left.N = (int)off;
+            left.safe = 7;
+            right.N = a.N - (int)off;
+            right.B = a.b_trans ? a.B + off : a.B + off * a.ldb;
+            right.C = (char*)a.C + off * c_bytes;
+            if (a.C2) right.C2 = (char*)a.C2 + off * 2;
+            if (a.aux) right.aux = (const char*)a.aux + off * aux_bytes;
+            int rc = of_gemm_w4_try(left, s);
+            if (rc == 0) rc = of_gemm_mid_try(right, s);
+            if (rc != OF_E_SHAPE) return rc;
+        }
         OfGemmArgs w = a;
         w.safe = 7;
         const int rc = of_gemm_w4_try(w, s);

@@ -322,6 +322,39 @@ def test_gemm_mid_kernel_epilogues_at_projection_shapes(ops):
     assert _rel(a_out, acc) < 1e-2 and _rel(b_out, torch.nn.functional.gelu(acc)) < 1e-2
 
 
+def test_gemm_n_split_of_a_partially_filled_last_round(ops):
+    """M = 8192, N = 2560 (OF-4B: 320 big tiles = 1.25 rounds) is launched as 8192 x 2048 on the 256x256 kernel + the 8192 x 512
+    strip on the 128x128 kernel: every epilogue of_gemm's own selection (safe = 0) can meet at that shape against the general
+    kernel (safe = 2) -- the seam at column 2048 included, aux / second output / gate-gradient partials of both parts."""
+    M, N, K = 8192, 2560, 1024
+    gate = torch.tensor([0.41], device="cuda")
+    A = _r((M, K), 91)
+    Wnt, Wnn = _r((N, K), 92, 0.05), _r((K, N), 93, 0.05)
+    res = torch.randn(M, N, device="cuda")
+    outs = {}
+    for safe in (0, 2):
+        y = torch.zeros(M, N, device="cuda")
+        ops.gemm(A, Wnt, y, epi=abi.EPI_GATE_RESID, aux=res, gate=gate, safe=safe)
+        yb = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm(A, Wnt, yb, epi=abi.EPI_GATE_RESID, aux=res.to(torch.bfloat16), gate=gate, safe=safe)
+        b_out, a_out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16), torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm(A, Wnt, b_out, epi=abi.EPI_GELU, out2=a_out, safe=safe)
+        dx = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm(A, Wnn, dx, tb=True, safe=safe)
+        sd, dot = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16), torch.zeros(1, device="cuda")
+        ops.gemm(A, Wnn, sd, tb=True, epi=abi.EPI_SCALE_DOT, aux=b_out, gate=gate, dot=dot, safe=safe)
+        At = _r((K, M), 94)                                   # TN: dW (M x N) = At^T Wnn, accumulated
+        acc = torch.ones(M, N, device="cuda")
+        ops.gemm(At, Wnn, acc, ta=True, tb=True, epi=abi.EPI_ACC_F32, beta=1.0, safe=safe)
+        outs[safe] = (y, yb, b_out, a_out, dx, sd, dot, acc)
+    names = ("gate_resid f32", "gate_resid bf16", "gelu", "pre-activation", "NN store", "scale_dot", "dot", "TN acc")
+    for name, got, want in zip(names, outs[0], outs[2]):
+        tol = 1e-2 if got.dtype == torch.bfloat16 else 2e-4
+        assert _rel(got, want) < tol, (name, _rel(got, want))
+        if got.dim() == 2:                                   # the seam: last column of the big part, first of the strip
+            assert _rel(got[:, 2040:2056], want[:, 2040:2056]) < tol, name
+
+
 @pytest.mark.parametrize("M,N,K,safe", [(8192, 8192, 2048, 0), (8192, 512, 2048, 0), (4096, 4096, 1024, 0), (8192, 8192, 2048, 7)])
 def test_gate_gradient_dot_is_bit_reproducible(ops, M, N, K, safe):
     """The gate gradient of the *_DOT epilogues (per-workgroup partials + ordered finish, no fp32 atomics): ten launches, one
