@@ -227,10 +227,13 @@ OF_DEV void epilogue_group(const OfGemmArgs& p, const f32x16& a0, const f32x16& 
 // vector lane l needs in row pass `it`, so the read is base + it*1024 + lane*16 (conflict-free).  Completion is the CALLER's
 // job: s_waitcnt vmcnt(n) with n = vector-memory operations issued after these four (vmcnt retires in order on gfx950).
 constexpr int AUX_LDS_BYTES = 4096;
+// ASM: the LDS-DMA form of the kernel's K loop (of_platform.h: a kernel issues ALL its LDS-DMA either through the builtins --
+// the compiler then owns M0 -- or by inline asm, never both)
+template <bool ASM>
 OF_DEV void epilogue_group_aux_dma(const OfGemmArgs& p, int m_base, int n_base, int lane, char* lds_dst) {
     const bf16_t* src = (const bf16_t*)p.aux + (size_t)(m_base + (lane >> 3)) * p.ldaux + n_base + (lane & 7) * 8;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) of_glds16(src + (size_t)it * 8 * p.ldaux, lds_dst + it * 1024);
+    for (int it = 0; it < 4; ++it) of_glds16<ASM>(src + (size_t)it * 8 * p.ldaux, lds_dst + it * 1024);
 }
 // as epilogue_group with the aux tile in LDS (aux_lds, landed); row passes in a ROLLED loop (one copy of the math)
 template <int EPI>

@@ -136,7 +136,7 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
     // or, for the *_DOT epilogues, by DMA in the 32 KiB of LDS behind the ring (no registers at all)
     constexpr bool AUXL = EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT;
     ofg::AuxPre pre0[4];
-    if (AUXL) ofg::epilogue_group_aux_dma(p, m0 + wm * 128, n0 + wn * 64, lane, smem + SMEM_PP + wave * ofg::AUX_LDS_BYTES);
+    if (AUXL) ofg::epilogue_group_aux_dma<false>(p, m0 + wm * 128, n0 + wn * 64, lane, smem + SMEM_PP + wave * ofg::AUX_LDS_BYTES);
     else ofg::epilogue_group_aux<EPI>(p, m0 + wm * 128, n0 + wn * 64, lane, pre0);
 
     // Stage p lives in slot p&1.  Reader/writer pairs (T = wall segment, see header):
@@ -186,11 +186,11 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_pp_kernel(OfGemmArgs p) {
         char* bufE = smem + SMEM_PP + wave * ofg::AUX_LDS_BYTES;
         char* bufR = smem + 8 * ofg::PATCH_BYTES + 256 + wave * ofg::AUX_LDS_BYTES;
         of_wait_vm<0>();
-        ofg::epilogue_group_aux_dma(p, m0 + wm * 128 + 32, n0 + wn * 64, lane, bufR);
+        ofg::epilogue_group_aux_dma<false>(p, m0 + wm * 128 + 32, n0 + wn * 64, lane, bufR);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             // the next group's tile goes where the previous group's was (its reads are consumed: their stores are issued)
-            if (mt >= 1 && mt < 3) ofg::epilogue_group_aux_dma(p, m0 + wm * 128 + (mt + 1) * 32, n0 + wn * 64, lane, (mt & 1) ? bufE : bufR);
+            if (mt >= 1 && mt < 3) ofg::epilogue_group_aux_dma<false>(p, m0 + wm * 128 + (mt + 1) * 32, n0 + wn * 64, lane, (mt & 1) ? bufE : bufR);
             if (mt == 1 || mt == 2) of_wait_vm<8>();        // newer than this group's pieces: 4 stores + the next group's 4 pieces
             if (mt == 3) of_wait_vm<4>();                   // ... 4 stores
             ofg::epilogue_group_auxlds<EPI>(p, acc[mt][0], acc[mt][1], patch, (mt & 1) ? bufR : bufE, m0 + wm * 128 + mt * 32, n0 + wn * 64, lane, gv,

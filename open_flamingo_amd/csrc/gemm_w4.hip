@@ -103,7 +103,7 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
     };
     const int par = wave & 1;
     constexpr bool AUXL = EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT;
-    if (AUXL) ofg::epilogue_group_aux_dma(p, m0 + wm * 128, n0 + wn * 128, lane, smem + SMEM_W4 + wave * ofg::AUX_LDS_BYTES);
+    if (AUXL) ofg::epilogue_group_aux_dma<(AT || BT) && DMA>(p, m0 + wm * 128, n0 + wn * 128, lane, smem + SMEM_W4 + wave * ofg::AUX_LDS_BYTES);
     s16x8 fa[2][4], fb[2][4];     // [register buffer][32-row fragment]
     // one operand fragment of k-step ks16 (16 deep) of a stage: slot order = the order the next phase's MFMAs need them
     // (fb0 fa0 fb1 fb2 fb3 fa1 fa2 fa3), one per MFMA gap
@@ -213,11 +213,11 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
         char* bufE = smem + SMEM_W4 + wave * ofg::AUX_LDS_BYTES;
         char* bufR = smem + 4 * ofg::PATCH_BYTES + 256 + wave * ofg::AUX_LDS_BYTES;
         of_wait_vm<0>();
-        ofg::epilogue_group_aux_dma(p, m0 + wm * 128, n0 + wn * 128 + 64, lane, bufR);
+        ofg::epilogue_group_aux_dma<(AT || BT) && DMA>(p, m0 + wm * 128, n0 + wn * 128 + 64, lane, bufR);
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             const int mt = g >> 1, np = g & 1;
-            if (g >= 1 && g < 7) ofg::epilogue_group_aux_dma(p, m0 + wm * 128 + ((g + 1) >> 1) * 32, n0 + wn * 128 + ((g + 1) & 1) * 64, lane, (g & 1) ? bufE : bufR);
+            if (g >= 1 && g < 7) ofg::epilogue_group_aux_dma<(AT || BT) && DMA>(p, m0 + wm * 128 + ((g + 1) >> 1) * 32, n0 + wn * 128 + ((g + 1) & 1) * 64, lane, (g & 1) ? bufE : bufR);
             if (g >= 1 && g < 7) of_wait_vm<8>();
             if (g == 7) of_wait_vm<4>();
             ofg::epilogue_group_auxlds<EPI>(p, acc[mt][np * 2], acc[mt][np * 2 + 1], patch, (g & 1) ? bufR : bufE, m0 + wm * 128 + mt * 32,
