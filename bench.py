@@ -304,6 +304,12 @@ def main():
             all_ms = sum(v[1] for v in groups.values())
         ach = fl / ms / 1e9
         traffic, traffic_note = pmc_traffic(key, top_shape)
+        if traffic is None:          # a family can hold two launch shapes of equal count (dW1 / dW2): quote the one on record
+            for sh in sorted(shapes, key=shapes.get, reverse=True):
+                t2, n2 = pmc_traffic(key, sh)
+                if t2 is not None:
+                    traffic, traffic_note = t2, n2
+                    break
         roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "kernel": f"{sym}  = of_gemm {LAYOUT_NAMES[key[:2]]}, epilogue {EPI_NAMES[key[2]]}",
