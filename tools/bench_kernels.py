@@ -92,6 +92,12 @@ def main():
     print(json.dumps(dict(kernel="ln_fwd_add", rows=8192, dim=2048, ms=round(ms, 4), GBps=round(8192 * 2048 * (4 + 2 + 4 + 2) / ms / 1e6, 1))), flush=True)
     g = torch.randn(36_700_000, device=dev)
     parts = torch.empty(ops.SUMSQ_PARTS, device=dev)
+    pp_, mm_, vv_ = torch.randn_like(g), torch.zeros_like(g), torch.zeros_like(g)
+    pb_ = torch.empty(g.numel(), dtype=torch.bfloat16, device=dev)
+    acc_ = torch.ones(1, device=dev)
+    ms = timeit(lambda: ops.adamw_clip(pp_, g, mm_, vv_, acc_, step=3, lr=1e-4, weight_decay=0.1, p_bf16=pb_, zero_grad=False))
+    print(json.dumps(dict(kernel="adamw_clip (one gated-block bucket, bf16 copy, no zero)", n=g.numel(), ms=round(ms, 4),
+                          GBps=round(g.numel() * 30 / ms / 1e6, 1))), flush=True)
     ms = timeit(lambda: ops.sumsq_partial(g, parts))
     print(json.dumps(dict(kernel="sumsq_partial (one gated-block bucket)", n=g.numel(), ms=round(ms, 4), GBps=round(g.numel() * 4 / ms / 1e6, 1))), flush=True)
     del g
