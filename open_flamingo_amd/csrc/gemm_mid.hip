@@ -66,11 +66,13 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_mid_kernel(OfGemmArgs p) {
     const unsigned stepA = 2u * (AT ? (unsigned)DK * (unsigned)p.lda : (unsigned)DK);
     const unsigned stepB = 2u * (BT ? (unsigned)DK * (unsigned)p.ldb : (unsigned)DK);
     unsigned sA = (unsigned)kt0 * stepA, sB = (unsigned)kt0 * stepB;      // stage the next issue() fetches
+    const unsigned smem_u = of_lds_base(smem) + (unsigned)wave * 1024u;      // LDS byte address of this wave's chunk 0 of slot 0
     auto issue = [&](char* slot) OF_INLINE_LAMBDA {
+        const unsigned dst = smem_u + (unsigned)(slot - smem);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) of_buf_load16_lds<AT || BT>(gA, offA[j], sA, slot + (j * 8 + wave) * 1024);
+        for (int j = 0; j < 2; ++j) of_buf_load16_lds_at<AT || BT>(gA, offA[j], sA, dst + j * 8 * 1024);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) of_buf_load16_lds<AT || BT>(gB, offB[j], sB, slot + MID_OPER + (j * 8 + wave) * 1024);
+        for (int j = 0; j < 2; ++j) of_buf_load16_lds_at<AT || BT>(gB, offB[j], sB, dst + MID_OPER + j * 8 * 1024);
         sA += stepA;
         sB += stepB;
     };

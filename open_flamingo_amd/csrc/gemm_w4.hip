@@ -21,6 +21,7 @@
 //     phases 0 and 1) -- and the 16 global loads ride with the reads of phases 1 and 2.
 #include <type_traits>
 #include "gemm_tile256.h"
+#include "gemm_w4_epi.h"
 
 namespace {
 using namespace oft;
@@ -95,11 +96,12 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
 
     // DMA variant: piece j of the stage at scalar offsets sA / sB straight into `slot`
     // ahead = 0: the stage at (sA, sB); 1: the stage after it
+    const unsigned smem_u = of_lds_base(smem) + (unsigned)wave * 1024u;      // LDS byte address of this wave's piece 0 of slot 0
     auto dma_piece = [&](char* slot, int j, int ahead) OF_INLINE_LAMBDA {
         const int op = j >> 3, hf = (j >> 2) & 1, jj = j & 3;
-        char* dst = slot + op * OPER_BYTES + hf * HALF_BYTES + jj * 4096 + wave * 1024;
-        if (op == 0) of_buf_load16_lds<AT || BT>(gA, offA[hf][jj], sA + (ahead ? stepA : 0u), dst);
-        else of_buf_load16_lds<AT || BT>(gB, offB[hf][jj], sB + (ahead ? stepB : 0u), dst);
+        const unsigned dst = smem_u + (unsigned)(slot - smem) + (unsigned)(op * OPER_BYTES + hf * HALF_BYTES + jj * 4096);
+        if (op == 0) of_buf_load16_lds_at<AT || BT>(gA, offA[hf][jj], sA + (ahead ? stepA : 0u), dst);
+        else of_buf_load16_lds_at<AT || BT>(gB, offB[hf][jj], sB + (ahead ? stepB : 0u), dst);
     };
     const int par = wave & 1;
     constexpr bool AUXL = EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT;
@@ -165,7 +167,11 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
                 } else if (!DMA && WR && wr0 >= 0) {
                     store_piece(nxt, wr0 + i - 8);
                 }
+#ifdef OF_W4_PLACE_NOREAD         // A/B variant (tools/ab builds only): all eight pieces of a phase in its gaps without fragment reads
+                if (DMA && dma_on && win >= 0 && win < 2 && i >= 8) dma_piece(dma_slot, win * 8 + (i - 8), win == 0);
+#else
                 if (DMA && dma_on && win >= 0 && win < 2 && (i & 1) == PARC) dma_piece(dma_slot, win * 8 + (i >> 1), win == 0);
+#endif
                 of_sched_fence();
             }
         };
@@ -175,9 +181,13 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
             phase(1, cur, 2, true, nxt, 8, 0, WR, LD, nxt, 2, WR);            // DMA: window phase 2 of stage d+1 -> nxt
             phase(0, cur, 3, true, nxt, -1, 8, WR, LD, nullptr, -1, false);
             if (!DMA && LD) next_stage_src();
+#ifndef OF_ABL_NOVMWAIT         // timing ablations (tools/ab builds only, results WRONG by design): where the stage's wait goes
             if (DMA) of_wait_vm<0>();      // own DMA pieces of stage d+1 have landed ...
+#endif
             of_wait_lgkm0();       // own writes of stage d+1 and reads of this slot are done ...
+#ifndef OF_ABL_NOBARRIER
             of_barrier_raw();      // ... and so are everybody else's
+#endif
             of_sched_fence();
             phase(1, nxt, 0, WR, nxt, -1, -1, false, false, cur, 0, LD);      // DMA: window phase 0 of stage d+2 -> cur (free since the barrier)
             if (DMA) {
@@ -187,6 +197,16 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
         };
 
         int d = 0;
+#ifndef OF_W4_NO_UNROLL2
+        // K-contiguous operands only (measured: NT -1..3 %, layouts with transposed-fragment reads +1..2 %): steady state two
+        // stages per trip, both slot addresses compile-time constants (fragment reads and M0 values become immediates instead
+        // of per-stage address arithmetic bunched into the first MFMA gaps of a phase)
+        if (!(AT || BT))
+            for (; d + 3 < nd; d += 2) {
+                stage_body(smem, smem + STAGE_BYTES, true, true);
+                stage_body(smem + STAGE_BYTES, smem, true, true);
+            }
+#endif
         for (; d + 2 < nd; ++d) stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, true, true);
         if (d + 1 < nd) {
             stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, true, false);
@@ -198,43 +218,7 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
     else main_loop(std::integral_constant<int, 0>{});
     of_barrier_raw();          // the last stage's k-step-3 fragments were read before its barrier: LDS is idle from here
 
-    // ---------------------------------------------------------------- epilogue, staged through LDS (as gemm_pp.hip)
-    // Each wave sends its eight 32 x 64 accumulator groups through a private LDS patch (ofg::epilogue_group); the aux row
-    // segments of group g + 1 are requested before group g is processed (group 0's right here: this kernel has no registers
-    // to spare across the K loop).
-    float gv = 1.0f;
-    if (p.gate) gv = of_tanh(*p.gate);
-    const float sc = gv * p.alpha;
-    float dot = 0.f;
-    char* patch = smem + wave * ofg::PATCH_BYTES;
-    if constexpr (AUXL) {
-        // *_DOT epilogues: aux tiles by DMA, alternating between two 4-KiB buffers per wave -- E behind the ring (group 0 was
-        // requested before the K loop) and R inside the idle ring; vmcnt counted by hand (a group issues 4 stores): gemm_pp.hip
-        char* bufE = smem + SMEM_W4 + wave * ofg::AUX_LDS_BYTES;
-        char* bufR = smem + 4 * ofg::PATCH_BYTES + 256 + wave * ofg::AUX_LDS_BYTES;
-        of_wait_vm<0>();
-        ofg::epilogue_group_aux_dma<(AT || BT) && DMA>(p, m0 + wm * 128, n0 + wn * 128 + 64, lane, bufR);
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const int mt = g >> 1, np = g & 1;
-            if (g >= 1 && g < 7) ofg::epilogue_group_aux_dma<(AT || BT) && DMA>(p, m0 + wm * 128 + ((g + 1) >> 1) * 32, n0 + wn * 128 + ((g + 1) & 1) * 64, lane, (g & 1) ? bufE : bufR);
-            if (g >= 1 && g < 7) of_wait_vm<8>();
-            if (g == 7) of_wait_vm<4>();
-            ofg::epilogue_group_auxlds<EPI>(p, acc[mt][np * 2], acc[mt][np * 2 + 1], patch, (g & 1) ? bufR : bufE, m0 + wm * 128 + mt * 32,
-                                            n0 + wn * 128 + np * 64, lane, gv, sc, dot);
-        }
-    } else {
-        ofg::AuxPre pre[2][4];
-        ofg::epilogue_group_aux<EPI>(p, m0 + wm * 128, n0 + wn * 128, lane, pre[0]);
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const int mt = g >> 1, np = g & 1;
-            if (g < 7) ofg::epilogue_group_aux<EPI>(p, m0 + wm * 128 + ((g + 1) >> 1) * 32, n0 + wn * 128 + ((g + 1) & 1) * 64, lane, pre[(g + 1) & 1]);
-            ofg::epilogue_group<EPI>(p, acc[mt][np * 2], acc[mt][np * 2 + 1], patch, m0 + wm * 128 + mt * 32, n0 + wn * 128 + np * 64, lane, gv, sc,
-                                     dot, pre[g & 1]);
-        }
-    }
-    ofg::epilogue_finish<EPI>(p, dot, lane, wave, 4, (float*)(smem + 4 * ofg::PATCH_BYTES), of_bid_x());
+    oft::w4_epilogue<EPI, (AT || BT) && DMA>(p, acc, smem, SMEM_W4, m0, n0, wm, wn, wave, lane);
 }
 
 template <bool AT, bool BT, int EPI>

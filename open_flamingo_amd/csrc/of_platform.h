@@ -133,6 +133,21 @@ OF_DEV void of_buf_load16_lds(of_buf_t b, unsigned voff, unsigned soff, void* ld
 #endif
     __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
 }
+// The same with the destination as a wave-uniform LDS byte address (of_lds_base(smem) + offset): the address arithmetic stays
+// on 32-bit scalars -- through a generic pointer every piece pays an address-space cast (null check + two v_readfirstlane)
+// in front of its M0 write.
+OF_DEV unsigned of_lds_base(const void* smem) { return (unsigned)__builtin_amdgcn_readfirstlane((int)of_lds_u32(smem)); }
+template <bool TRSAFE = true>
+OF_DEV void of_buf_load16_lds_at(of_buf_t b, unsigned voff, unsigned soff, unsigned lds_addr) {
+#ifndef OF_DMA_VIA_BUILTIN
+    if (TRSAFE) {
+        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(b.w), "s"(soff), "s"(lds_addr) : "memory");
+        return;
+    }
+#endif
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (lds_ptr_t)(size_t)lds_addr, 16, (int)voff, (int)soff, 0, 0);
+}
 template <int N>
 OF_DEV void of_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

@@ -230,6 +230,11 @@ template <bool TRSAFE = true>
 OF_DEV void of_buf_load16_lds(of_buf_t b, unsigned voff, unsigned soff, void* lds_wave_base) {
     *(u32x4*)((char*)lds_wave_base + (of_emu::g_blk->cur & 63) * 16) = *(const u32x4*)(b.base + voff + soff);
 }
+OF_DEV unsigned of_lds_base(const void* smem) { return (unsigned)((const char*)smem - of_emu::g_blk->smem); }
+template <bool TRSAFE = true>
+OF_DEV void of_buf_load16_lds_at(of_buf_t b, unsigned voff, unsigned soff, unsigned lds_addr) {
+    *(u32x4*)(of_emu::g_blk->smem + lds_addr + (of_emu::g_blk->cur & 63) * 16) = *(const u32x4*)(b.base + voff + soff);
+}
 OF_DEV void of_barrier_raw() { of_emu::block_barrier(); }
 OF_DEV float of_shfl(float v, int src) {
     of_emu::Block* blk = of_emu::g_blk;

@@ -114,6 +114,30 @@ def ladder(ops):
         print(json.dumps(dict(ksweep="NT store_bf16 w4dma256", MNK=[M, N, K], ms=round(min(timed(fn, 10) for _ in range(4)), 4))), flush=True)
 
 
+def ksweep(ops):
+    """us per 1024 of K (slope) and per-launch intercept of the two 4-wave 256x256 kernels: 8192 x 8192, one tile round = 4 per CU"""
+    E = abi
+    M = N = 8192
+    for ta, tb, epi in ((0, 0, E.EPI_STORE_BF16), (0, 1, E.EPI_STORE_BF16), (1, 1, E.EPI_ACC_F32)):
+        for K in (1024, 2048, 4096, 8192):
+            A, B, C, kw = make(M, N, K, ta, tb, epi)
+            rec = dict(ksweep="NT NN ?? TN".split()[ta * 2 + tb], MNK=[M, N, K])
+            fns = {"w4dma256": lambda: ops.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=7, **kw),
+                   "w4ring256": lambda: ops.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=16, **kw)}
+            best = {k: 1e9 for k in fns}
+            for fn in fns.values():
+                for _ in range(3):
+                    fn()
+            torch.cuda.synchronize()
+            for _ in range(4):
+                for k, fn in fns.items():
+                    best[k] = min(best[k], timed(fn, 10))
+            for k, ms in best.items():
+                rec[k + "_ms"] = round(ms, 4)
+                rec[k + "_tflops"] = round(2.0 * M * N * K / ms / 1e9, 1)
+            print(json.dumps(rec), flush=True)
+
+
 def main():
     import argparse
     ap = argparse.ArgumentParser()
@@ -123,8 +147,12 @@ def main():
     ap.add_argument("--only-big", action="store_true", help="only shapes with >= 128 big tiles")
     ap.add_argument("--builtin", default=os.path.join(HERE, "ab", "libofhip_builtin_dma.so"),
                     help="same sources as the product library built with -DOF_DMA_VIA_BUILTIN (tools/build_ab_variant.sh)")
+    ap.add_argument("--arms", default="", help="comma-separated subset of the arms to time (default: all)")
+    ap.add_argument("--ksweep", action="store_true", help="K sweep at M = N = 8192 of the two 4-wave kernels, three layouts")
     a = ap.parse_args()
     fam = a.family
+    if a.ksweep:
+        return ksweep(Ops.default())
     old = load(a.old)
     builtin = load(a.builtin) if os.path.exists(a.builtin) else None
     new = Ops.default()
@@ -144,8 +172,11 @@ def main():
             arms["new_mid128"] = lambda: new.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=5, **kw)
             arms["new_pp256"] = lambda: new.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=4, **kw)
             arms["new_w4dma256"] = lambda: new.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=7, **kw)
+            arms["new_w4ring256"] = lambda: new.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=16, **kw)
             if builtin is not None:
                 arms["builtin_w4dma256"] = lambda: builtin.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=7, **kw)
+        if a.arms:
+            arms = {k: v for k, v in arms.items() if k in a.arms.split(",")}
         best = {k: 1e9 for k in arms}
         for k, fn in arms.items():
             for _ in range(3):
@@ -155,11 +186,19 @@ def main():
             for k, fn in arms.items():
                 best[k] = min(best[k], timed(fn, 10))
         fl = 2.0 * M * N * K
+        if "old" in arms and "new" in arms:      # same operands through both libraries: the results must agree
+            arms["old"]()
+            c_old = C.float().clone()
+            arms["new"]()
+            diff_old_new = float((C.float() - c_old).abs().max())
+        else:
+            diff_old_new = None
         rec = dict(family=fam, name=name, MNK=[M, N, K], layout="NT NN ?? TN".split()[ta * 2 + tb], epi=epi,
                    tiles256=(M // 256) * (N // 256) if big_ok else None, tiles128=(M // 128) * (N // 128) if mid_ok else None)
         for k, ms in best.items():
             rec[k + "_ms"] = round(ms, 4)
             rec[k + "_tflops"] = round(fl / ms / 1e9, 1)
+        rec["max_abs_diff_old_new"] = diff_old_new
         print(json.dumps(rec), flush=True)
 
 
