@@ -386,11 +386,7 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
         const int rc = of_gemm_w4_try(a, s);
         if (rc != OF_E_SHAPE) return rc;
     }
-    if (a.safe == 16) {                            // force the 4-wave kernel on the four-slot half-stage ring (gemm_w4r.hip)
-        const int rc = of_gemm_w4r_try(a, s);
-        if (rc != OF_E_SHAPE) return rc;
-    }
-    if (a.safe >= 17) return OF_E_ARG;
+    if (a.safe >= 16) return OF_E_ARG;
     const bool pp_forced = a.safe == 4;
     // Big-tile selection (measured on MI355X, random operands, same box: profiles/r03b_gemm_ab_*.jsonl): every layout -> the
     // 4-wave LDS-DMA kernel.  Round 2 sent layouts with a K-strided operand (NN: dX = dY W, TN: dW = dY^T X) to the 8-wave

@@ -290,7 +290,6 @@ inline bool of_gemm_has_dot(const OfGemmArgs& a) {
 }
 // implemented in gemm_mid.hip (8 waves, 128x128 tile, 4-slot LDS-DMA ring); OF_E_SHAPE when not eligible
 int of_gemm_mid_try(const OfGemmArgs& a, of_stream_t s);
-int of_gemm_w4r_try(const OfGemmArgs& a, of_stream_t s);   // gemm_w4r.hip: the 4-wave 256x256 kernel on a ring of four half stages
 // implemented in gemm_skinny.hip: M <= 16 rows (decode step), HBM-bound weight streaming; OF_E_SHAPE when not eligible
 int of_gemm_skinny_try(const OfGemmArgs& a, of_stream_t s);
 inline bool of_gemm_is_skinny(const OfGemmArgs& a) {

@@ -21,11 +21,6 @@ constexpr int NSLOT = 2;
 constexpr int SMEM_PP = NSLOT * STAGE_BYTES;    // 128 KiB
 
 OF_DEV int fN(int row) { return (4 - ((row >> 2) & 3)) & 3; }
-#ifdef OF_KC_LINE
-// A/B variant (tools/ab builds only): K-contiguous chunk = [8 rows][128 B], eight CONSECUTIVE lanes fetch one full 128-byte line
-// (the product layout splits a line between lanes l and l + 32); 16-B slot s of row r at s ^ ((r >> 1) & 7)
-OF_DEV int gN(int row) { return (row >> 1) & 7; }
-#endif
 OF_DEV int fT(int krow) { return (krow & 3) << 1; }
 
 constexpr int HALF_BYTES = OPER_BYTES / 2;        // 16 KiB: tile rows (or columns) 0-127 / 128-255 of one operand
@@ -34,15 +29,10 @@ constexpr int HALF_BYTES = OPER_BYTES / 2;        // 16 KiB: tile rows (or colum
 template <bool TR>
 OF_DEV const bf16_t* chunk_src(const bf16_t* __restrict__ base, long ld, int row0, int hf, int c, int lane) {
     if (!TR) {
-#ifdef OF_KC_LINE
-        const int row = hf * 128 + c * 8 + (lane >> 3);
-        return base + (size_t)(row0 + row) * ld + ((lane & 7) ^ gN(row)) * 8;
-#else
         const int row = hf * 128 + c * 8 + ((lane >> 2) & 7);
         const int kh = lane >> 5;
         const int lslot = (lane & 3) ^ fN(row);
         return base + (size_t)(row0 + row) * ld + kh * 32 + lslot * 8;
-#endif
     } else {
         const int krow = c * 4 + (lane >> 4);
         const int pc = (lane & 15) >> 1, half16 = lane & 1;
@@ -60,15 +50,10 @@ OF_DEV const bf16_t* chunk_base(const bf16_t* __restrict__ base, long ld, int ro
 template <bool TR>
 OF_DEV unsigned chunk_off(long ld, int hf, int c, int lane) {
     if (!TR) {
-#ifdef OF_KC_LINE
-        const int row = hf * 128 + c * 8 + (lane >> 3);
-        return (unsigned)(row * ld + ((lane & 7) ^ gN(row)) * 8);
-#else
         const int row = hf * 128 + c * 8 + ((lane >> 2) & 7);
         const int kh = lane >> 5;
         const int lslot = (lane & 3) ^ fN(row);
         return (unsigned)(row * ld + kh * 32 + lslot * 8);
-#endif
     } else {
         const int krow = c * 4 + (lane >> 4);
         const int pc = (lane & 15) >> 1, half16 = lane & 1;
@@ -83,12 +68,8 @@ OF_DEV s16x8 frag32(const char* oper, int row_base, int h, int ks, int lane) {
     if (!TR) {
         const int row = row_base + (lane & 31);
         const int slot = ks * 2 + (lane >> 5);
-#ifdef OF_KC_LINE
-        return *(const s16x8*)(oper + (row >> 7) * HALF_BYTES + ((row & 127) >> 3) * 1024 + (row & 7) * 128 + (((h * 4 + slot) ^ gN(row)) << 4));
-#else
         return *(const s16x8*)(oper + (row >> 7) * HALF_BYTES + ((row & 127) >> 3) * 1024 + h * 512 + (row & 7) * 64 +
                                ((slot ^ fN(row)) << 4));
-#endif
     } else {
         const int q = lane >> 4, i = lane & 15;
         s16x8 f;

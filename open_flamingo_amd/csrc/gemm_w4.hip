@@ -167,11 +167,7 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
                 } else if (!DMA && WR && wr0 >= 0) {
                     store_piece(nxt, wr0 + i - 8);
                 }
-#ifdef OF_W4_PLACE_NOREAD         // A/B variant (tools/ab builds only): all eight pieces of a phase in its gaps without fragment reads
-                if (DMA && dma_on && win >= 0 && win < 2 && i >= 8) dma_piece(dma_slot, win * 8 + (i - 8), win == 0);
-#else
                 if (DMA && dma_on && win >= 0 && win < 2 && (i & 1) == PARC) dma_piece(dma_slot, win * 8 + (i >> 1), win == 0);
-#endif
                 of_sched_fence();
             }
         };
@@ -181,13 +177,9 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
             phase(1, cur, 2, true, nxt, 8, 0, WR, LD, nxt, 2, WR);            // DMA: window phase 2 of stage d+1 -> nxt
             phase(0, cur, 3, true, nxt, -1, 8, WR, LD, nullptr, -1, false);
             if (!DMA && LD) next_stage_src();
-#ifndef OF_ABL_NOVMWAIT         // timing ablations (tools/ab builds only, results WRONG by design): where the stage's wait goes
             if (DMA) of_wait_vm<0>();      // own DMA pieces of stage d+1 have landed ...
-#endif
             of_wait_lgkm0();       // own writes of stage d+1 and reads of this slot are done ...
-#ifndef OF_ABL_NOBARRIER
             of_barrier_raw();      // ... and so are everybody else's
-#endif
             of_sched_fence();
             phase(1, nxt, 0, WR, nxt, -1, -1, false, false, cur, 0, LD);      // DMA: window phase 0 of stage d+2 -> cur (free since the barrier)
             if (DMA) {
@@ -197,7 +189,6 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
         };
 
         int d = 0;
-#ifndef OF_W4_NO_UNROLL2
         // K-contiguous operands only (measured: NT -1..3 %, layouts with transposed-fragment reads +1..2 %): steady state two
         // stages per trip, both slot addresses compile-time constants (fragment reads and M0 values become immediates instead
         // of per-stage address arithmetic bunched into the first MFMA gaps of a phase)
@@ -206,7 +197,6 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4_kernel(OfGemmArgs p) {
                 stage_body(smem, smem + STAGE_BYTES, true, true);
                 stage_body(smem + STAGE_BYTES, smem, true, true);
             }
-#endif
         for (; d + 2 < nd; ++d) stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, true, true);
         if (d + 1 < nd) {
             stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, true, false);

@@ -1,5 +1,5 @@
-// Epilogue of the two 4-wave 256x256 kernels (gemm_w4.hip: two 64-KiB slots; gemm_w4r.hip: ring of four 32-KiB half stages):
-// a wave owns 128 x 128 = 4 x 4 accumulators of 32 x 32 and sends them as eight 32 x 64 groups through a private LDS patch.
+// Epilogue of the 4-wave 256x256 kernel (gemm_w4.hip; kept apart from its K loop: a second K loop on a ring of four half
+// stages shared it -- built, parity-green, 2-8 % slower, removed after commit dd27936): a wave owns 128 x 128 = 4 x 4 accumulators of 32 x 32 and sends them as eight 32 x 64 groups through a private LDS patch.
 // `ring_bytes` = size of the (now idle) operand ring at the start of dynamic LDS; the *_DOT epilogues keep one 4-KiB aux
 // buffer per wave behind it (requested before the K loop) and one inside it.  ASMDMA: LDS-DMA form of the kernel (of_platform.h).
 #pragma once

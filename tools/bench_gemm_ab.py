@@ -115,7 +115,7 @@ def ladder(ops):
 
 
 def ksweep(ops):
-    """us per 1024 of K (slope) and per-launch intercept of the two 4-wave 256x256 kernels: 8192 x 8192, one tile round = 4 per CU"""
+    """us per 1024 of K (slope) and per-launch intercept of the two 256x256 kernels: 8192 x 8192, one tile round = 4 per CU"""
     E = abi
     M = N = 8192
     for ta, tb, epi in ((0, 0, E.EPI_STORE_BF16), (0, 1, E.EPI_STORE_BF16), (1, 1, E.EPI_ACC_F32)):
@@ -123,7 +123,7 @@ def ksweep(ops):
             A, B, C, kw = make(M, N, K, ta, tb, epi)
             rec = dict(ksweep="NT NN ?? TN".split()[ta * 2 + tb], MNK=[M, N, K])
             fns = {"w4dma256": lambda: ops.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=7, **kw),
-                   "w4ring256": lambda: ops.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=16, **kw)}
+                   "pp256": lambda: ops.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=4, **kw)}
             best = {k: 1e9 for k in fns}
             for fn in fns.values():
                 for _ in range(3):
@@ -148,7 +148,7 @@ def main():
     ap.add_argument("--builtin", default=os.path.join(HERE, "ab", "libofhip_builtin_dma.so"),
                     help="same sources as the product library built with -DOF_DMA_VIA_BUILTIN (tools/build_ab_variant.sh)")
     ap.add_argument("--arms", default="", help="comma-separated subset of the arms to time (default: all)")
-    ap.add_argument("--ksweep", action="store_true", help="K sweep at M = N = 8192 of the two 4-wave kernels, three layouts")
+    ap.add_argument("--ksweep", action="store_true", help="K sweep at M = N = 8192 of the 4-wave and the ping-pong kernel, three layouts")
     a = ap.parse_args()
     fam = a.family
     if a.ksweep:
@@ -172,7 +172,6 @@ def main():
             arms["new_mid128"] = lambda: new.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=5, **kw)
             arms["new_pp256"] = lambda: new.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=4, **kw)
             arms["new_w4dma256"] = lambda: new.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=7, **kw)
-            arms["new_w4ring256"] = lambda: new.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=16, **kw)
             if builtin is not None:
                 arms["builtin_w4dma256"] = lambda: builtin.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=7, **kw)
         if a.arms:

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (as run at commit dd27936: the ring kernel were removed from the sources afterwards; results in profiles/)
 # Round 3, sixth GPU call: the 4-wave kernel on the four-slot half-stage ring (gemm_w4r.hip, safe = 16) -- race screen and
 # fused-epilogue parity on hardware, K sweep and same-box A/B against the two-slot 4-wave kernel (safe = 7).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; mkdir -p gpurun_out

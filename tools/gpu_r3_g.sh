@@ -1,4 +1,5 @@
 #!/bin/bash
+# (as run at commit dd27936: the ring kernel and the -DOF_KC_LINE layout were removed from the sources afterwards; results in profiles/)
 # Round 3, seventh GPU call: full-line K-contiguous DMA pieces (-DOF_KC_LINE build) against the product, timing + counters;
 # counters of the two-slot / ring 4-wave kernels and the vendor kernel on the same launch.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; mkdir -p gpurun_out

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (as run at commit dd27936: the -DOF_ABL_* switches were removed from the sources afterwards; results in profiles/)
 # Round 3, eighth GPU call: where the 4-wave kernel's per-stage wait goes -- timing ablations (no vmcnt wait / no barrier / neither)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; mkdir -p gpurun_out
 TAG=${1:-r03h}

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (as run at commit dd27936: the ring kernel and the -DOF_*_PLACE_NOREAD switches were removed from the sources afterwards; results in profiles/)
 # Round 3, tenth GPU call: DMA pieces only in MFMA gaps without fragment reads (two-slot kernel: dense in gaps 8-15 of the two
 # request phases; ring kernel: every other gap of 8-15 of every phase) against the product placements
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; mkdir -p gpurun_out

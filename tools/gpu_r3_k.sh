@@ -1,4 +1,5 @@
 #!/bin/bash
+# (as run at commit dd27936: the -DOF_W4_NO_UNROLL2 switch were removed from the sources afterwards; results in profiles/)
 # Round 3, GPU call: the two-slot 4-wave kernel with scalar LDS addresses for its DMA pieces and (K-contiguous operands only) the
 # steady state unrolled by two stages, against the rolled loop (-DOF_W4_NO_UNROLL2) and the previous build (generic LDS pointers)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; mkdir -p gpurun_out
