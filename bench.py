@@ -288,9 +288,9 @@ def main():
             gsum[2] += 1
         key = max(groups, key=lambda k: groups[k][1])
         fl, ms, n = groups[key]
-        sym = {"w4dma256": "of_gemm_w4_kernel", "pingpong256": "of_gemm_pp_kernel", "mid128": "of_gemm_mid_kernel",
+        sym = {"w4m256": "of_gemm_w4m_kernel", "w4dma256": "of_gemm_w4_kernel", "pingpong256": "of_gemm_pp_kernel", "mid128": "of_gemm_mid_kernel",
                "general128": "of_gemm_kernel", "skinny": "of_gemm_skinny_kernel"}[key[3]]
-        sym += f"<{str(bool(key[0])).lower()}, {str(bool(key[1])).lower()}, {key[2]}, ...>"
+        sym += f"<{str(bool(key[0])).lower()}, {str(bool(key[1])).lower()}, {key[2]}" + (">" if key[3] in ("w4m256", "mid128") else ", ...>")
         shapes = {}
         for k2, _, shape, _, _ in timing:
             if k2 == key:

@@ -314,8 +314,7 @@ static int gemm_grouped(const OfGemmArgs& a, of_stream_t s) {
     if (a.group_kind == 1) {              // y[:, gE:(g+1)E] = x W_g^T
         if (a.b_trans || (a.group_extent % 256) || (a.N % a.group_extent)) return OF_E_SHAPE;
         OfGemmArgs w = a;
-        w.safe = 7;
-        return of_gemm_w4_try(w, s);
+        return of_gemm_w4m_try(w, s);
     }
     if (a.group_kind == 2) {              // dX = sum_g dY[:, gE:(g+1)E] W_g
         if (!a.b_trans || (a.group_extent % 64) || (a.K % a.group_extent)) return OF_E_SHAPE;
@@ -386,14 +385,19 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
         const int rc = of_gemm_w4_try(a, s);
         if (rc != OF_E_SHAPE) return rc;
     }
-    if (a.safe >= 16) return OF_E_ARG;
+    if (a.safe == 16) {                            // force the 4-wave kernel on 16x16x32 MFMAs (gemm_w4m.hip)
+        const int rc = of_gemm_w4m_try(a, s);
+        if (rc != OF_E_SHAPE) return rc;
+    }
+    if (a.safe >= 17) return OF_E_ARG;
     const bool pp_forced = a.safe == 4;
-    // Big-tile selection (measured on MI355X, random operands, same box: profiles/r03b_gemm_ab_*.jsonl): every layout -> the
-    // 4-wave LDS-DMA kernel.  Round 2 sent layouts with a K-strided operand (NN: dX = dY W, TN: dW = dY^T X) to the 8-wave
-    // ping-pong kernel because the 4-wave DMA schedule lost 15-25 % there -- that was hipcc draining the DMA ring in front of
-    // every transposed-fragment read (of_platform.h); with the DMA issued by inline asm the 4-wave kernel is 3-9 % ahead on
-    // those layouts too (NN 8192x2048x8192: 206 vs 221 us; TN: 215 vs 228 us).  The ping-pong kernel keeps the K-grouped B
-    // launches (gemm_grouped) and safe = 4.
+    // Big-tile selection (measured on MI355X, random operands, same box): every layout -> the 4-wave LDS-DMA kernel ON 16x16x32
+    // MFMAs (gemm_w4m.hip).  With every CU busy the K loop is bound by the chip's power budget and the 16x16x32 shape spends
+    // less energy per FLOP than 32x32x16: -7.4..-7.9 % on the K = 8192 launches, -2..-4 % on the K = 2048 ones
+    // (profiles/r03r_gemm_ab_w4m_OF-3B.jsonl).  The same kernel on 32x32x16 stays as safe = 7 (6: register
+    // staged), the 8-wave ping-pong kernel keeps the K-grouped B launches (gemm_grouped) and safe = 4.  History: round 2 sent
+    // layouts with a K-strided operand to the ping-pong kernel because the 4-wave DMA schedule lost 15-25 % there -- that was
+    // hipcc draining the DMA ring in front of every transposed-fragment read (of_platform.h).
     if (a.safe == 0 && pp_ok) {
         // Tile quantisation: a grid whose last round of 256x256 tiles would be under half full (OF-4B: M = 8192, N = 2560 ->
         // 320 tiles = 1.25 rounds of 256 CUs, 790-870 TFLOP/s where full rounds reach 1250) is split along N into whole rounds
@@ -410,19 +414,16 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
             const int aux_bytes = a.epi == OF_EPI_GATE_RESID ? (a.io_f32 ? 4 : 2) : 2;
             OfGemmArgs left = a, right = b;
             left.N = (int)off;
-            left.safe = 7;
             right.N = a.N - (int)off;
             right.B = a.b_trans ? a.B + off : a.B + off * a.ldb;
             right.C = (char*)a.C + off * c_bytes;
             if (a.C2) right.C2 = (char*)a.C2 + off * 2;
             if (a.aux) right.aux = (const char*)a.aux + off * aux_bytes;
-            int rc = of_gemm_w4_try(left, s);
+            int rc = of_gemm_w4m_try(left, s);
             if (rc == 0) rc = of_gemm_mid_try(right, s);
             if (rc != OF_E_SHAPE) return rc;
         }
-        OfGemmArgs w = a;
-        w.safe = 7;
-        const int rc = of_gemm_w4_try(w, s);
+        const int rc = of_gemm_w4m_try(a, s);
         if (rc != OF_E_SHAPE) return rc;
     }
     if ((a.safe == 0 && pp_ok) || pp_forced) {   // 4 = force the ping-pong kernel whenever the shape is eligible

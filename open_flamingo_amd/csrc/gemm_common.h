@@ -199,16 +199,28 @@ OF_DEV void epilogue_group_aux(const OfGemmArgs& p, int m_base, int n_base, int 
 // transposition, math and stores; the first group's is requested before the K loop where registers allow).
 // The four row passes are unrolled with a scheduling fence between them: without the fence the compiler interleaves the four
 // copies of the erf-GELU math of the *_DOT epilogues on top of the live accumulators and spills.
-template <int EPI>
-OF_DEV void epilogue_group(const OfGemmArgs& p, const f32x16& a0, const f32x16& a1, char* patch, int m_base, int n_base, int lane,
-                           float gv, float sc, float& dot, const AuxPre (&pre)[4]) {
+// the wave's two 32x32 MFMA fragments of a group -> its LDS patch (lane l holds row l & 31, columns 8q + 4 (l >> 5) + 0..3)
+OF_DEV void patch_write32(char* patch, const f32x16& a0, const f32x16& a1, int lane) {
     const int wr_off = (lane & 31) * PATCH_PITCH + (lane >> 5) * 16;
-    const int rd_row = lane >> 3, rd_col = (lane & 7) * 8;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         *(f32x4*)(patch + wr_off + (q * 8) * 4) = f32x4{a0[4 * q], a0[4 * q + 1], a0[4 * q + 2], a0[4 * q + 3]};
         *(f32x4*)(patch + wr_off + (32 + q * 8) * 4) = f32x4{a1[4 * q], a1[4 * q + 1], a1[4 * q + 2], a1[4 * q + 3]};
     }
+}
+// the same group held as 2 (M) x 4 (N) fragments of 16x16 MFMAs (lane l holds row l & 15, columns 4 (l >> 4) + 0..3 of a fragment)
+OF_DEV void patch_write16(char* patch, const f32x4 (&t)[2][4], int lane) {
+    const int wr_off = (lane & 15) * PATCH_PITCH + (lane >> 4) * 16;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) *(f32x4*)(patch + wr_off + a * 16 * PATCH_PITCH + b * 64) = t[a][b];
+}
+// the row passes of a group whose accumulators are in the patch (written by this wave, not yet synchronised)
+template <int EPI>
+OF_DEV void epilogue_group_rows(const OfGemmArgs& p, char* patch, int m_base, int n_base, int lane, float gv, float sc, float& dot,
+                                const AuxPre (&pre)[4]) {
+    const int rd_row = lane >> 3, rd_col = (lane & 7) * 8;
     of_wave_sync();
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -219,6 +231,12 @@ OF_DEV void epilogue_group(const OfGemmArgs& p, const f32x16& a0, const f32x16& 
         if (EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT || EPI == OF_EPI_GELU) of_sched_fence();
     }
     of_wave_sync();
+}
+template <int EPI>
+OF_DEV void epilogue_group(const OfGemmArgs& p, const f32x16& a0, const f32x16& a1, char* patch, int m_base, int n_base, int lane,
+                           float gv, float sc, float& dot, const AuxPre (&pre)[4]) {
+    patch_write32(patch, a0, a1, lane);
+    epilogue_group_rows<EPI>(p, patch, m_base, n_base, lane, gv, sc, dot, pre);
 }
 
 // *_DOT epilogues in the big-tile kernels: the saved bf16 activation of a group travels global -> LDS by DMA instead of through
@@ -235,18 +253,12 @@ OF_DEV void epilogue_group_aux_dma(const OfGemmArgs& p, int m_base, int n_base, 
 #pragma unroll
     for (int it = 0; it < 4; ++it) of_glds16<ASM>(src + (size_t)it * 8 * p.ldaux, lds_dst + it * 1024);
 }
-// as epilogue_group with the aux tile in LDS (aux_lds, landed); row passes in a ROLLED loop (one copy of the math)
+// as epilogue_group_rows with the aux tile in LDS (aux_lds, landed); row passes in a ROLLED loop (one copy of the math)
 template <int EPI>
-OF_DEV void epilogue_group_auxlds(const OfGemmArgs& p, const f32x16& a0, const f32x16& a1, char* patch, const char* aux_lds, int m_base,
-                                  int n_base, int lane, float gv, float sc, float& dot) {
+OF_DEV void epilogue_group_rows_auxlds(const OfGemmArgs& p, char* patch, const char* aux_lds, int m_base, int n_base, int lane, float gv,
+                                       float sc, float& dot) {
     static_assert(EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT, "bf16 aux epilogues only");
-    const int wr_off = (lane & 31) * PATCH_PITCH + (lane >> 5) * 16;
     const int rd_row = lane >> 3, rd_col = (lane & 7) * 8;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        *(f32x4*)(patch + wr_off + (q * 8) * 4) = f32x4{a0[4 * q], a0[4 * q + 1], a0[4 * q + 2], a0[4 * q + 3]};
-        *(f32x4*)(patch + wr_off + (32 + q * 8) * 4) = f32x4{a1[4 * q], a1[4 * q + 1], a1[4 * q + 2], a1[4 * q + 3]};
-    }
     of_wave_sync();
 #pragma unroll 1
     for (int it = 0; it < 4; ++it) {
@@ -258,6 +270,12 @@ OF_DEV void epilogue_group_auxlds(const OfGemmArgs& p, const f32x16& a0, const f
         epilogue_row8<EPI>(p, a8, m_base + r, n_base + rd_col, gv, sc, dot, &pre);
     }
     of_wave_sync();
+}
+template <int EPI>
+OF_DEV void epilogue_group_auxlds(const OfGemmArgs& p, const f32x16& a0, const f32x16& a1, char* patch, const char* aux_lds, int m_base,
+                                  int n_base, int lane, float gv, float sc, float& dot) {
+    patch_write32(patch, a0, a1, lane);
+    epilogue_group_rows_auxlds<EPI>(p, patch, aux_lds, m_base, n_base, lane, gv, sc, dot);
 }
 
 // Gate-gradient reduction of the *_DOT epilogues, deterministic: every workgroup writes ONE partial sum (wave sums meet in
@@ -290,6 +308,8 @@ inline bool of_gemm_has_dot(const OfGemmArgs& a) {
 }
 // implemented in gemm_mid.hip (8 waves, 128x128 tile, 4-slot LDS-DMA ring); OF_E_SHAPE when not eligible
 int of_gemm_mid_try(const OfGemmArgs& a, of_stream_t s);
+// implemented in gemm_w4m.hip: the 4-wave 256x256 kernel on 16x16x32 MFMAs; same eligibility and return convention as of_gemm_w4_try
+int of_gemm_w4m_try(const OfGemmArgs& a, of_stream_t s);
 // implemented in gemm_skinny.hip: M <= 16 rows (decode step), HBM-bound weight streaming; OF_E_SHAPE when not eligible
 int of_gemm_skinny_try(const OfGemmArgs& a, of_stream_t s);
 inline bool of_gemm_is_skinny(const OfGemmArgs& a) {

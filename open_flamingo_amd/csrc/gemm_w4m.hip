@@ -1,0 +1,249 @@
+// 256x256 bf16 MFMA GEMM tile, FOUR waves x (128 x 128) per wave, LDS-DMA operands -- the 4-wave kernel of gemm_w4.hip on
+// v_mfma_f32_16x16x32_bf16 instead of v_mfma_f32_32x32x16_bf16 (gfx950).
+//
+// Why a second instruction shape: with every CU busy the big tile's K loop is bound by the chip's POWER budget, not by cycles
+// (1.54 us per stage at ~1.56 GHz on 256 CUs against 0.93 us at ~2.4 GHz on 128).  On random operands a bare stream of
+// 16x16x32 MFMAs sustains 2030 TFLOP/s where the same FLOPs as 32x32x16 sustain 1760 (tools/probes/mfma_power_probe.hip,
+// profiles/r03q_*: both reach 2450 on zeros, i.e. both issue at full rate -- the difference is energy per FLOP: a 32x32x16
+// reads and writes 4x the accumulator registers per operand register it reads).  The vendor library's 256x256x64 kernel uses
+// the same shape.
+//
+// Structure (everything not listed is gemm_w4.hip's: tile mapping, LDS-DMA pieces, the two 64-KiB slots, epilogues):
+//   * a wave owns 128 x 128 = 8 x 8 accumulators of 16 x 16 (256 registers); one 64-deep stage = FOUR phases of 32 MFMAs:
+//     (k-step of 32, half of the wave's rows).  In registers: the 8 B fragments of both k-steps and two sets of 4 A fragments
+//     (96 registers; both operands of a whole k-step double buffered would be 128 and spills);
+//   * stage d lives in slot d & 1.  Phases 0-2 read the rest of the slot (A rows 64-127 of k-step 0, k-step 1), ONE barrier,
+//     phase 3 reads the first fragments of stage d + 1 from the other slot -- the schedule of gemm_w4.hip: A of stage d + 2 is
+//     requested in phase 3 (into the slot the barrier freed), B of stage d + 1 in phase 0, eight pieces over the 32 MFMA gaps
+//     of the phase, odd waves two gaps after the even ones; one vmcnt(0) in front of the barrier covers both;
+//   * LDS images: the K-contiguous image of gemm_tile256.h serves 16-row fragments conflict-free as it is (a lane's 16-byte
+//     slot is (k-step, lane >> 4)); the K-strided image gets one more swizzle bit (piece ^ ((k-row >> 3) & 1)): the four
+//     16-lane groups of a transposed read sit 8 k-rows apart in the same 32-byte column piece.
+#include <type_traits>
+#include "gemm_tile256.h"
+#include "gemm_w4_epi.h"
+
+namespace {
+using namespace oft;
+
+constexpr int SMEM_W4M = NSLOT * STAGE_BYTES;    // 128 KiB
+
+OF_DEV int fT16(int krow) { return ((krow & 3) << 1) ^ ((krow >> 3) & 1); }
+
+// per-lane element offset of 1-KiB chunk c (0..15) of half hf of one operand at k0 = 0 (K-strided: this kernel's swizzle)
+template <bool TR>
+OF_DEV unsigned mchunk_off(long ld, int hf, int c, int lane) {
+    if (!TR) return chunk_off<false>(ld, hf, c, lane);
+    const int krow = c * 4 + (lane >> 4);
+    const int pc = (lane & 15) >> 1, half16 = lane & 1;
+    const int col = hf * 128 + ((pc ^ fT16(krow)) << 4) + half16 * 8;
+    return (unsigned)(krow * ld + col);
+}
+
+// this lane's 16-byte piece of a 16-row operand fragment: k-step ks (32 deep) of the stage.  Lane l holds row l & 15,
+// k = 32 ks + 8 (l >> 4) + 0..7 -- the same k assignment for both operands, which is all the MFMA needs.
+template <bool TR>
+OF_DEV s16x8 mfrag16(const char* oper, int row_base, int ks, int lane) {
+    if (!TR) {
+        const int row = row_base + (lane & 15);
+        const int slot = lane >> 4;       // 16-byte slot of the row's 64 bytes of k-half ks
+        return *(const s16x8*)(oper + (row >> 7) * HALF_BYTES + ((row & 127) >> 3) * 1024 + ks * 512 + (row & 7) * 64 + ((slot ^ fN(row)) << 4));
+    } else {
+        const int q = lane >> 4, i = lane & 15;
+        s16x8 f;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int krow = ks * 32 + q * 8 + hh * 4 + (i >> 2);
+            const int col = row_base + (i & 3) * 4;
+            const int cw = col & 127;
+            s16x4 t = of_lds_tr(oper + (col >> 7) * HALF_BYTES + krow * 256 + ((((cw >> 4)) ^ fT16(krow)) << 5) + ((cw & 15) << 1));
+            f[hh * 4 + 0] = t[0];
+            f[hh * 4 + 1] = t[1];
+            f[hh * 4 + 2] = t[2];
+            f[hh * 4 + 3] = t[3];
+        }
+        return f;
+    }
+}
+
+template <bool AT, bool BT, int EPI>
+OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
+    char* smem = of_smem();
+    const int tid = of_tid(), lane = tid & 63;
+    const int wave = of_uniform(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_m = p.M / TM, tiles_n = p.N / TN;
+    int pm, pn;
+    ofg::tile_coords(of_bid_x(), of_gdim_x(), tiles_m, tiles_n, pm, pn);
+    const int m0 = pm * TM, n0 = pn * TN;
+
+    f32x4 acc[8][8];      // [16-row block of M][16-column block of N]
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[a][b][e] = 0.f;
+
+    // DMA duty of this wave: 1-KiB chunks c = jj*4 + wave (jj = 0..3) of both halves of both operands = 16 pieces per stage
+    const of_buf_t gA = of_buf_make(chunk_base<AT>(p.A, p.lda, m0));
+    const bf16_t* Bmat = p.B;
+    int nB = n0;
+    if (!BT && p.group_kind == 1) {       // grouped B along N: this tile's columns belong to weight matrix n0 / extent
+        const int grp = n0 / p.group_extent;
+        Bmat = (const bf16_t*)p.groups[grp];
+        nB = n0 - grp * p.group_extent;
+    }
+    const of_buf_t gB = of_buf_make(chunk_base<BT>(Bmat, p.ldb, nB));
+    unsigned offA[2][4], offB[2][4];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            offA[hf][jj] = 2u * mchunk_off<AT>(p.lda, hf, jj * 4 + wave, lane);
+            offB[hf][jj] = 2u * mchunk_off<BT>(p.ldb, hf, jj * 4 + wave, lane);
+        }
+    const unsigned stepA = 2u * (AT ? (unsigned)DK * (unsigned)p.lda : (unsigned)DK);
+    const unsigned stepB = 2u * (BT ? (unsigned)DK * (unsigned)p.ldb : (unsigned)DK);
+    unsigned sA = 0, sB = 0;              // scalar byte offsets of the next stage to request
+    const int nd = p.K / DK;
+    const unsigned smem_u = of_lds_base(smem) + (unsigned)wave * 1024u;
+    // piece j (0..15 = op * 8 + hf * 4 + jj) of the stage at (sA, sB) -- ahead = 1: of the stage after it -- into the slot at
+    // byte offset slot_off
+    auto dma_piece = [&](unsigned slot_off, int j, int ahead) OF_INLINE_LAMBDA {
+        const int op = j >> 3, hf = (j >> 2) & 1, jj = j & 3;
+        const unsigned dst = smem_u + slot_off + (unsigned)(op * OPER_BYTES + hf * HALF_BYTES + jj * 4096);
+        if (op == 0) of_buf_load16_lds_at<AT || BT>(gA, offA[hf][jj], sA + (ahead ? stepA : 0u), dst);
+        else of_buf_load16_lds_at<AT || BT>(gB, offB[hf][jj], sB + (ahead ? stepB : 0u), dst);
+    };
+
+    constexpr bool AUXL = EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT;
+    if (AUXL) ofg::epilogue_group_aux_dma<AT || BT>(p, m0 + wm * 128, n0 + wn * 128, lane, smem + SMEM_W4M + wave * ofg::AUX_LDS_BYTES);
+
+    s16x8 fa[2][4], fb[2][8];     // [register buffer][16-row fragment]: B of a whole k-step, A of half of the wave's rows
+    // Fragment reads, one per call.  A stage is four phases (k-step ks = phase >> 1, row half ah = phase & 1 of the wave's 128
+    // rows); fb[ks] holds the 8 B fragments of k-step ks, fa[phase & 1] the 4 A fragments of (ks, ah).
+    auto read_a = [&](const char* stage, int ks, int ah, int buf, int r) OF_INLINE_LAMBDA {
+        fa[buf][r] = mfrag16<AT>(stage, wm * 128 + ah * 64 + r * 16, ks, lane);
+    };
+    auto read_b = [&](const char* stage, int ks, int r) OF_INLINE_LAMBDA {
+        fb[ks][r] = mfrag16<BT>(stage + OPER_BYTES, wn * 128 + r * 16, ks, lane);
+    };
+    // the 12 fragments a phase that starts a k-step needs, in the order of first use: fb0 fa0 fb1 .. fb7 fa1 fa2 fa3
+    auto read_kstep = [&](const char* stage, int ks, int abuf, int r) OF_INLINE_LAMBDA {
+        if (r == 1) read_a(stage, ks, 0, abuf, 0);
+        else if (r < 9) read_b(stage, ks, r == 0 ? 0 : r - 1);
+        else read_a(stage, ks, 0, abuf, r - 8);
+    };
+
+    // ---- prologue: stage 0 landed in slot 0; A of stage 1 requested into slot 1 (what phase 3 of "stage -1" would have done)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dma_piece(0, j, 0);
+    sA += stepA;                       // (sA, sB) = stage 1 from here on: "the next stage"
+    sB += stepB;
+    of_wait_vm<0>();
+    if (nd > 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dma_piece(STAGE_BYTES, j, 0);
+    }
+    of_barrier_raw();
+#pragma unroll
+    for (int r = 0; r < 12; ++r) read_kstep(smem, 0, 0, r);
+
+    // The K loop, compiled once per wave parity (odd waves request their pieces two MFMA gaps after the even ones).
+    auto main_loop = [&](auto parc) OF_INLINE_LAMBDA {
+        constexpr int PARC = decltype(parc)::value;
+        // One phase = 32 MFMAs: B fragments fb[ks] x A fragments fa[ph & 1] (rows 64 (ph & 1) .. of the wave's 128).  Its MFMA gaps
+        // carry the fragment reads of the NEXT phase (4 or 12, from the gap after the previous read on, every other gap) and,
+        // with `dma`, eight LDS-DMA pieces (gaps 4j + 2 PARC).
+        auto phase = [&](int ph, const char* rd_stage, bool rd, unsigned dma_slot, int dma0, bool dma, int ahead) OF_INLINE_LAMBDA {
+            const int ks = ph >> 1, ah = ph & 1;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                of_mfma_acc(fb[ks][i & 7], fa[ph & 1][i >> 3], acc[ah * 4 + (i >> 3)][i & 7]);
+                if (rd && !(i & 1)) {
+                    const int r = i >> 1;
+                    if (ph == 0 || ph == 2) {          // next phase: same k-step, the other row half
+                        if (r < 4) read_a(rd_stage, ks, 1, (ph + 1) & 1, r);
+                    } else if (r < 12) {               // next phase starts a k-step (ph 1: k-step 1 of this stage; ph 3: k-step 0 of the next)
+                        read_kstep(rd_stage, ph == 1 ? 1 : 0, (ph + 1) & 1, r);
+                    }
+                }
+                if (dma && (i & 3) == 2 * PARC) dma_piece(dma_slot, dma0 + (i >> 2), ahead);
+                of_sched_fence();
+            }
+        };
+        // One K stage in slot `cur`.  WR: stage d + 1 exists, LD: stage d + 2 exists.  (sA, sB) = offsets of stage d + 1.
+        auto stage_body = [&](char* cur, char* nxt, const bool WR, const bool LD) OF_INLINE_LAMBDA {
+            const unsigned cur_u = (unsigned)(cur - smem), nxt_u = (unsigned)(nxt - smem);
+            phase(0, cur, true, nxt_u, 8, WR, 0);          // + B of stage d + 1 -> nxt (its A went there in phase 3 of stage d - 1)
+            phase(1, cur, true, 0u, 0, false, 0);
+            phase(2, cur, true, 0u, 0, false, 0);
+            of_wait_vm<0>();       // own pieces of stage d + 1 have landed ...
+            of_wait_lgkm0();       // ... own reads of this slot are done ...
+            of_barrier_raw();      // ... and so are everybody else's
+            of_sched_fence();
+            phase(3, nxt, WR, cur_u, 0, LD, 1);            // + A of stage d + 2 -> cur (free since the barrier)
+            sA += stepA;
+            sB += stepB;
+        };
+        int d = 0;
+        for (; d + 2 < nd; ++d) stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, true, true);
+        if (d + 1 < nd) {
+            stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, true, false);
+            ++d;
+        }
+        stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, false, false);
+    };
+    if (wave & 1) main_loop(std::integral_constant<int, 1>{});
+    else main_loop(std::integral_constant<int, 0>{});
+    of_mfma_acc_settle();
+    of_barrier_raw();          // the ring is idle from here
+
+    w4_epilogue_with<EPI, AT || BT>(
+        p,
+        [&](int g, char* patch) OF_INLINE_LAMBDA {
+            const int mt = g >> 1, np = g & 1;
+            const f32x4 t[2][4] = {{acc[2 * mt][4 * np], acc[2 * mt][4 * np + 1], acc[2 * mt][4 * np + 2], acc[2 * mt][4 * np + 3]},
+                                   {acc[2 * mt + 1][4 * np], acc[2 * mt + 1][4 * np + 1], acc[2 * mt + 1][4 * np + 2], acc[2 * mt + 1][4 * np + 3]}};
+            ofg::patch_write16(patch, t, lane);
+        },
+        smem, SMEM_W4M, m0, n0, wm, wn, wave, lane);
+}
+
+template <bool AT, bool BT, int EPI>
+int launch_w4m(const OfGemmArgs& a, of_stream_t s) {
+    of_dim3 grid{(unsigned)((a.M / TM) * (a.N / TN)), 1, 1};
+    // *_DOT epilogues: + 4 KiB per wave behind the ring for the first group's aux tile
+    constexpr int smem_bytes = SMEM_W4M + ((EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) ? 4 * ofg::AUX_LDS_BYTES : 0);
+    const int rc = of_launch(of_gemm_w4m_kernel<AT, BT, EPI>, grid, 256, smem_bytes, s, a);
+    if (rc || !of_gemm_has_dot(a)) return rc;
+    return of_gemm_dot_finish(a, (int)grid.x, s);
+}
+}  // namespace
+
+int of_gemm_w4m_try(const OfGemmArgs& a, of_stream_t s) {
+    if ((a.M % TM) || (a.N % TN) || (a.K % DK)) return OF_E_SHAPE;
+    const int layout = a.a_trans * 2 + a.b_trans;
+    if (layout == 0) {
+        switch (a.epi) {
+            case OF_EPI_STORE_BF16: return launch_w4m<false, false, OF_EPI_STORE_BF16>(a, s);
+            case OF_EPI_GELU: return launch_w4m<false, false, OF_EPI_GELU>(a, s);
+            case OF_EPI_GATE_RESID: return launch_w4m<false, false, OF_EPI_GATE_RESID>(a, s);
+            case OF_EPI_ACC_F32: return launch_w4m<false, false, OF_EPI_ACC_F32>(a, s);
+        }
+    } else if (layout == 1) {
+        switch (a.epi) {
+            case OF_EPI_STORE_BF16: return launch_w4m<false, true, OF_EPI_STORE_BF16>(a, s);
+            case OF_EPI_DGELU_DOT: return launch_w4m<false, true, OF_EPI_DGELU_DOT>(a, s);
+            case OF_EPI_SCALE_DOT: return launch_w4m<false, true, OF_EPI_SCALE_DOT>(a, s);
+            case OF_EPI_ACC_F32: return launch_w4m<false, true, OF_EPI_ACC_F32>(a, s);
+        }
+    } else if (layout == 3) {
+        switch (a.epi) {
+            case OF_EPI_STORE_BF16: return launch_w4m<true, true, OF_EPI_STORE_BF16>(a, s);
+            case OF_EPI_ACC_F32: return launch_w4m<true, true, OF_EPI_ACC_F32>(a, s);
+        }
+    }
+    return OF_E_SHAPE;
+}

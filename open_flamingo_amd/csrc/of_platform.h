@@ -49,6 +49,12 @@ OF_DEV f32x4 of_mfma(s16x8 a, s16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(of_bf16x8n, a),
                                                    __builtin_bit_cast(of_bf16x8n, b), c, 0, 0, 0);
 }
+// The same accumulating IN PLACE in an accumulation register (AGPR), by inline asm: with 64 such accumulators per wave
+// (gemm_w4m.hip) the builtin form leaves hipcc shuttling accumulators between AGPRs and VGPRs around every MFMA
+// (390 v_accvgpr_* + 74 s_nop per 128 MFMAs in the cross-compiled loop).  Results are read only after of_mfma_acc_settle().
+OF_DEV void of_mfma_acc(s16x8 a, s16x8 b, f32x4& c) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); }
+// the compiler does not see the MFMAs inside the asm: cover the MFMA-write -> read hazard before the accumulators are used
+OF_DEV void of_mfma_acc_settle() { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); }
 // D(32x32, f32) += A(32x16 bf16) * B(16x32 bf16).  Lane l supplies A[l&31][8*(l>>5)+0..7] and B[8*(l>>5)+0..7][l&31];
 // it receives D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31], r=0..15 (cdna_hip_programming.md section 3).
 OF_DEV f32x16 of_mfma32(s16x8 a, s16x8 b, f32x16 c) {

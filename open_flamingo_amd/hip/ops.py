@@ -63,7 +63,7 @@ class Ops:
         if M <= 16 and not ta and not tb:
             return "skinny"
         if M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and (M // 256) * (N // 256) >= 128:
-            return "w4dma256"
+            return "w4m256"
         if M % 128 == 0 and N % 128 == 0 and K % 64 == 0:
             return "mid128"
         return "general128"

@@ -109,7 +109,8 @@ def test_gemm_narrow_tiles_match_wide_tiles(at, bt, M, N, K):
     np.testing.assert_allclose(o_n.double().numpy(), _ref(A, B, at, bt).numpy(), rtol=1e-5, atol=1e-4)
 
 
-BIG_TILE = [4, 6, 7]   # OfGemmArgs.safe: 4 = 8-wave ping-pong LDS-DMA kernel, 6 / 7 = 4-wave 128x128-per-wave kernel (register staged / LDS-DMA)
+BIG_TILE = [4, 6, 7, 16]   # OfGemmArgs.safe: 4 = 8-wave ping-pong LDS-DMA kernel, 6 / 7 = 4-wave 128x128-per-wave kernel (register staged / LDS-DMA),
+                           # 16 = the 4-wave LDS-DMA kernel on 16x16x32 MFMAs
 
 
 @pytest.mark.parametrize("big", BIG_TILE)
@@ -188,7 +189,7 @@ def test_gemm_mid_kernel_epilogues_and_auto_selection():
             assert abs(float(dot) - 3.0 - float(wdot)) <= 1e-3 * abs(float(wdot)) + 1e-2
 
 
-@pytest.mark.parametrize("safe", [2, 4, 5, 6, 7])
+@pytest.mark.parametrize("safe", [2, 4, 5, 6, 7, 16])
 def test_gate_gradient_dot_is_deterministic_and_needs_its_workspace(safe):
     """The *_DOT epilogues reduce the gate gradient from per-workgroup partials in a fixed order (no floating-point atomics):
     repeated launches give the same BITS whatever order the workgroups ran in (the emulator runs them on parallel host threads);

@@ -232,7 +232,7 @@ def test_layernorm(ops, x_f32):
     assert _rel(dw, wd.grad) < 1e-3 and _rel(db, bd.grad) < 1e-3
 
 
-@pytest.mark.parametrize("big", [4, 6, 7])
+@pytest.mark.parametrize("big", [4, 6, 7, 16])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
 def test_gemm_pingpong_race_screen(ops, ta, tb, big):
     """The 256x256 kernels (safe=4: 8-wave ping-pong, LDS-DMA slots ordered only by counted vmcnt + segment barriers;
@@ -423,7 +423,7 @@ def _close(got, want, name, rtol=1e-2, atol_rms=2e-3, l2=4e-3):
     assert e <= l2, f"{name}: rel L2 {e:.3e}"
 
 
-@pytest.mark.parametrize("safe", [0, 4, 6, 7])
+@pytest.mark.parametrize("safe", [0, 4, 6, 7, 16])
 def test_big_tile_gemm_fused_epilogues_at_benchmark_shapes(ops, safe):
     """The launches bench.py times at BASELINE config 2 (per gated block: rows = B*L = 8192, d = 2048, hidden 8192) run the
     256x256 kernel with FUSED epilogues; small-batch tests select the 128x128 kernel.  Every (layout, epilogue) pair the
@@ -433,7 +433,7 @@ def test_big_tile_gemm_fused_epilogues_at_benchmark_shapes(ops, safe):
     gate = torch.tensor([0.37], device="cuda")
     g = float(torch.tanh(gate))
     rows, d, hid, inner = 8192, 2048, 8192, 512
-    assert Ops.kernel_label(rows, hid, d, False, False) == "w4dma256" and Ops.kernel_label(rows, d, hid, False, True) == "w4dma256"
+    assert Ops.kernel_label(rows, hid, d, False, False) == "w4m256" and Ops.kernel_label(rows, d, hid, False, True) == "w4m256"
     # ---- up-projection + erf-GELU, two outputs (pre-activation kept for the backward): NT 8192 x 8192 x 2048
     u, W1 = _r((rows, d), 41), _r((hid, d), 42, d ** -0.5)
     acc = u.float() @ W1.float().t()

@@ -123,7 +123,7 @@ def ksweep(ops):
             A, B, C, kw = make(M, N, K, ta, tb, epi)
             rec = dict(ksweep="NT NN ?? TN".split()[ta * 2 + tb], MNK=[M, N, K])
             fns = {"w4dma256": lambda: ops.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=7, **kw),
-                   "pp256": lambda: ops.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=4, **kw)}
+                   "w4m256": lambda: ops.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=16, **kw)}
             best = {k: 1e9 for k in fns}
             for fn in fns.values():
                 for _ in range(3):
@@ -148,7 +148,7 @@ def main():
     ap.add_argument("--builtin", default=os.path.join(HERE, "ab", "libofhip_builtin_dma.so"),
                     help="same sources as the product library built with -DOF_DMA_VIA_BUILTIN (tools/build_ab_variant.sh)")
     ap.add_argument("--arms", default="", help="comma-separated subset of the arms to time (default: all)")
-    ap.add_argument("--ksweep", action="store_true", help="K sweep at M = N = 8192 of the 4-wave and the ping-pong kernel, three layouts")
+    ap.add_argument("--ksweep", action="store_true", help="K sweep at M = N = 8192 of the 4-wave kernel on 32x32x16 and on 16x16x32 MFMAs, three layouts")
     a = ap.parse_args()
     fam = a.family
     if a.ksweep:
@@ -172,6 +172,7 @@ def main():
             arms["new_mid128"] = lambda: new.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=5, **kw)
             arms["new_pp256"] = lambda: new.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=4, **kw)
             arms["new_w4dma256"] = lambda: new.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=7, **kw)
+            arms["new_w4m256"] = lambda: new.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=16, **kw)      # 16x16x32 MFMAs
             if builtin is not None:
                 arms["builtin_w4dma256"] = lambda: builtin.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=7, **kw)
         if a.arms:

@@ -30,11 +30,12 @@ __global__ void __launch_bounds__(256, 1) probe(const s16x8* __restrict__ src, f
             for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)          // one "stage": 64 MFMAs = 4 k-steps x 4 x 4 fragments
+            for (int k = 0; k < 4; ++k)          // one "stage": 64 MFMAs = 4 k-steps x 4 x 4 fragments, accumulators in place (AGPRs)
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(i >> 2) + (k & 1) * 4], b[(i & 3) + (k >> 1) * 4], acc[i], 0, 0, 0);
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a[(i >> 2) + (k & 1) * 4]), "v"(b[(i & 3) + (k >> 1) * 4]));
         }
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
 #pragma unroll
         for (int i = 0; i < 16; ++i)
 #pragma unroll
@@ -47,11 +48,12 @@ __global__ void __launch_bounds__(256, 1) probe(const s16x8* __restrict__ src, f
             for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k)          // one "stage": 128 MFMAs = 2 k-steps x 8 x 8 fragments
+            for (int k = 0; k < 2; ++k)          // one "stage": 128 MFMAs = 2 k-steps x 8 x 8 fragments, accumulators in place (AGPRs)
 #pragma unroll
                 for (int i = 0; i < 64; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(i >> 3)], b[(i & 7)], acc[i], 0, 0, 0);
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a[(i >> 3)]), "v"(b[(i & 7)]));
         }
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // MFMA results -> VALU reads
 #pragma unroll
         for (int i = 0; i < 64; ++i)
 #pragma unroll
