@@ -74,13 +74,14 @@ typedef struct OfGemmArgs {
                           otherwise) and a second one-workgroup launch adds the partials in a fixed order -- no fp atomics */
     int io_f32;        /* OF_EPI_GATE_RESID: 1 = fp32 stream, 0 = bf16 stream */
     int safe;          /* DEBUG / SELF-CHECK ONLY -- production callers pass 0 (auto: M <= 16 untransposed -> weight-streaming
-                          skinny kernel; tile-aligned shapes that fill the chip -> a 256x256 big-tile kernel; otherwise the
-                          general 128x128 kernel, split along K when the output is small).  Non-zero values force one
+                          skinny kernel; tile-aligned shapes that fill the chip -> the 4-wave 256x256 kernel on 16x16x32
+                          MFMAs; tile-aligned smaller shapes -> the 8-wave 128x128 LDS-DMA kernel; otherwise the general
+                          128x128 kernel, split along K when the output is small).  Non-zero values force one
                           correct kernel so tests can compare kernels with each other: 1 = general kernel, slow scalar-LDS
                           transposed-fragment path; 2 = general kernel; 3 = general kernel with 128 x 64 tiles; 4 = 8-wave ping-pong big-tile kernel;
                           5 = 8-wave LDS-DMA 128x128 kernel; 6 / 7 = 4-wave
-                          big-tile kernel (register-staged / LDS-DMA operands); 8..15 = general kernel with 2^(safe-8) K
-                          slices.  Every value the product library accepts gives correct results; anything else returns
+                          big-tile kernel on 32x32x16 MFMAs (register-staged / LDS-DMA operands); 8..15 = general kernel with
+                          2^(safe-8) K slices; 16 = 4-wave LDS-DMA big-tile kernel on 16x16x32 MFMAs (what 0 selects).  Every value the product library accepts gives correct results; anything else returns
                           OF_E_ARG (timing ablations live in tools/libofhip_tools.so, built with -DOF_TOOLS_BUILD, never
                           shipped). */
     int ksplit;        /* internal: filled in by of_gemm (number of K slices of a split-K launch); callers pass 0 */

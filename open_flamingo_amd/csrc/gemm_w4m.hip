@@ -188,6 +188,13 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
             sB += stepB;
         };
         int d = 0;
+        // K-contiguous operands only (as gemm_w4.hip: NT -1..3 %, layouts with transposed-fragment reads +1..2 %): steady state two
+        // stages per trip, slot addresses compile-time constants
+        if (!(AT || BT))
+            for (; d + 3 < nd; d += 2) {
+                stage_body(smem, smem + STAGE_BYTES, true, true);
+                stage_body(smem + STAGE_BYTES, smem, true, true);
+            }
         for (; d + 2 < nd; ++d) stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, true, true);
         if (d + 1 < nd) {
             stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, true, false);

@@ -30,6 +30,10 @@ F32 = torch.float32
 # dX GEMMs of the frozen blocks against pre-transposed weight copies (see _transposed); same-box A/B, round 2: 123.2 -> 121.8 ms
 # per step (a tool that wants the other arm sets this module attribute; the product reads no environment switch)
 _DX_PRETRANSPOSED = True
+# Frozen MPT MLP: which of its two GEMMs run as ONE of_gemm launch with a fused epilogue instead of vendor GEMM + element-wise pass
+# (constants, set from measurements: DESIGN.md 4.9; tools/ab_frozen_mlp.py flips them for the same-box A/B)
+_MLP_FUSED_UP = False      # up_proj + erf-GELU (OF_EPI_GELU; the pre-activation is kept for the backward)
+_MLP_FUSED_DOWN = False    # down_proj + residual add into the fp32 stream (OF_EPI_GATE_RESID without a gate)
 
 
 def _ops():
@@ -93,9 +97,22 @@ class _FrozenMptBlockFn(torch.autograd.Function):
         m = torch.empty(rows, d, dtype=BF16, device=dev)
         st2 = torch.empty(rows, 2, dtype=F32, device=dev)
         ops.ln_fwd_add(x2, t, x1, w2, b2, m, st2)                    # x1 = x + attn branch;  m = norm_2(x1)
-        h = torch.mm(m, Wup.t())
-        u = torch.mm(ops.gelu_fwd(h), Wdown.t())
-        y = ops.add_bf16(x1, u)                                      # fp32 stream + bf16 branch -> fp32
+        if _MLP_FUSED_UP:
+            from ..hip import abi
+            h = torch.empty(rows, Wup.shape[0], dtype=BF16, device=dev)
+            g = torch.empty_like(h)
+            ops.gemm(m, Wup, g, epi=abi.EPI_GELU, out2=h)            # g = gelu(m Wup^T) from the fp32 accumulator, h = pre-activation
+        else:
+            h = torch.mm(m, Wup.t())
+            g = ops.gelu_fwd(h)
+        if _MLP_FUSED_DOWN:
+            from ..hip import abi
+            y = torch.empty(rows, d, dtype=F32, device=dev)
+            ops.gemm(g, Wdown, y, epi=abi.EPI_GATE_RESID, aux=x1)    # y = x1 + g Wdown^T (no gate: plain residual), fp32 stream
+        else:
+            u = torch.mm(g, Wdown.t())
+            y = ops.add_bf16(x1, u)                                  # fp32 stream + bf16 branch -> fp32
+        del g
         ctx.save_for_backward(x2, st1, qkv, o, lse, x1, st2, h, w1, w2, Wqkv, Wo, Wup, Wdown, slopes, kv_len)
         ctx.kw, ctx.shape, ctx.wts = kw, (B, L, d), wts      # wts: (Wqkv^T, Wo^T, Wup^T, Wdown^T) or None: frozen, not autograd inputs
         return y.view(B, L, d)

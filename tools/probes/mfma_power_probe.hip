@@ -12,7 +12,7 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int SHAPE>
+template <int SHAPE, int ORDER>
 __global__ void __launch_bounds__(256, 1) probe(const s16x8* __restrict__ src, float* __restrict__ out, int iters) {
     const int lane = threadIdx.x;
     s16x8 a[8], b[8];
@@ -51,7 +51,11 @@ __global__ void __launch_bounds__(256, 1) probe(const s16x8* __restrict__ src, f
             for (int k = 0; k < 2; ++k)          // one "stage": 128 MFMAs = 2 k-steps x 8 x 8 fragments, accumulators in place (AGPRs)
 #pragma unroll
                 for (int i = 0; i < 64; ++i)
-                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a[(i >> 3)]), "v"(b[(i & 7)]));
+                {
+                    if (ORDER == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a[(i >> 3)]), "v"(b[(i & 7)]));
+                    else if (ORDER == 1) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a[(i & 7)]), "v"(b[(i >> 3)]));
+                    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a[(i & 7)]), "v"(b[((i & 7) + (i >> 3)) & 7]));
+                }
         }
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // MFMA results -> VALU reads
 #pragma unroll
@@ -83,13 +87,15 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int shape : {32, 16, 32, 16}) {
+    for (int shape : {32, 16, 161, 162, 32, 16, 161, 162}) {
         float best = 1e9f;
         for (int rep = 0; rep < 6; ++rep) {
             hipEventRecord(e0);
             for (int j = 0; j < 10; ++j) {
-                if (shape == 32) probe<32><<<grid, 256>>>(d, o, iters);
-                else probe<16><<<grid, 256>>>(d, o, iters);
+                if (shape == 32) probe<32, 0><<<grid, 256>>>(d, o, iters);
+                else if (shape == 16) probe<16, 0><<<grid, 256>>>(d, o, iters);
+                else if (shape == 161) probe<16, 1><<<grid, 256>>>(d, o, iters);
+                else probe<16, 2><<<grid, 256>>>(d, o, iters);
             }
             hipEventRecord(e1);
             hipEventSynchronize(e1);
@@ -98,7 +104,7 @@ int main(int argc, char** argv) {
             if (ms / 10 < best) best = ms / 10;
         }
         const double flops = 2.0 * 256 * 256 * 64 * (double)iters * grid;      // one 256x256x64 stage per iteration per workgroup
-        printf("{\"mfma\": \"%s\", \"fill\": \"%s\", \"stages\": %d, \"us\": %.1f, \"tflops\": %.0f}\n", shape == 32 ? "32x32x16" : "16x16x32",
+        printf("{\"mfma\": \"%s\", \"fill\": \"%s\", \"stages\": %d, \"us\": %.1f, \"tflops\": %.0f}\n", shape == 32 ? "32x32x16" : shape == 16 ? "16x16x32 first operand held over 8" : shape == 161 ? "16x16x32 second operand held over 8" : "16x16x32 both operands change",
                zeros ? "zeros" : "random", iters, best * 1e3, flops / best / 1e9);
     }
     return 0;
