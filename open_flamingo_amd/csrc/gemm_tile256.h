@@ -88,4 +88,45 @@ OF_DEV s16x8 frag32(const char* oper, int row_base, int h, int ks, int lane) {
     }
 }
 
+OF_DEV int fT16(int krow) { return ((krow & 3) << 1) ^ ((krow >> 3) & 1); }
+
+// ---- the same images for kernels on 16x16x32 MFMAs (gemm_w4m.hip, gemm_mid.hip): 16-row fragments.  The K-contiguous image
+// serves them conflict-free as it is; the K-strided image gets one more swizzle bit (piece ^ ((k-row >> 3) & 1)): the four
+// 16-lane groups of a transposed read sit 8 k-rows apart in the same 32-byte column piece.
+// per-lane element offset of 1-KiB chunk c (0..15) of half hf of one operand at k0 = 0
+template <bool TR>
+OF_DEV unsigned mchunk_off(long ld, int hf, int c, int lane) {
+    if (!TR) return chunk_off<false>(ld, hf, c, lane);
+    const int krow = c * 4 + (lane >> 4);
+    const int pc = (lane & 15) >> 1, half16 = lane & 1;
+    const int col = hf * 128 + ((pc ^ fT16(krow)) << 4) + half16 * 8;
+    return (unsigned)(krow * ld + col);
+}
+
+// this lane's 16-byte piece of a 16-row operand fragment: k-step ks (32 deep) of the stage.  Lane l holds row l & 15,
+// k = 32 ks + 8 (l >> 4) + 0..7 -- the same k assignment for both operands, which is all the MFMA needs.
+template <bool TR>
+OF_DEV s16x8 mfrag16(const char* oper, int row_base, int ks, int lane) {
+    if (!TR) {
+        const int row = row_base + (lane & 15);
+        const int slot = lane >> 4;       // 16-byte slot of the row's 64 bytes of k-half ks
+        return *(const s16x8*)(oper + (row >> 7) * HALF_BYTES + ((row & 127) >> 3) * 1024 + ks * 512 + (row & 7) * 64 + ((slot ^ fN(row)) << 4));
+    } else {
+        const int q = lane >> 4, i = lane & 15;
+        s16x8 f;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int krow = ks * 32 + q * 8 + hh * 4 + (i >> 2);
+            const int col = row_base + (i & 3) * 4;
+            const int cw = col & 127;
+            s16x4 t = of_lds_tr(oper + (col >> 7) * HALF_BYTES + krow * 256 + ((((cw >> 4)) ^ fT16(krow)) << 5) + ((cw & 15) << 1));
+            f[hh * 4 + 0] = t[0];
+            f[hh * 4 + 1] = t[1];
+            f[hh * 4 + 2] = t[2];
+            f[hh * 4 + 3] = t[3];
+        }
+        return f;
+    }
+}
+
 }  // namespace oft

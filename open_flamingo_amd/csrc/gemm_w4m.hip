@@ -28,46 +28,9 @@ using namespace oft;
 
 constexpr int SMEM_W4M = NSLOT * STAGE_BYTES;    // 128 KiB
 
-OF_DEV int fT16(int krow) { return ((krow & 3) << 1) ^ ((krow >> 3) & 1); }
-
-// per-lane element offset of 1-KiB chunk c (0..15) of half hf of one operand at k0 = 0 (K-strided: this kernel's swizzle)
-template <bool TR>
-OF_DEV unsigned mchunk_off(long ld, int hf, int c, int lane) {
-    if (!TR) return chunk_off<false>(ld, hf, c, lane);
-    const int krow = c * 4 + (lane >> 4);
-    const int pc = (lane & 15) >> 1, half16 = lane & 1;
-    const int col = hf * 128 + ((pc ^ fT16(krow)) << 4) + half16 * 8;
-    return (unsigned)(krow * ld + col);
-}
-
-// this lane's 16-byte piece of a 16-row operand fragment: k-step ks (32 deep) of the stage.  Lane l holds row l & 15,
-// k = 32 ks + 8 (l >> 4) + 0..7 -- the same k assignment for both operands, which is all the MFMA needs.
-template <bool TR>
-OF_DEV s16x8 mfrag16(const char* oper, int row_base, int ks, int lane) {
-    if (!TR) {
-        const int row = row_base + (lane & 15);
-        const int slot = lane >> 4;       // 16-byte slot of the row's 64 bytes of k-half ks
-        return *(const s16x8*)(oper + (row >> 7) * HALF_BYTES + ((row & 127) >> 3) * 1024 + ks * 512 + (row & 7) * 64 + ((slot ^ fN(row)) << 4));
-    } else {
-        const int q = lane >> 4, i = lane & 15;
-        s16x8 f;
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int krow = ks * 32 + q * 8 + hh * 4 + (i >> 2);
-            const int col = row_base + (i & 3) * 4;
-            const int cw = col & 127;
-            s16x4 t = of_lds_tr(oper + (col >> 7) * HALF_BYTES + krow * 256 + ((((cw >> 4)) ^ fT16(krow)) << 5) + ((cw & 15) << 1));
-            f[hh * 4 + 0] = t[0];
-            f[hh * 4 + 1] = t[1];
-            f[hh * 4 + 2] = t[2];
-            f[hh * 4 + 3] = t[3];
-        }
-        return f;
-    }
-}
-
 template <bool AT, bool BT, int EPI>
 OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
+    constexpr bool ASMD = AT || BT;       // LDS-DMA form (of_platform.h): inline asm wherever a transposed-fragment read follows
     char* smem = of_smem();
     const int tid = of_tid(), lane = tid & 63;
     const int wave = of_uniform(tid >> 6);
@@ -113,12 +76,12 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
     auto dma_piece = [&](unsigned slot_off, int j, int ahead) OF_INLINE_LAMBDA {
         const int op = j >> 3, hf = (j >> 2) & 1, jj = j & 3;
         const unsigned dst = smem_u + slot_off + (unsigned)(op * OPER_BYTES + hf * HALF_BYTES + jj * 4096);
-        if (op == 0) of_buf_load16_lds_at<AT || BT>(gA, offA[hf][jj], sA + (ahead ? stepA : 0u), dst);
-        else of_buf_load16_lds_at<AT || BT>(gB, offB[hf][jj], sB + (ahead ? stepB : 0u), dst);
+        if (op == 0) of_buf_load16_lds_at<ASMD>(gA, offA[hf][jj], sA + (ahead ? stepA : 0u), dst);
+        else of_buf_load16_lds_at<ASMD>(gB, offB[hf][jj], sB + (ahead ? stepB : 0u), dst);
     };
 
     constexpr bool AUXL = EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT;
-    if (AUXL) ofg::epilogue_group_aux_dma<AT || BT>(p, m0 + wm * 128, n0 + wn * 128, lane, smem + SMEM_W4M + wave * ofg::AUX_LDS_BYTES);
+    if (AUXL) ofg::epilogue_group_aux_dma<ASMD>(p, m0 + wm * 128, n0 + wn * 128, lane, smem + SMEM_W4M + wave * ofg::AUX_LDS_BYTES);
 
     s16x8 fa[2][4], fb[2][8];     // [register buffer][16-row fragment]: B of a whole k-step, A of half of the wave's rows
     // Fragment reads, one per call.  A stage is four phases (k-step ks = phase >> 1, row half ah = phase & 1 of the wave's 128
@@ -188,13 +151,9 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
             sB += stepB;
         };
         int d = 0;
-        // K-contiguous operands only (as gemm_w4.hip: NT -1..3 %, layouts with transposed-fragment reads +1..2 %): steady state two
-        // stages per trip, slot addresses compile-time constants
-        if (!(AT || BT))
-            for (; d + 3 < nd; d += 2) {
-                stage_body(smem, smem + STAGE_BYTES, true, true);
-                stage_body(smem + STAGE_BYTES, smem, true, true);
-            }
+        // (gemm_w4.hip unrolls its NT steady state by two stages for compile-time slot addresses: -1..3 %.  Here the same unrolling
+        // gave deterministic WRONG results on hardware -- with the builtin and with the asm DMA form alike, emulator green -- and
+        // was taken out again, unexplained: DESIGN.md 4.1.)
         for (; d + 2 < nd; ++d) stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, true, true);
         if (d + 1 < nd) {
             stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, true, false);
@@ -207,7 +166,7 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
     of_mfma_acc_settle();
     of_barrier_raw();          // the ring is idle from here
 
-    w4_epilogue_with<EPI, AT || BT>(
+    w4_epilogue_with<EPI, ASMD>(
         p,
         [&](int g, char* patch) OF_INLINE_LAMBDA {
             const int mt = g >> 1, np = g & 1;
