@@ -152,8 +152,16 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
         };
         int d = 0;
         // (gemm_w4.hip unrolls its NT steady state by two stages for compile-time slot addresses: -1..3 %.  Here the same unrolling
-        // gave deterministic WRONG results on hardware -- with the builtin and with the asm DMA form alike, emulator green -- and
-        // was taken out again, unexplained: DESIGN.md 4.1.)
+        // gives deterministic WRONG results on hardware -- stage 0 loses 16 of its 64 k for part of the tile, with the builtin and the
+        // asm DMA form alike, emulator green (tools/probes/w4m_unroll_diag.py, profiles/r03y_*) -- and no speed (+-1 %); not
+        // understood, not in the product.  -DOF_W4M_UNROLL2 (tools/ab builds only) reproduces it.)
+#ifdef OF_W4M_UNROLL2
+        if (!(AT || BT))
+            for (; d + 3 < nd; d += 2) {
+                stage_body(smem, smem + STAGE_BYTES, true, true);
+                stage_body(smem + STAGE_BYTES, smem, true, true);
+            }
+#endif
         for (; d + 2 < nd; ++d) stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, true, true);
         if (d + 1 < nd) {
             stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, true, false);

@@ -159,8 +159,16 @@ OF_DEV void of_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 OF_DEV void of_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-// bare s_barrier (no implicit vmcnt(0) drain, unlike __syncthreads with LDS-DMA in flight)
-OF_DEV void of_barrier_raw() { __builtin_amdgcn_s_barrier(); }
+// bare s_barrier (no implicit vmcnt(0) drain, unlike __syncthreads with LDS-DMA in flight) -- fenced for the COMPILER on both
+// sides: llvm.amdgcn.s.barrier is IntrNoMem, so nothing but these two empty asm statements tells hipcc that LDS reads must not
+// move across it (the kernels' loops happen to have an asm s_waitcnt in front of every barrier; their prologues and epilogues do
+// not).  Added in round 3 while chasing wrong results of an unrolled K loop (gemm_w4m.hip, -DOF_W4M_UNROLL2): it changed the
+// register allocation of the GEMM kernels, not their order, and it did NOT cure that build -- kept as the correct contract.
+OF_DEV void of_barrier_raw() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 OF_DEV float of_shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 OF_DEV int of_shfl_xor_i(int v, int m) { return __shfl_xor(v, m, 64); }
 OF_DEV float of_shfl(float v, int src) { return __shfl(v, src, 64); }
