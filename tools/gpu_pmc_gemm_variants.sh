@@ -4,10 +4,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
 TAG=${1:-t}; shift; OUT=gpurun_out/pmc_variants_$TAG; rm -rf $OUT; mkdir -p $OUT
 i=0; fails=0
-for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
-         "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "TD_TD_BUSY_sum TA_TA_BUSY_sum TA_BUSY_avr" "TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
-         "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCP_TOTAL_ACCESSES_sum TCP_TA_TCP_STATE_READ_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
-         "TCP_GATE_EN1_sum TCP_GATE_EN2_sum" "TCP_TD_TCP_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum" "TCC_HIT_sum TCC_MISS_sum"; do
+for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TD_TD_BUSY_sum TA_TA_BUSY_sum"; do
   i=$((i+1))
   timeout 100 rocprofv3 --pmc $c --kernel-trace -d $OUT/p$i -o run --output-format csv -- python tools/pmc_gemm_variants.py "$@" > $OUT/p$i.log 2>&1 || { echo "pass $i ($c) failed: $(grep -m2 -i "fault\|error" $OUT/p$i.log)"; fails=$((fails+1)); [ $fails -ge 2 ] && break; }
 done

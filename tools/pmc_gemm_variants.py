@@ -3,7 +3,7 @@
     python tools/pmc_gemm_variants.py [--lib path.so] [--layouts NT,NN,TN]
 
 8192 x 2048 x 8192 (one 256x256 tile per CU, 128 stages), bf16 store / fp32 accumulate epilogue, random operands: the
-4-wave kernel (safe = 7), the 8-wave ping-pong kernel (safe = 4) and the vendor library (torch.mm).  (profiles/r03g_*: run at
+4-wave kernel on 32x32x16 (safe = 7) and on 16x16x32 MFMAs (safe = 16) and the vendor library (torch.mm).  (profiles/r03g_*: run at
 commit dd27936, which still had the half-stage-ring variant of the 4-wave kernel as safe = 16.)  PROFILING TOOL."""
 import argparse, ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +14,7 @@ from open_flamingo_amd.hip.ops import Ops
 ap = argparse.ArgumentParser()
 ap.add_argument("--lib", default="")
 ap.add_argument("--layouts", default="NT,TN")
-ap.add_argument("--safes", default="7,4")
+ap.add_argument("--safes", default="7,16")
 a = ap.parse_args()
 if a.lib:
     lib = ctypes.CDLL(a.lib)
