@@ -103,13 +103,13 @@ struct AuxPre {
     u32x4 lo, hi;      // bf16 aux: lo only (8 values); fp32 aux: lo | hi (2 x 4 values)
 };
 template <int EPI>
-OF_DEV AuxPre epilogue_aux_load(const OfGemmArgs& p, int m, int n) {
+OF_DEV AuxPre epilogue_aux_load(const OfGemmArgs& p, int m, int n, int hi = 4) {
     AuxPre r{};
     if (EPI == OF_EPI_GATE_RESID) {
         const size_t aoff = (size_t)m * p.ldaux + n;
         if (p.io_f32) {
             r.lo = *(const u32x4*)((const float*)p.aux + aoff);
-            r.hi = *(const u32x4*)((const float*)p.aux + aoff + 4);
+            r.hi = *(const u32x4*)((const float*)p.aux + aoff + hi);
         } else {
             r.lo = *(const u32x4*)((const bf16_t*)p.aux + aoff);
         }
@@ -118,9 +118,11 @@ OF_DEV AuxPre epilogue_aux_load(const OfGemmArgs& p, int m, int n) {
     }
     return r;
 }
+// `hi`: column distance of a[4..7] from a[0..3] in the fp32-output forms (4: eight consecutive n; 32: the split lane map of
+// epilogue_group_rows); the bf16-output forms always take eight consecutive n.
 template <int EPI>
 OF_DEV void epilogue_row8(const OfGemmArgs& p, const float (&a)[8], int m, int n, float gv, float sc, float& dot,
-                          const AuxPre* pre = nullptr) {
+                          const AuxPre* pre = nullptr, int hi = 4) {
     const size_t off = (size_t)m * p.ldc + n;
     float o[8];
     if (EPI == OF_EPI_STORE_BF16) {
@@ -136,9 +138,9 @@ OF_DEV void epilogue_row8(const OfGemmArgs& p, const float (&a)[8], int m, int n
         const size_t aoff = (size_t)m * p.ldaux + n;
         if (p.io_f32) {
             const f32x4 r0 = pre ? __builtin_bit_cast(f32x4, pre->lo) : *(const f32x4*)((const float*)p.aux + aoff);
-            const f32x4 r1 = pre ? __builtin_bit_cast(f32x4, pre->hi) : *(const f32x4*)((const float*)p.aux + aoff + 4);
+            const f32x4 r1 = pre ? __builtin_bit_cast(f32x4, pre->hi) : *(const f32x4*)((const float*)p.aux + aoff + hi);
             *(f32x4*)((float*)p.C + off) = f32x4{r0[0] + sc * a[0], r0[1] + sc * a[1], r0[2] + sc * a[2], r0[3] + sc * a[3]};
-            *(f32x4*)((float*)p.C + off + 4) = f32x4{r1[0] + sc * a[4], r1[1] + sc * a[5], r1[2] + sc * a[6], r1[3] + sc * a[7]};
+            *(f32x4*)((float*)p.C + off + hi) = f32x4{r1[0] + sc * a[4], r1[1] + sc * a[5], r1[2] + sc * a[6], r1[3] + sc * a[7]};
         } else {
             float r[8];
             unpack8(pre ? pre->lo : *(const u32x4*)((const bf16_t*)p.aux + aoff), r);
@@ -166,7 +168,7 @@ OF_DEV void epilogue_row8(const OfGemmArgs& p, const float (&a)[8], int m, int n
         float* c = (float*)p.C + off;
         f32x4 o0 = {sc * a[0], sc * a[1], sc * a[2], sc * a[3]}, o1 = {sc * a[4], sc * a[5], sc * a[6], sc * a[7]};
         if (p.beta != 0.f) {
-            const f32x4 c0 = *(const f32x4*)c, c1 = *(const f32x4*)(c + 4);
+            const f32x4 c0 = *(const f32x4*)c, c1 = *(const f32x4*)(c + hi);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 o0[e] += p.beta * c0[e];
@@ -174,7 +176,7 @@ OF_DEV void epilogue_row8(const OfGemmArgs& p, const float (&a)[8], int m, int n
             }
         }
         *(f32x4*)c = o0;
-        *(f32x4*)(c + 4) = o1;
+        *(f32x4*)(c + hi) = o1;
     }
 }
 
@@ -186,13 +188,21 @@ constexpr int PATCH_PITCH = 64 * 4 + 16;
 constexpr int PATCH_BYTES = 32 * PATCH_PITCH;
 template <int EPI>
 constexpr bool epi_has_aux() { return EPI == OF_EPI_GATE_RESID || EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT; }
+// Lane map of a row pass over the 64 columns of a group: eight lanes per row.  bf16 outputs: a lane takes 8 consecutive n (one
+// 16-byte store; the 8 lanes cover a 128-byte line).  fp32 outputs (weight gradients, the fp32 stream): a lane takes n = 4j..4j+3
+// and 32+4j..32+4j+3 (j = lane & 7), so that each of its two 16-byte stores / residual loads is contiguous with its
+// neighbours' -- with 8 consecutive n per lane every store instruction wrote every other 16 bytes of a line and each line was
+// completed by a second instruction.
+template <int EPI>
+OF_DEV bool epi_split_cols(const OfGemmArgs& p) { return EPI == OF_EPI_ACC_F32 || (EPI == OF_EPI_GATE_RESID && p.io_f32); }
 // the four aux row segments (residual / saved activation) this lane needs for the group at (m_base, n_base)
 template <int EPI>
 OF_DEV void epilogue_group_aux(const OfGemmArgs& p, int m_base, int n_base, int lane, AuxPre (&pre)[4]) {
     if (!epi_has_aux<EPI>()) return;
-    const int rd_row = lane >> 3, rd_col = (lane & 7) * 8;
+    const bool split = epi_split_cols<EPI>(p);
+    const int rd_row = lane >> 3, rd_col = (lane & 7) * (split ? 4 : 8);
 #pragma unroll
-    for (int it = 0; it < 4; ++it) pre[it] = epilogue_aux_load<EPI>(p, m_base + it * 8 + rd_row, n_base + rd_col);
+    for (int it = 0; it < 4; ++it) pre[it] = epilogue_aux_load<EPI>(p, m_base + it * 8 + rd_row, n_base + rd_col, split ? 32 : 4);
 }
 // a0 / a1: the fragments of columns [0, 32) / [32, 64) of the group.  `pre` = epilogue_group_aux of the SAME group, requested
 // a whole group earlier by the callers (software pipelining: a group's aux latency hides behind the previous group's
@@ -220,14 +230,16 @@ OF_DEV void patch_write16(char* patch, const f32x4 (&t)[2][4], int lane) {
 template <int EPI>
 OF_DEV void epilogue_group_rows(const OfGemmArgs& p, char* patch, int m_base, int n_base, int lane, float gv, float sc, float& dot,
                                 const AuxPre (&pre)[4]) {
-    const int rd_row = lane >> 3, rd_col = (lane & 7) * 8;
+    const bool split = epi_split_cols<EPI>(p);
+    const int hi = split ? 32 : 4;
+    const int rd_row = lane >> 3, rd_col = (lane & 7) * (split ? 4 : 8);
     of_wave_sync();
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int r = it * 8 + rd_row;
-        const f32x4 v0 = *(const f32x4*)(patch + r * PATCH_PITCH + rd_col * 4), v1 = *(const f32x4*)(patch + r * PATCH_PITCH + rd_col * 4 + 16);
+        const f32x4 v0 = *(const f32x4*)(patch + r * PATCH_PITCH + rd_col * 4), v1 = *(const f32x4*)(patch + r * PATCH_PITCH + (rd_col + hi) * 4);
         const float a8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        epilogue_row8<EPI>(p, a8, m_base + r, n_base + rd_col, gv, sc, dot, epi_has_aux<EPI>() ? &pre[it] : nullptr);
+        epilogue_row8<EPI>(p, a8, m_base + r, n_base + rd_col, gv, sc, dot, epi_has_aux<EPI>() ? &pre[it] : nullptr, hi);
         if (EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT || EPI == OF_EPI_GELU) of_sched_fence();
     }
     of_wave_sync();
