@@ -34,6 +34,22 @@
 #include "../../include/of_hip.h"
 
 namespace {
+// A lane (row i16, group g = lane >> 4) holds 4 packed-bf16 columns (8 bytes) of every 16-column block of its output row.
+// Stored as they are, one store instruction writes 32-byte pieces of 16 rows and every 128-byte line takes four instructions.
+// Blocks 2m / 2m+1 are exchanged between the lane groups g and g ^ 1 first (v_permlane16_swap), so that a lane owns 8 consecutive
+// columns: 16-byte stores, half as many, 64 contiguous bytes of a row per instruction.  All 64 lanes must call (cross-lane);
+// `live` masks the stores of rows beyond the end.
+template <int NB>
+OF_DEV void store_row_blocks(bf16_t* rowp, const u32x2 (&v)[NB], int g, bool live) {
+#pragma unroll
+    for (int m = 0; m < NB / 2; ++m) {
+        unsigned a0 = v[2 * m][0], a1 = v[2 * m][1], b0 = v[2 * m + 1][0], b1 = v[2 * m + 1][1];
+        of_pair_rows16(a0, b0);
+        of_pair_rows16(a1, b1);
+        if (live) *(u32x4*)(rowp + (2 * m + (g & 1)) * 16 + 4 * (g & ~1)) = u32x4{a0, a1, b0, b1};
+    }
+}
+
 
 constexpr float NEG_BIG = -1.0e30f;
 // one [64 rows][DH] bf16 LDS image; two swizzles of the same data:
@@ -452,26 +468,17 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
         }
         of_sync();
     }
-    if (my_row < p.Lq) {
-        if (!BWD) {
-            const float inv = l_i > 0.f ? 1.0f / l_i : 0.f;
-            bf16_t* ob = p.o + ((size_t)batch * p.Lq + my_row) * p.ldo + hc;
+    {
+        const bool live = my_row < p.Lq;
+        const float osc = BWD ? p.scale : (l_i > 0.f ? 1.0f / l_i : 0.f);
+        u32x2 o[NDT];
 #pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                u32x2 o = {of_pack_bf16(acc[dt][0] * inv, acc[dt][1] * inv),
-                           of_pack_bf16(acc[dt][2] * inv, acc[dt][3] * inv)};
-                *(u32x2*)(ob + dt * 16 + g * 4) = o;
-            }
-            if (g == 0) p.lse[stat_idx] = l_i > 0.f ? (m_i + of_log2(l_i)) * LN2 : __builtin_inff();
-        } else {
-            bf16_t* dqb = p.dq + ((size_t)batch * p.Lq + my_row) * p.lddq + hc;
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                u32x2 o = {of_pack_bf16(acc[dt][0] * p.scale, acc[dt][1] * p.scale),
-                           of_pack_bf16(acc[dt][2] * p.scale, acc[dt][3] * p.scale)};
-                *(u32x2*)(dqb + dt * 16 + g * 4) = o;
-            }
-        }
+        for (int dt = 0; dt < NDT; ++dt)
+            o[dt] = u32x2{of_pack_bf16(acc[dt][0] * osc, acc[dt][1] * osc), of_pack_bf16(acc[dt][2] * osc, acc[dt][3] * osc)};
+        const long row = live ? my_row : 0;
+        bf16_t* ob = BWD ? p.dq + ((size_t)batch * p.Lq + row) * p.lddq + hc : p.o + ((size_t)batch * p.Lq + row) * p.ldo + hc;
+        store_row_blocks(ob, o, g, live);
+        if (!BWD && live && g == 0) p.lse[stat_idx] = l_i > 0.f ? (m_i + of_log2(l_i)) * LN2 : __builtin_inff();
     }
 }
 
@@ -544,16 +551,16 @@ OF_GLOBAL void OF_BOUNDS(NW * 64, 2) of_attn_fwd_res_kernel(OfAttnArgs p) {
 
     u32x2 po[NDT];                 // previous tile's packed output, stored while the next tile computes
     long po_row = -1;
+    bool po_live = false;          // the wave holds a finished tile (rows beyond Lq have po_row = -1 and store nothing)
     for (int t = 0; t < nsteps; ++t) {
         const bool more = progressive && (t + 1) * BPS < nkb;
         if (more) {
             for (int kb = (t + 1) * BPS; kb < (t + 2) * BPS && kb < nkb; ++kb) issue(kb);
         }
-        if (po_row >= 0) {
-            bf16_t* ob = p.o + ((size_t)batch * p.Lq + po_row) * p.ldo + hc;
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) *(u32x2*)(ob + dt * 16 + g * 4) = po[dt];
+        if (po_live) {         // wave-uniform: set by the whole wave's tile
+            store_row_blocks(p.o + ((size_t)batch * p.Lq + (po_row >= 0 ? po_row : 0)) * p.ldo + hc, po, g, po_row >= 0);
             po_row = -1;
+            po_live = false;
         }
         const int ti = t * NW + wave;
         if (ti < ntiles) {     // wave-uniform
@@ -604,13 +611,15 @@ OF_GLOBAL void OF_BOUNDS(NW * 64, 2) of_attn_fwd_res_kernel(OfAttnArgs p) {
                     softmax_pv<DH, false, 2>(s, mb, vimg, fo, lane, acc, m_i, l_i);
                 }
             }
-            if (my_row < p.Lq) {
+            {
                 const float inv = l_i > 0.f ? 1.0f / l_i : 0.f;
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt)
                     po[dt] = u32x2{of_pack_bf16(acc[dt][0] * inv, acc[dt][1] * inv), of_pack_bf16(acc[dt][2] * inv, acc[dt][3] * inv)};
-                po_row = my_row;
-                if (g == 0) p.lse[((size_t)batch * p.heads + h) * p.Lq + my_row] = l_i > 0.f ? (m_i + of_log2(l_i)) * LN2 : __builtin_inff();
+                po_live = true;
+                po_row = my_row < p.Lq ? my_row : -1;
+                if (my_row < p.Lq && g == 0)
+                    p.lse[((size_t)batch * p.heads + h) * p.Lq + my_row] = l_i > 0.f ? (m_i + of_log2(l_i)) * LN2 : __builtin_inff();
             }
         }
         if (more) {            // workgroup-uniform
@@ -618,11 +627,7 @@ OF_GLOBAL void OF_BOUNDS(NW * 64, 2) of_attn_fwd_res_kernel(OfAttnArgs p) {
             of_sync();
         }
     }
-    if (po_row >= 0) {
-        bf16_t* ob = p.o + ((size_t)batch * p.Lq + po_row) * p.ldo + hc;
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) *(u32x2*)(ob + dt * 16 + g * 4) = po[dt];
-    }
+    if (po_live) store_row_blocks(p.o + ((size_t)batch * p.Lq + (po_row >= 0 ? po_row : 0)) * p.ldo + hc, po, g, po_row >= 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -769,17 +774,17 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_dkv_kernel(OfAttnArgs p) {
         }
         of_sync();
     }
-    if (my_key < p.Lk) {
-        bf16_t* dkb = p.dk + ((size_t)batch * p.Lk + my_key) * p.lddk + hc;
-        bf16_t* dvb = p.dv + ((size_t)batch * p.Lk + my_key) * p.lddv + hc;
+    {
+        const bool live = my_key < p.Lk;
+        const long row = live ? my_key : 0;
+        u32x2 ok[NDT], ov[NDT];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
-            u32x2 ok = {of_pack_bf16(acck[dt][0] * p.scale, acck[dt][1] * p.scale),
-                        of_pack_bf16(acck[dt][2] * p.scale, acck[dt][3] * p.scale)};
-            u32x2 ov = {of_pack_bf16(accv[dt][0], accv[dt][1]), of_pack_bf16(accv[dt][2], accv[dt][3])};
-            *(u32x2*)(dkb + dt * 16 + g * 4) = ok;
-            *(u32x2*)(dvb + dt * 16 + g * 4) = ov;
+            ok[dt] = u32x2{of_pack_bf16(acck[dt][0] * p.scale, acck[dt][1] * p.scale), of_pack_bf16(acck[dt][2] * p.scale, acck[dt][3] * p.scale)};
+            ov[dt] = u32x2{of_pack_bf16(accv[dt][0], accv[dt][1]), of_pack_bf16(accv[dt][2], accv[dt][3])};
         }
+        store_row_blocks(p.dk + ((size_t)batch * p.Lk + row) * p.lddk + hc, ok, g, live);
+        store_row_blocks(p.dv + ((size_t)batch * p.Lk + row) * p.lddv + hc, ov, g, live);
     }
 }
 

@@ -184,6 +184,9 @@ OF_DEV float of_max(float a, float b) { return __builtin_fmaxf(a, b); }      // 
 // lane-wise pure); the s_nop covers the VALU-write -> permlane-read hazard the compiler would otherwise pad.
 OF_DEV void of_swap_rows16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
 OF_DEV void of_swap_rows32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+// 2 x 2 exchange between the 16-lane rows r and r ^ 1 of a wave: afterwards an even row holds (own a, partner's a) and an odd
+// row (partner's b, own b) -- turns "4 columns of block 2m and of block 2m+1 per lane" into 8 consecutive columns of one block
+OF_DEV void of_pair_rows16(unsigned& a, unsigned& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
 OF_DEV float of_rows_max(float x) {
     float a = x, b = x;
     of_swap_rows16(a, b);        // a = rows {0,0,2,2}, b = rows {1,1,3,3} of x

@@ -261,6 +261,11 @@ OF_DEV bool of_wave_any(bool p) {
     for (int m = 32; m >= 1; m >>= 1) v |= of_shfl_xor_i(v, m);
     return v != 0;
 }
+OF_DEV void of_pair_rows16(unsigned& a, unsigned& b) {
+    const unsigned pa = (unsigned)of_shfl_xor_i((int)a, 16), pb = (unsigned)of_shfl_xor_i((int)b, 16);
+    if (((of_emu::g_blk->cur >> 4) & 1) == 0) b = pa;
+    else a = pb;
+}
 OF_DEV float of_rows_max(float x) {
     x = fmaxf(x, of_shfl_xor(x, 16));
     return fmaxf(x, of_shfl_xor(x, 32));
