@@ -11,8 +11,9 @@ def _ln_ref(x, w, b):
 
 
 @pytest.mark.parametrize("x_f32", [1, 0])
-# (70, 2048) / (67, 2560): the workgroup-per-row backward (dim >= 1536 with dw/db), both instantiations, ragged last workgroup
-@pytest.mark.parametrize("rows,dim", [(37, 64), (9, 1024), (70, 2048), (67, 2560)])
+# (70, 2048) / (67, 2560) / (66, 4096): the workgroup-per-row backward (dim >= 1536 with dw/db), both instantiations, ragged last
+# workgroup; 64: 8-consecutive-columns lane map, 1024 / 2048 / 2560 / 4096: the split map of the wave kernels, 2048 / 4096: of the workgroup kernel
+@pytest.mark.parametrize("rows,dim", [(37, 64), (9, 1024), (70, 2048), (67, 2560), (66, 4096)])
 def test_layernorm_fwd_bwd(x_f32, rows, dim):
     g = torch.Generator().manual_seed(rows * dim)
     x = torch.randn(rows, dim, generator=g) * 2 + 0.5
