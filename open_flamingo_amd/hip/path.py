@@ -84,12 +84,46 @@ def feed_forward_fwd(ops, P, W, x, *, prefix="", gate=None, residual=False, keep
     return y, dict(x=x, u=u, st=st, a=a, b=b)
 
 
+# ---- bf16 twins of fp32 gradient-stream tensors, handed from one module's backward to the next -------------------------------
+# Every backward on the fp32 stream ends in a LayerNorm backward that can emit the bf16 copy of its dx in the same pass (+2 B per
+# element) and every backward starts by casting its incoming gradient to bf16 for its GEMMs (a pass of its own: 6 B per element,
+# 60 launches per step at cfg-2).  The producer offers the twin here, the consumer takes it: matched by storage address, element
+# count and version counter of the fp32 tensor, which the entry keeps ALIVE (its address cannot be recycled while the entry
+# exists); an entry is consumed by its first taker, the list holds at most four (a gradient nobody takes ages out).
+_bf16_twins = []
+TWINS = True          # constant; tools/ab_bf16_twins.py clears it for the same-box A/B
+
+
+def offer_bf16_twin(t, twin):
+    """t: fp32 gradient tensor about to be returned from a backward; twin: bf16 tensor with the same values."""
+    if t.dtype != F32 or twin is None or twin.numel() != t.numel():
+        return
+    _bf16_twins.append((t, t._version, twin))
+    del _bf16_twins[:-4]
+
+
+def take_bf16_twin(t):
+    """bf16 twin of the contiguous fp32 tensor t (any view of what was offered), or None."""
+    for i, (src, ver, twin) in enumerate(_bf16_twins):
+        if (src.data_ptr() == t.data_ptr() and src.numel() == t.numel() and src._version == ver and t._version == ver
+                and t.dtype == F32 and t.is_contiguous() and twin.device == t.device):
+            del _bf16_twins[i]
+            return twin.view(t.shape)
+    return None
+
+
+def bf16_of(ops, t):
+    """t as a bf16 GEMM operand: the twin a producer offered, else a cast pass."""
+    twin = take_bf16_twin(t) if t.dtype == F32 else None
+    return twin if twin is not None else ops.to_bf16(t)
+
+
 def feed_forward_bwd(ops, P, W, S, dy, G, *, prefix="", gate=None, gate_name=None, residual=False):
     """dy (rows, d) stream dtype, contiguous.  Returns (dx, dx_bf16 or None): dx = [dy +] LN_bwd(...)."""
     dev = dy.device
     rows, d = S["x"].shape
     hid = W[prefix + "1.weight"].shape[0]
-    dyb = ops.to_bf16(dy)
+    dyb = bf16_of(ops, dy)
     da = _e((rows, hid), BF16, dev)
     ops.gemm(dyb, W[prefix + "3.weight"], da, tb=True, epi=EPI_DGELU_DOT, aux=S["a"], gate=gate,
              dot=G.acc(gate_name, (1,)) if gate_name else None)
@@ -141,7 +175,7 @@ def masked_cross_attention_fwd(ops, P, W, x, media_bf, tt, *, B, L, T, n, heads,
 
 def masked_cross_attention_bwd(ops, P, W, S, media_bf, tt, dy, dyb, G, *, B, L, T, n, heads, only_immediate,
                                prefix="attn.", gate=None, gate_name=None, residual=False, need_dmedia=True, safe=0,
-                               dim_head=64, dkv_out=None):
+                               dim_head=64, dkv_out=None, offer_twin=False):
     """dy stream dtype + its bf16 copy dyb.  Returns (dx, dmedia fp32 or None).
     dkv_out: (B*T*n, 2*inner) bf16 destination of d(k|v) owned by the caller (a column block of the buffer shared by all
     blocks when their to_kv projections are grouped); the caller then forms the media gradient of all
@@ -167,8 +201,11 @@ def masked_cross_attention_bwd(ops, P, W, S, media_bf, tt, dy, dyb, G, *, B, L, 
     t, beta = G.mat(prefix + "to_q.weight", (inner, d))
     ops.gemm(dq, S["xn"], t, ta=True, tb=True, epi=EPI_ACC_F32, beta=beta)
     dx = torch.empty_like(dy)
-    ops.ln_bwd(dxn, S["x"], S["st"], P[prefix + "norm.weight"], resid=dy if residual else None, dx=dx,
+    dxb = _e((rows, d), BF16, dev) if (offer_twin and TWINS and dy.dtype == F32) else None     # for the next backward down the stream
+    ops.ln_bwd(dxn, S["x"], S["st"], P[prefix + "norm.weight"], resid=dy if residual else None, dx=dx, dx_bf16=dxb,
                dw=G.acc(prefix + "norm.weight", (d,)), db=G.acc(prefix + "norm.bias", (d,)))
+    if dxb is not None:
+        offer_bf16_twin(dx, dxb)
     t, beta = G.mat(prefix + "to_kv.weight", (2 * inner, Dv))
     ops.gemm(dkv, media_bf, t, ta=True, tb=True, epi=EPI_ACC_F32, beta=beta)
     dmedia = None
@@ -207,7 +244,7 @@ def xattn_block_bwd(ops, P, W, S, media_bf, tt, dy, *, B, L, T, n, heads, only_i
     dx, dmedia = masked_cross_attention_bwd(ops, P, W, S["attn"], media_bf, tt, dy1, dy1b, G, B=B, L=L, T=T, n=n,
                                             heads=heads, only_immediate=only_immediate, gate=P["attn_gate"],
                                             gate_name="attn_gate", residual=True, need_dmedia=need_dmedia, safe=safe,
-                                            dim_head=dim_head, dkv_out=dkv_out)
+                                            dim_head=dim_head, dkv_out=dkv_out, offer_twin=True)
     return dx, dmedia, G.g
 
 

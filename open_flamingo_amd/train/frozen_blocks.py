@@ -23,6 +23,8 @@ import types
 import torch
 from torch import nn
 
+from ..hip import path as _path
+
 import os
 
 BF16 = torch.bfloat16
@@ -128,7 +130,7 @@ class _FrozenMptBlockFn(torch.autograd.Function):
         dy2 = dy.reshape(rows, d)
         if dy2.dtype != F32 or not dy2.is_contiguous():
             dy2 = dy2.to(F32).contiguous()
-        dact = _mm_dx(ops.to_bf16(dy2), Wdown, td)                   # (rows, 4d)
+        dact = _mm_dx(_path.bf16_of(ops, dy2), Wdown, td)            # (rows, 4d); the bf16 copy the backward above left, or a cast
         dh = ops.gelu_bwd(dact, h, out=dact)                         # in place: dact * gelu'(h)
         del dact
         dm = _mm_dx(dh, Wup, tu)                                     # (rows, d)
@@ -142,7 +144,9 @@ class _FrozenMptBlockFn(torch.autograd.Function):
         ops.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, do, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
                      delta, **ctx.kw)
         da = _mm_dx(dqkv, Wqkv, tq)                                  # (rows, d)
-        ops.ln_bwd(da, x2, st1, w1, resid=dx1, dx=dx1)               # in place: dx = dx1 + norm_1'(da)
+        dxb = torch.empty(rows, d, dtype=BF16, device=dev) if _path.TWINS else None
+        ops.ln_bwd(da, x2, st1, w1, resid=dx1, dx=dx1, dx_bf16=dxb)  # in place: dx = dx1 + norm_1'(da); + its bf16 twin for the
+        _path.offer_bf16_twin(dx1, dxb)                              # backward of whatever produced x
         return (dx1.view(B, L, d),) + (None,) * 14
 
 
@@ -387,7 +391,7 @@ class _FrozenNeoXBlockFn(torch.autograd.Function):
         dy2 = dy.reshape(rows, d)
         if dy2.dtype != F32 or not dy2.is_contiguous():
             dy2 = dy2.to(F32).contiguous()
-        dyb = ops.to_bf16(dy2)
+        dyb = _path.bf16_of(ops, dy2)
         dact = _mm_dx(dyb, Wdown, tdn)                                   # (rows, 4d)
         dh = ops.gelu_bwd(dact, h, out=dact)
         del dact
@@ -409,7 +413,9 @@ class _FrozenNeoXBlockFn(torch.autograd.Function):
         dqkv = torch.empty(rows, heads * 3 * hs, dtype=BF16, device=dev)
         ops.rotary_neox(dqkv, cos, sin, dqp[0], dqp[1], dqp[2], L=L, heads=heads, head_size=hs, rot_dims=rot, head_pad=pad, inverse=True)
         da = _mm_dx(dqkv, Wqkv, tq)
-        ops.ln_bwd(da, x2, st1, w1, resid=dx1, dx=dx1)                   # in place: dx = dx1 + norm_1'(da)
+        dxb = torch.empty(rows, d, dtype=BF16, device=dev) if _path.TWINS else None
+        ops.ln_bwd(da, x2, st1, w1, resid=dx1, dx=dx1, dx_bf16=dxb)      # in place: dx = dx1 + norm_1'(da); + its bf16 twin
+        _path.offer_bf16_twin(dx1, dxb)
         return (dx1.view(B, L, d),) + (None,) * 20
 
 

@@ -289,3 +289,48 @@ def test_grouped_media_projections_match_per_block_projections(on_emulator, monk
     assert g0.keys() == g1.keys()
     for k in g0:
         assert _rel(g1[k], g0[k]) < 2e-2, (k, _rel(g1[k], g0[k]))     # Perceiver grads: dmedia summed in fp32 once vs 4 bf16->fp32 partial sums
+
+
+def test_bf16_twins_travel_between_backwards_and_change_nothing(on_emulator, monkeypatch):
+    """Every backward on the fp32 stream ends in a LayerNorm backward that also emits the bf16 copy of its dx and offers it
+    (hip/path.py: offer_bf16_twin); the next backward down the stream takes it instead of running a cast pass.  Gated blocks and
+    fused frozen MPT blocks alternate in the LM: with the hand-off on, the stream-sized casts of a backward disappear (all but the
+    first consumer's) and every gradient is bit-identical to the run with the hand-off off."""
+    from open_flamingo_amd.hip import path as P
+    from open_flamingo_amd.train import frozen_blocks
+
+    def run(handoff):
+        model, info = _tiny()
+        lm = model.lang_encoder
+        for mod in lm.modules():      # what towers.hold_frozen_linears_in_bf16 does, for the LM blocks only (no autocast on this path)
+            if isinstance(mod, torch.nn.Linear) and mod is not lm.get_output_embeddings() and not mod.weight.requires_grad:
+                mod.weight.data = mod.weight.data.to(torch.bfloat16)
+        assert frozen_blocks.use_fused_frozen_mpt_blocks(lm, allow_cpu=True) > 0
+        P._bf16_twins.clear()
+        if not handoff:
+            monkeypatch.setattr(P, "offer_bf16_twin", lambda t, twin: None)
+        casts, taken = [], []
+        ops = H.emu_ops()
+        orig_cast, orig_take = type(ops).to_bf16, P.take_bf16_twin
+        monkeypatch.setattr(type(ops), "to_bf16", lambda self, x, out=None: (casts.append(tuple(x.shape)), orig_cast(self, x, out))[1])
+        monkeypatch.setattr(P, "take_bf16_twin", lambda t: (lambda r: (taken.append(r is not None), r)[1])(orig_take(t)))
+        red = GradReducer(model, embedding_rows=[info["media_token_id"], info["eoc_token_id"]])
+        batch = synthetic.make_batch(2, 2, 24, info, "cpu", seed=5, image_size=56)
+        opt = FlatAdamW(red, lr=1e-3, ops=ops)
+        loss = float(step.train_step(model, red, opt, batch, info, amp=False))
+        monkeypatch.undo()
+        monkeypatch.setattr(helpers, "_require_hip", lambda t, what: None)
+        monkeypatch.setattr(Ops, "default", staticmethod(H.emu_ops))
+        return loss, {k: p.detach().clone() for k, p in model.named_parameters() if p.requires_grad}, casts, sum(taken)
+
+    l1, p1, casts1, taken1 = run(True)
+    l0, p0, casts0, taken0 = run(False)
+    assert taken0 == 0 and taken1 >= 2, (taken0, taken1)
+    assert len(casts1) <= len(casts0) - taken1, (len(casts1), len(casts0), taken1)
+    assert l1 == l0
+    # the GEMM-made gradients of the gated blocks (deterministic on the emulator; LayerNorm dw / db are summed by atomics in thread
+    # order there) -> bit-identical parameters after the step
+    keys = [k for k in p0 if "gated_cross_attn_layer." in k and k.endswith(".weight") and "norm" not in k and ".ff.0." not in k]
+    assert len(keys) >= 8
+    for k in keys:
+        assert torch.equal(p1[k], p0[k]), k
