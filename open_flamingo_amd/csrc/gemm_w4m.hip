@@ -139,6 +139,7 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
         // One K stage in slot `cur`.  WR: stage d + 1 exists, LD: stage d + 2 exists.  (sA, sB) = offsets of stage d + 1.
         auto stage_body = [&](char* cur, char* nxt, const bool WR, const bool LD) OF_INLINE_LAMBDA {
             const unsigned cur_u = (unsigned)(cur - smem), nxt_u = (unsigned)(nxt - smem);
+            of_mfma_acc_guard();       // fragments may have been moved between registers on the way into this stage (of_platform.h)
             phase(0, cur, true, nxt_u, 8, WR, 0);          // + B of stage d + 1 -> nxt (its A went there in phase 3 of stage d - 1)
             phase(1, cur, true, 0u, 0, false, 0);
             phase(2, cur, true, 0u, 0, false, 0);
@@ -151,17 +152,9 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
             sB += stepB;
         };
         int d = 0;
-        // (gemm_w4.hip unrolls its NT steady state by two stages for compile-time slot addresses: -1..3 %.  Here the same unrolling
-        // gives deterministic WRONG results on hardware -- stage 0 loses 16 of its 64 k for part of the tile, with the builtin and the
-        // asm DMA form alike, emulator green (tools/probes/w4m_unroll_diag.py, profiles/r03y_*) -- and no speed (+-1 %); not
-        // understood, not in the product.  -DOF_W4M_UNROLL2 (tools/ab builds only) reproduces it.)
-#ifdef OF_W4M_UNROLL2
-        if (!(AT || BT))
-            for (; d + 3 < nd; d += 2) {
-                stage_body(smem, smem + STAGE_BYTES, true, true);
-                stage_body(smem + STAGE_BYTES, smem, true, true);
-            }
-#endif
+        // (gemm_w4.hip unrolls its NT steady state by two stages for compile-time slot addresses; here that measured +-1 % and
+        // is not done.  It is how the VALU-write -> asm-MFMA hazard of of_mfma_acc_guard() was found: the unrolled build moved stage
+        // 0's fragments between registers right in front of the loop and lost half a k-step -- DESIGN.md 4.1.)
         for (; d + 2 < nd; ++d) stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, true, true);
         if (d + 1 < nd) {
             stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, true, false);

@@ -53,7 +53,12 @@ OF_DEV f32x4 of_mfma(s16x8 a, s16x8 b, f32x4 c) {
 // (gemm_w4m.hip) the builtin form leaves hipcc shuttling accumulators between AGPRs and VGPRs around every MFMA
 // (390 v_accvgpr_* + 74 s_nop per 128 MFMAs in the cross-compiled loop).  Results are read only after of_mfma_acc_settle().
 OF_DEV void of_mfma_acc(s16x8 a, s16x8 b, f32x4& c) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); }
-// the compiler does not see the MFMAs inside the asm: cover the MFMA-write -> read hazard before the accumulators are used
+// The compiler does not see the MFMAs inside the asm, so its hazard recognizer does not cover VALU-write -> MFMA-read either: a
+// register copy it places right in front of the first MFMA of a loop (fragments that change registers on the way into a loop)
+// can still be under way for the upper half of the wave when the MFMA reads it.  Callers put of_mfma_acc_guard() at the points
+// where such copies can appear (top of a K stage).
+OF_DEV void of_mfma_acc_guard() { asm volatile("s_nop 4" ::: "memory"); }
+// ... and cover the MFMA-write -> read hazard before the accumulators are used
 OF_DEV void of_mfma_acc_settle() { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); }
 // D(32x32, f32) += A(32x16 bf16) * B(16x32 bf16).  Lane l supplies A[l&31][8*(l>>5)+0..7] and B[8*(l>>5)+0..7][l&31];
 // it receives D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31], r=0..15 (cdna_hip_programming.md section 3).
@@ -162,8 +167,8 @@ OF_DEV void of_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 // bare s_barrier (no implicit vmcnt(0) drain, unlike __syncthreads with LDS-DMA in flight) -- fenced for the COMPILER on both
 // sides: llvm.amdgcn.s.barrier is IntrNoMem, so nothing but these two empty asm statements tells hipcc that LDS reads must not
 // move across it (the kernels' loops happen to have an asm s_waitcnt in front of every barrier; their prologues and epilogues do
-// not).  Added in round 3 while chasing wrong results of an unrolled K loop (gemm_w4m.hip, -DOF_W4M_UNROLL2): it changed the
-// register allocation of the GEMM kernels, not their order, and it did NOT cure that build -- kept as the correct contract.
+// not).  Added in round 3 while chasing wrong results of an unrolled K loop in gemm_w4m.hip: it changed the register allocation
+// of the GEMM kernels, not their order, and was not that bug's cause (of_mfma_acc_guard() is) -- kept as the correct contract.
 OF_DEV void of_barrier_raw() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();

@@ -168,6 +168,7 @@ OF_DEV f32x4 of_mfma(s16x8 a, s16x8 b, f32x4 c) {
 }
 OF_DEV void of_mfma_acc(s16x8 a, s16x8 b, f32x4& c) { c = of_mfma(a, b, c); }
 OF_DEV void of_mfma_acc_settle() {}
+OF_DEV void of_mfma_acc_guard() {}
 OF_DEV f32x16 of_mfma32(s16x8 a, s16x8 b, f32x16 c) {
     of_emu::Block* blk = of_emu::g_blk;
     int t = blk->cur, l = t & 63, w0 = t & ~63;

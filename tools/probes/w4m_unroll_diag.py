@@ -1,5 +1,7 @@
-"""Which K stages go wrong in the unrolled NT loop of gemm_w4m.hip (-DOF_W4M_UNROLL2 build)?  A = ones, B = indicator of one 64-deep
-stage: every output must be 64 for every stage.  PROFILING / DIAGNOSIS TOOL."""
+"""Which K stages of a big-tile GEMM build go wrong?  A = ones, B = indicator of one 64-deep stage (and the mirror image): every
+output must be 64 for every stage.  Found the VALU-write -> asm-MFMA hazard of gemm_w4m.hip in round 3 (an experimental build with
+the K loop unrolled by two lost 16 of stage 0's 64 k: profiles/r03y_*, r03ak_*; of_platform.h: of_mfma_acc_guard).
+DIAGNOSIS TOOL.      python tools/probes/w4m_unroll_diag.py path/to/libofhip.so"""
 import ctypes, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
