@@ -140,3 +140,31 @@ def test_tuned_vendor_gemm_table_is_inert_without_a_gpu():
     validators = {r[1]: r[2] for r in rows if r[0] == "Validator"}
     assert validators["GCN_ARCH_NAME"].startswith("gfx950") and "HIPBLASLT_VERSION" in validators
     assert sum(r[0].startswith("Gemm") for r in rows) >= 10
+
+
+def test_bf16_twin_registry_semantics():
+    """hip/path.py: offer_bf16_twin / take_bf16_twin -- matched by storage address + element count + version counter of the fp32 tensor
+    (views included), consumed by the first taker, never served after an in-place change of the fp32 tensor, at most four entries."""
+    import torch
+    from open_flamingo_amd.hip import path as P
+    P._bf16_twins.clear()
+    x = torch.randn(6, 8)
+    tw = x.to(torch.bfloat16)
+    P.offer_bf16_twin(x, tw)
+    got = P.take_bf16_twin(x.view(2, 3, 8).reshape(6, 8))             # a view of what was offered
+    assert got is not None and got.data_ptr() == tw.data_ptr() and got.shape == (6, 8)
+    assert P.take_bf16_twin(x) is None                                 # consumed by the first taker
+    P.offer_bf16_twin(x, tw)
+    x.add_(1.0)                                                        # the fp32 tensor changed after the offer: the twin is stale
+    assert P.take_bf16_twin(x) is None
+    P._bf16_twins.clear()
+    y = torch.randn(6, 8)
+    P.offer_bf16_twin(y, y.to(torch.bfloat16))
+    assert P.take_bf16_twin(torch.randn(6, 8)) is None                 # another tensor of the same shape
+    assert P.take_bf16_twin(y[:3]) is None                             # a part of it
+    assert P.take_bf16_twin(y.to(torch.bfloat16)) is None              # not fp32
+    keep = [torch.randn(4, 4) for _ in range(6)]
+    for t in keep:
+        P.offer_bf16_twin(t, t.to(torch.bfloat16))
+    assert len(P._bf16_twins) == 4 and P.take_bf16_twin(keep[0]) is None and P.take_bf16_twin(keep[5]) is not None
+    P._bf16_twins.clear()
