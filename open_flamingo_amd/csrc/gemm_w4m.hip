@@ -16,6 +16,10 @@
 //     phase 3 reads the first fragments of stage d + 1 from the other slot -- the schedule of gemm_w4.hip: A of stage d + 2 is
 //     requested in phase 3 (into the slot the barrier freed), B of stage d + 1 in phase 0, eight pieces over the 32 MFMA gaps
 //     of the phase, odd waves two gaps after the even ones; one vmcnt(0) in front of the barrier covers both;
+//   * the MFMAs are inline asm accumulating in place (of_mfma_acc: through the builtin hipcc shuttled the 64 small accumulators
+//     between AGPRs and VGPRs, 390 v_accvgpr_* per 128 MFMAs).  The price: the compiler's hazard recognizer does not know them,
+//     so every K stage opens with of_mfma_acc_guard() and tests/test_isa_lint.py checks the cross-compiled ISA for a VALU write
+//     of an MFMA operand right in front of an MFMA (found on hardware: DESIGN.md 4.1);
 //   * LDS images: the K-contiguous image of gemm_tile256.h serves 16-row fragments conflict-free as it is (a lane's 16-byte
 //     slot is (k-step, lane >> 4)); the K-strided image gets one more swizzle bit (piece ^ ((k-row >> 3) & 1)): the four
 //     16-lane groups of a transposed read sit 8 k-rows apart in the same 32-byte column piece.
