@@ -187,7 +187,9 @@ typedef struct OfAttnArgs {
 
 int of_attn_fwd(const OfAttnArgs* args, void* stream);
 /* Backward = two passes (dq: one workgroup per query tile; dk/dv: one per key block) -- deterministic,
- * no atomics.  dq/dk/dv are bf16 (they feed the projection-weight GEMMs as operands). */
+ * no atomics.  dq/dk/dv are bf16 (they feed the projection-weight GEMMs as operands).
+ * Alignment: q, k, v, o, dout, dq, dk, dv 16-byte aligned, every leading dimension a multiple of 8 elements (all loads and
+ * stores are 16 bytes wide), else OF_E_ALIGN. */
 int of_attn_bwd(const OfAttnArgs* args, void* stream);
 
 /* text_time (helpers.py:199-208): cumsum of media_locations along the sequence, or (cached decode branch)

@@ -830,6 +830,8 @@ int check(const OfAttnArgs& a, bool bwd) {
     if (bwd) {
         if (!a.dout || !a.dq || !a.dk || !a.dv || !a.delta) return OF_E_ARG;
         if ((a.lddo & 7) || (a.lddq & 7) || (a.lddk & 7) || (a.lddv & 7)) return OF_E_ALIGN;
+        // dq / dk / dv leave through 16-byte stores (store_row_blocks), dout is read 16 bytes wide
+        if (((uintptr_t)a.dout & 15) || ((uintptr_t)a.dq & 15) || ((uintptr_t)a.dk & 15) || ((uintptr_t)a.dv & 15)) return OF_E_ALIGN;
     }
     return 0;
 }

@@ -419,9 +419,13 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
             right.C = (char*)a.C + off * c_bytes;
             if (a.C2) right.C2 = (char*)a.C2 + off * 2;
             if (a.aux) right.aux = (const char*)a.aux + off * aux_bytes;
-            int rc = of_gemm_w4m_try(left, s);
-            if (rc == 0) rc = of_gemm_mid_try(right, s);
-            if (rc != OF_E_SHAPE) return rc;
+            // Both halves are checked BEFORE anything is launched: once the left part has run, falling through to
+            // the whole-problem launch below would apply its columns twice for the accumulating epilogues (ACC beta = 1, *_DOT,
+            // in-place GATE_RESID).
+            if (of_gemm_w4m_eligible(left) && of_gemm_mid_eligible(right)) {
+                const int rc = of_gemm_w4m_try(left, s);
+                return rc ? rc : of_gemm_mid_try(right, s);
+            }
         }
         const int rc = of_gemm_w4m_try(a, s);
         if (rc != OF_E_SHAPE) return rc;

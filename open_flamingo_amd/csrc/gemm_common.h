@@ -320,8 +320,10 @@ inline bool of_gemm_has_dot(const OfGemmArgs& a) {
 }
 // implemented in gemm_mid.hip (8 waves, 128x128 tile, 4-slot LDS-DMA ring); OF_E_SHAPE when not eligible
 int of_gemm_mid_try(const OfGemmArgs& a, of_stream_t s);
+bool of_gemm_mid_eligible(const OfGemmArgs& a);     // what of_gemm_mid_try would accept, without launching
 // implemented in gemm_w4m.hip: the 4-wave 256x256 kernel on 16x16x32 MFMAs; same eligibility and return convention as of_gemm_w4_try
 int of_gemm_w4m_try(const OfGemmArgs& a, of_stream_t s);
+bool of_gemm_w4m_eligible(const OfGemmArgs& a);
 // implemented in gemm_skinny.hip: M <= 16 rows (decode step), HBM-bound weight streaming; OF_E_SHAPE when not eligible
 int of_gemm_skinny_try(const OfGemmArgs& a, of_stream_t s);
 inline bool of_gemm_is_skinny(const OfGemmArgs& a) {

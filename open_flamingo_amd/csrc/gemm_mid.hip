@@ -150,11 +150,25 @@ int launch_mid(const OfGemmArgs& a, of_stream_t s) {
 
 // Eligibility: M, N multiples of 128, K a multiple of 64; split-K (a.ksplit > 1) only with OF_EPI_ACC_F32 and fp32 slabs in
 // a.workspace (the caller, of_gemm, has checked their size).  Byte offsets are 32-bit: operands up to 4 GiB.
-int of_gemm_mid_try(const OfGemmArgs& a, of_stream_t s) {
-    if ((a.M % MT) || (a.N % MN) || (a.K % DK) || a.group_kind) return OF_E_SHAPE;
-    if (a.ksplit > 1 && (a.epi != OF_EPI_ACC_F32 || !a.workspace)) return OF_E_SHAPE;
+bool of_gemm_mid_eligible(const OfGemmArgs& a) {
+    if ((a.M % MT) || (a.N % MN) || (a.K % DK) || a.group_kind || a.M <= 0 || a.N <= 0 || a.K <= 0) return false;
+    if (a.ksplit > 1 && (a.epi != OF_EPI_ACC_F32 || !a.workspace)) return false;
     const size_t a_bytes = 2u * (size_t)(a.a_trans ? a.K : a.M) * a.lda, b_bytes = 2u * (size_t)(a.b_trans ? a.K : a.N) * a.ldb;
-    if (a_bytes >= (1ull << 32) || b_bytes >= (1ull << 32)) return OF_E_SHAPE;
+    if (a_bytes >= (1ull << 32) || b_bytes >= (1ull << 32)) return false;
+    const int layout = a.a_trans * 2 + a.b_trans;
+    switch (a.epi) {
+        case OF_EPI_STORE_BF16:
+        case OF_EPI_ACC_F32: return layout == 0 || layout == 1 || layout == 3;
+        case OF_EPI_GELU:
+        case OF_EPI_GATE_RESID: return layout == 0;
+        case OF_EPI_DGELU_DOT:
+        case OF_EPI_SCALE_DOT: return layout == 1;
+    }
+    return false;
+}
+
+int of_gemm_mid_try(const OfGemmArgs& a, of_stream_t s) {
+    if (!of_gemm_mid_eligible(a)) return OF_E_SHAPE;
     const int layout = a.a_trans * 2 + a.b_trans;
     if (layout == 0) {
         switch (a.epi) {

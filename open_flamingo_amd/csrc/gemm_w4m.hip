@@ -193,8 +193,29 @@ int launch_w4m(const OfGemmArgs& a, of_stream_t s) {
 }
 }  // namespace
 
+// Eligibility, separate from the launch so that a caller splitting a problem over two kernels can check both parts before it
+// launches either (of_gemm's N-split).  Byte offsets inside the kernel are 32-bit (per-lane offset + scalar stage offset against a
+// buffer descriptor based at the tile's first row / column): an operand whose 256-row window (K-contiguous) or whole K extent
+// (K-strided) spans >= 4 GiB is refused, the general kernel takes it (gemm_mid.hip has the same guard).
+bool of_gemm_w4m_eligible(const OfGemmArgs& a) {
+    if ((a.M % TM) || (a.N % TN) || (a.K % DK) || a.M <= 0 || a.N <= 0 || a.K <= 0) return false;
+    const unsigned long long a_span = 2ull * (unsigned long long)(a.a_trans ? a.K : TM) * (unsigned long long)a.lda;
+    const unsigned long long b_span = 2ull * (unsigned long long)(a.b_trans ? a.K : TN) * (unsigned long long)a.ldb;
+    if (a_span >= (1ull << 32) || b_span >= (1ull << 32)) return false;
+    const int layout = a.a_trans * 2 + a.b_trans;
+    switch (a.epi) {
+        case OF_EPI_STORE_BF16:
+        case OF_EPI_ACC_F32: return layout == 0 || layout == 1 || layout == 3;
+        case OF_EPI_GELU:
+        case OF_EPI_GATE_RESID: return layout == 0;
+        case OF_EPI_DGELU_DOT:
+        case OF_EPI_SCALE_DOT: return layout == 1;
+    }
+    return false;
+}
+
 int of_gemm_w4m_try(const OfGemmArgs& a, of_stream_t s) {
-    if ((a.M % TM) || (a.N % TN) || (a.K % DK)) return OF_E_SHAPE;
+    if (!of_gemm_w4m_eligible(a)) return OF_E_SHAPE;
     const int layout = a.a_trans * 2 + a.b_trans;
     if (layout == 0) {
         switch (a.epi) {

@@ -58,7 +58,10 @@ OF_DEV void of_mfma_acc(s16x8 a, s16x8 b, f32x4& c) { asm volatile("v_mfma_f32_1
 // can still be under way for the upper half of the wave when the MFMA reads it.  Callers put of_mfma_acc_guard() at the points
 // where such copies can appear (top of a K stage).
 OF_DEV void of_mfma_acc_guard() { asm volatile("s_nop 4" ::: "memory"); }
-// ... and cover the MFMA-write -> read hazard before the accumulators are used
+// ... and cover the MFMA-write -> read hazard before the accumulators are used.  The statement has no operand tie to the 64
+// accumulators (an asm statement takes at most 30 operands), so formally nothing stops hipcc from placing a read of one above the
+// s_nops: tests/test_isa_lint.py counts the wait states between the last v_mfma and the first read of an accumulation register in
+// the cross-compiled ISA of every instantiation (>= 11 for an 8-pass MFMA) and fails the CPU suite otherwise.
 OF_DEV void of_mfma_acc_settle() { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); }
 // D(32x32, f32) += A(32x16 bf16) * B(16x32 bf16).  Lane l supplies A[l&31][8*(l>>5)+0..7] and B[8*(l>>5)+0..7][l&31];
 // it receives D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31], r=0..15 (cdna_hip_programming.md section 3).
@@ -99,6 +102,10 @@ OF_DEV s16x4 of_lds_tr(const void* p) {
 // the other waves); as inline asm the compiler neither tracks nor "protects" it.  Its own vmcnt bookkeeping for ordinary
 // loads stays correct: vmcnt retires in order, so untracked operations only make its waits conservative.
 // M0 = LDS destination of the wave (base + lane*16 is applied by the hardware); s_nop 0 = the M0-write -> LDS-DMA hazard.
+// M0 cannot be declared as a clobber: hipcc reserves it ("inline asm clobber list contains reserved registers: m0" -- behaviour
+// undefined if listed).  It is sound undeclared because the compiler never holds a value in M0 across statements on gfx950: its own
+// uses (the LDS-DMA builtins) write M0 right in front of each use, and LDS instructions need no M0 on gfx9+.
+// tests/test_isa_lint.py pins that on the ISA: every mention of m0 is a write, each followed by an LDS-DMA load before the next.
 OF_DEV unsigned of_lds_u32(const void* p) { return (unsigned)(size_t)((__attribute__((address_space(3))) const char*)p); }
 // Kernels WITHOUT transposed-fragment reads (both operands K-contiguous) keep the builtin form: nothing there triggers the
 // extra wait and the compiler schedules the M0 set-up better than the asm's fixed s_mov + s_nop (same-box: 1-2 % faster,

@@ -447,7 +447,10 @@ def _neox_layer_fused_forward(self, hidden_states, attention_mask=None, position
         ok = False          # key counts = right padding only (see _mpt_block_fused_forward)
     if ok:
         cos, sin = position_embeddings
-        ok = cos.dim() == 3 and cos.shape[1] == x.shape[1] and cos.shape[2] == at.rotary_ndims
+        # of_rotary_neox takes ONE [L][rot] table (position = row % L): the default position_ids = arange(L) of a cache-less
+        # forward, which HF hands down as a (1, L, rot) table.  A caller-supplied per-row position_ids makes it (B, L, rot) with
+        # differing rows -- that forward keeps HF's own rotary embedding (row 0's positions were applied to the batch).
+        ok = cos.dim() == 3 and cos.shape[0] == 1 and cos.shape[1] == x.shape[1] and cos.shape[2] == at.rotary_ndims
     if not ok:
         mask = lite.hf_mask() if lite is not None else attention_mask
         return self._of_eager_forward(hidden_states, attention_mask=mask, position_ids=position_ids, use_cache=use_cache,

@@ -249,3 +249,42 @@ def test_fused_clip_tower_matches_hf_modules(on_emulator, attention):
         vis.model.float()
         from open_flamingo_amd.train.frozen_blocks import clip_tower_tokens_fused
         assert clip_tower_tokens_fused(vm, x) is None
+
+
+def test_per_row_position_ids_keep_hf_rotary(on_emulator):
+    """the fused GPT-NeoX layer takes one [L][rot] rotary table for the whole batch.  A caller-supplied per-row
+    ``position_ids`` (HF then hands down a (B, L, rot) table with differing rows) must not take that path -- it silently applied
+    row 0's positions to every row -- while the default arange (a (1, L, rot) table) still does."""
+    from transformers import GPTNeoXConfig, GPTNeoXForCausalLM
+    torch.manual_seed(0)
+    hs = 64
+    cfg = GPTNeoXConfig(hidden_size=2 * hs, num_hidden_layers=1, num_attention_heads=2, intermediate_size=4 * hs, vocab_size=64,
+                        max_position_embeddings=64, rotary_pct=1.0, use_parallel_residual=False, attn_implementation="eager")
+    lm = GPTNeoXForCausalLM(cfg)
+    lm.requires_grad_(False)
+    for mod in lm.modules():
+        if isinstance(mod, torch.nn.Linear) and mod is not lm.get_output_embeddings():
+            mod.weight.data = mod.weight.data.to(torch.bfloat16)
+            mod.bias.data = mod.bias.data.to(torch.bfloat16)
+    ids = torch.randint(0, 64, (2, 24))
+    pos = torch.arange(24)[None].repeat(2, 1)
+    pos[1] += 5
+
+    def run(**kw):
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+            return lm(input_ids=ids, use_cache=False, **kw).logits.float()
+
+    want = run(position_ids=pos)
+    lm.train()
+    assert frozen_blocks.use_fused_frozen_neox_blocks(lm, allow_cpu=True) == 1
+    calls = []
+    orig = frozen_blocks._FrozenNeoXBlockFn.apply
+    frozen_blocks._FrozenNeoXBlockFn.apply = staticmethod(lambda *a: (calls.append(1), orig(*a))[1])
+    try:
+        got = run(position_ids=pos)
+        assert calls == [], "per-row positions must stay on HF's rotary embedding"
+        assert _rel(got, want) < 1e-6, _rel(got, want)
+        run()
+        assert len(calls) == 1, "the default positions still take the fused layer"
+    finally:
+        frozen_blocks._FrozenNeoXBlockFn.apply = orig

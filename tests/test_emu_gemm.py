@@ -310,3 +310,42 @@ def test_skinny_gemm_strided_operands():
     H.gemm(A, B, C_out=Cbig[:, 8:8 + N])
     np.testing.assert_allclose(Cbig[:, 8:8 + N].double().numpy(), _ref(A, B, 0, 0).numpy(), rtol=1e-2, atol=1e-2)
     assert Cbig[:, :8].abs().sum() == 0 and Cbig[:, 8 + N:].abs().sum() == 0
+
+
+def test_tile_quantisation_n_split_applies_every_column_once():
+    """of_gemm's N-split (gemm.hip: a grid whose last round of 256x256 tiles would be under half full -> whole rounds on the big
+    tile + the remainder strip on the 128x128 kernel) with the ACCUMULATING epilogues (had the strip's launch been
+    refused after the left part had run, the whole-problem launch behind it would have applied the left columns twice).  288 tiles:
+    M = 8192, N = 2304 -> 8192 x 2048 (256 tiles) + 8192 x 256; K = 64.  Both halves are now checked before either is launched."""
+    M, N, K = 8192, 2304, 64
+    A = _rand((M, K), 61)
+    gate = torch.tensor([0.37])
+    g = float(torch.tanh(gate))
+    # ACC_F32 with beta = 1, weight-gradient layout (TN): C += alpha g A^T B
+    At, Bt = _rand((K, M), 62), _rand((K, N), 63)
+    c0 = torch.randn(M, N)
+    c = c0.clone()
+    H.gemm(At, Bt, a_trans=1, b_trans=1, epi=abi.EPI_ACC_F32, C_out=c, alpha=0.5, beta=1.0, gate=gate)
+    want = c0.double() + 0.5 * g * _ref(At, Bt, 1, 1)
+    np.testing.assert_allclose(c.double().numpy(), want.numpy(), rtol=1e-5, atol=1e-4)
+    # *_DOT: output once, the gate gradient = the sum over ALL columns exactly once (on top of what the scalar held)
+    W, aux = _rand((K, N), 64) * 0.2, _rand((M, N), 65)
+    acc = A.double() @ W.double()
+    for epi in (abi.EPI_SCALE_DOT, abi.EPI_DGELU_DOT):
+        o, dot = torch.zeros(M, N, dtype=torch.bfloat16), torch.full((1,), 3.0)
+        H.gemm(A, W, b_trans=1, epi=epi, C_out=o, aux=aux, gate=gate, dot_out=dot)
+        x = aux.double()
+        if epi == abi.EPI_DGELU_DOT:
+            xx = x.clone().requires_grad_(True)
+            torch.nn.functional.gelu(xx).sum().backward()
+            wo, wdot = g * acc * xx.grad, (1 - g * g) * (torch.nn.functional.gelu(x) * acc).sum()
+        else:
+            wo, wdot = g * acc, (1 - g * g) * (x * acc).sum()
+        np.testing.assert_allclose(o.double().numpy(), wo.numpy(), rtol=1e-2, atol=2e-2)
+        assert abs(float(dot) - 3.0 - float(wdot)) <= 1e-3 * abs(float(wdot)) + 1e-2
+    # in-place gate + residual (C aliases aux)
+    B = _rand((N, K), 66) * 0.1
+    y = torch.randn(M, N)
+    y0 = y.clone()
+    H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=y, aux=y, gate=gate, io_f32=1)
+    np.testing.assert_allclose(y.double().numpy(), (y0.double() + g * _ref(A, B, 0, 0)).numpy(), rtol=1e-5, atol=1e-4)

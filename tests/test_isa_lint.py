@@ -56,3 +56,94 @@ def test_no_valu_write_right_in_front_of_an_asm_mfma(tmp_path):
         window = window[-4:]
     assert n_mfma > 5000, n_mfma              # ten instantiations x several unrolled stage bodies
     assert not bad, bad[:5]
+
+
+def _compile_to_asm(src, out):
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-I", CSRC, "-Wno-unused-function",
+                    "-fno-fast-math", "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", str(out)], check=True, capture_output=True)
+
+
+def _instructions(path):
+    for ln, raw in enumerate(open(path), 1):
+        line = raw.split(";")[0].strip()
+        if not line or line.startswith(".") or line.endswith(":"):
+            continue
+        parts = line.replace(",", " ").split()
+        yield ln, line, parts[0], parts[1:]
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc to cross-compile")
+def test_accumulators_of_asm_mfmas_are_read_only_after_the_settle_wait(tmp_path):
+    """The other direction of the same blind spot: of_mfma_acc_settle() is an asm statement with no operand tie to the
+    accumulators, so nothing formally stops hipcc from moving a read of an accumulation register (v_accvgpr_read / an `a` source
+    operand of a store) above its s_nops.  An 8-pass MFMA (16x16x32 bf16) needs 11 wait states between its issue and a VALU /
+    memory read of its result: count them in the cross-compiled ISA (s_nop n = n + 1 wait states, any other instruction 1)."""
+    out = tmp_path / "gemm_w4m.s"
+    _compile_to_asm("gemm_w4m.hip", out)
+    # Per basic block, conservatively: a label that follows an MFMA of the same kernel in the listing counts as "an MFMA was just
+    # issued" (the block may be entered from the K loop).  Registers (re)written by v_accvgpr_write / v_accvgpr_mov inside the
+    # block are exempt -- the accumulator zero-fill blocks read those right away.
+    since, bad, n_reads, seen, clean = None, [], 0, False, set()
+    for ln, raw in enumerate(open(out), 1):
+        line = raw.split(";")[0].strip()
+        if not line or line.startswith("."):
+            if line.startswith(".L") and line.endswith(":"):
+                since, clean = (0 if seen else None), set()
+            continue
+        if line.endswith(":"):
+            seen, since, clean = False, None, set()          # a new kernel
+            continue
+        parts = line.replace(",", " ").split()
+        op, args = parts[0], parts[1:]
+        if op.startswith("v_mfma"):
+            seen, since = True, 0
+            r = _regs(args[0])
+            if r:
+                clean -= r[1]
+            continue
+        srcs = args if op.startswith(("global_store", "buffer_store", "ds_write")) else args[1:]
+        acc_reads = set()
+        for a in srcs:
+            r = _regs(a)
+            if r and r[0] == "a":
+                acc_reads |= r[1]
+        if acc_reads and since is not None:
+            n_reads += 1
+            # (v_accvgpr_mov is what the zero-fill blocks are made of -- a zero written in an earlier block copied around, placed
+            # behind the K loop in the listing; a copy of a live MFMA result does not occur and would surface at its consumer)
+            if since < 11 and not acc_reads <= clean and not op.startswith("v_accvgpr_mov"):
+                bad.append((ln, since, line))
+        if op.startswith(("v_accvgpr_write", "v_accvgpr_mov")):
+            r = _regs(args[0])
+            if r and (not acc_reads or acc_reads <= clean or since is None or since >= 11):
+                clean |= r[1]
+        if since is not None:
+            since += (int(args[0]) + 1) if op == "s_nop" else 1
+            if since >= 11:
+                seen = False          # every MFMA in front of this point has retired: later blocks start settled
+    assert n_reads > 100, n_reads
+    assert not bad, bad[:5]
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc to cross-compile")
+@pytest.mark.parametrize("src", ["gemm_w4m.hip", "gemm_mid.hip", "gemm_pp.hip", "attention.hip"])
+def test_m0_is_only_ever_the_lds_dma_destination(tmp_path, src):
+    """The inline-asm LDS-DMA (of_platform.h) writes M0 without declaring it: hipcc reserves M0 and refuses it in a clobber list
+    ("inline asm clobber list contains reserved registers").  That is sound as long as the compiler itself never keeps a value in M0
+    across those statements -- on gfx950 its only M0 uses are the LDS-DMA builtins (which re-write M0 right in front of every use),
+    s_movrel / GWS / sendmsg (none in these kernels).  Pinned here: in the cross-compiled ISA every mention of m0 is a scalar write
+    of it (`s_mov_b32 m0, ...`, the builtins also `s_add_i32 m0, ...`) and every one of them is followed -- before the next M0 write -- by an `... lds` DMA load."""
+    out = tmp_path / (src + ".s")
+    _compile_to_asm(src, out)
+    pending, n = None, 0
+    for ln, line, op, args in _instructions(out):
+        if "m0" in args:
+            assert op.startswith("s_") and args[0] == "m0" and "m0" not in args[1:], (ln, line)      # written (s_mov / s_add ...), never read
+            assert pending is None, ("M0 written twice without a DMA in between", pending, ln)
+            pending = ln
+            n += 1
+        elif op.startswith(("buffer_load", "global_load")) and ("_lds_" in op or (args and args[-1] == "lds")):
+            pending = None
+        elif op == "s_endpgm":
+            assert pending is None, (pending, "M0 written, never used")
+    assert n >= 4, n
