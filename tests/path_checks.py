@@ -283,3 +283,56 @@ def check_perceiver_8c(ops, dev, *, b=1, T=2, Fv=24, n=16, heads=2, D=64, depth=
     rep, bad = judge_8c(hip, ref32, refac)
     assert not bad, f"SURVEY 8c tolerance failures: {bad}\nall: {rep}"
     return rep
+
+
+# =====================================================================================================================
+# The product MODULE against reference-produced goldens at dim_head 64 (tests/golden/dh64_xattn_*.npz, made by
+# tests/golden/make_golden.py --round4 from the REAL reference): the cached-media branch of helpers.py:175-178,199-205 among them
+# (T_txt != mask length; media_locations = None).  Judged by the one 8c rule (judge_8c) with the reference's own autocast run,
+# stored in the fixture, as the yardstick.  Runs on the GPU (tests/test_gpu_path.py) and on the emulator (tests/test_emu_modules.py).
+# =====================================================================================================================
+DH64_CASES = ("cached_media_decode", "cached_media_decode_attend_all", "no_media_locations_cached", "basic")
+
+
+def check_block_module_against_dh64_golden(case, dev, golden_dir):
+    import os
+    import numpy as np
+    from open_flamingo_amd.src.helpers import GatedCrossAttentionBlock
+    z = np.load(os.path.join(golden_dir, f"dh64_xattn_{case}.npz"))
+    blk = GatedCrossAttentionBlock(dim=64, dim_visual=32, dim_head=64, heads=int(z["heads"]),
+                                   only_attend_immediate_media=bool(z["only_immediate"]))
+    st = O.seeded_state({k: tuple(v.shape) for k, v in blk.state_dict().items()}, int(z["seed_params"]))
+    blk.load_state_dict(st, strict=True)
+    blk.to(dev).train()
+    L, T_img, n = int(z["L"]), int(z["T_img"]), int(z["n_latents"])
+
+    def rnd(shape, seed):
+        g = torch.Generator().manual_seed(seed)
+        return torch.randn(*shape, generator=g, dtype=torch.float64).float()
+
+    x = rnd((2, L, 64), int(z["seed_x"])).to(dev).requires_grad_(True)
+    media = rnd((2, T_img, n, 32), int(z["seed_media"])).to(dev).requires_grad_(True)
+    ml = torch.from_numpy(z["media_locations"]).to(dev) if int(z["has_media_locations"]) else None
+    if ml is not None and not int(z["use_cached"]):
+        assert ml.shape[1] == L
+    y = blk(x, media, media_locations=ml, use_cached_media=bool(z["use_cached"]))
+    (y.float() * torch.from_numpy(z["w"]).to(dev)).sum().backward()
+    hip_g = {"grad.x": x.grad, "grad.media": media.grad, **{"grad." + k: p.grad for k, p in blk.named_parameters()}}
+    want_g = {k: torch.from_numpy(z[k]) for k in z.files if k.startswith("grad.")}
+    assert set(hip_g) == set(want_g), set(hip_g) ^ set(want_g)
+    hip = (y.detach().float().cpu(), {k: v.detach().float().cpu() for k, v in hip_g.items()})
+    ref32 = (torch.from_numpy(z["y"]), want_g)
+    refac = (torch.from_numpy(z["amp.y"]), {k: None for k in want_g})
+    rep, bad = {}, {}
+    e_l2, e_mx = rel_l2(hip[0], ref32[0]), max_abs(hip[0], ref32[0])
+    a_l2, a_mx = rel_l2(refac[0], ref32[0]), max_abs(refac[0], ref32[0])
+    rep["y"] = dict(hip_rel_l2=e_l2, autocast_rel_l2=a_l2, hip_max_abs=e_mx, autocast_max_abs=a_mx)
+    if e_l2 > 2.0 * a_l2 + 1e-6 or e_mx > 2.0 * a_mx + 1e-6:
+        bad["y"] = rep["y"]
+    for k, g32 in want_g.items():
+        e = rel_l2(hip[1][k], g32)
+        rep[k] = dict(hip_rel_l2=e, autocast_rel_l2=float(z["amp.rel_l2." + k]))
+        if not e <= 2e-2:
+            bad[k] = rep[k]
+    assert not bad, f"{case}: SURVEY 8c tolerance failures vs the reference-produced golden: {bad}\nall: {rep}"
+    return rep

@@ -54,11 +54,14 @@ def test_cpu_boundary_matches_reference_flamingo():
 @pytest.mark.gpu
 def test_gpu_boundary_matches_reference_flamingo():
     """The product: libofhip-backed modules inside our Flamingo, fp32 residual stream, bf16 MFMA operands.
-    Tolerances: loss 1e-2 relative; gradient tensors 5e-2 of their max-abs; the (1,)-shaped tanh-gate gradients are
-    whole-tensor reductions sum(dy * branch) that can cancel almost completely (golden: layer-1 ff_gate 1.2e-4 next
-    to layer-3 ff_gate 2.7e-2), so they are held to 5e-2 of the LARGEST gate gradient instead of their own value;
+    Tolerances: loss 1e-2 relative; gradient tensors 5e-2 of their max-abs; the (1,)-shaped tanh-gate gradients
+    PER GATE: 5e-2 of the gate's own value + a floor of 2e-3 of the largest gate gradient (they are whole-tensor reductions
+    sum(dy * branch) that can cancel almost completely -- golden: layer-1 ff_gate 1.2e-4 next to layer-3 ff_gate 2.7e-2 -- so a
+    pure relative rule would measure the cancellation of the small ones; round 3 held every gate to 5e-2 of the LARGEST, which
+    would not have noticed a wrong small gate gradient; the sums themselves are bit-reproducible since round 3).  The tight rule
+    for gate gradients (relative L2 <= 2e-2 on a conditioned loss) lives in tests/path_checks.py::judge_8c;
     greedy tokens may legitimately differ once logits are within bf16 noise, so only the first generated token and
-    >= 50 % agreement are required."""
+    >= 50 % agreement are required here (token equality up to ties: test_gpu_greedy_tokens_equal_reference_up_to_ties)."""
     from open_flamingo_amd.train import towers
     model, info = towers.build_flamingo("OF-tiny", device="cpu", seed=0, gates=0.5)   # CPU RNG = the golden's weights
     model.cuda()
@@ -71,10 +74,14 @@ def test_gpu_boundary_matches_reference_flamingo():
     for k in z.files:
         if k.startswith("grad."):
             g = sd[k[5:]].grad.float().cpu().numpy()
-            scale = gate_scale if k.endswith("_gate") else np.abs(z[k]).max()
-            assert np.abs(g - z[k]).max() <= 5e-2 * scale + 1e-7, k
+            if k.endswith("_gate"):
+                err = float(np.abs(g - z[k]).max())
+                print(k, f"reference {float(z[k].reshape(-1)[0]):+.3e}  error {err:.1e}")
+                assert err <= 5e-2 * float(np.abs(z[k]).max()) + 2e-3 * gate_scale, (k, g, z[k])
+            else:
+                assert np.abs(g - z[k]).max() <= 5e-2 * np.abs(z[k]).max() + 1e-7, k
         elif k.startswith("gradnorm.") and k.endswith("_gate"):
-            assert abs(float(sd[k[9:]].grad.norm()) - float(z[k])) <= 5e-2 * gate_scale + 1e-7, k
+            assert abs(float(sd[k[9:]].grad.norm()) - float(z[k])) <= 5e-2 * float(z[k]) + 2e-3 * gate_scale, k
         elif k.startswith("gradnorm."):
             assert abs(float(sd[k[9:]].grad.norm()) - float(z[k])) <= 5e-2 * float(z[k]) + 1e-7, k
     gen = gen.cpu().numpy()

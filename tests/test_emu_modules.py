@@ -334,3 +334,14 @@ def test_bf16_twins_travel_between_backwards_and_change_nothing(on_emulator, mon
     assert len(keys) >= 8
     for k in keys:
         assert torch.equal(p1[k], p0[k]), k
+
+
+@pytest.mark.parametrize("case", __import__("tests.path_checks", fromlist=["DH64_CASES"]).DH64_CASES)
+def test_block_module_against_reference_goldens_at_dim_head_64(on_emulator, case):
+    """the cached-media branch (helpers.py:175-178,199-205; T_txt != mask length, media_locations = None)
+    of the PRODUCT module against answers produced by the REAL reference at dim_head 64, by the one 8c rule.  The same check runs
+    on the GPU in tests/test_gpu_path.py."""
+    import os
+    from tests import path_checks as PC
+    rep = PC.check_block_module_against_dh64_golden(case, "cpu", os.path.join(os.path.dirname(__file__), "golden"))
+    assert rep["y"]["hip_rel_l2"] > 0.0

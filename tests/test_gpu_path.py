@@ -910,3 +910,30 @@ def test_grouped_media_projections_match_per_block_projections():
     assert abs(l0 - l1) <= 1e-3 * abs(l0), (l0, l1)
     for k in g0:
         assert PC.rel_err(g1[k], g0[k]) < 3e-2, (k, PC.rel_err(g1[k], g0[k]))
+
+
+@pytest.mark.parametrize("case", PC.DH64_CASES)
+def test_block_module_against_reference_goldens_at_dim_head_64(case, golden_dir):
+    """VERDICT r3 weak #1 / SURVEY A7: the cached-media branch of helpers.py:175-178,199-205 -- ``count_nonzero`` text_time
+    broadcast to T_txt new tokens, T_txt != mask length, ``media_locations=None`` -- of the PRODUCT module on the GPU against
+    answers of the REAL reference (tests/golden/dh64_xattn_*.npz: fp64 run = the known answer, autocast(bf16) run = the
+    yardstick), forward and every gradient, by the one 8c rule.  Then the same inputs through the no-grad decode path (projected
+    media cache, eval mode): its forward obeys the same rule."""
+    import os
+    import numpy as np
+    rep = PC.check_block_module_against_dh64_golden(case, "cuda", golden_dir)
+    print(case, {k: f"{v['hip_rel_l2']:.1e}" for k, v in rep.items()})
+    from oracle import flamingo_oracle as O
+    from open_flamingo_amd.src.helpers import GatedCrossAttentionBlock
+    z = np.load(os.path.join(golden_dir, f"dh64_xattn_{case}.npz"))
+    blk = GatedCrossAttentionBlock(dim=64, dim_visual=32, dim_head=64, heads=2, only_attend_immediate_media=bool(z["only_immediate"]))
+    blk.load_state_dict(O.seeded_state({k: tuple(v.shape) for k, v in blk.state_dict().items()}, int(z["seed_params"])))
+    blk.cuda().eval()
+    L, T_img, n = int(z["L"]), int(z["T_img"]), int(z["n_latents"])
+    x = _rnd((2, L, 64), int(z["seed_x"])).cuda()
+    media = _rnd((2, T_img, n, 32), int(z["seed_media"])).cuda()
+    ml = torch.from_numpy(z["media_locations"]).cuda() if int(z["has_media_locations"]) else None
+    with torch.no_grad():
+        y = blk(x, media, media_locations=ml, use_cached_media=bool(z["use_cached"])).float().cpu()
+    y32, yac = torch.from_numpy(z["y"]), torch.from_numpy(z["amp.y"])
+    assert PC.rel_l2(y, y32) <= 2 * PC.rel_l2(yac, y32) + 1e-6 and PC.max_abs(y, y32) <= 2 * PC.max_abs(yac, y32) + 1e-6
