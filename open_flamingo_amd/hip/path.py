@@ -87,43 +87,93 @@ def feed_forward_fwd(ops, P, W, x, *, prefix="", gate=None, residual=False, keep
 # ---- bf16 twins of fp32 gradient-stream tensors, handed from one module's backward to the next -------------------------------
 # Every backward on the fp32 stream ends in a LayerNorm backward that can emit the bf16 copy of its dx in the same pass (+2 B per
 # element) and every backward starts by casting its incoming gradient to bf16 for its GEMMs (a pass of its own: 6 B per element,
-# 60 launches per step at cfg-2).  The producer offers the twin here, the consumer takes it: matched by storage address, element
+# 60 launches per step at cfg-2).  The producer offers the twin, the consumer takes it: matched by storage address, element
 # count and version counter of the fp32 tensor, which the entry keeps ALIVE (its address cannot be recycled while the entry
-# exists); an entry is consumed by its first taker, the list holds at most four (a gradient nobody takes ages out).
-_bf16_twins = []
+# exists); an entry is consumed by its first taker, a scope holds at most four (a gradient nobody takes ages out).
+#
+# The registry lives in a Scope that belongs to ONE model: Flamingo.__init__ makes one and hands it to every module of its tree
+# (`_of_scope`), the autograd Functions pass their module's scope down here.  Two models in one process therefore never see each
+# other's entries; modules used on their own share DEFAULT_SCOPE.
+class _SharedCache:
+    """per-forward artefacts shared by all blocks that see the same media / media_locations tensors (the reference recomputes them
+    in each of the 24 blocks: helpers.py:187-189, 199-208); identity-keyed, a handful of entries"""
+
+    def __init__(self, cap=8):
+        self.cap, self.items = cap, []
+
+    def get(self, key_tensor, tag, make):
+        key = (key_tensor.data_ptr(), key_tensor._version, tuple(key_tensor.shape), key_tensor.dtype, tag)
+        for k, src, val in self.items:
+            if k == key and src is key_tensor:
+                return val
+        val = make()
+        self.items.append((key, key_tensor, val))
+        if len(self.items) > self.cap:
+            self.items.pop(0)
+        return val
+
+
+class Scope:
+    """Mutable per-model host state of the product path: the bf16-twin registry and the shared per-forward artefacts."""
+
+    def __init__(self):
+        self.twins = []
+        self.shared = _SharedCache()
+
+    def clear(self):
+        self.twins.clear()
+        self.shared.items.clear()
+
+
+DEFAULT_SCOPE = Scope()
 TWINS = True          # constant; tools/ab_bf16_twins.py clears it for the same-box A/B
 
 
-def offer_bf16_twin(t, twin):
+def scope_of(mod):
+    """the Scope a module's forward / backward works in: its model's, or DEFAULT_SCOPE for a module used on its own"""
+    return getattr(mod, "_of_scope", None) or DEFAULT_SCOPE
+
+
+def adopt(model, scope=None):
+    """Give every module of ``model``'s tree one Scope (a new one unless given).  Called by Flamingo.__init__."""
+    scope = scope or Scope()
+    for m in model.modules():
+        m.__dict__["_of_scope"] = scope
+    return scope
+
+
+def offer_bf16_twin(t, twin, scope=None):
     """t: fp32 gradient tensor about to be returned from a backward; twin: bf16 tensor with the same values."""
     if t.dtype != F32 or twin is None or twin.numel() != t.numel():
         return
-    _bf16_twins.append((t, t._version, twin))
-    del _bf16_twins[:-4]
+    twins = (scope or DEFAULT_SCOPE).twins
+    twins.append((t, t._version, twin))
+    del twins[:-4]
 
 
-def take_bf16_twin(t):
+def take_bf16_twin(t, scope=None):
     """bf16 twin of the contiguous fp32 tensor t (any view of what was offered), or None."""
-    for i, (src, ver, twin) in enumerate(_bf16_twins):
+    twins = (scope or DEFAULT_SCOPE).twins
+    for i, (src, ver, twin) in enumerate(twins):
         if (src.data_ptr() == t.data_ptr() and src.numel() == t.numel() and src._version == ver and t._version == ver
                 and t.dtype == F32 and t.is_contiguous() and twin.device == t.device):
-            del _bf16_twins[i]
+            del twins[i]
             return twin.view(t.shape)
     return None
 
 
-def bf16_of(ops, t):
+def bf16_of(ops, t, scope=None):
     """t as a bf16 GEMM operand: the twin a producer offered, else a cast pass."""
-    twin = take_bf16_twin(t) if t.dtype == F32 else None
+    twin = take_bf16_twin(t, scope) if t.dtype == F32 else None
     return twin if twin is not None else ops.to_bf16(t)
 
 
-def feed_forward_bwd(ops, P, W, S, dy, G, *, prefix="", gate=None, gate_name=None, residual=False):
+def feed_forward_bwd(ops, P, W, S, dy, G, *, prefix="", gate=None, gate_name=None, residual=False, scope=None):
     """dy (rows, d) stream dtype, contiguous.  Returns (dx, dx_bf16 or None): dx = [dy +] LN_bwd(...)."""
     dev = dy.device
     rows, d = S["x"].shape
     hid = W[prefix + "1.weight"].shape[0]
-    dyb = bf16_of(ops, dy)
+    dyb = bf16_of(ops, dy, scope)
     da = _e((rows, hid), BF16, dev)
     ops.gemm(dyb, W[prefix + "3.weight"], da, tb=True, epi=EPI_DGELU_DOT, aux=S["a"], gate=gate,
              dot=G.acc(gate_name, (1,)) if gate_name else None)
@@ -175,7 +225,7 @@ def masked_cross_attention_fwd(ops, P, W, x, media_bf, tt, *, B, L, T, n, heads,
 
 def masked_cross_attention_bwd(ops, P, W, S, media_bf, tt, dy, dyb, G, *, B, L, T, n, heads, only_immediate,
                                prefix="attn.", gate=None, gate_name=None, residual=False, need_dmedia=True, safe=0,
-                               dim_head=64, dkv_out=None, offer_twin=False):
+                               dim_head=64, dkv_out=None, offer_twin=False, scope=None):
     """dy stream dtype + its bf16 copy dyb.  Returns (dx, dmedia fp32 or None).
     dkv_out: (B*T*n, 2*inner) bf16 destination of d(k|v) owned by the caller (a column block of the buffer shared by all
     blocks when their to_kv projections are grouped); the caller then forms the media gradient of all
@@ -205,7 +255,7 @@ def masked_cross_attention_bwd(ops, P, W, S, media_bf, tt, dy, dyb, G, *, B, L, 
     ops.ln_bwd(dxn, S["x"], S["st"], P[prefix + "norm.weight"], resid=dy if residual else None, dx=dx, dx_bf16=dxb,
                dw=G.acc(prefix + "norm.weight", (d,)), db=G.acc(prefix + "norm.bias", (d,)))
     if dxb is not None:
-        offer_bf16_twin(dx, dxb)
+        offer_bf16_twin(dx, dxb, scope)
     t, beta = G.mat(prefix + "to_kv.weight", (2 * inner, Dv))
     ops.gemm(dkv, media_bf, t, ta=True, tb=True, epi=EPI_ACC_F32, beta=beta)
     dmedia = None
@@ -233,18 +283,18 @@ def xattn_block_fwd(ops, P, W, x, media_bf, tt, *, B, L, T, n, heads, only_immed
 
 
 def xattn_block_bwd(ops, P, W, S, media_bf, tt, dy, *, B, L, T, n, heads, only_immediate, need_dmedia=True, safe=0,
-                    sinks=None, dim_head=64, fresh=(), dkv_out=None):
+                    sinks=None, dim_head=64, fresh=(), dkv_out=None, scope=None):
     """Returns (dx, dmedia fp32 (B*T*n, Dv) or None, grads dict keyed like P).  sinks / fresh: see _GradOut."""
     G = _GradOut(sinks, dy.device, fresh)
     dy = dy.contiguous()
     # ---- feed forward branch: y2 = y1 + tanh(gf) * F(y1)
     dy1, dy1b = feed_forward_bwd(ops, P, W, S["ff"], dy, G, prefix="ff.", gate=P["ff_gate"], gate_name="ff_gate",
-                                 residual=True)
+                                 residual=True, scope=scope)
     # ---- attention branch: y1 = x + tanh(ga) * A(x, media)
     dx, dmedia = masked_cross_attention_bwd(ops, P, W, S["attn"], media_bf, tt, dy1, dy1b, G, B=B, L=L, T=T, n=n,
                                             heads=heads, only_immediate=only_immediate, gate=P["attn_gate"],
                                             gate_name="attn_gate", residual=True, need_dmedia=need_dmedia, safe=safe,
-                                            dim_head=dim_head, dkv_out=dkv_out, offer_twin=True)
+                                            dim_head=dim_head, dkv_out=dkv_out, offer_twin=True, scope=scope)
     return dx, dmedia, G.g
 
 

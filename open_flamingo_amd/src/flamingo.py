@@ -34,6 +34,10 @@ class Flamingo(nn.Module):
                                    gradient_checkpointing=gradient_checkpointing)
         self._use_gradient_checkpointing = gradient_checkpointing
         self.perceiver._use_gradient_checkpointing = gradient_checkpointing
+        # one Scope (hip/path.py: bf16-twin registry + shared per-forward artefacts) for this model's whole module tree: two
+        # models in one process never see each other's host-side state
+        from ..hip import path as _path
+        _path.adopt(self)
 
     group_media_projections = True     # class-level switch (instance attribute overrides): see _encode_vision_x
 

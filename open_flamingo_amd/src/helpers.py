@@ -34,25 +34,9 @@ def _require_hip(t, what):
         raise TypeError(f"{what}: activations must be float32 or bfloat16 (got {t.dtype})")
 
 
-# per-forward artefacts shared by all blocks that see the same media / media_locations tensors (the reference
-# recomputes them in each of the 24 blocks: helpers.py:187-189, 199-208)
-class _SharedCache:
-    def __init__(self, cap=8):
-        self.cap, self.items = cap, []
-
-    def get(self, key_tensor, tag, make):
-        key = (key_tensor.data_ptr(), key_tensor._version, tuple(key_tensor.shape), key_tensor.dtype, tag)
-        for k, src, val in self.items:
-            if k == key and src is key_tensor:
-                return val
-        val = make()
-        self.items.append((key, key_tensor, val))
-        if len(self.items) > self.cap:
-            self.items.pop(0)
-        return val
-
-
-_shared = _SharedCache()
+# per-forward artefacts shared by all blocks that see the same media / media_locations tensors live in the model's Scope
+# (hip/path.py: Scope.shared); modules used on their own share the default scope
+_shared = _path.DEFAULT_SCOPE.shared
 
 
 class _HipParamModule(nn.Module):
@@ -390,8 +374,9 @@ def _xattn_operands(mod, x, media, media_locations, use_cached_media, params, na
     if not xr.is_contiguous():
         xr = xr.contiguous()
     med = media.detach()
-    media_bf = _shared.get(media, "bf16", lambda: ops.to_bf16(med.reshape(B * T * n, Dv).contiguous())
-                           if med.dtype == F32 else med.reshape(B * T * n, Dv).contiguous())
+    shared = _path.scope_of(mod).shared
+    media_bf = shared.get(media, "bf16", lambda: ops.to_bf16(med.reshape(B * T * n, Dv).contiguous())
+                          if med.dtype == F32 else med.reshape(B * T * n, Dv).contiguous())
     tt = None
     if media_locations is not None:
         def _tt():
@@ -399,7 +384,7 @@ def _xattn_operands(mod, x, media, media_locations, use_cached_media, params, na
             ml = media_locations.to(torch.uint8).contiguous()
             ops.text_time(ml, out, L, bool(use_cached_media))
             return out
-        tt = _shared.get(media_locations, ("tt", L, bool(use_cached_media)), _tt)
+        tt = shared.get(media_locations, ("tt", L, bool(use_cached_media)), _tt)
     dims = dict(B=B, L=L, T=T, n=n, heads=attn.heads, only_immediate=attn.only_attend_immediate_media,
                 dim_head=attn.dim_head)
     return ops, P, W, xr, media_bf, tt, dims
@@ -506,8 +491,8 @@ class _GroupedMediaKVFn(torch.autograd.Function):
         ops = Ops.default()
         B, T, n, Dv = media.shape
         med = media.detach()
-        grp.media_bf = _shared.get(media, "bf16", lambda: ops.to_bf16(med.reshape(B * T * n, Dv).contiguous())
-                                   if med.dtype == F32 else med.reshape(B * T * n, Dv).contiguous())
+        grp.media_bf = _path.scope_of(grp.blocks[0]).shared.get(
+            media, "bf16", lambda: ops.to_bf16(med.reshape(B * T * n, Dv).contiguous()) if med.dtype == F32 else med.reshape(B * T * n, Dv).contiguous())
         grp.Ws = [b._weights_bf16(ops, [("attn.to_kv.weight", b.attn.to_kv.weight)])["attn.to_kv.weight"] for b in grp.blocks]
         ptrs = tuple(w.data_ptr() for w in grp.Ws)           # stable while the step epilogue owns the bf16 copies
         if _GroupedMediaKVFn._table is None or _GroupedMediaKVFn._table[0] != (ptrs, media.device):
@@ -557,7 +542,8 @@ class _GatedXAttnFn(torch.autograd.Function):
         sinks, fresh = _grad_sinks(_XATTN_NAMES, ctx.params)
         dx, dmedia, g = _path.xattn_block_bwd(ops, ctx.P, ctx.W, ctx.S, ctx.media_bf, ctx.tt, dy.reshape(-1, d),
                                               need_dmedia=need_dmedia, sinks=sinks, fresh=fresh,
-                                              dkv_out=grp.dkv_of(ctx.mod) if grp is not None else None, **ctx.dims)
+                                              dkv_out=grp.dkv_of(ctx.mod) if grp is not None else None,
+                                              scope=_path.scope_of(ctx.mod), **ctx.dims)
         ctx.S = None
         if dmedia is not None:
             dmedia = (dmedia if ctx.mdtype == F32 else ops.to_bf16(dmedia)).view(ctx.mshape)

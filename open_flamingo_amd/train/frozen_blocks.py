@@ -77,7 +77,7 @@ class _FrozenMptBlockFn(torch.autograd.Function):
     with frozen weights.  x: (B, L, d) fp32 residual stream; returns the new stream (fp32)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, Wqkv, Wo, Wup, Wdown, slopes, kv_len, heads, head_dim, scale, wts):
+    def forward(ctx, x, w1, b1, w2, b2, Wqkv, Wo, Wup, Wdown, slopes, kv_len, heads, head_dim, scale, wts, scope=None):
         ops = _ops()
         B, L, d = x.shape
         rows = B * L
@@ -116,6 +116,7 @@ class _FrozenMptBlockFn(torch.autograd.Function):
             y = ops.add_bf16(x1, u)                                  # fp32 stream + bf16 branch -> fp32
         del g
         ctx.save_for_backward(x2, st1, qkv, o, lse, x1, st2, h, w1, w2, Wqkv, Wo, Wup, Wdown, slopes, kv_len)
+        ctx.scope = scope        # the model's hip/path.py Scope (bf16-twin registry), or None = the default one
         ctx.kw, ctx.shape, ctx.wts = kw, (B, L, d), wts      # wts: (Wqkv^T, Wo^T, Wup^T, Wdown^T) or None: frozen, not autograd inputs
         return y.view(B, L, d)
 
@@ -130,7 +131,7 @@ class _FrozenMptBlockFn(torch.autograd.Function):
         dy2 = dy.reshape(rows, d)
         if dy2.dtype != F32 or not dy2.is_contiguous():
             dy2 = dy2.to(F32).contiguous()
-        dact = _mm_dx(_path.bf16_of(ops, dy2), Wdown, td)            # (rows, 4d); the bf16 copy the backward above left, or a cast
+        dact = _mm_dx(_path.bf16_of(ops, dy2, ctx.scope), Wdown, td)            # (rows, 4d); the bf16 copy the backward above left, or a cast
         dh = ops.gelu_bwd(dact, h, out=dact)                         # in place: dact * gelu'(h)
         del dact
         dm = _mm_dx(dh, Wup, tu)                                     # (rows, d)
@@ -146,8 +147,13 @@ class _FrozenMptBlockFn(torch.autograd.Function):
         da = _mm_dx(dqkv, Wqkv, tq)                                  # (rows, d)
         dxb = torch.empty(rows, d, dtype=BF16, device=dev) if _path.TWINS else None
         ops.ln_bwd(da, x2, st1, w1, resid=dx1, dx=dx1, dx_bf16=dxb)  # in place: dx = dx1 + norm_1'(da); + its bf16 twin for the
-        _path.offer_bf16_twin(dx1, dxb)                              # backward of whatever produced x
-        return (dx1.view(B, L, d),) + (None,) * 14
+        _path.offer_bf16_twin(dx1, dxb, ctx.scope)                   # backward of whatever produced x
+        return (dx1.view(B, L, d),) + (None,) * 15
+
+
+# Debug switch (module attribute, set by the caller -- bench.py --check-right-padding, tests): verify on the host that every
+# attention mask the fused blocks reduce to key counts really is a prefix of ones.  Off by default: the check synchronises.
+CHECK_RIGHT_PADDING = False
 
 
 class _LiteMask:
@@ -172,6 +178,10 @@ class _LiteMask:
         if self.am is None:
             return None
         if self._lens is None:       # right padding (train/data.py pads on the right): real keys per sequence
+            if CHECK_RIGHT_PADDING:  # debug: the per-sequence COUNT is only the mask if the ones are a prefix (one host sync)
+                if not right_padded(self.am):
+                    raise ValueError("fused frozen blocks: attention_mask is not right-padded (a 1 follows a 0 in some row); the "
+                                     "kernels take per-sequence key counts -- left-padded / holey masks need the HF block forward")
             self._lens = self.am.ne(0).sum(-1).to(torch.int32).contiguous()
         return self._lens
 
@@ -287,7 +297,7 @@ def _mpt_block_fused_forward(self, hidden_states, position_bias, attention_mask,
                _transposed(ffn, "up_proj", ffn.up_proj.weight), _transposed(ffn, "down_proj", ffn.down_proj.weight))
     y = _FrozenMptBlockFn.apply(x, self.norm_1.weight, _zero_bias(self.norm_1), self.norm_2.weight, _zero_bias(self.norm_2),
                                 attn.Wqkv.weight, attn.out_proj.weight, ffn.up_proj.weight, ffn.down_proj.weight,
-                                slopes, lens, attn.n_heads, attn.head_dim, float(attn.softmax_scale), wts)
+                                slopes, lens, attn.n_heads, attn.head_dim, float(attn.softmax_scale), wts, _path.scope_of(self))
     return y, None
 
 
@@ -340,7 +350,7 @@ class _FrozenNeoXBlockFn(torch.autograd.Function):
     the bias in the GEMM (addmm).  Backward = the chain reversed, dX GEMMs only (against pre-transposed weights)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, Wqkv, bqkv, Wd, bd, Wup, bup, Wdown, bdown, cos, sin, kv_len, heads, hs, rot, parallel, wts):
+    def forward(ctx, x, w1, b1, w2, b2, Wqkv, bqkv, Wd, bd, Wup, bup, Wdown, bdown, cos, sin, kv_len, heads, hs, rot, parallel, wts, scope=None):
         ops = _ops()
         B, L, d = x.shape
         rows = B * L
@@ -376,6 +386,7 @@ class _FrozenNeoXBlockFn(torch.autograd.Function):
         if parallel:
             ops.add_bf16(y, t, out=y)                                    # x + mlp + attn
         ctx.save_for_backward(x2, st1, qp, op, lse, x1, st2, h, w1, w2, Wqkv, Wd, Wup, Wdown, cos, sin, kv_len)
+        ctx.scope = scope
         ctx.kw, ctx.shape, ctx.wts, ctx.cfg = kw, (B, L, d), wts, (heads, hs, rot, pad, parallel)
         return y.view(B, L, d)
 
@@ -391,7 +402,7 @@ class _FrozenNeoXBlockFn(torch.autograd.Function):
         dy2 = dy.reshape(rows, d)
         if dy2.dtype != F32 or not dy2.is_contiguous():
             dy2 = dy2.to(F32).contiguous()
-        dyb = _path.bf16_of(ops, dy2)
+        dyb = _path.bf16_of(ops, dy2, ctx.scope)
         dact = _mm_dx(dyb, Wdown, tdn)                                   # (rows, 4d)
         dh = ops.gelu_bwd(dact, h, out=dact)
         del dact
@@ -415,8 +426,8 @@ class _FrozenNeoXBlockFn(torch.autograd.Function):
         da = _mm_dx(dqkv, Wqkv, tq)
         dxb = torch.empty(rows, d, dtype=BF16, device=dev) if _path.TWINS else None
         ops.ln_bwd(da, x2, st1, w1, resid=dx1, dx=dx1, dx_bf16=dxb)      # in place: dx = dx1 + norm_1'(da); + its bf16 twin
-        _path.offer_bf16_twin(dx1, dxb)
-        return (dx1.view(B, L, d),) + (None,) * 20
+        _path.offer_bf16_twin(dx1, dxb, ctx.scope)
+        return (dx1.view(B, L, d),) + (None,) * 21
 
 
 def _is_exact_gelu(act):
@@ -468,7 +479,7 @@ def _neox_layer_fused_forward(self, hidden_states, attention_mask=None, position
                                     at.dense.weight, at.dense.bias, mlp.dense_h_to_4h.weight, mlp.dense_h_to_4h.bias,
                                     mlp.dense_4h_to_h.weight, mlp.dense_4h_to_h.bias, cs[1], cs[2], lite.lens(),
                                     at.config.num_attention_heads, at.head_size, at.rotary_ndims,
-                                    bool(self.use_parallel_residual), wts)
+                                    bool(self.use_parallel_residual), wts, _path.scope_of(self))
 
 
 def use_fused_frozen_neox_blocks(lm, allow_cpu=False, assume_right_padding=False):

@@ -76,7 +76,7 @@ def train_step(model, reducer, optimizer, batch_mmc4, info, batch_laion=None, lo
     of NaN batches (use nan_check=True where that matters more than the sync); False = no check."""
     fused = hasattr(optimizer, "reducer")         # FlatAdamW: clip + AdamW + zero_grad in two device passes
     from ..hip import path as _path
-    _path._bf16_twins.clear()                     # a gradient twin nobody took in the previous backward (the embedding's) is not kept alive
+    _path.scope_of(getattr(model, "module", model)).twins.clear()         # a gradient twin nobody took in the previous backward (the embedding's) is not kept alive
     params = None if fused else [p for g in optimizer.param_groups for p in g["params"]]
     if batch_laion is not None:
         with reducer.no_sync() if reducer is not None else contextlib.nullcontext():

@@ -220,6 +220,14 @@ def test_left_padded_eval_forward_keeps_hf_masking(on_emulator):
         calls.clear()
         lm.train()                                                              # training: right padding by contract
         assert _rel(logits(right), ref_right) < 2e-2 and len(calls) == 2
+        # ... a contract the debug switch verifies at run time: a left-padded TRAINING batch is refused
+        frozen_blocks.CHECK_RIGHT_PADDING = True
+        try:
+            logits(right)
+            with pytest.raises(ValueError, match="not right-padded"):
+                logits(left)
+        finally:
+            frozen_blocks.CHECK_RIGHT_PADDING = False
     finally:
         frozen_blocks._FrozenMptBlockFn.apply = orig
 

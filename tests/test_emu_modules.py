@@ -306,14 +306,13 @@ def test_bf16_twins_travel_between_backwards_and_change_nothing(on_emulator, mon
             if isinstance(mod, torch.nn.Linear) and mod is not lm.get_output_embeddings() and not mod.weight.requires_grad:
                 mod.weight.data = mod.weight.data.to(torch.bfloat16)
         assert frozen_blocks.use_fused_frozen_mpt_blocks(lm, allow_cpu=True) > 0
-        P._bf16_twins.clear()
         if not handoff:
-            monkeypatch.setattr(P, "offer_bf16_twin", lambda t, twin: None)
+            monkeypatch.setattr(P, "offer_bf16_twin", lambda t, twin, scope=None: None)
         casts, taken = [], []
         ops = H.emu_ops()
         orig_cast, orig_take = type(ops).to_bf16, P.take_bf16_twin
         monkeypatch.setattr(type(ops), "to_bf16", lambda self, x, out=None: (casts.append(tuple(x.shape)), orig_cast(self, x, out))[1])
-        monkeypatch.setattr(P, "take_bf16_twin", lambda t: (lambda r: (taken.append(r is not None), r)[1])(orig_take(t)))
+        monkeypatch.setattr(P, "take_bf16_twin", lambda t, scope=None: (lambda r: (taken.append(r is not None), r)[1])(orig_take(t, scope)))
         red = GradReducer(model, embedding_rows=[info["media_token_id"], info["eoc_token_id"]])
         batch = synthetic.make_batch(2, 2, 24, info, "cpu", seed=5, image_size=56)
         opt = FlatAdamW(red, lr=1e-3, ops=ops)

@@ -147,7 +147,7 @@ def test_bf16_twin_registry_semantics():
     (views included), consumed by the first taker, never served after an in-place change of the fp32 tensor, at most four entries."""
     import torch
     from open_flamingo_amd.hip import path as P
-    P._bf16_twins.clear()
+    P.DEFAULT_SCOPE.twins.clear()
     x = torch.randn(6, 8)
     tw = x.to(torch.bfloat16)
     P.offer_bf16_twin(x, tw)
@@ -157,7 +157,7 @@ def test_bf16_twin_registry_semantics():
     P.offer_bf16_twin(x, tw)
     x.add_(1.0)                                                        # the fp32 tensor changed after the offer: the twin is stale
     assert P.take_bf16_twin(x) is None
-    P._bf16_twins.clear()
+    P.DEFAULT_SCOPE.twins.clear()
     y = torch.randn(6, 8)
     P.offer_bf16_twin(y, y.to(torch.bfloat16))
     assert P.take_bf16_twin(torch.randn(6, 8)) is None                 # another tensor of the same shape
@@ -166,5 +166,32 @@ def test_bf16_twin_registry_semantics():
     keep = [torch.randn(4, 4) for _ in range(6)]
     for t in keep:
         P.offer_bf16_twin(t, t.to(torch.bfloat16))
-    assert len(P._bf16_twins) == 4 and P.take_bf16_twin(keep[0]) is None and P.take_bf16_twin(keep[5]) is not None
-    P._bf16_twins.clear()
+    assert len(P.DEFAULT_SCOPE.twins) == 4 and P.take_bf16_twin(keep[0]) is None and P.take_bf16_twin(keep[5]) is not None
+    P.DEFAULT_SCOPE.twins.clear()
+
+
+def test_host_state_is_scoped_to_the_model_instance():
+    """the bf16-twin registry and the shared per-forward artefacts belong to a hip/path.py Scope that
+    Flamingo.__init__ gives to its whole module tree -- two models in one process never see each other's entries, a module used on
+    its own works in the default scope."""
+    import torch
+    from open_flamingo_amd.hip import path as P
+    a, b = torch.nn.Sequential(torch.nn.Linear(2, 2)), torch.nn.Sequential(torch.nn.Linear(2, 2))
+    sa, sb = P.adopt(a), P.adopt(b)
+    assert sa is not sb and P.scope_of(a[0]) is sa and P.scope_of(b[0]) is sb and P.scope_of(torch.nn.Linear(1, 1)) is P.DEFAULT_SCOPE
+    x = torch.randn(4, 8)
+    tw = x.to(torch.bfloat16)
+    P.offer_bf16_twin(x, tw, sa)
+    assert P.take_bf16_twin(x, sb) is None and P.take_bf16_twin(x) is None          # another model / no model: not visible
+    assert P.take_bf16_twin(x, sa) is not None and P.take_bf16_twin(x, sa) is None   # its own model: once
+    made = []
+    key = torch.zeros(3)
+    assert sa.shared.get(key, "t", lambda: made.append(1) or "A") == "A"
+    assert sb.shared.get(key, "t", lambda: made.append(1) or "B") == "B" and sa.shared.get(key, "t", lambda: "never") == "A"
+    assert len(made) == 2
+    from tests.cpu_model import tiny_cpu_flamingo
+    m1, _ = tiny_cpu_flamingo(seed=0, oracle=False)
+    m2, _ = tiny_cpu_flamingo(seed=1, oracle=False)
+    s1, s2 = P.scope_of(m1), P.scope_of(m2)
+    assert s1 is not s2 and s1 is not P.DEFAULT_SCOPE
+    assert all(P.scope_of(m) is s1 for m in m1.modules()) and all(P.scope_of(m) is s2 for m in m2.modules())
