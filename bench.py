@@ -161,6 +161,17 @@ CONFIGS = {   # BASELINE.json configs that fit one GPU: family, p
 }
 
 
+def _lib_sha16():
+    """which build of the HIP library this line was measured on (the .so is built in-tree and shipped, not committed)"""
+    import hashlib
+    path = os.path.join(ROOT, "open_flamingo_amd", "csrc", "libofhip.so")
+    try:
+        with open(path, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def pmc_traffic(key, shape):
     """HBM-side bytes per launch of the dominant kernel.  PMC counters cannot be collected inside a timed run (rocprofv3
     --pmc serialises kernels and needs separate passes per counter group), so the live line quotes the committed PMC
@@ -416,7 +427,8 @@ def main():
                           "grad_wire_dtype": "bf16" if args.wire_bf16 else "fp32",
                           "embedding_row_gradient": "sparse taps" if args.sparse_embedding_rows else "dense, masked",
                           "laion_pass": (f"B={args.laion_batch} T=1 L=32, loss x0.2, same optimizer step" if args.laion_batch else "off")},
-               "loss": None if loss is None else round(float(loss), 4)}
+               "loss": None if loss is None else round(float(loss), 4),
+               "libofhip_sha16": _lib_sha16()}
         fl = step_flops(info, args.batch, args.T, args.L)
         if args.laion_batch:
             fl = {k: v + step_flops(info, args.laion_batch, 1, 32)[k] for k, v in fl.items()}
