@@ -264,6 +264,9 @@ def main():
                          "32 text tokens, loss multiplier 0.2, its backward under no_sync) before the MMC4-style pass -- the two-pass "
                          "step of the reference's training script (run_train.sh: batch_size_laion = 2 x batch_size_mmc4); BASELINE.json "
                          "names only the MMC4-style batch, so the default (0) is the primary number")
+    ap.add_argument("--no-vision-prefetch", action="store_true",
+                    help="run the frozen vision tower at the start of each step (as the reference does) instead of enqueuing the NEXT "
+                         "step's tower forward on a side stream next to the step epilogue (train/step.py: next_vision_x)")
     ap.add_argument("--gemm-report", default=None, help="write a per-(layout,epilogue,shape) GEMM time table (JSON lines)")
     args = ap.parse_args()
     cfg_family, cfg_batch, cfg_T, cfg_L, cfg_name = CONFIGS[args.config]
@@ -306,6 +309,8 @@ def main():
     batch = synthetic.make_batch(args.batch, args.T, args.L, info, device, seed=1 + rank)
     laion = synthetic.make_batch(args.laion_batch, 1, 32, info, device, seed=101 + rank) if args.laion_batch > 0 else None
     step_kw = dict(batch_laion=laion, loss_multiplier_laion=0.2) if laion is not None else {}
+    if not args.no_vision_prefetch:       # the next step's first forward sees this tensor (a loader is one batch ahead anyway)
+        step_kw["next_vision_x"] = (laion if laion is not None else batch)["vision_x"]
     ops = Ops.default()
     nan_check = "device" if (args.nan_check == "device" and not args.torch_optimizer) else True
 
@@ -426,6 +431,8 @@ def main():
                           "vendor_gemm_table": f"TunableOp table, {n_tuned} shapes, tuning off" if n_tuned else "library defaults",
                           "grad_wire_dtype": "bf16" if args.wire_bf16 else "fp32",
                           "embedding_row_gradient": "sparse taps" if args.sparse_embedding_rows else "dense, masked",
+                          "vision_tower_schedule": ("at the start of the step" if args.no_vision_prefetch else
+                                                    "next step's tower forward on a side stream next to the step epilogue"),
                           "laion_pass": (f"B={args.laion_batch} T=1 L=32, loss x0.2, same optimizer step" if args.laion_batch else "off")},
                "loss": None if loss is None else round(float(loss), 4),
                "libofhip_sha16": _lib_sha16()}

@@ -265,6 +265,48 @@ OF_DEV void epilogue_group_aux_dma(const OfGemmArgs& p, int m_base, int n_base, 
 #pragma unroll
     for (int it = 0; it < 4; ++it) of_glds16<ASM>(src + (size_t)it * 8 * p.ldaux, lds_dst + it * 1024);
 }
+// The residual of the GATE_RESID epilogue the same way (big-tile kernel on 16x16x32 MFMAs: three groups in flight instead of one
+// through registers).  bf16 stream: the *_DOT layout above (4 pieces).  fp32 stream: a group's residual tile = 32 rows x 256 B =
+// eight 1-KiB pieces of 4 rows; piece q, lane l holds row 4q + (l >> 4), 16-byte chunk (l & 15) ^ (8 * ((l >> 4) & 1)) of the row:
+// odd rows have their two 128-byte halves exchanged, so that the split lane map of the fp32 row passes (a lane reads chunks j and
+// 8 + j of row lane >> 3) hits 64 distinct banks per 16 lanes.
+constexpr int RESID_LDS_BYTES = 8192;
+template <bool ASM>
+OF_DEV void epilogue_group_resid_dma(const OfGemmArgs& p, int m_base, int n_base, int lane, char* lds_dst) {
+    if (p.io_f32) {
+        const int r4 = lane >> 4, ch = (lane & 15) ^ ((r4 & 1) << 3);
+        const float* src = (const float*)p.aux + (size_t)(m_base + r4) * p.ldaux + n_base + ch * 4;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) of_glds16<ASM>(src + (size_t)q * 4 * p.ldaux, lds_dst + q * 1024);
+    } else {
+        epilogue_group_aux_dma<ASM>(p, m_base, n_base, lane, lds_dst);
+    }
+}
+// row passes of a GATE_RESID group whose accumulators are in the patch and whose residual tile is in LDS (landed)
+template <bool F32>
+OF_DEV void epilogue_group_rows_residlds(const OfGemmArgs& p, char* patch, const char* res_lds, int m_base, int n_base, int lane, float gv,
+                                         float sc, float& dot) {
+    const int hi = F32 ? 32 : 4;
+    const int rd_row = lane >> 3, j = lane & 7, rd_col = j * (F32 ? 4 : 8);
+    of_wave_sync();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + rd_row;
+        const f32x4 v0 = *(const f32x4*)(patch + r * PATCH_PITCH + rd_col * 4), v1 = *(const f32x4*)(patch + r * PATCH_PITCH + (rd_col + hi) * 4);
+        AuxPre pre;
+        if (F32) {
+            const char* row = res_lds + (r >> 2) * 1024 + (r & 3) * 256;
+            const int x = (r & 1) << 3;
+            pre.lo = *(const u32x4*)(row + ((j ^ x) << 4));
+            pre.hi = *(const u32x4*)(row + (((8 + j) ^ x) << 4));
+        } else {
+            pre.lo = *(const u32x4*)(res_lds + it * 1024 + lane * 16);
+        }
+        const float a8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        epilogue_row8<OF_EPI_GATE_RESID>(p, a8, m_base + r, n_base + rd_col, gv, sc, dot, &pre, hi);
+    }
+    of_wave_sync();
+}
 // as epilogue_group_rows with the aux tile in LDS (aux_lds, landed); row passes in a ROLLED loop (one copy of the math)
 template <int EPI>
 OF_DEV void epilogue_group_rows_auxlds(const OfGemmArgs& p, char* patch, const char* aux_lds, int m_base, int n_base, int lane, float gv,

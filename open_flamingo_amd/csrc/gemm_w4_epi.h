@@ -9,7 +9,39 @@ namespace oft {
 
 // `to_patch(g, patch)` writes the wave's accumulator group g (rows 32 (g >> 1).., columns 64 (g & 1).. of its 128 x 128) into the
 // patch: ofg::patch_write32 for 32x32x16 accumulators, ofg::patch_write16 for 16x16x32 ones.
-template <int EPI, bool ASMDMA, class ToPatch>
+// GATE_RESID with the residual tiles by LDS-DMA (RESID_DMA: the caller has requested group 0's tile into the 8-KiB slot behind
+// the ring before its K loop and launched with 4 * ofg::RESID_LDS_BYTES of LDS behind the ring): three groups in flight -- slot 0
+// behind the ring, slots 1 / 2 behind the patches inside the idle ring (4 * PATCH_BYTES + 256 + 8 * 8 KiB = 100608 B); group g + 3
+// takes group g's slot.  vmcnt by hand as for the *_DOT epilogues: PC pieces and ST stores per group.
+template <bool ASMDMA, bool F32, class ToPatch>
+OF_DEV void w4_epilogue_resid_dma(const OfGemmArgs& p, ToPatch to_patch, char* smem, int ring_bytes, int m0, int n0, int wm, int wn, int wave,
+                                  int lane, float gv, float sc, char* patch) {
+    constexpr int PC = F32 ? 8 : 4, ST = F32 ? 8 : 4;
+    float dot = 0.f;
+    auto slot = [&](int g) OF_INLINE_LAMBDA -> char* {
+        const int sl = g % 3;
+        return sl == 0 ? smem + ring_bytes + wave * ofg::RESID_LDS_BYTES
+                       : smem + 4 * ofg::PATCH_BYTES + 256 + ((sl - 1) * 4 + wave) * ofg::RESID_LDS_BYTES;
+    };
+    auto request = [&](int g) OF_INLINE_LAMBDA {
+        ofg::epilogue_group_resid_dma<ASMDMA>(p, m0 + wm * 128 + (g >> 1) * 32, n0 + wn * 128 + (g & 1) * 64, lane, slot(g));
+    };
+    of_wait_vm<0>();
+    request(1);
+    request(2);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        if (g == 1) of_wait_vm<PC + ST + PC>();
+        if (g >= 2 && g <= 5) of_wait_vm<2 * (ST + PC)>();
+        if (g == 6) of_wait_vm<ST + PC + ST>();
+        if (g == 7) of_wait_vm<2 * ST>();
+        to_patch(g, patch);
+        ofg::epilogue_group_rows_residlds<F32>(p, patch, slot(g), m0 + wm * 128 + (g >> 1) * 32, n0 + wn * 128 + (g & 1) * 64, lane, gv, sc, dot);
+        if (g < 5) request(g + 3);
+    }
+}
+
+template <int EPI, bool ASMDMA, class ToPatch, bool RESID_DMA = false>
 OF_DEV void w4_epilogue_with(const OfGemmArgs& p, ToPatch to_patch, char* smem, int ring_bytes, int m0, int n0, int wm, int wn, int wave, int lane) {
     constexpr bool AUXL = EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT;
     // ---------------------------------------------------------------- epilogue, staged through LDS (as gemm_pp.hip)
@@ -21,6 +53,11 @@ OF_DEV void w4_epilogue_with(const OfGemmArgs& p, ToPatch to_patch, char* smem, 
     const float sc = gv * p.alpha;
     float dot = 0.f;
     char* patch = smem + wave * ofg::PATCH_BYTES;
+    if constexpr (RESID_DMA && EPI == OF_EPI_GATE_RESID) {
+        if (p.io_f32) w4_epilogue_resid_dma<ASMDMA, true>(p, to_patch, smem, ring_bytes, m0, n0, wm, wn, wave, lane, gv, sc, patch);
+        else w4_epilogue_resid_dma<ASMDMA, false>(p, to_patch, smem, ring_bytes, m0, n0, wm, wn, wave, lane, gv, sc, patch);
+        return;
+    }
     if constexpr (AUXL) {
         // *_DOT epilogues: the saved activation of a group (32 rows x 128 B = 4 KiB per wave) travels global -> LDS by DMA, SIX groups
         // deep.  Round 3 kept one group in flight (two 4-KiB buffers per wave): every group then waited out a full global-load

@@ -27,6 +27,36 @@
 #include "gemm_tile256.h"
 #include "gemm_w4_epi.h"
 
+#if defined(OF_TOOLS_BUILD) && !defined(OF_HOST_EMU)
+// tools/libofhip_tools.so only (tools/probes/tile_phase_probe.py): where a tile's time goes.  Wave 0 of every workgroup stamps
+// the 100-MHz wall clock at kernel entry, after the prologue (stage 0 landed), after the K loop and after its last epilogue
+// instruction, plus the hardware id (XCC / SE / CU) it ran on: 8 x u64 per workgroup into a buffer the tool registers.
+__device__ unsigned long long* of_tools_stamps = nullptr;
+extern "C" int of_tools_set_stamp_buffer(void* p) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(of_tools_stamps), &p, sizeof(p));
+}
+#define OF_STAMP(i) (of_stamp_t[i] = wall_clock64())          /* wave-uniform: stays in SGPRs until the one store block at the end */
+#define OF_STAMP_DECL() unsigned long long of_stamp_t[5] = {0, 0, 0, 0, 0}
+#define OF_STAMP_FLUSH()                                                                                              \
+    do {                                                                                                              \
+        if (of_tools_stamps) {                                                                                        \
+            of_wait_vm<0>();          /* probe only: every store of the wave acknowledged (the product wave just ends) */ \
+            OF_STAMP(4);                                                                                              \
+            if (of_tid() == 0) {                                                                                      \
+                unsigned hw;          /* workgroups go round-robin over the 8 XCDs: XCC = block id & 7 */             \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                                     \
+                unsigned long long* o = of_tools_stamps + (size_t)of_bid_x() * 8;                                     \
+                for (int i_ = 0; i_ < 5; ++i_) o[i_] = of_stamp_t[i_];                                                \
+                o[7] = ((unsigned long long)(of_bid_x() & 7) << 32) | hw;                                             \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
+#else
+#define OF_STAMP(i) ((void)0)
+#define OF_STAMP_DECL() ((void)0)
+#define OF_STAMP_FLUSH() ((void)0)
+#endif
+
 namespace {
 using namespace oft;
 
@@ -35,6 +65,8 @@ constexpr int SMEM_W4M = NSLOT * STAGE_BYTES;    // 128 KiB
 template <bool AT, bool BT, int EPI>
 OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
     constexpr bool ASMD = AT || BT;       // LDS-DMA form (of_platform.h): inline asm wherever a transposed-fragment read follows
+    OF_STAMP_DECL();
+    OF_STAMP(0);
     char* smem = of_smem();
     const int tid = of_tid(), lane = tid & 63;
     const int wave = of_uniform(tid >> 6);
@@ -86,6 +118,8 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
 
     constexpr bool AUXL = EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT;
     if (AUXL) ofg::epilogue_group_aux_dma<ASMD>(p, m0 + wm * 128, n0 + wn * 128, lane, smem + SMEM_W4M + wave * ofg::AUX_LDS_BYTES);
+    // GATE_RESID: the residual tile of the wave's first group, likewise (gemm_w4_epi.h: w4_epilogue_resid_dma)
+    if (EPI == OF_EPI_GATE_RESID) ofg::epilogue_group_resid_dma<ASMD>(p, m0 + wm * 128, n0 + wn * 128, lane, smem + SMEM_W4M + wave * ofg::RESID_LDS_BYTES);
 
     s16x8 fa[2][4], fb[2][8];     // [register buffer][16-row fragment]: B of a whole k-step, A of half of the wave's rows
     // Fragment reads, one per call.  A stage is four phases (k-step ks = phase >> 1, row half ah = phase & 1 of the wave's 128
@@ -114,6 +148,7 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
         for (int j = 0; j < 8; ++j) dma_piece(STAGE_BYTES, j, 0);
     }
     of_barrier_raw();
+    OF_STAMP(1);
 #pragma unroll
     for (int r = 0; r < 12; ++r) read_kstep(smem, 0, 0, r);
 
@@ -170,23 +205,26 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
     else main_loop(std::integral_constant<int, 0>{});
     of_mfma_acc_settle();
     of_barrier_raw();          // the ring is idle from here
+    OF_STAMP(2);
 
-    w4_epilogue_with<EPI, ASMD>(
-        p,
-        [&](int g, char* patch) OF_INLINE_LAMBDA {
-            const int mt = g >> 1, np = g & 1;
-            const f32x4 t[2][4] = {{acc[2 * mt][4 * np], acc[2 * mt][4 * np + 1], acc[2 * mt][4 * np + 2], acc[2 * mt][4 * np + 3]},
-                                   {acc[2 * mt + 1][4 * np], acc[2 * mt + 1][4 * np + 1], acc[2 * mt + 1][4 * np + 2], acc[2 * mt + 1][4 * np + 3]}};
-            ofg::patch_write16(patch, t, lane);
-        },
-        smem, SMEM_W4M, m0, n0, wm, wn, wave, lane);
+    auto acc_to_patch = [&](int g, char* patch) OF_INLINE_LAMBDA {
+        const int mt = g >> 1, np = g & 1;
+        const f32x4 t[2][4] = {{acc[2 * mt][4 * np], acc[2 * mt][4 * np + 1], acc[2 * mt][4 * np + 2], acc[2 * mt][4 * np + 3]},
+                               {acc[2 * mt + 1][4 * np], acc[2 * mt + 1][4 * np + 1], acc[2 * mt + 1][4 * np + 2], acc[2 * mt + 1][4 * np + 3]}};
+        ofg::patch_write16(patch, t, lane);
+    };
+    w4_epilogue_with<EPI, ASMD, decltype(acc_to_patch), true>(p, acc_to_patch, smem, SMEM_W4M, m0, n0, wm, wn, wave, lane);
+    OF_STAMP(3);
+    OF_STAMP_FLUSH();
 }
 
 template <bool AT, bool BT, int EPI>
 int launch_w4m(const OfGemmArgs& a, of_stream_t s) {
     of_dim3 grid{(unsigned)((a.M / TM) * (a.N / TN)), 1, 1};
     // *_DOT epilogues: + 4 KiB per wave behind the ring for the first group's aux tile
-    constexpr int smem_bytes = SMEM_W4M + ((EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) ? 4 * ofg::AUX_LDS_BYTES : 0);
+    // GATE_RESID: + 8 KiB per wave for the first group's residual tile (160 KiB in all: the CU's whole LDS)
+    constexpr int smem_bytes = SMEM_W4M + ((EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) ? 4 * ofg::AUX_LDS_BYTES
+                                           : EPI == OF_EPI_GATE_RESID ? 4 * ofg::RESID_LDS_BYTES : 0);
     const int rc = of_launch(of_gemm_w4m_kernel<AT, BT, EPI>, grid, 256, smem_bytes, s, a);
     if (rc || !of_gemm_has_dot(a)) return rc;
     return of_gemm_dot_finish(a, (int)grid.x, s);

@@ -41,6 +41,45 @@ class Flamingo(nn.Module):
 
     group_media_projections = True     # class-level switch (instance attribute overrides): see _encode_vision_x
 
+    # ------------------------------------------------------------------------------------------------ vision prefetch
+    def prefetch_vision(self, vision_x: torch.Tensor, amp_dtype=None):
+        """Run the frozen vision tower (reference flamingo.py:194-195: no_grad, depends on no trainable parameter) for the
+        ``vision_x`` of a FUTURE forward now, on a side HIP stream that starts behind everything enqueued so far on the current
+        stream.  Called by ``train_step`` between the backward and the step epilogue: the tower's MFMA-bound GEMMs then share
+        the chip with the HBM-bound clip + AdamW passes (and, under data parallelism, with the wait for the last gradient
+        all-reduce) instead of opening the next step.  The forward that is later called with the SAME tensor object (unchanged:
+        version counter) waits for the side stream and takes the tokens; any other input runs the tower inline as before.  The
+        arithmetic is the tower's own forward under the same autocast dtype (``amp_dtype``; None = no autocast): identical bits."""
+        assert vision_x.ndim == 6, "vision_x should be of shape (b, T_img, F, C, H, W)"
+        import contextlib
+        ac = (torch.autocast(device_type=vision_x.device.type, dtype=amp_dtype) if amp_dtype is not None else contextlib.nullcontext())
+        if vision_x.is_cuda:
+            main = torch.cuda.current_stream(vision_x.device)
+            side = self.__dict__.get("_of_vision_stream")
+            if side is None or side.device != vision_x.device:
+                side = self.__dict__["_of_vision_stream"] = torch.cuda.Stream(device=vision_x.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side), torch.no_grad(), ac:
+                tokens = self.vision_encoder(vision_x.flatten(0, 2))[1]
+            done = torch.cuda.Event()
+            done.record(side)
+        else:
+            with torch.no_grad(), ac:
+                tokens = self.vision_encoder(vision_x.flatten(0, 2))[1]
+            done = None
+        self.__dict__["_of_vision_prefetch"] = (vision_x, vision_x._version, tokens, done)
+
+    def _take_prefetched_vision(self, vision_x):
+        hit = self.__dict__.pop("_of_vision_prefetch", None)
+        if hit is None or hit[0] is not vision_x or hit[1] != vision_x._version:
+            return None
+        tokens, done = hit[2], hit[3]
+        if done is not None:
+            main = torch.cuda.current_stream(vision_x.device)
+            main.wait_event(done)
+            tokens.record_stream(main)         # allocated on the side stream, consumed (and later freed) on this one
+        return tokens
+
     # ------------------------------------------------------------------------------------------------ conditioning
     def _layers(self):
         return self.lang_encoder._get_decoder_layers()
@@ -51,8 +90,10 @@ class Flamingo(nn.Module):
         assert vision_x.ndim == 6, "vision_x should be of shape (b, T_img, F, C, H, W)"
         batch, n_media, n_frames = vision_x.shape[0], vision_x.shape[1], vision_x.shape[2]
         assert n_frames == 1, "Only single frame supported"
-        with torch.no_grad():
-            tokens = self.vision_encoder(vision_x.flatten(0, 2))[1]           # (b*T*F, patches, vis_dim)
+        tokens = self._take_prefetched_vision(vision_x)
+        if tokens is None:
+            with torch.no_grad():
+                tokens = self.vision_encoder(vision_x.flatten(0, 2))[1]       # (b*T*F, patches, vis_dim)
         latents = self.perceiver(tokens.unflatten(0, (batch, n_media, n_frames)))
         # (not while media are being cached: several forwards may then run over the same latents, each with its own graph)
         if self.group_media_projections and torch.is_grad_enabled() and not self.lang_encoder._use_cached_vision_x:

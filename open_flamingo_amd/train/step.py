@@ -63,7 +63,7 @@ def mask_embedding_gradient(model, info):
 
 def train_step(model, reducer, optimizer, batch_mmc4, info, batch_laion=None, loss_multiplier_laion=1.0,
                loss_multiplier_mmc4=1.0, clip_norm=1.0, amp=True, nan_check=True, lr_scheduler=None,
-               mask_embedding_rows=True):
+               mask_embedding_rows=True, next_vision_x=None):
     """Returns the (detached) MMC4 loss tensor, or None if the step was skipped because the loss was NaN.
     reducer=None is the single-process form of the reference loop (embedding-gradient mask applied in place).
     nan_check: True = the reference's host-side ``torch.isnan(loss)`` (train_utils.py:161-169: one host sync per step, and under
@@ -73,7 +73,12 @@ def train_step(model, reducer, optimizer, batch_mmc4, info, batch_laion=None, lo
     instead of None).  Adam's step count lives on the device and only counts applied updates, so a skipped step leaves the
     bias correction where the reference's `continue` leaves it; a host-side ``lr_scheduler`` cannot see the skip without a
     sync and does advance by one step per NaN batch -- the one remaining difference from the reference, bounded by the number
-    of NaN batches (use nan_check=True where that matters more than the sync); False = no check."""
+    of NaN batches (use nan_check=True where that matters more than the sync); False = no check.
+    next_vision_x: the ``vision_x`` tensor the NEXT step's first forward will be called with (a data loader is one batch ahead
+    anyway).  Its frozen vision-tower forward -- which depends on no trainable parameter (flamingo.py:194-195) -- is enqueued on
+    a side stream between this step's backward and its step epilogue (Flamingo.prefetch_vision): MFMA-bound work next to the
+    HBM-bound clip + AdamW passes and the wait for the last all-reduce.  Same arithmetic, same bits; every step still runs
+    exactly one tower forward per forward pass."""
     fused = hasattr(optimizer, "reducer")         # FlatAdamW: clip + AdamW + zero_grad in two device passes
     from ..hip import path as _path
     _path.scope_of(getattr(model, "module", model)).twins.clear()         # a gradient twin nobody took in the previous backward (the embedding's) is not kept alive
@@ -92,6 +97,8 @@ def train_step(model, reducer, optimizer, batch_mmc4, info, batch_laion=None, lo
             optimizer.zero_grad(set_to_none=True)
         return None
     (loss * loss_multiplier_mmc4).backward()
+    if next_vision_x is not None:
+        getattr(model, "module", model).prefetch_vision(next_vision_x, amp_dtype=torch.bfloat16 if amp else None)
     if reducer is None and mask_embedding_rows:
         mask_embedding_gradient(model, info)
     if reducer is not None:

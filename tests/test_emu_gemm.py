@@ -239,6 +239,16 @@ def test_gemm_pingpong_epilogues(big):
     out = torch.zeros(M, N)
     H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=out, aux=res, gate=gate, io_f32=1, safe=big)
     np.testing.assert_allclose(out.double().numpy(), (res.double() + g * acc).numpy(), rtol=1e-5, atol=1e-4)
+    # bf16 stream, and in place on a strided fp32 stream (C aliases aux, leading dimension > N): every group of every wave reads its
+    # own residual tile (the 16x16x32 kernel fetches them by LDS-DMA, three groups deep, with its own LDS image)
+    resb, outb = res.to(torch.bfloat16), torch.zeros(M, N, dtype=torch.bfloat16)
+    H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=outb, aux=resb, gate=gate, io_f32=0, safe=big)
+    np.testing.assert_allclose(outb.double().numpy(), (resb.double() + g * acc).numpy(), rtol=1e-2, atol=2e-2)
+    wide = torch.randn(M, N + 64)
+    y = wide[:, 32:32 + N]
+    y0 = y.clone()
+    H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=y, aux=y, gate=gate, io_f32=1, safe=big)
+    np.testing.assert_allclose(y.double().numpy(), (y0.double() + g * acc).numpy(), rtol=1e-5, atol=1e-4)
     W = _rand((K, N), 15) * 0.2
     acc2 = A.double() @ W.double()
     aux = _rand((M, N), 16)

@@ -937,3 +937,34 @@ def test_block_module_against_reference_goldens_at_dim_head_64(case, golden_dir)
         y = blk(x, media, media_locations=ml, use_cached_media=bool(z["use_cached"])).float().cpu()
     y32, yac = torch.from_numpy(z["y"]), torch.from_numpy(z["amp.y"])
     assert PC.rel_l2(y, y32) <= 2 * PC.rel_l2(yac, y32) + 1e-6 and PC.max_abs(y, y32) <= 2 * PC.max_abs(yac, y32) + 1e-6
+
+
+def test_vision_prefetch_on_a_side_stream_changes_no_bit():
+    """train_step(next_vision_x=...): the next step's frozen vision-tower forward runs on a side HIP stream between this step's
+    backward and its step epilogue (Flamingo.prefetch_vision).  Same kernels on the same inputs -> losses AND every trained
+    parameter after four steps on alternating batches are bit-identical with and without it (fused towers, libofhip step
+    epilogue, amp_bf16: bench.py's configuration at tiny size)."""
+    from open_flamingo_amd.train import sparse_rows, step, synthetic, towers
+    from open_flamingo_amd.train.reducer import GradReducer
+
+    def run(prefetch):
+        model, info = towers.build_flamingo("OF-tiny", device="cuda", seed=0, gates=0.5, frozen_bf16=True, fused_lm_attention="libofhip",
+                                            tower_layernorm="libofhip", lm_loss="libofhip", fused_lm_blocks=True, fused_vision="libofhip")
+        model.train()
+        rows = [info["media_token_id"], info["eoc_token_id"]]
+        sparse_rows.enable(model, rows)
+        red = GradReducer(model, embedding_rows=rows)
+        opt = step.build_optimizer(model, lr=1e-3, reducer=red)
+        batches = [synthetic.make_batch(2, 2, 24, info, "cuda", seed=5 + i) for i in range(2)]
+        losses = []
+        for i in range(4):
+            nxt = batches[(i + 1) % 2]["vision_x"] if prefetch else None
+            losses.append(step.train_step(model, red, opt, batches[i % 2], info, nan_check="device", next_vision_x=nxt))
+        torch.cuda.synchronize()
+        return [float(l) for l in losses], {k: p.detach().clone() for k, p in model.named_parameters() if p.requires_grad}
+
+    l1, p1 = run(True)
+    l0, p0 = run(False)
+    assert l1 == l0, (l1, l0)
+    for k in p0:
+        assert torch.equal(p1[k], p0[k]), k
