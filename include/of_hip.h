@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OF_ABI_VERSION 7
+#define OF_ABI_VERSION 8
 #define OF_E_ARG (-1)      /* null pointer / negative size */
 #define OF_E_SHAPE (-2)    /* shape not supported by the kernels (see each function) */
 #define OF_E_ALIGN (-3)    /* pointer or leading dimension not 16-byte aligned */
@@ -100,11 +100,23 @@ typedef struct OfGemmArgs {
     const void* const* groups;
     int group_kind;
     int group_extent;
+    /* Stream-K scheduling of the big-tile kernel (ABI v8).  cu_limit: how many CUs this launch may count on, 0 = all 256 -- a
+     * caller that knows another kernel holds CUs for the duration (an RCCL collective on a side stream) passes what is left, and the
+     * launch is laid out for that many workgroups instead of running a second round for the displaced tiles.  Whenever the number
+     * of 256x256 tiles is not a multiple of the workgroup count (OF-4B's 400-tile weight gradients, OF-9B's 128-tile launches, any
+     * launch under a cu_limit) and `workspace` holds of_gemm_workspace_bytes(args) bytes, every workgroup takes the same share of
+     * (tile, K-stage) units: whole tiles first, then a fraction of the remaining ones; a tile shared between workgroups is finished
+     * by the one that holds its last K stages, which adds the others' fp32 partial sums (through `workspace`) in ascending K
+     * order -- deterministic for a given (shape, workgroup count).  Without the workspace the launch falls back to one tile per
+     * workgroup.  sk_grid: internal, filled in by of_gemm; callers pass 0. */
+    int cu_limit;
+    int sk_grid;
 } OfGemmArgs;
 
 int of_gemm(const OfGemmArgs* args, void* stream);
 /* Bytes of workspace of_gemm would use for these arguments: split-K slabs (optional, see `workspace`), the per-workgroup
- * partials of a *_DOT launch with dot_out (required), else 0. */
+ * partials of a *_DOT launch with dot_out (required), the stream-K partial tiles + flags of a big-tile launch whose tile count
+ * is not a multiple of its workgroup count (optional, see cu_limit), else 0. */
 size_t of_gemm_workspace_bytes(const OfGemmArgs* args);
 
 /* ---------------------------------------------------------------------------------------------------

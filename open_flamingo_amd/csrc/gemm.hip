@@ -295,15 +295,40 @@ int of_gemm_dot_finish(const OfGemmArgs& a, int nslots, of_stream_t s) {
     OfDotFinishArgs f{(const float*)a.workspace, nslots, a.gate, a.dot_out};
     return of_launch(of_dot_finish_kernel, of_dim3{1, 1, 1}, 256, 256 * sizeof(float), s, f);
 }
-// slots of per-workgroup gate-gradient partials a *_DOT launch with dot_out may use: the finest tiling any kernel picks
-static size_t dot_slots(const OfGemmArgs& a) { return (size_t)((a.M + 127) / 128) * ((a.N + 63) / 64); }
+static size_t dot_slots(const OfGemmArgs& a) { return of_gemm_dot_slots(a); }
+
+// Stream-K scheduling of a big-tile launch (gemm_w4m.hip): the workgroup count, or 0 for the classic one-tile-per-workgroup launch.
+// G = the CUs the caller says it may count on (cu_limit, whole groups of 8; default all); stream-K whenever that does not divide
+// the tile count -- OF-4B's 400-tile weight gradients (1.56 rounds -> every workgroup 1.5625 tiles), OF-9B's 128-tile launches
+// (half a tile per workgroup instead of half the chip idle), any launch next to a collective that holds CUs.
+static int sk_grid_for(const OfGemmArgs& a, long tiles256) {
+    int G = a.cu_limit > 0 ? (a.cu_limit & ~7) : OF_NUM_CUS;
+    if (G > OF_NUM_CUS) G = OF_NUM_CUS;
+    if (G < 8) G = 8;
+    if (a.safe == 17) return G;                 // forced (tests): persistent even when G divides the tile count
+    return tiles256 % G ? G : 0;
+}
+static bool sk_usable(const OfGemmArgs& a, int G) {
+    if (G <= 0 || a.group_kind || !of_gemm_w4m_eligible(a)) return false;
+    const size_t need = of_gemm_w4m_sk_bytes(a, G);
+    return !need || (a.workspace && a.workspace_bytes >= need && !((uintptr_t)a.workspace & 15));
+}
 
 extern "C" size_t of_gemm_workspace_bytes(const OfGemmArgs* args) {
     if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return 0;
-    if (of_gemm_has_dot(*args)) return dot_slots(*args) * sizeof(float);
-    if (of_gemm_is_skinny(*args)) return 0;
-    const int split = pick_ksplit(*args, true);
-    return split > 1 ? (size_t)split * args->M * args->N * sizeof(float) : 0;
+    const OfGemmArgs& a = *args;
+    size_t need = of_gemm_has_dot(a) ? dot_slots(a) * sizeof(float) : 0;
+    if (of_gemm_is_skinny(a)) return need;
+    const long tiles256 = (long)(a.M / 256) * (a.N / 256);
+    const bool big = !(a.M % 256) && !(a.N % 256) && !(a.K % 64) && !a.group_kind && ((a.safe == 0 && tiles256 >= 128) || a.safe == 17);
+    if (big && of_gemm_w4m_eligible(a)) {       // stream-K partial tiles + flags (behind the *_DOT partials)
+        const size_t sk = of_gemm_w4m_sk_bytes(a, sk_grid_for(a, tiles256));
+        if (sk > need) need = sk;
+    }
+    if (of_gemm_has_dot(a)) return need;
+    const int split = pick_ksplit(a, true);
+    const size_t slabs = split > 1 ? (size_t)split * a.M * a.N * sizeof(float) : 0;
+    return slabs > need ? slabs : need;
 }
 
 // grouped-B launches (OfGemmArgs.group_kind): big-tile kernels only
@@ -389,7 +414,13 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
         const int rc = of_gemm_w4m_try(a, s);
         if (rc != OF_E_SHAPE) return rc;
     }
-    if (a.safe >= 17) return OF_E_ARG;
+    if (a.safe == 17) {                            // force the stream-K schedule of that kernel (persistent workgroups; tests)
+        OfGemmArgs w = a;
+        w.sk_grid = sk_grid_for(a, (long)(a.M / 256) * (a.N / 256));
+        const int rc = of_gemm_w4m_try(w, s);
+        if (rc != OF_E_SHAPE) return rc;
+    }
+    if (a.safe >= 18) return OF_E_ARG;
     const bool pp_forced = a.safe == 4;
     // Big-tile selection (measured on MI355X, random operands, same box): every layout -> the 4-wave LDS-DMA kernel ON 16x16x32
     // MFMAs (gemm_w4m.hip).  With every CU busy the K loop is bound by the chip's power budget and the 16x16x32 shape spends
@@ -399,6 +430,14 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
     // layouts with a K-strided operand to the ping-pong kernel because the 4-wave DMA schedule lost 15-25 % there -- that was
     // hipcc draining the DMA ring in front of every transposed-fragment read (of_platform.h).
     if (a.safe == 0 && pp_ok) {
+        // Stream-K first: a tile count the workgroup count does not divide is shared out evenly (needs the workspace; without
+        // it the N-split / partial-round forms below).
+        const int G = sk_grid_for(a, tiles256);
+        if (G > 0 && sk_usable(a, G)) {
+            OfGemmArgs w = a;
+            w.sk_grid = G;
+            return of_gemm_w4m_try(w, s);
+        }
         // Tile quantisation: a grid whose last round of 256x256 tiles would be under half full (OF-4B: M = 8192, N = 2560 ->
         // 320 tiles = 1.25 rounds of 256 CUs, 790-870 TFLOP/s where full rounds reach 1250) is split along N into whole rounds
         // of big tiles + a remainder strip on the 128x128 kernel (8192 x 512 -> 256 small tiles: one round).  Two launches on

@@ -226,6 +226,20 @@ OF_DEV void patch_write16(char* patch, const f32x4 (&t)[2][4], int lane) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) *(f32x4*)(patch + wr_off + a * 16 * PATCH_PITCH + b * 64) = t[a][b];
 }
+// ... plus another partial sum of the same group, added lane by lane to the entries this lane has just written (stream-K fix-up
+// of gemm_w4m.hip: the accumulators themselves stay untouched in their accumulation registers -- arithmetic on them in C made
+// hipcc park all 256 in VGPRs)
+OF_DEV void patch_add16(char* patch, const f32x4 (&t)[2][4], int lane) {
+    const int wr_off = (lane & 15) * PATCH_PITCH + (lane >> 4) * 16;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            f32x4* e = (f32x4*)(patch + wr_off + a * 16 * PATCH_PITCH + b * 64);
+            const f32x4 c = *e;
+            *e = f32x4{c[0] + t[a][b][0], c[1] + t[a][b][1], c[2] + t[a][b][2], c[3] + t[a][b][3]};
+        }
+}
 // the row passes of a group whose accumulators are in the patch (written by this wave, not yet synchronised)
 template <int EPI>
 OF_DEV void epilogue_group_rows(const OfGemmArgs& p, char* patch, int m_base, int n_base, int lane, float gv, float sc, float& dot,
@@ -357,15 +371,23 @@ OF_DEV void epilogue_finish(const OfGemmArgs& p, float dot, int lane, int wave, 
 
 // implemented in gemm.hip: the second launch of a *_DOT GEMM with dot_out (see epilogue_finish); nslots = workgroups of the GEMM
 int of_gemm_dot_finish(const OfGemmArgs& a, int nslots, of_stream_t s);
-inline bool of_gemm_has_dot(const OfGemmArgs& a) {
+OF_HOSTDEV bool of_gemm_has_dot(const OfGemmArgs& a) {
     return (a.epi == OF_EPI_DGELU_DOT || a.epi == OF_EPI_SCALE_DOT) && a.dot_out;
 }
+// slots of per-workgroup gate-gradient partials a *_DOT launch with dot_out may use (the finest tiling any kernel picks), and the
+// bytes they take at the start of the workspace (a multiple of 256: the stream-K region of the big-tile kernel follows)
+OF_HOSTDEV size_t of_gemm_dot_slots(const OfGemmArgs& a) { return (size_t)((a.M + 127) / 128) * ((a.N + 63) / 64); }
+OF_HOSTDEV size_t of_gemm_dot_bytes(const OfGemmArgs& a) {
+    return of_gemm_has_dot(a) ? ((of_gemm_dot_slots(a) * sizeof(float) + 255) & ~(size_t)255) : 0;
+}
+constexpr int OF_NUM_CUS = 256;      // MI355X
 // implemented in gemm_mid.hip (8 waves, 128x128 tile, 4-slot LDS-DMA ring); OF_E_SHAPE when not eligible
 int of_gemm_mid_try(const OfGemmArgs& a, of_stream_t s);
 bool of_gemm_mid_eligible(const OfGemmArgs& a);     // what of_gemm_mid_try would accept, without launching
 // implemented in gemm_w4m.hip: the 4-wave 256x256 kernel on 16x16x32 MFMAs; same eligibility and return convention as of_gemm_w4_try
 int of_gemm_w4m_try(const OfGemmArgs& a, of_stream_t s);
 bool of_gemm_w4m_eligible(const OfGemmArgs& a);
+size_t of_gemm_w4m_sk_bytes(const OfGemmArgs& a, int grid);      // workspace of a stream-K launch over `grid` workgroups (0: none needed)
 // implemented in gemm_skinny.hip: M <= 16 rows (decode step), HBM-bound weight streaming; OF_E_SHAPE when not eligible
 int of_gemm_skinny_try(const OfGemmArgs& a, of_stream_t s);
 inline bool of_gemm_is_skinny(const OfGemmArgs& a) {

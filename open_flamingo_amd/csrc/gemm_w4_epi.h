@@ -41,8 +41,10 @@ OF_DEV void w4_epilogue_resid_dma(const OfGemmArgs& p, ToPatch to_patch, char* s
     }
 }
 
+// dot_slot: where this tile's gate-gradient partial goes in the workspace (-1: the workgroup's id)
 template <int EPI, bool ASMDMA, class ToPatch, bool RESID_DMA = false>
-OF_DEV void w4_epilogue_with(const OfGemmArgs& p, ToPatch to_patch, char* smem, int ring_bytes, int m0, int n0, int wm, int wn, int wave, int lane) {
+OF_DEV void w4_epilogue_with(const OfGemmArgs& p, ToPatch to_patch, char* smem, int ring_bytes, int m0, int n0, int wm, int wn, int wave, int lane,
+                             int dot_slot = -1) {
     constexpr bool AUXL = EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT;
     // ---------------------------------------------------------------- epilogue, staged through LDS (as gemm_pp.hip)
     // Each wave sends its eight 32 x 64 accumulator groups through a private LDS patch (ofg::epilogue_group); the aux row
@@ -99,7 +101,7 @@ OF_DEV void w4_epilogue_with(const OfGemmArgs& p, ToPatch to_patch, char* smem, 
             ofg::epilogue_group_rows<EPI>(p, patch, m0 + wm * 128 + mt * 32, n0 + wn * 128 + np * 64, lane, gv, sc, dot, pre[g & 1]);
         }
     }
-    ofg::epilogue_finish<EPI>(p, dot, lane, wave, 4, (float*)(smem + 4 * ofg::PATCH_BYTES), of_bid_x());
+    ofg::epilogue_finish<EPI>(p, dot, lane, wave, 4, (float*)(smem + 4 * ofg::PATCH_BYTES), dot_slot < 0 ? of_bid_x() : dot_slot);
 }
 
 template <int EPI, bool ASMDMA>

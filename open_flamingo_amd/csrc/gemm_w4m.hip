@@ -62,6 +62,23 @@ using namespace oft;
 
 constexpr int SMEM_W4M = NSLOT * STAGE_BYTES;    // 128 KiB
 
+// ---- stream-K layout of the optional workspace region behind the *_DOT partials (of_gemm fills p.sk_grid, gemm.hip):
+//   [ flags: one int per workgroup, zeroed by of_gemm in front of the launch ][ slabs: one 256 x 256 fp32 partial tile per workgroup ]
+constexpr size_t SK_SLAB_BYTES = (size_t)TM * TN * 4;
+OF_HOSTDEV size_t sk_flags_bytes(int grid) { return ((size_t)grid * 4 + 255) & ~(size_t)255; }
+OF_HOSTDEV size_t sk_dot_bytes(const OfGemmArgs& a) { return of_gemm_dot_bytes(a); }
+
+// Schedule.  The grid is G workgroups.  Classic launch (p.sk_grid == 0): G = number of tiles, workgroup b owns tile b.  Stream-K
+// launch (p.sk_grid = G): every workgroup takes the same share of the launch's (tile, K-stage) units --
+//   * rounds = tiles / G whole tiles, b, b + G, b + 2G, ... (no fix-up: exactly the classic launch's work per workgroup);
+//   * the remaining r = tiles - rounds * G tiles are r * nd units in (tile, stage) order, workgroup b takes units
+//     [r nd b / G, r nd (b + 1) / G): less than one tile's worth, so at most the TAIL of one tile and the HEAD of the next.
+// A tile shared between workgroups is finished by the one that holds its LAST K stage (the owner); the others write their fp32
+// partial tile to their slab and raise their flag.  A workgroup walks its unit range BACKWARDS -- head of the later tile first
+// (never an owner unless it is the whole tile), tail of the earlier tile last -- so partial tiles are published early, owners
+// wait late and only for workgroups with LOWER ids: no deadlock even when fewer than G workgroups are resident (the hardware
+// dispatches in id order; a workgroup's first segment never waits).  The owner adds the partials in ascending K order, on top
+// of its own: the same bits for the same (shape, G), whatever the timing.
 template <bool AT, bool BT, int EPI>
 OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
     constexpr bool ASMD = AT || BT;       // LDS-DMA form (of_platform.h): inline asm wherever a transposed-fragment read follows
@@ -71,29 +88,17 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
     const int tid = of_tid(), lane = tid & 63;
     const int wave = of_uniform(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_m = p.M / TM, tiles_n = p.N / TN;
-    int pm, pn;
-    ofg::tile_coords(of_bid_x(), of_gdim_x(), tiles_m, tiles_n, pm, pn);
-    const int m0 = pm * TM, n0 = pn * TN;
+    const int tiles_m = p.M / TM, tiles_n = p.N / TN, ntiles = tiles_m * tiles_n;
+    const int nd_all = p.K / DK;
+    const int G = of_gdim_x(), bid = of_bid_x();
+    const int rounds = p.sk_grid > 0 ? ntiles / G : 1;
+    const long rem_units = p.sk_grid > 0 ? (long)(ntiles - rounds * G) * nd_all : 0;
+    const long r0 = rem_units * bid / G;
+    long ue = rem_units * (bid + 1) / G;          // end of the not yet processed part of [r0, ue)
+    int* sk_flags = (int*)((char*)p.workspace + sk_dot_bytes(p));
+    float* sk_slabs = (float*)((char*)sk_flags + sk_flags_bytes(G));
 
     f32x4 acc[8][8];      // [16-row block of M][16-column block of N]
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[a][b][e] = 0.f;
-
-    // DMA duty of this wave: 1-KiB chunks c = jj*4 + wave (jj = 0..3) of both halves of both operands = 16 pieces per stage
-    const of_buf_t gA = of_buf_make(chunk_base<AT>(p.A, p.lda, m0));
-    const bf16_t* Bmat = p.B;
-    int nB = n0;
-    if (!BT && p.group_kind == 1) {       // grouped B along N: this tile's columns belong to weight matrix n0 / extent
-        const int grp = n0 / p.group_extent;
-        Bmat = (const bf16_t*)p.groups[grp];
-        nB = n0 - grp * p.group_extent;
-    }
-    const of_buf_t gB = of_buf_make(chunk_base<BT>(Bmat, p.ldb, nB));
     unsigned offA[2][4], offB[2][4];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
@@ -104,130 +109,220 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
         }
     const unsigned stepA = 2u * (AT ? (unsigned)DK * (unsigned)p.lda : (unsigned)DK);
     const unsigned stepB = 2u * (BT ? (unsigned)DK * (unsigned)p.ldb : (unsigned)DK);
-    unsigned sA = 0, sB = 0;              // scalar byte offsets of the next stage to request
-    const int nd = p.K / DK;
     const unsigned smem_u = of_lds_base(smem) + (unsigned)wave * 1024u;
-    // piece j (0..15 = op * 8 + hf * 4 + jj) of the stage at (sA, sB) -- ahead = 1: of the stage after it -- into the slot at
-    // byte offset slot_off
-    auto dma_piece = [&](unsigned slot_off, int j, int ahead) OF_INLINE_LAMBDA {
-        const int op = j >> 3, hf = (j >> 2) & 1, jj = j & 3;
-        const unsigned dst = smem_u + slot_off + (unsigned)(op * OPER_BYTES + hf * HALF_BYTES + jj * 4096);
-        if (op == 0) of_buf_load16_lds_at<ASMD>(gA, offA[hf][jj], sA + (ahead ? stepA : 0u), dst);
-        else of_buf_load16_lds_at<ASMD>(gB, offB[hf][jj], sB + (ahead ? stepB : 0u), dst);
-    };
-
     constexpr bool AUXL = EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT;
-    if (AUXL) ofg::epilogue_group_aux_dma<ASMD>(p, m0 + wm * 128, n0 + wn * 128, lane, smem + SMEM_W4M + wave * ofg::AUX_LDS_BYTES);
-    // GATE_RESID: the residual tile of the wave's first group, likewise (gemm_w4_epi.h: w4_epilogue_resid_dma)
-    if (EPI == OF_EPI_GATE_RESID) ofg::epilogue_group_resid_dma<ASMD>(p, m0 + wm * 128, n0 + wn * 128, lane, smem + SMEM_W4M + wave * ofg::RESID_LDS_BYTES);
 
-    s16x8 fa[2][4], fb[2][8];     // [register buffer][16-row fragment]: B of a whole k-step, A of half of the wave's rows
-    // Fragment reads, one per call.  A stage is four phases (k-step ks = phase >> 1, row half ah = phase & 1 of the wave's 128
-    // rows); fb[ks] holds the 8 B fragments of k-step ks, fa[phase & 1] the 4 A fragments of (ks, ah).
-    auto read_a = [&](const char* stage, int ks, int ah, int buf, int r) OF_INLINE_LAMBDA {
-        fa[buf][r] = mfrag16<AT>(stage, wm * 128 + ah * 64 + r * 16, ks, lane);
-    };
-    auto read_b = [&](const char* stage, int ks, int r) OF_INLINE_LAMBDA {
-        fb[ks][r] = mfrag16<BT>(stage + OPER_BYTES, wn * 128 + r * 16, ks, lane);
-    };
-    // the 12 fragments a phase that starts a k-step needs, in the order of first use: fb0 fa0 fb1 .. fb7 fa1 fa2 fa3
-    auto read_kstep = [&](const char* stage, int ks, int abuf, int r) OF_INLINE_LAMBDA {
-        if (r == 1) read_a(stage, ks, 0, abuf, 0);
-        else if (r < 9) read_b(stage, ks, r == 0 ? 0 : r - 1);
-        else read_a(stage, ks, 0, abuf, r - 8);
-    };
+    for (int seg = 0;; ++seg) {
+        // ---- this segment: tile `vt` (virtual block id for the XCD-aware tile map), K stages [s0, s0 + nd)
+        int vt, s0, nd;
+        if (seg < rounds) {
+            vt = bid + seg * G;
+            s0 = 0;
+            nd = nd_all;
+        } else {
+            if (ue <= r0) break;
+            const int t = (int)((ue - 1) / nd_all);
+            const long ts = (long)t * nd_all, us = ts > r0 ? ts : r0;
+            vt = rounds * G + t;
+            s0 = (int)(us - ts);
+            nd = (int)(ue - us);
+            ue = us;
+        }
+        const bool last_k = s0 + nd == nd_all;       // this workgroup finishes the tile (epilogue), else it publishes a partial tile
+        int pm, pn;
+        ofg::tile_coords(vt, ntiles, tiles_m, tiles_n, pm, pn);
+        const int m0 = pm * TM, n0 = pn * TN;
+        if (seg > 0) of_barrier_raw();                // the previous segment's epilogue is done with the ring
 
-    // ---- prologue: stage 0 landed in slot 0; A of stage 1 requested into slot 1 (what phase 3 of "stage -1" would have done)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) dma_piece(0, j, 0);
-    sA += stepA;                       // (sA, sB) = stage 1 from here on: "the next stage"
-    sB += stepB;
-    of_wait_vm<0>();
-    if (nd > 1) {
+        for (int a = 0; a < 8; ++a)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dma_piece(STAGE_BYTES, j, 0);
-    }
-    of_barrier_raw();
-    OF_STAMP(1);
+            for (int b = 0; b < 8; ++b)
 #pragma unroll
-    for (int r = 0; r < 12; ++r) read_kstep(smem, 0, 0, r);
+                for (int e = 0; e < 4; ++e) acc[a][b][e] = 0.f;
 
-    // The K loop, compiled once per wave parity (odd waves request their pieces two MFMA gaps after the even ones).
-    auto main_loop = [&](auto parc) OF_INLINE_LAMBDA {
-        constexpr int PARC = decltype(parc)::value;
-        // One phase = 32 MFMAs: B fragments fb[ks] x A fragments fa[ph & 1] (rows 64 (ph & 1) .. of the wave's 128).  Its MFMA gaps
-        // carry the fragment reads of the NEXT phase (4 or 12, from the gap after the previous read on, every other gap) and,
-        // with `dma`, eight LDS-DMA pieces (gaps 4j + 2 PARC).
-        auto phase = [&](int ph, const char* rd_stage, bool rd, unsigned dma_slot, int dma0, bool dma, int ahead) OF_INLINE_LAMBDA {
-            const int ks = ph >> 1, ah = ph & 1;
+        // DMA duty of this wave: 1-KiB chunks c = jj*4 + wave (jj = 0..3) of both halves of both operands = 16 pieces per stage
+        const of_buf_t gA = of_buf_make(chunk_base<AT>(p.A, p.lda, m0));
+        const bf16_t* Bmat = p.B;
+        int nB = n0;
+        if (!BT && p.group_kind == 1) {       // grouped B along N: this tile's columns belong to weight matrix n0 / extent
+            const int grp = n0 / p.group_extent;
+            Bmat = (const bf16_t*)of_uniform_ptr(p.groups[grp]);      // loaded behind the previous segment's stores: a vector load
+            nB = n0 - grp * p.group_extent;
+        }
+        const of_buf_t gB = of_buf_make(chunk_base<BT>(Bmat, p.ldb, nB));
+        unsigned sA = (unsigned)s0 * stepA, sB = (unsigned)s0 * stepB;              // scalar byte offsets of the next stage to request
+        // piece j (0..15 = op * 8 + hf * 4 + jj) of the stage at (sA, sB) -- ahead = 1: of the stage after it -- into the slot at
+        // byte offset slot_off
+        auto dma_piece = [&](unsigned slot_off, int j, int ahead) OF_INLINE_LAMBDA {
+            const int op = j >> 3, hf = (j >> 2) & 1, jj = j & 3;
+            const unsigned dst = smem_u + slot_off + (unsigned)(op * OPER_BYTES + hf * HALF_BYTES + jj * 4096);
+            if (op == 0) of_buf_load16_lds_at<ASMD>(gA, offA[hf][jj], sA + (ahead ? stepA : 0u), dst);
+            else of_buf_load16_lds_at<ASMD>(gB, offB[hf][jj], sB + (ahead ? stepB : 0u), dst);
+        };
+
+        if (last_k) {      // the epilogue's first aux / residual tile travels during the K loop (gemm_w4_epi.h)
+            if (AUXL) ofg::epilogue_group_aux_dma<ASMD>(p, m0 + wm * 128, n0 + wn * 128, lane, smem + SMEM_W4M + wave * ofg::AUX_LDS_BYTES);
+            if (EPI == OF_EPI_GATE_RESID) ofg::epilogue_group_resid_dma<ASMD>(p, m0 + wm * 128, n0 + wn * 128, lane, smem + SMEM_W4M + wave * ofg::RESID_LDS_BYTES);
+        }
+
+        s16x8 fa[2][4], fb[2][8];     // [register buffer][16-row fragment]: B of a whole k-step, A of half of the wave's rows
+        // Fragment reads, one per call.  A stage is four phases (k-step ks = phase >> 1, row half ah = phase & 1 of the wave's 128
+        // rows); fb[ks] holds the 8 B fragments of k-step ks, fa[phase & 1] the 4 A fragments of (ks, ah).
+        auto read_a = [&](const char* stage, int ks, int ah, int buf, int r) OF_INLINE_LAMBDA {
+            fa[buf][r] = mfrag16<AT>(stage, wm * 128 + ah * 64 + r * 16, ks, lane);
+        };
+        auto read_b = [&](const char* stage, int ks, int r) OF_INLINE_LAMBDA {
+            fb[ks][r] = mfrag16<BT>(stage + OPER_BYTES, wn * 128 + r * 16, ks, lane);
+        };
+        // the 12 fragments a phase that starts a k-step needs, in the order of first use: fb0 fa0 fb1 .. fb7 fa1 fa2 fa3
+        auto read_kstep = [&](const char* stage, int ks, int abuf, int r) OF_INLINE_LAMBDA {
+            if (r == 1) read_a(stage, ks, 0, abuf, 0);
+            else if (r < 9) read_b(stage, ks, r == 0 ? 0 : r - 1);
+            else read_a(stage, ks, 0, abuf, r - 8);
+        };
+
+        // ---- prologue: stage 0 landed in slot 0; A of stage 1 requested into slot 1 (what phase 3 of "stage -1" would have done)
 #pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                of_mfma_acc(fb[ks][i & 7], fa[ph & 1][i >> 3], acc[ah * 4 + (i >> 3)][i & 7]);
-                if (rd && !(i & 1)) {
-                    const int r = i >> 1;
-                    if (ph == 0 || ph == 2) {          // next phase: same k-step, the other row half
-                        if (r < 4) read_a(rd_stage, ks, 1, (ph + 1) & 1, r);
-                    } else if (r < 12) {               // next phase starts a k-step (ph 1: k-step 1 of this stage; ph 3: k-step 0 of the next)
-                        read_kstep(rd_stage, ph == 1 ? 1 : 0, (ph + 1) & 1, r);
+        for (int j = 0; j < 16; ++j) dma_piece(0, j, 0);
+        sA += stepA;                       // (sA, sB) = stage 1 from here on: "the next stage"
+        sB += stepB;
+        of_wait_vm<0>();
+        if (nd > 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dma_piece(STAGE_BYTES, j, 0);
+        }
+        of_barrier_raw();
+        OF_STAMP(1);
+#pragma unroll
+        for (int r = 0; r < 12; ++r) read_kstep(smem, 0, 0, r);
+
+        // The K loop, compiled once per wave parity (odd waves request their pieces two MFMA gaps after the even ones).
+        auto main_loop = [&](auto parc) OF_INLINE_LAMBDA {
+            constexpr int PARC = decltype(parc)::value;
+            // One phase = 32 MFMAs: B fragments fb[ks] x A fragments fa[ph & 1] (rows 64 (ph & 1) .. of the wave's 128).  Its MFMA gaps
+            // carry the fragment reads of the NEXT phase (4 or 12, from the gap after the previous read on, every other gap) and,
+            // with `dma`, eight LDS-DMA pieces (gaps 4j + 2 PARC).
+            auto phase = [&](int ph, const char* rd_stage, bool rd, unsigned dma_slot, int dma0, bool dma, int ahead) OF_INLINE_LAMBDA {
+                const int ks = ph >> 1, ah = ph & 1;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    of_mfma_acc(fb[ks][i & 7], fa[ph & 1][i >> 3], acc[ah * 4 + (i >> 3)][i & 7]);
+                    if (rd && !(i & 1)) {
+                        const int r = i >> 1;
+                        if (ph == 0 || ph == 2) {          // next phase: same k-step, the other row half
+                            if (r < 4) read_a(rd_stage, ks, 1, (ph + 1) & 1, r);
+                        } else if (r < 12) {               // next phase starts a k-step (ph 1: k-step 1 of this stage; ph 3: k-step 0 of the next)
+                            read_kstep(rd_stage, ph == 1 ? 1 : 0, (ph + 1) & 1, r);
+                        }
                     }
+                    if (dma && (i & 3) == 2 * PARC) dma_piece(dma_slot, dma0 + (i >> 2), ahead);
+                    of_sched_fence();
                 }
-                if (dma && (i & 3) == 2 * PARC) dma_piece(dma_slot, dma0 + (i >> 2), ahead);
+            };
+            // One K stage in slot `cur`.  WR: stage d + 1 exists, LD: stage d + 2 exists.  (sA, sB) = offsets of stage d + 1.
+            auto stage_body = [&](char* cur, char* nxt, const bool WR, const bool LD) OF_INLINE_LAMBDA {
+                const unsigned cur_u = (unsigned)(cur - smem), nxt_u = (unsigned)(nxt - smem);
+                of_mfma_acc_guard();       // fragments may have been moved between registers on the way into this stage (of_platform.h)
+                phase(0, cur, true, nxt_u, 8, WR, 0);          // + B of stage d + 1 -> nxt (its A went there in phase 3 of stage d - 1)
+                phase(1, cur, true, 0u, 0, false, 0);
+                phase(2, cur, true, 0u, 0, false, 0);
+                of_wait_vm<0>();       // own pieces of stage d + 1 have landed ...
+                of_wait_lgkm0();       // ... own reads of this slot are done ...
+                of_barrier_raw();      // ... and so are everybody else's
+                of_sched_fence();
+                phase(3, nxt, WR, cur_u, 0, LD, 1);            // + A of stage d + 2 -> cur (free since the barrier)
+                sA += stepA;
+                sB += stepB;
+            };
+            int d = 0;
+            // (gemm_w4.hip unrolls its NT steady state by two stages for compile-time slot addresses; here that measured +-1 % and
+            // is not done.  It is how the VALU-write -> asm-MFMA hazard of of_mfma_acc_guard() was found: the unrolled build moved stage
+            // 0's fragments between registers right in front of the loop and lost half a k-step -- DESIGN.md 4.1.)
+            for (; d + 2 < nd; ++d) stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, true, true);
+            if (d + 1 < nd) {
+                stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, true, false);
+                ++d;
+            }
+            stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, false, false);
+        };
+        if (wave & 1) main_loop(std::integral_constant<int, 1>{});
+        else main_loop(std::integral_constant<int, 0>{});
+        of_mfma_acc_settle();
+        of_barrier_raw();          // the ring is idle from here
+        OF_STAMP(2);
+
+        if (!last_k) {
+            // ---- partial tile (stream-K): raw accumulators -> this workgroup's slab, fragment-major so that every store is one
+            // contiguous KiB per wave; then the flag.  Every lane's stores are released to the device before the barrier, the
+            // flag goes up behind it.
+            // (buffer-descriptor addressing: wave-uniform base + scalar fragment offset + one per-lane offset -- with plain pointers
+            // every fragment, 4 KiB from the last, needs a 64-bit address of its own in VGPRs, which this kernel does not have)
+            const of_buf_t slab = of_buf_make(of_uniform_ptr(sk_slabs + (size_t)bid * (TM * TN)));
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+#pragma unroll
+                for (int b = 0; b < 8; ++b) of_buf_store16(slab, (unsigned)tid * 16u, (unsigned)(a * 8 + b) * 4096u, __builtin_bit_cast(u32x4, acc[a][b]));
                 of_sched_fence();
             }
-        };
-        // One K stage in slot `cur`.  WR: stage d + 1 exists, LD: stage d + 2 exists.  (sA, sB) = offsets of stage d + 1.
-        auto stage_body = [&](char* cur, char* nxt, const bool WR, const bool LD) OF_INLINE_LAMBDA {
-            const unsigned cur_u = (unsigned)(cur - smem), nxt_u = (unsigned)(nxt - smem);
-            of_mfma_acc_guard();       // fragments may have been moved between registers on the way into this stage (of_platform.h)
-            phase(0, cur, true, nxt_u, 8, WR, 0);          // + B of stage d + 1 -> nxt (its A went there in phase 3 of stage d - 1)
-            phase(1, cur, true, 0u, 0, false, 0);
-            phase(2, cur, true, 0u, 0, false, 0);
-            of_wait_vm<0>();       // own pieces of stage d + 1 have landed ...
-            of_wait_lgkm0();       // ... own reads of this slot are done ...
-            of_barrier_raw();      // ... and so are everybody else's
-            of_sched_fence();
-            phase(3, nxt, WR, cur_u, 0, LD, 1);            // + A of stage d + 2 -> cur (free since the barrier)
-            sA += stepA;
-            sB += stepB;
-        };
-        int d = 0;
-        // (gemm_w4.hip unrolls its NT steady state by two stages for compile-time slot addresses; here that measured +-1 % and
-        // is not done.  It is how the VALU-write -> asm-MFMA hazard of of_mfma_acc_guard() was found: the unrolled build moved stage
-        // 0's fragments between registers right in front of the loop and lost half a k-step -- DESIGN.md 4.1.)
-        for (; d + 2 < nd; ++d) stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, true, true);
-        if (d + 1 < nd) {
-            stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, true, false);
-            ++d;
+            of_fence_release_device();
+            of_sync();
+            if (tid == 0) of_flag_publish(sk_flags + bid, 1);
+            continue;
         }
-        stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, false, false);
-    };
-    if (wave & 1) main_loop(std::integral_constant<int, 1>{});
-    else main_loop(std::integral_constant<int, 0>{});
-    of_mfma_acc_settle();
-    of_barrier_raw();          // the ring is idle from here
-    OF_STAMP(2);
-
-    auto acc_to_patch = [&](int g, char* patch) OF_INLINE_LAMBDA {
-        const int mt = g >> 1, np = g & 1;
-        const f32x4 t[2][4] = {{acc[2 * mt][4 * np], acc[2 * mt][4 * np + 1], acc[2 * mt][4 * np + 2], acc[2 * mt][4 * np + 3]},
-                               {acc[2 * mt + 1][4 * np], acc[2 * mt + 1][4 * np + 1], acc[2 * mt + 1][4 * np + 2], acc[2 * mt + 1][4 * np + 3]}};
-        ofg::patch_write16(patch, t, lane);
-    };
-    w4_epilogue_with<EPI, ASMD, decltype(acc_to_patch), true>(p, acc_to_patch, smem, SMEM_W4M, m0, n0, wm, wn, wave, lane);
-    OF_STAMP(3);
+        // (fewer remainder units than workgroups: some workgroups hold none -- they publish nothing and are skipped)
+        auto sk_has_units = [&](int w) OF_INLINE_LAMBDA { return rem_units * w / G != rem_units * (w + 1) / G; };
+        // ---- owner of a shared tile: the partial tiles of K stages [0, s0) -- workgroups sk_first .. bid - 1, ascending K -- are
+        // added group by group on the way through the LDS patch (acc_to_patch below); here: wait until all of them are published
+        int sk_first = bid;
+        if (s0 > 0) {
+            const long ts = (long)(vt - rounds * G) * nd_all;
+            sk_first = (int)(((ts + 1) * G + rem_units - 1) / rem_units) - 1;      // the workgroup whose range holds unit ts
+            if (tid == 0)
+                for (int w = sk_first; w < bid; ++w)
+                    if (sk_has_units(w)) of_flag_await(sk_flags + w, 1);
+            of_sync();
+            of_fence_acquire_device();
+        }
+        auto acc_to_patch = [&](int g, char* patch) OF_INLINE_LAMBDA {
+            const int mt = g >> 1, np = g & 1;
+            const f32x4 t[2][4] = {{acc[2 * mt][4 * np], acc[2 * mt][4 * np + 1], acc[2 * mt][4 * np + 2], acc[2 * mt][4 * np + 3]},
+                                   {acc[2 * mt + 1][4 * np], acc[2 * mt + 1][4 * np + 1], acc[2 * mt + 1][4 * np + 2], acc[2 * mt + 1][4 * np + 3]}};
+            ofg::patch_write16(patch, t, lane);
+            for (int w = sk_first; w < bid; ++w) {          // (no iteration unless this tile is shared)
+                if (!sk_has_units(w)) continue;
+                const of_buf_t slab = of_buf_make(of_uniform_ptr(sk_slabs + (size_t)w * (TM * TN)));
+                f32x4 q[2][4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        q[i][j] = __builtin_bit_cast(f32x4, of_buf_load16(slab, (unsigned)tid * 16u, (unsigned)((2 * mt + i) * 8 + 4 * np + j) * 4096u));
+                ofg::patch_add16(patch, q, lane);
+            }
+        };
+        // gate-gradient partial of this TILE: slot = its position in the (m-major) tile grid, whichever workgroup finishes it
+        w4_epilogue_with<EPI, ASMD, decltype(acc_to_patch), true>(p, acc_to_patch, smem, SMEM_W4M, m0, n0, wm, wn, wave, lane, pm * tiles_n + pn);
+        OF_STAMP(3);
+    }
     OF_STAMP_FLUSH();
 }
 
 template <bool AT, bool BT, int EPI>
 int launch_w4m(const OfGemmArgs& a, of_stream_t s) {
-    of_dim3 grid{(unsigned)((a.M / TM) * (a.N / TN)), 1, 1};
+    const int ntiles = (a.M / TM) * (a.N / TN);
+    of_dim3 grid{(unsigned)(a.sk_grid > 0 ? a.sk_grid : ntiles), 1, 1};
     // *_DOT epilogues: + 4 KiB per wave behind the ring for the first group's aux tile
     // GATE_RESID: + 8 KiB per wave for the first group's residual tile (160 KiB in all: the CU's whole LDS)
     constexpr int smem_bytes = SMEM_W4M + ((EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) ? 4 * ofg::AUX_LDS_BYTES
                                            : EPI == OF_EPI_GATE_RESID ? 4 * ofg::RESID_LDS_BYTES : 0);
+    if (a.sk_grid > 0 && ntiles % a.sk_grid) {       // tiles will be shared: every workgroup's flag starts at 0
+        const int rc = of_memset_async((char*)a.workspace + sk_dot_bytes(a), 0, sk_flags_bytes(a.sk_grid), s);
+        if (rc) return rc;
+    }
     const int rc = of_launch(of_gemm_w4m_kernel<AT, BT, EPI>, grid, 256, smem_bytes, s, a);
     if (rc || !of_gemm_has_dot(a)) return rc;
-    return of_gemm_dot_finish(a, (int)grid.x, s);
+    return of_gemm_dot_finish(a, ntiles, s);
 }
 }  // namespace
 
@@ -252,8 +347,21 @@ bool of_gemm_w4m_eligible(const OfGemmArgs& a) {
     return false;
 }
 
+// Workspace a stream-K launch over `grid` workgroups needs (0: grid divides the tile count -- nothing is shared): the *_DOT
+// partials of the launch, one flag and one fp32 partial tile per workgroup.
+size_t of_gemm_w4m_sk_bytes(const OfGemmArgs& a, int grid) {
+    const int ntiles = (a.M / TM) * (a.N / TN);
+    if (grid <= 0 || ntiles % grid == 0) return 0;
+    return sk_dot_bytes(a) + sk_flags_bytes(grid) + (size_t)grid * SK_SLAB_BYTES;
+}
+
 int of_gemm_w4m_try(const OfGemmArgs& a, of_stream_t s) {
     if (!of_gemm_w4m_eligible(a)) return OF_E_SHAPE;
+    if (a.sk_grid < 0 || (a.sk_grid & 7)) return OF_E_ARG;         // the XCD-aware tile map wants whole groups of 8 workgroups
+    if (a.sk_grid > 0) {
+        const size_t need = of_gemm_w4m_sk_bytes(a, a.sk_grid);
+        if (need && (!a.workspace || a.workspace_bytes < need || ((uintptr_t)a.workspace & 15))) return OF_E_WORKSPACE;
+    }
     const int layout = a.a_trans * 2 + a.b_trans;
     if (layout == 0) {
         switch (a.epi) {

@@ -53,6 +53,9 @@ OF_DEV f32x4 of_mfma(s16x8 a, s16x8 b, f32x4 c) {
 // (gemm_w4m.hip) the builtin form leaves hipcc shuttling accumulators between AGPRs and VGPRs around every MFMA
 // (390 v_accvgpr_* + 74 s_nop per 128 MFMAs in the cross-compiled loop).  Results are read only after of_mfma_acc_settle().
 OF_DEV void of_mfma_acc(s16x8 a, s16x8 b, f32x4& c) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); }
+// pins a value that C code has just computed back into an accumulation register (the compiler would otherwise be free to keep
+// the 256 updated accumulators of gemm_w4m.hip's stream-K fix-up in VGPRs until the epilogue reads them: spills)
+OF_DEV void of_acc_pin(f32x4& c) { asm volatile("" : "+a"(c)); }
 // The compiler does not see the MFMAs inside the asm, so its hazard recognizer does not cover VALU-write -> MFMA-read either: a
 // register copy it places right in front of the first MFMA of a loop (fragments that change registers on the way into a loop)
 // can still be under way for the upper half of the wave when the MFMA reads it.  Callers put of_mfma_acc_guard() at the points
@@ -84,6 +87,13 @@ OF_DEV void of_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // MFMA 0x8, VMEM read 0x20, DS read 0x100, DS write 0x200); compile-time only, the emulator ignores it
 #define OF_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 OF_DEV int of_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// a pointer every lane holds the same value of, moved to SGPRs (e.g. one LOADED from global memory behind earlier stores of the
+// kernel: such a load is a vector load, its result formally divergent -- a buffer descriptor made from it would be waterfalled)
+OF_DEV const void* of_uniform_ptr(const void* p) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    return (const void*)(((unsigned long long)hi << 32) | lo);
+}
 // Point where the lanes of ONE wave exchange data through LDS: hardware executes a wave in lock-step and its LDS
 // operations in program order, so this is only a compiler scheduling fence (the emulator needs a real rendezvous).
 OF_DEV void of_wave_sync() { __builtin_amdgcn_wave_barrier(); }
@@ -137,6 +147,9 @@ OF_DEV of_buf_t of_buf_make(const void* base) {
 OF_DEV u32x4 of_buf_load16(of_buf_t b, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)voff, (int)soff, 0));
 }
+OF_DEV void of_buf_store16(of_buf_t b, unsigned voff, unsigned soff, u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, b.r, (int)voff, (int)soff, 0);
+}
 // LDS-DMA through a buffer descriptor: 16 bytes per lane straight into LDS at (wave-uniform base + lane*16); completion is
 // tracked only by the issuing wave's vmcnt (+ a barrier for other waves), like of_glds16
 template <bool TRSAFE = true>
@@ -181,6 +194,18 @@ OF_DEV void of_barrier_raw() {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
+// ---- workgroup-to-workgroup hand-off inside ONE launch (stream-K fix-up of gemm_w4m.hip): a producer publishes data it
+// wrote to global memory, a consumer on another CU -- possibly another XCD, whose L2 is a different cache -- picks it up.
+// Device (agent) scope: the release makes this XCD's dirty L2 lines visible to the others, the acquire drops stale lines
+// (LLVM AMDGPU memory model for gfx942 / gfx950: buffer_wbl2 sc1 / buffer_inv sc1 around the flag access).
+OF_DEV void of_flag_publish(int* flag, int value) {
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+OF_DEV void of_flag_await(const int* flag, int value) {       // spin with a short sleep: the producer needs the memory pipes
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != value) __builtin_amdgcn_s_sleep(8);
+}
+OF_DEV void of_fence_release_device() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+OF_DEV void of_fence_acquire_device() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 OF_DEV float of_shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 OF_DEV int of_shfl_xor_i(int v, int m) { return __shfl_xor(v, m, 64); }
 OF_DEV float of_shfl(float v, int src) { return __shfl(v, src, 64); }

@@ -5,7 +5,7 @@ Pure declarations: nothing here loads a library.  ``open_flamingo_amd.hip.lib`` 
 """
 import ctypes as C
 
-OF_ABI_VERSION = 7
+OF_ABI_VERSION = 8
 OF_SUMSQ_PARTS = 512
 EPI_STORE_BF16, EPI_GELU, EPI_GATE_RESID, EPI_DGELU_DOT, EPI_SCALE_DOT, EPI_ACC_F32 = range(6)
 
@@ -28,6 +28,7 @@ class OfGemmArgs(C.Structure):
         ("io_f32", C.c_int), ("safe", C.c_int), ("ksplit", C.c_int),
         ("workspace", vp), ("workspace_bytes", C.c_size_t),
         ("groups", vp), ("group_kind", C.c_int), ("group_extent", C.c_int),
+        ("cu_limit", C.c_int), ("sk_grid", C.c_int),
     ]
 
 

@@ -33,7 +33,7 @@ def bf16(t):
 
 
 def gemm(A, B, *, a_trans=0, b_trans=0, epi=abi.EPI_STORE_BF16, C_out=None, C2=None, aux=None, gate=None,
-         alpha=1.0, beta=0.0, dot_out=None, io_f32=0, safe=0, M=None, N=None, K=None, workspace=None):
+         alpha=1.0, beta=0.0, dot_out=None, io_f32=0, safe=0, M=None, N=None, K=None, workspace=None, cu_limit=0):
     if M is None:
         M = A.shape[1] if a_trans else A.shape[0]
         K = A.shape[0] if a_trans else A.shape[1]
@@ -50,8 +50,9 @@ def gemm(A, B, *, a_trans=0, b_trans=0, epi=abi.EPI_STORE_BF16, C_out=None, C2=N
     a.gate = gate.data_ptr() if gate is not None else None
     a.alpha, a.beta = alpha, beta
     a.dot_out = dot_out.data_ptr() if dot_out is not None else None
-    a.io_f32, a.safe = io_f32, safe
-    if workspace is None and dot_out is not None:      # per-workgroup gate-gradient partials (deterministic finish)
+    a.io_f32, a.safe, a.cu_limit = io_f32, safe, cu_limit
+    if workspace is None and (dot_out is not None or cu_limit or safe == 17):
+        # per-workgroup gate-gradient partials (deterministic finish); stream-K partial tiles + flags
         workspace = torch.empty(max(1, lib().of_gemm_workspace_bytes(C.byref(a)) // 4))
     if workspace is not None:
         a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()

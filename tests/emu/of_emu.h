@@ -130,6 +130,17 @@ inline int launch(of_dim3 grid, int block, size_t smem, F body) {
 }
 }  // namespace of_emu
 
+// workgroup-to-workgroup hand-off (stream-K fix-up): workgroups run on parallel OS threads here, taken in block-id order; a
+// waiting fiber yields so that the other fibers of its workgroup (and, on other threads, the producer) keep running
+OF_DEV void of_flag_publish(int* flag, int value) { __atomic_store_n(flag, value, __ATOMIC_RELEASE); }
+OF_DEV void of_flag_await(const int* flag, int value) {
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != value) {
+        of_emu::yield();
+        std::this_thread::yield();
+    }
+}
+OF_DEV void of_fence_release_device() { std::atomic_thread_fence(std::memory_order_release); }
+OF_DEV void of_fence_acquire_device() { std::atomic_thread_fence(std::memory_order_acquire); }
 OF_DEV int of_tid() { return of_emu::g_blk->cur; }
 OF_DEV int of_bid_x() { return (int)of_emu::g_blk->bid.x; }
 OF_DEV int of_bid_y() { return (int)of_emu::g_blk->bid.y; }
@@ -168,6 +179,7 @@ OF_DEV f32x4 of_mfma(s16x8 a, s16x8 b, f32x4 c) {
 }
 OF_DEV void of_mfma_acc(s16x8 a, s16x8 b, f32x4& c) { c = of_mfma(a, b, c); }
 OF_DEV void of_mfma_acc_settle() {}
+OF_DEV void of_acc_pin(f32x4&) {}
 OF_DEV void of_mfma_acc_guard() {}
 OF_DEV f32x16 of_mfma32(s16x8 a, s16x8 b, f32x16 c) {
     of_emu::Block* blk = of_emu::g_blk;
@@ -197,6 +209,7 @@ OF_DEV void of_setprio_lo() {}
 OF_DEV void of_sched_fence() {}
 #define OF_SCHED_GROUP(mask, n) ((void)0)
 OF_DEV int of_uniform(int v) { return v; }
+OF_DEV const void* of_uniform_ptr(const void* p) { return p; }
 OF_DEV void of_wave_sync() { of_emu::wave_barrier(); }
 OF_DEV s16x4 of_lds_tr(const void* p) {
     of_emu::Block* blk = of_emu::g_blk;
@@ -229,6 +242,7 @@ struct of_buf_t {
 };
 OF_DEV of_buf_t of_buf_make(const void* base) { return of_buf_t{(const char*)base}; }
 OF_DEV u32x4 of_buf_load16(of_buf_t b, unsigned voff, unsigned soff) { return *(const u32x4*)(b.base + voff + soff); }
+OF_DEV void of_buf_store16(of_buf_t b, unsigned voff, unsigned soff, u32x4 v) { *(u32x4*)(const_cast<char*>(b.base) + voff + soff) = v; }
 template <bool TRSAFE = true>
 OF_DEV void of_buf_load16_lds(of_buf_t b, unsigned voff, unsigned soff, void* lds_wave_base) {
     *(u32x4*)((char*)lds_wave_base + (of_emu::g_blk->cur & 63) * 16) = *(const u32x4*)(b.base + voff + soff);

@@ -359,3 +359,105 @@ def test_tile_quantisation_n_split_applies_every_column_once():
     y0 = y.clone()
     H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=y, aux=y, gate=gate, io_f32=1)
     np.testing.assert_allclose(y.double().numpy(), (y0.double() + g * _ref(A, B, 0, 0)).numpy(), rtol=1e-5, atol=1e-4)
+
+
+# ---- stream-K schedule of the 16x16x32 big-tile kernel (gemm_w4m.hip; OfGemmArgs.cu_limit, safe = 17 forces it) ------------------
+# (tiles, K stages) over G = cu_limit workgroups:  4 tiles / 8: every tile shared by two workgroups;  3 tiles x 8 stages / 8: three
+# (2 tiles x 2 stages / 8: half of the workgroups hold no unit at all;)  units per workgroup -> tiles shared by three, workgroups with a tail AND a head segment;  12 / 8: one whole round + 4 shared
+# tiles;  16 / 16 and 8 / 8: whole rounds only (the persistent loop, no fix-up);  5 tiles x 3 stages / 8: ranges of 1 and 2 units.
+_SK = [(512, 256, 128, 8), (512, 512, 256, 8), (768, 256, 512, 8), (768, 1024, 192, 8), (1024, 1024, 128, 16), (512, 1024, 64, 8), (1280, 256, 192, 8)]
+
+
+@pytest.mark.parametrize("at,bt", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K,G", _SK)
+def test_stream_k_matches_one_tile_per_workgroup(at, bt, M, N, K, G):
+    """Same products, fp32 accumulation; a shared tile's sum is split at the workgroup boundaries (own stages + the others' partial
+    tiles, ascending K) -> equal to the classic launch (safe = 16) up to fp32 summation order, exactly equal where no tile is
+    shared, and bit-reproducible run to run (fixed-order fix-up, no atomics)."""
+    A = _rand((K, M) if at else (M, K), 71)
+    B = _rand((K, N) if bt else (N, K), 72)
+    ref = _ref(A, B, at, bt)
+    o_sk, o_sk2, o_cl = torch.zeros(M, N), torch.zeros(M, N), torch.zeros(M, N)
+    H.gemm(A, B, a_trans=at, b_trans=bt, epi=abi.EPI_ACC_F32, C_out=o_sk, safe=17, cu_limit=G)
+    H.gemm(A, B, a_trans=at, b_trans=bt, epi=abi.EPI_ACC_F32, C_out=o_sk2, safe=17, cu_limit=G)
+    H.gemm(A, B, a_trans=at, b_trans=bt, epi=abi.EPI_ACC_F32, C_out=o_cl, safe=16)
+    assert torch.equal(o_sk, o_sk2)
+    np.testing.assert_allclose(o_sk.double().numpy(), ref.numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(o_sk.numpy(), o_cl.numpy(), rtol=1e-6, atol=5e-5)
+    if ((M // 256) * (N // 256)) % G == 0:
+        assert torch.equal(o_sk, o_cl)
+
+
+@pytest.mark.parametrize("M,N,K,G", [(768, 256, 512, 8), (768, 1024, 192, 8)])
+def test_stream_k_epilogues(M, N, K, G):
+    """Every fused epilogue behind a shared tile: the owner adds the partial tiles on the way through its LDS patch, then the
+    epilogue runs as ever (residual tiles by LDS-DMA, *_DOT partial per TILE, beta = 1 accumulation, in-place gate + residual)."""
+    A, B = _rand((M, K), 73), _rand((N, K), 74) * 0.1
+    acc = _ref(A, B, 0, 0)
+    gate = torch.tensor([0.37])
+    g = float(torch.tanh(gate))
+    kw = dict(safe=17, cu_limit=G)
+    b_out, a_out = torch.zeros(M, N, dtype=torch.bfloat16), torch.zeros(M, N, dtype=torch.bfloat16)
+    H.gemm(A, B, epi=abi.EPI_GELU, C_out=b_out, C2=a_out, **kw)
+    np.testing.assert_allclose(a_out.double().numpy(), acc.numpy(), rtol=1e-2, atol=1e-2)
+    np.testing.assert_allclose(b_out.double().numpy(), torch.nn.functional.gelu(acc).numpy(), rtol=1e-2, atol=1e-2)
+    ob = torch.zeros(M, N, dtype=torch.bfloat16)
+    H.gemm(A, B, epi=abi.EPI_STORE_BF16, C_out=ob, alpha=0.5, **kw)
+    np.testing.assert_allclose(ob.double().numpy(), 0.5 * acc.numpy(), rtol=1e-2, atol=2e-2)
+    res = torch.randn(M, N)
+    out = torch.zeros(M, N)
+    H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=out, aux=res, gate=gate, io_f32=1, **kw)
+    np.testing.assert_allclose(out.double().numpy(), (res.double() + g * acc).numpy(), rtol=1e-5, atol=1e-4)
+    y = res.clone()
+    H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=y, aux=y, gate=gate, io_f32=1, **kw)          # in place
+    np.testing.assert_allclose(y.double().numpy(), (res.double() + g * acc).numpy(), rtol=1e-5, atol=1e-4)
+    resb, outb = res.to(torch.bfloat16), torch.zeros(M, N, dtype=torch.bfloat16)
+    H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=outb, aux=resb, gate=gate, io_f32=0, **kw)
+    np.testing.assert_allclose(outb.double().numpy(), (resb.double() + g * acc).numpy(), rtol=1e-2, atol=2e-2)
+    c = torch.randn(M, N)
+    c0 = c.clone()
+    H.gemm(A, B, epi=abi.EPI_ACC_F32, C_out=c, alpha=0.5, beta=1.0, gate=gate, **kw)
+    np.testing.assert_allclose(c.double().numpy(), (c0.double() + 0.5 * g * acc).numpy(), rtol=1e-5, atol=1e-4)
+    W = _rand((K, N), 75) * 0.2
+    acc2 = A.double() @ W.double()
+    aux = _rand((M, N), 76)
+    for epi in (abi.EPI_DGELU_DOT, abi.EPI_SCALE_DOT):
+        vals = []
+        for _ in range(2):
+            o, dot = torch.zeros(M, N, dtype=torch.bfloat16), torch.full((1,), 3.0)
+            H.gemm(A, W, b_trans=1, epi=epi, C_out=o, aux=aux, gate=gate, dot_out=dot, **kw)
+            vals.append(dot.clone())
+        x = aux.double()
+        if epi == abi.EPI_DGELU_DOT:
+            xx = x.clone().requires_grad_(True)
+            torch.nn.functional.gelu(xx).sum().backward()
+            want, wdot = g * acc2 * xx.grad, (1 - g * g) * (torch.nn.functional.gelu(x) * acc2).sum()
+        else:
+            want, wdot = g * acc2, (1 - g * g) * (x * acc2).sum()
+        np.testing.assert_allclose(o.double().numpy(), want.numpy(), rtol=1e-2, atol=2e-2)
+        assert abs(float(dot) - 3.0 - float(wdot)) <= 1e-3 * abs(float(wdot)) + 1e-2
+        assert torch.equal(vals[0], vals[1])
+
+
+def test_stream_k_is_of_gemms_own_choice_when_the_workgroup_count_does_not_divide_the_tiles():
+    """safe = 0: with a workspace of of_gemm_workspace_bytes() a launch whose tile count the workgroup count does not divide goes
+    stream-K -- 144 tiles under cu_limit = 128 (one whole round + 16 tiles shared out over 128 workgroups) -- and equals the classic
+    launch; without the workspace the same call still works (one tile per workgroup).  An explicit cu_limit that divides the tile
+    count changes nothing."""
+    M, N, K = 2304, 4096, 128            # 9 x 16 = 144 tiles
+    A, B = _rand((M, K), 77), _rand((N, K), 78)
+    o_cl, o_sk, o_nw = torch.zeros(M, N), torch.zeros(M, N), torch.zeros(M, N)
+    H.gemm(A, B, epi=abi.EPI_ACC_F32, C_out=o_cl, safe=16)
+    H.gemm(A, B, epi=abi.EPI_ACC_F32, C_out=o_sk, cu_limit=128)
+    np.testing.assert_allclose(o_sk.numpy(), o_cl.numpy(), rtol=1e-6, atol=5e-5)
+    assert not torch.equal(o_sk, o_cl)          # the 16 shared tiles were summed in two parts
+    a = abi.OfGemmArgs()
+    a.A, a.B, a.M, a.N, a.K, a.lda, a.ldb, a.epi = A.data_ptr(), B.data_ptr(), M, N, K, K, K, abi.EPI_ACC_F32
+    a.C, a.ldc, a.alpha, a.cu_limit = o_nw.data_ptr(), N, 1.0, 128
+    import ctypes
+    assert H.lib().of_gemm_workspace_bytes(ctypes.byref(a)) >= 128 * 256 * 256 * 4
+    assert H.lib().of_gemm(ctypes.byref(a), None) == 0
+    assert torch.equal(o_nw, o_cl)
+    o_div = torch.zeros(M, N)
+    H.gemm(A, B, epi=abi.EPI_ACC_F32, C_out=o_div, cu_limit=144)
+    assert torch.equal(o_div, o_cl)
