@@ -264,6 +264,9 @@ def main():
                          "32 text tokens, loss multiplier 0.2, its backward under no_sync) before the MMC4-style pass -- the two-pass "
                          "step of the reference's training script (run_train.sh: batch_size_laion = 2 x batch_size_mmc4); BASELINE.json "
                          "names only the MMC4-style batch, so the default (0) is the primary number")
+    ap.add_argument("--reserve-cus", type=int, default=0,
+                    help="multi-GPU: CUs to leave to RCCL's kernels while gradient collectives are in flight -- the libofhip GEMMs of the "
+                         "backward are then laid out stream-K for 256 - R workgroups (GradReducer.reserve_cus; default 0 = off)")
     ap.add_argument("--no-vision-prefetch", action="store_true",
                     help="run the frozen vision tower at the start of each step (as the reference does) instead of enqueuing the NEXT "
                          "step's tower forward on a side stream next to the step epilogue (train/step.py: next_vision_x)")
@@ -303,7 +306,7 @@ def main():
         from open_flamingo_amd.train import sparse_rows
         sparse_rows.enable(model, [info["media_token_id"], info["eoc_token_id"]])
     reducer = GradReducer(model, wire_dtype=torch.bfloat16 if args.wire_bf16 else torch.float32,
-                          embedding_rows=[info["media_token_id"], info["eoc_token_id"]])
+                          embedding_rows=[info["media_token_id"], info["eoc_token_id"]], reserve_cus=args.reserve_cus)
     reducer.broadcast_parameters()
     opt = step.build_optimizer(model, reducer=None if args.torch_optimizer else reducer)
     batch = synthetic.make_batch(args.batch, args.T, args.L, info, device, seed=1 + rank)
@@ -429,7 +432,7 @@ def main():
                           "frozen_lm_attention": args.lm_attention, "frozen_tower_layernorm": args.tower_layernorm,
                           "lm_loss": args.lm_loss, "nan_check": "device (step epilogue)" if nan_check == "device" else "host (torch.isnan(loss))",
                           "vendor_gemm_table": f"TunableOp table, {n_tuned} shapes, tuning off" if n_tuned else "library defaults",
-                          "grad_wire_dtype": "bf16" if args.wire_bf16 else "fp32",
+                          "grad_wire_dtype": "bf16" if args.wire_bf16 else "fp32", "reserve_cus": args.reserve_cus,
                           "embedding_row_gradient": "sparse taps" if args.sparse_embedding_rows else "dense, masked",
                           "vision_tower_schedule": ("at the start of the step" if args.no_vision_prefetch else
                                                     "next step's tower forward on a side stream next to the step epilogue"),

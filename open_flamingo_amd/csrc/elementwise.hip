@@ -485,4 +485,19 @@ extern "C" int of_tools_hold_cus(int nwg, long long ticks, void* stream) {
     if (nwg <= 0 || ticks <= 0) return OF_E_ARG;
     return of_launch(of_tools_hold_kernel, of_dim3{(unsigned)nwg, 1, 1}, 64, 0, (of_stream_t)stream, HoldArgs{ticks});
 }
+// the same with a collective kernel's footprint: 256 threads, 128 registers per lane, `lds_bytes` of LDS per workgroup -- does not
+// fit next to a 4-wave GEMM workgroup (448 registers per lane on every SIMD, 128-160 KiB of LDS): the CU is lost to the GEMM
+namespace {
+OF_GLOBAL void OF_BOUNDS(256, 1) of_tools_hold_heavy_kernel(HoldArgs a) {
+    asm volatile("v_mov_b32 v127, 0" ::: "v127");          // forces a 128-register allocation
+    extern __shared__ char hold_lds[];
+    hold_lds[threadIdx.x] = 0;
+    const long long t0 = (long long)wall_clock64();
+    while ((long long)wall_clock64() - t0 < a.ticks) __builtin_amdgcn_s_sleep(32);
+}
+}  // namespace
+extern "C" int of_tools_hold_cus_heavy(int nwg, long long ticks, int lds_bytes, void* stream) {
+    if (nwg <= 0 || ticks <= 0 || lds_bytes < 256) return OF_E_ARG;
+    return of_launch(of_tools_hold_heavy_kernel, of_dim3{(unsigned)nwg, 1, 1}, 256, (size_t)lds_bytes, (of_stream_t)stream, HoldArgs{ticks});
+}
 #endif

@@ -32,6 +32,9 @@ class Ops:
     def __init__(self, lib, stream_fn):
         self.lib = lib
         self._stream_fn = stream_fn
+        # CUs a big-tile GEMM launch may count on (OfGemmArgs.cu_limit; 0 = all): train/reducer.py lowers it while its collectives
+        # hold CUs on the side stream, so that the GEMMs of the backward are laid out (stream-K) for the CUs that are left
+        self.cu_limit = 0
         self.gemm_timing = None   # bench.py sets this to a list to collect (key, flops, start_evt, end_evt) per launch
         self.gemm_timing_only = None   # optional set of (ta, tb, epi, kernel label) keys: only those launches are bracketed by events
 
@@ -99,9 +102,15 @@ class Ops:
         else:
             assert out.dtype == BF16
         a.safe = safe
-        # scratch: split-K fp32 slabs (EPI_ACC_F32) or the per-workgroup gate-gradient partials of a *_DOT launch (summed in
-        # a fixed order by a second launch: deterministic); one grow-only buffer, reused in stream order
-        if epi == abi.EPI_ACC_F32 or dot is not None:
+        a.cu_limit = self.cu_limit
+        # scratch: split-K fp32 slabs (EPI_ACC_F32), the per-workgroup gate-gradient partials of a *_DOT launch (summed in
+        # a fixed order by a second launch: deterministic), or the partial tiles + flags of a stream-K big-tile launch (tile count
+        # not a multiple of the workgroup count: csrc/gemm.hip sk_grid_for); one grow-only buffer, reused in stream order
+        sk = False
+        if safe in (0, 17) and M % 256 == 0 and N % 256 == 0 and K % 64 == 0:
+            tiles, grid = (M // 256) * (N // 256), ((self.cu_limit & ~7) or 256)
+            sk = safe == 17 or (tiles >= 128 and tiles % min(max(grid, 8), 256) != 0)
+        if epi == abi.EPI_ACC_F32 or dot is not None or sk:
             need = self.lib.of_gemm_workspace_bytes(C.byref(a))
             if need:
                 ws = self.__dict__.get("_gemm_ws")

@@ -29,10 +29,16 @@ import torch.distributed as dist
 
 class GradReducer:
     def __init__(self, model, process_group=None, wire_dtype=torch.float32, embedding_rows=None,
-                 force_collectives=False, perceiver_buckets="layer"):
+                 force_collectives=False, perceiver_buckets="layer", reserve_cus=0):
         """model: a Flamingo (or any module exposing .perceiver and .lang_encoder.gated_cross_attn_layers);
         embedding_rows: token ids whose input-embedding gradient rows are kept (media + endofchunk);
-        perceiver_buckets: "layer" (one bucket per Perceiver layer, backward order) or "one"."""
+        perceiver_buckets: "layer" (one bucket per Perceiver layer, backward order) or "one";
+        reserve_cus: CUs to leave to RCCL's kernels while collectives are in flight (0 = off).  A 256-tile GEMM launch needs every
+        CU: the workgroups a collective displaces run as a SECOND ROUND (measured with a stand-in: +3..5 % per step, DESIGN.md
+        section 5).  With reserve_cus = R the libofhip GEMMs of the backward are laid out stream-K for 256 - R workgroups from the
+        first bucket's launch until finish() (hip/ops.py: Ops.cu_limit -> OfGemmArgs.cu_limit): every workgroup gets the same share
+        of the launch, nothing waits for a second round.  What R should be on a real node (RCCL's channel count x workgroup
+        footprint) is a measurement this one-GPU pool cannot make; the default leaves the launches as they are."""
         self.module = model                      # DDP-style handle (train_utils.py:181 reaches through .module)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -41,6 +47,7 @@ class GradReducer:
         # exact RCCL / stream code path the multi-GPU runs take)
         self.force_collectives = bool(force_collectives) and dist.is_initialized()
         self.embedding_rows = list(embedding_rows) if embedding_rows is not None else None
+        self.reserve_cus = int(reserve_cus)
         self._sync = True
         self._pending = []
         self._stream = None
@@ -137,6 +144,9 @@ class GradReducer:
         if self.world == 1 and not self.force_collectives:
             return
         side = self._side_stream(flat.device)
+        if self.reserve_cus > 0 and side is not None:          # GEMMs enqueued from here on count on the CUs RCCL leaves
+            from ..hip.ops import Ops
+            Ops.default().cu_limit = 256 - self.reserve_cus
         compute = None
         if side is not None:
             compute = torch.cuda.current_stream(flat.device)
@@ -218,6 +228,9 @@ class GradReducer:
         # flight.  On CPU / gloo the waits complete on the host.
         for work, _, _ in self._pending:
             work.wait()
+        if self.reserve_cus > 0 and self._stream is not None:
+            from ..hip.ops import Ops
+            Ops.default().cu_limit = 0
         for _, flat, wire in self._pending:
             if wire is not None:
                 flat.copy_(wire)

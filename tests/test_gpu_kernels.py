@@ -423,7 +423,7 @@ def _close(got, want, name, rtol=1e-2, atol_rms=2e-3, l2=4e-3):
     assert e <= l2, f"{name}: rel L2 {e:.3e}"
 
 
-@pytest.mark.parametrize("safe", [0, 4, 6, 7, 16])
+@pytest.mark.parametrize("safe", [0, 4, 6, 7, 16, 17])
 def test_big_tile_gemm_fused_epilogues_at_benchmark_shapes(ops, safe):
     """The launches bench.py times at BASELINE config 2 (per gated block: rows = B*L = 8192, d = 2048, hidden 8192) run the
     256x256 kernel with FUSED epilogues; small-batch tests select the 128x128 kernel.  Every (layout, epilogue) pair the
@@ -487,3 +487,81 @@ def test_big_tile_gemm_fused_epilogues_at_benchmark_shapes(ops, safe):
     du = torch.empty(rows, d, device="cuda", dtype=torch.bfloat16)
     ops.gemm(da, W1, du, tb=True, safe=safe)
     _close(du, da.float() @ W1.float(), "dU")
+
+
+# ---- stream-K schedule of the 16x16x32 big-tile kernel (csrc/gemm_w4m.hip): tile counts the workgroup count does not divide --------
+_SK_SHAPES = [  # (M, N, K, ta, tb, epi, cu_limit)   tiles / workgroups
+    (10240, 2560, 8192, True, True, abi.EPI_ACC_F32, 0),      # OF-4B ffn dW: 400 tiles / 256 -> 1.5625 tiles per workgroup
+    (2048, 4096, 16384, False, True, abi.EPI_STORE_BF16, 0),  # OF-9B L = 256 dX: 128 tiles / 256 -> half a tile per workgroup
+    (8192, 2048, 8192, False, False, abi.EPI_STORE_BF16, 192),   # 256 tiles next to a collective holding 64 CUs: 1 1/3 tiles each
+    (8192, 8192, 2048, False, True, abi.EPI_STORE_BF16, 224),    # 1024 tiles / 224 workgroups: 4 rounds + 128 shared tiles
+    (8192, 2560, 2560, False, False, abi.EPI_STORE_BF16, 0),  # OF-4B to-2560 projection shape class: 320 tiles
+]
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb,epi,cu", _SK_SHAPES)
+def test_stream_k_matches_classic_launch_and_is_bit_reproducible(ops, M, N, K, ta, tb, epi, cu):
+    """of_gemm's own selection (safe = 0) with the stream-K workspace vs the classic one-tile-per-workgroup launch (safe = 16) of the
+    same kernel and vs fp32 torch: same products, fp32 accumulation, a shared tile's sum split at workgroup boundaries.  Five
+    launches of the stream-K form give ONE bit pattern (fixed-order fix-up through the workspace; this is also the race screen of
+    the flag / partial-tile hand-off between workgroups on different XCDs)."""
+    A = _r((K, M) if ta else (M, K), 81)
+    B = _r((K, N) if tb else (N, K), 82, K ** -0.5)
+    ref = (A.float().t() if ta else A.float()) @ (B.float() if tb else B.float().t())
+    dt = torch.float32 if epi == abi.EPI_ACC_F32 else torch.bfloat16
+    old = ops.cu_limit
+    try:
+        ops.cu_limit = cu
+        outs = []
+        for _ in range(5):
+            o = torch.empty(M, N, device="cuda", dtype=dt)
+            ops.gemm(A, B, o, ta=ta, tb=tb, epi=epi)
+            outs.append(o)
+    finally:
+        ops.cu_limit = old
+    cl = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm(A, B, cl, ta=ta, tb=tb, epi=epi, safe=16)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    if dt == torch.float32:
+        _close(outs[0], ref, "stream-K vs fp32", rtol=1e-5, atol_rms=1e-4, l2=1e-5)
+        assert (outs[0] - cl).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    else:
+        _close(outs[0], ref, "stream-K vs fp32")
+        assert (outs[0].float() - cl.float()).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()      # one bf16 ulp at the top
+    assert not torch.equal(outs[0], cl) or dt == torch.bfloat16     # fp32: the split sums differ in the last bits somewhere
+
+
+def test_stream_k_fused_epilogues_at_of4b_shapes(ops):
+    """The fused epilogues behind shared tiles at OF-4B's widths (d = 2560: 320- and 400-tile launches that round 3 ran as an
+    N-split or a partial second round): up-projection + GELU (two outputs), gate + residual on the fp32 stream, dGELU + gate dot,
+    accumulating weight gradient -- stream-K (of_gemm's choice) against fp32 torch."""
+    gate = torch.tensor([0.37], device="cuda")
+    g = float(torch.tanh(gate))
+    rows, d, hid = 8192, 2560, 10240
+    u, W1 = _r((rows, d), 91), _r((hid, d), 92, d ** -0.5)
+    acc = u.float() @ W1.float().t()
+    b, a = torch.empty(rows, hid, device="cuda", dtype=torch.bfloat16), torch.empty(rows, hid, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(u, W1, b, epi=abi.EPI_GELU, out2=a)                                   # 1280 tiles = 5 whole rounds
+    _close(a, acc, "pre-GELU")
+    W2 = _r((d, hid), 93, hid ** -0.5)
+    acc2 = b.float() @ W2.float().t()
+    res = _r((rows, d), 94, dtype=torch.float32)
+    y = torch.empty(rows, d, device="cuda")
+    ops.gemm(b, W2, y, epi=abi.EPI_GATE_RESID, aux=res, gate=gate)                   # 320 tiles: 1 round + 64 shared
+    _close(y, res + g * acc2, "GATE_RESID fp32 (320 tiles)", rtol=1e-5, atol_rms=1e-4, l2=1e-5)
+    dy = _r((rows, d), 95)
+    accd = dy.float() @ W2.float()
+    da, dot = torch.empty(rows, hid, device="cuda", dtype=torch.bfloat16), torch.zeros(1, device="cuda")
+    ops.gemm(dy, W2, da, tb=True, epi=abi.EPI_DGELU_DOT, aux=a, gate=gate, dot=dot)
+    ad = a.double().requires_grad_(True)
+    ge = torch.nn.functional.gelu(ad)
+    ge.sum().backward()
+    _close(da, g * accd.double() * ad.grad, "DGELU")
+    wdot = (1 - g * g) * (ge.detach() * accd.double()).sum().item()
+    ref_scale = (1 - g * g) * (ge.detach() * accd.double()).abs().sum().item()
+    assert abs(float(dot) - wdot) <= 1e-5 * ref_scale
+    c = torch.randn(d, hid, device="cuda")
+    want = c + g * (dy.float().t() @ b.float())
+    ops.gemm(dy, b, c, ta=True, tb=True, epi=abi.EPI_ACC_F32, gate=gate, beta=1.0)   # 400 tiles: 1 round + 144 shared
+    _close(c, want, "dW2 beta=1 (400 tiles)", rtol=1e-5, atol_rms=1e-4, l2=1e-5)
