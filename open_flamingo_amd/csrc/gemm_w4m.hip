@@ -91,10 +91,16 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
     const int tiles_m = p.M / TM, tiles_n = p.N / TN, ntiles = tiles_m * tiles_n;
     const int nd_all = p.K / DK;
     const int G = of_gdim_x(), bid = of_bid_x();
-    const int rounds = p.sk_grid > 0 ? ntiles / G : 1;
-    const long rem_units = p.sk_grid > 0 ? (long)(ntiles - rounds * G) * nd_all : 0;
-    const long r0 = rem_units * bid / G;
-    long ue = rem_units * (bid + 1) / G;          // end of the not yet processed part of [r0, ue)
+    // (32-bit arithmetic: r * nd * G < 2^31 for every K < 2 M; the classic launch skips the divisions altogether -- a 64-bit
+    // division is ~150 instructions, and this code sits in front of every tile)
+    int rounds = 1;
+    unsigned rem_units = 0, r0 = 0, ue = 0;      // [r0, ue): the not yet processed part of this workgroup's remainder units
+    if (p.sk_grid > 0) {
+        rounds = (int)((unsigned)ntiles / (unsigned)G);
+        rem_units = (unsigned)(ntiles - rounds * G) * (unsigned)nd_all;
+        r0 = rem_units * (unsigned)bid / (unsigned)G;
+        ue = rem_units * (unsigned)(bid + 1) / (unsigned)G;
+    }
     int* sk_flags = (int*)((char*)p.workspace + sk_dot_bytes(p));
     float* sk_slabs = (float*)((char*)sk_flags + sk_flags_bytes(G));
 
@@ -121,9 +127,9 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
             nd = nd_all;
         } else {
             if (ue <= r0) break;
-            const int t = (int)((ue - 1) / nd_all);
-            const long ts = (long)t * nd_all, us = ts > r0 ? ts : r0;
-            vt = rounds * G + t;
+            const unsigned t = (ue - 1) / (unsigned)nd_all;
+            const unsigned ts = t * (unsigned)nd_all, us = ts > r0 ? ts : r0;
+            vt = rounds * G + (int)t;
             s0 = (int)(us - ts);
             nd = (int)(ue - us);
             ue = us;
@@ -254,7 +260,7 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
 
         if (!last_k) {
             // ---- partial tile (stream-K): raw accumulators -> this workgroup's slab, fragment-major so that every store is one
-            // contiguous KiB per wave; then the flag.  Every lane's stores are released to the device before the barrier, the
+            // contiguous KiB per wave; then the flag.  Every lane waits for its (system-scope) stores in front of the barrier, the
             // flag goes up behind it.
             // (buffer-descriptor addressing: wave-uniform base + scalar fragment offset + one per-lane offset -- with plain pointers
             // every fragment, 4 KiB from the last, needs a 64-bit address of its own in VGPRs, which this kernel does not have)
@@ -262,27 +268,26 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
 #pragma unroll
             for (int a = 0; a < 8; ++a) {
 #pragma unroll
-                for (int b = 0; b < 8; ++b) of_buf_store16(slab, (unsigned)tid * 16u, (unsigned)(a * 8 + b) * 4096u, __builtin_bit_cast(u32x4, acc[a][b]));
+                for (int b = 0; b < 8; ++b) of_buf_store16_sys(slab, (unsigned)tid * 16u, (unsigned)(a * 8 + b) * 4096u, __builtin_bit_cast(u32x4, acc[a][b]));
                 of_sched_fence();
             }
-            of_fence_release_device();
+            of_wait_vm<0>();       // system-scope stores: acknowledged = visible to every XCD
             of_sync();
             if (tid == 0) of_flag_publish(sk_flags + bid, 1);
             continue;
         }
         // (fewer remainder units than workgroups: some workgroups hold none -- they publish nothing and are skipped)
-        auto sk_has_units = [&](int w) OF_INLINE_LAMBDA { return rem_units * w / G != rem_units * (w + 1) / G; };
+        auto sk_has_units = [&](int w) OF_INLINE_LAMBDA { return rem_units * (unsigned)w / (unsigned)G != rem_units * (unsigned)(w + 1) / (unsigned)G; };
         // ---- owner of a shared tile: the partial tiles of K stages [0, s0) -- workgroups sk_first .. bid - 1, ascending K -- are
         // added group by group on the way through the LDS patch (acc_to_patch below); here: wait until all of them are published
         int sk_first = bid;
         if (s0 > 0) {
-            const long ts = (long)(vt - rounds * G) * nd_all;
-            sk_first = (int)(((ts + 1) * G + rem_units - 1) / rem_units) - 1;      // the workgroup whose range holds unit ts
+            const unsigned ts = (unsigned)(vt - rounds * G) * (unsigned)nd_all;
+            sk_first = (int)(((ts + 1) * (unsigned)G + rem_units - 1) / rem_units) - 1;      // the workgroup whose range holds unit ts
             if (tid == 0)
                 for (int w = sk_first; w < bid; ++w)
                     if (sk_has_units(w)) of_flag_await(sk_flags + w, 1);
             of_sync();
-            of_fence_acquire_device();
         }
         auto acc_to_patch = [&](int g, char* patch) OF_INLINE_LAMBDA {
             const int mt = g >> 1, np = g & 1;
@@ -297,7 +302,7 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        q[i][j] = __builtin_bit_cast(f32x4, of_buf_load16(slab, (unsigned)tid * 16u, (unsigned)((2 * mt + i) * 8 + 4 * np + j) * 4096u));
+                        q[i][j] = __builtin_bit_cast(f32x4, of_buf_load16_sys(slab, (unsigned)tid * 16u, (unsigned)((2 * mt + i) * 8 + 4 * np + j) * 4096u));
                 ofg::patch_add16(patch, q, lane);
             }
         };

@@ -150,6 +150,16 @@ OF_DEV u32x4 of_buf_load16(of_buf_t b, unsigned voff, unsigned soff) {
 OF_DEV void of_buf_store16(of_buf_t b, unsigned voff, unsigned soff, u32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(v, b.r, (int)voff, (int)soff, 0);
 }
+// The same at SYSTEM scope (sc0 sc1: cache-policy bits 0 and 4 on gfx940+): the store writes through this XCD's L2, the load does
+// not take a line this XCD's L2 may hold from before -- data handed from one workgroup to another inside a launch (stream-K partial
+// tiles) crosses XCDs this way without flushing / invalidating a whole L2 (what a device-scope release / acquire fence costs: every
+// other workgroup of the XCD then re-fetches its operand panels).  Completion of the store = s_waitcnt vmcnt(0) of the issuing wave.
+OF_DEV void of_buf_store16_sys(of_buf_t b, unsigned voff, unsigned soff, u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, b.r, (int)voff, (int)soff, 17);
+}
+OF_DEV u32x4 of_buf_load16_sys(of_buf_t b, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)voff, (int)soff, 17));
+}
 // LDS-DMA through a buffer descriptor: 16 bytes per lane straight into LDS at (wave-uniform base + lane*16); completion is
 // tracked only by the issuing wave's vmcnt (+ a barrier for other waves), like of_glds16
 template <bool TRSAFE = true>
@@ -198,11 +208,14 @@ OF_DEV void of_barrier_raw() {
 // wrote to global memory, a consumer on another CU -- possibly another XCD, whose L2 is a different cache -- picks it up.
 // Device (agent) scope: the release makes this XCD's dirty L2 lines visible to the others, the acquire drops stale lines
 // (LLVM AMDGPU memory model for gfx942 / gfx950: buffer_wbl2 sc1 / buffer_inv sc1 around the flag access).
+// The flag itself is a relaxed device-scope atomic; ordering against the data is the caller's: the producer waits for its
+// system-scope stores (of_buf_store16_sys + of_wait_vm<0>, then a workgroup barrier) before it raises the flag, the consumer reads
+// the data with system-scope loads (of_buf_load16_sys) after it has seen the flag.
 OF_DEV void of_flag_publish(int* flag, int value) {
-    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 OF_DEV void of_flag_await(const int* flag, int value) {       // spin with a short sleep: the producer needs the memory pipes
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != value) __builtin_amdgcn_s_sleep(8);
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != value) __builtin_amdgcn_s_sleep(8);
 }
 OF_DEV void of_fence_release_device() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
 OF_DEV void of_fence_acquire_device() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }

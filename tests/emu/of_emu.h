@@ -243,6 +243,8 @@ struct of_buf_t {
 OF_DEV of_buf_t of_buf_make(const void* base) { return of_buf_t{(const char*)base}; }
 OF_DEV u32x4 of_buf_load16(of_buf_t b, unsigned voff, unsigned soff) { return *(const u32x4*)(b.base + voff + soff); }
 OF_DEV void of_buf_store16(of_buf_t b, unsigned voff, unsigned soff, u32x4 v) { *(u32x4*)(const_cast<char*>(b.base) + voff + soff) = v; }
+OF_DEV void of_buf_store16_sys(of_buf_t b, unsigned voff, unsigned soff, u32x4 v) { of_buf_store16(b, voff, soff, v); }
+OF_DEV u32x4 of_buf_load16_sys(of_buf_t b, unsigned voff, unsigned soff) { return of_buf_load16(b, voff, soff); }
 template <bool TRSAFE = true>
 OF_DEV void of_buf_load16_lds(of_buf_t b, unsigned voff, unsigned soff, void* lds_wave_base) {
     *(u32x4*)((char*)lds_wave_base + (of_emu::g_blk->cur & 63) * 16) = *(const u32x4*)(b.base + voff + soff);

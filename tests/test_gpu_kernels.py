@@ -565,3 +565,26 @@ def test_stream_k_fused_epilogues_at_of4b_shapes(ops):
     want = c + g * (dy.float().t() @ b.float())
     ops.gemm(dy, b, c, ta=True, tb=True, epi=abi.EPI_ACC_F32, gate=gate, beta=1.0)   # 400 tiles: 1 round + 144 shared
     _close(c, want, "dW2 beta=1 (400 tiles)", rtol=1e-5, atol_rms=1e-4, l2=1e-5)
+
+
+def test_stream_k_partial_tiles_are_never_stale(ops):
+    """The partial tiles cross XCDs with system-scope stores / loads instead of device-scope fences (of_platform.h).  A load that
+    took a line left in this XCD's L2 by an EARLIER launch would go unnoticed by a test that repeats one problem (the stale bytes
+    would be the right ones): alternate two different problems through the same workspace, eight launches, each checked against
+    the classic launch of its own operands."""
+    M, N, K = 2048, 4096, 8192              # 128 tiles: every tile shared by two workgroups
+    probs = []
+    for seed in (101, 202):
+        A, B = _r((M, K), seed), _r((K, N), seed + 1, K ** -0.5)
+        cl = torch.empty(M, N, device="cuda")
+        ops.gemm(A, B, cl, tb=True, epi=abi.EPI_ACC_F32, safe=16)
+        probs.append((A, B, cl))
+    first = {}
+    for i in range(8):
+        A, B, cl = probs[i % 2]
+        o = torch.empty(M, N, device="cuda")
+        ops.gemm(A, B, o, tb=True, epi=abi.EPI_ACC_F32)
+        assert (o - cl).abs().max().item() <= 1e-4 * cl.abs().max().item(), i
+        if i % 2 in first:
+            assert torch.equal(o, first[i % 2]), i
+        first.setdefault(i % 2, o)
