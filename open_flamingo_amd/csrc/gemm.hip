@@ -306,7 +306,15 @@ static int sk_grid_for(const OfGemmArgs& a, long tiles256) {
     if (G > OF_NUM_CUS) G = OF_NUM_CUS;
     if (G < 8) G = 8;
     if (a.safe == 17) return G;                 // forced (tests): persistent even when G divides the tile count
-    return tiles256 % G ? G : 0;
+    // Sharing a tile costs its workgroups one 256-KiB partial tile written through to memory and read back (~20-30 us per
+    // workgroup): worth it against a K loop of >= 64 stages per tile, not against K = 512 / 1024 (measured: 8192 x 2560 x 512,
+    // 320 tiles, 47 -> 83 us; profiles/r04g_gemm_ab_stream_k_v2_OF-4B.jsonl) -- those keep the N-split / partial last round.
+    if (a.K < 4096) return 0;
+    // More tiles than workgroups and a partial last round (OF-4B's 320- and 400-tile launches): stream-K measured +2..+7 % SLOWER
+    // than the N-split / partial round (the fix-up's exposed load latency eats the balance gain) -- it is used where it wins:
+    // fewer tiles than workgroups (OF-9B's 128-tile launches: 300 -> 216 us, 296 -> 204 us), and under an explicit cu_limit.
+    if (a.cu_limit > 0) return tiles256 % G ? G : 0;
+    return tiles256 < G ? G : 0;
 }
 static bool sk_usable(const OfGemmArgs& a, int G) {
     if (G <= 0 || a.group_kind || !of_gemm_w4m_eligible(a)) return false;

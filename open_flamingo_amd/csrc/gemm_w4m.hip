@@ -79,7 +79,9 @@ OF_HOSTDEV size_t sk_dot_bytes(const OfGemmArgs& a) { return of_gemm_dot_bytes(a
 // wait late and only for workgroups with LOWER ids: no deadlock even when fewer than G workgroups are resident (the hardware
 // dispatches in id order; a workgroup's first segment never waits).  The owner adds the partials in ascending K order, on top
 // of its own: the same bits for the same (shape, G), whatever the timing.
-template <bool AT, bool BT, int EPI>
+// SK = false: the classic launch compiled on its own -- one tile per workgroup, none of the schedule arithmetic, flags or partial
+// tile code (as one kernel the bookkeeping cost every tile of every launch 0.7-1 us of prologue: profiles/r04g_tile_phase_probe.jsonl).
+template <bool AT, bool BT, int EPI, bool SK>
 OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
     constexpr bool ASMD = AT || BT;       // LDS-DMA form (of_platform.h): inline asm wherever a transposed-fragment read follows
     OF_STAMP_DECL();
@@ -95,7 +97,7 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
     // division is ~150 instructions, and this code sits in front of every tile)
     int rounds = 1;
     unsigned rem_units = 0, r0 = 0, ue = 0;      // [r0, ue): the not yet processed part of this workgroup's remainder units
-    if (p.sk_grid > 0) {
+    if constexpr (SK) {
         rounds = (int)((unsigned)ntiles / (unsigned)G);
         rem_units = (unsigned)(ntiles - rounds * G) * (unsigned)nd_all;
         r0 = rem_units * (unsigned)bid / (unsigned)G;
@@ -121,7 +123,12 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
     for (int seg = 0;; ++seg) {
         // ---- this segment: tile `vt` (virtual block id for the XCD-aware tile map), K stages [s0, s0 + nd)
         int vt, s0, nd;
-        if (seg < rounds) {
+        if constexpr (!SK) {
+            if (seg > 0) break;
+            vt = bid;
+            s0 = 0;
+            nd = nd_all;
+        } else if (seg < rounds) {
             vt = bid + seg * G;
             s0 = 0;
             nd = nd_all;
@@ -134,11 +141,11 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
             nd = (int)(ue - us);
             ue = us;
         }
-        const bool last_k = s0 + nd == nd_all;       // this workgroup finishes the tile (epilogue), else it publishes a partial tile
+        const bool last_k = !SK || s0 + nd == nd_all;       // this workgroup finishes the tile (epilogue), else it publishes a partial tile
         int pm, pn;
         ofg::tile_coords(vt, ntiles, tiles_m, tiles_n, pm, pn);
         const int m0 = pm * TM, n0 = pn * TN;
-        if (seg > 0) of_barrier_raw();                // the previous segment's epilogue is done with the ring
+        if (SK && seg > 0) of_barrier_raw();          // the previous segment's epilogue is done with the ring
 
 #pragma unroll
         for (int a = 0; a < 8; ++a)
@@ -258,7 +265,7 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
         of_barrier_raw();          // the ring is idle from here
         OF_STAMP(2);
 
-        if (!last_k) {
+        if (SK && !last_k) {
             // ---- partial tile (stream-K): raw accumulators -> this workgroup's slab, fragment-major so that every store is one
             // contiguous KiB per wave; then the flag.  Every lane waits for its (system-scope) stores in front of the barrier, the
             // flag goes up behind it.
@@ -281,7 +288,7 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
         // ---- owner of a shared tile: the partial tiles of K stages [0, s0) -- workgroups sk_first .. bid - 1, ascending K -- are
         // added group by group on the way through the LDS patch (acc_to_patch below); here: wait until all of them are published
         int sk_first = bid;
-        if (s0 > 0) {
+        if (SK && s0 > 0) {
             const unsigned ts = (unsigned)(vt - rounds * G) * (unsigned)nd_all;
             sk_first = (int)(((ts + 1) * (unsigned)G + rem_units - 1) / rem_units) - 1;      // the workgroup whose range holds unit ts
             if (tid == 0)
@@ -289,21 +296,26 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
                     if (sk_has_units(w)) of_flag_await(sk_flags + w, 1);
             of_sync();
         }
+        // (Prefetching the next group's partial fragments into registers was tried: it pushed hipcc into spilling ACCUMULATORS to
+        // scratch right behind the last MFMA -- in front of of_mfma_acc_settle(), which tests/test_isa_lint.py caught.  The eight
+        // 16-byte loads of a group therefore pay one global-load latency per group and contributor: ~20 us per shared tile.)
         auto acc_to_patch = [&](int g, char* patch) OF_INLINE_LAMBDA {
             const int mt = g >> 1, np = g & 1;
             const f32x4 t[2][4] = {{acc[2 * mt][4 * np], acc[2 * mt][4 * np + 1], acc[2 * mt][4 * np + 2], acc[2 * mt][4 * np + 3]},
                                    {acc[2 * mt + 1][4 * np], acc[2 * mt + 1][4 * np + 1], acc[2 * mt + 1][4 * np + 2], acc[2 * mt + 1][4 * np + 3]}};
             ofg::patch_write16(patch, t, lane);
-            for (int w = sk_first; w < bid; ++w) {          // (no iteration unless this tile is shared)
-                if (!sk_has_units(w)) continue;
-                const of_buf_t slab = of_buf_make(of_uniform_ptr(sk_slabs + (size_t)w * (TM * TN)));
-                f32x4 q[2][4];
+            if constexpr (SK) {
+                for (int w = sk_first; w < bid; ++w) {          // ascending K = ascending workgroup id (no iteration unless the tile is shared)
+                    if (!sk_has_units(w)) continue;
+                    const of_buf_t slab = of_buf_make(of_uniform_ptr(sk_slabs + (size_t)w * (TM * TN)));
+                    f32x4 q[2][4];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        q[i][j] = __builtin_bit_cast(f32x4, of_buf_load16_sys(slab, (unsigned)tid * 16u, (unsigned)((2 * mt + i) * 8 + 4 * np + j) * 4096u));
-                ofg::patch_add16(patch, q, lane);
+                        for (int j = 0; j < 4; ++j)
+                            q[i][j] = __builtin_bit_cast(f32x4, of_buf_load16_sys(slab, (unsigned)tid * 16u, (unsigned)((2 * mt + i) * 8 + 4 * np + j) * 4096u));
+                    ofg::patch_add16(patch, q, lane);
+                }
             }
         };
         // gate-gradient partial of this TILE: slot = its position in the (m-major) tile grid, whichever workgroup finishes it
@@ -325,7 +337,8 @@ int launch_w4m(const OfGemmArgs& a, of_stream_t s) {
         const int rc = of_memset_async((char*)a.workspace + sk_dot_bytes(a), 0, sk_flags_bytes(a.sk_grid), s);
         if (rc) return rc;
     }
-    const int rc = of_launch(of_gemm_w4m_kernel<AT, BT, EPI>, grid, 256, smem_bytes, s, a);
+    const int rc = a.sk_grid > 0 ? of_launch(of_gemm_w4m_kernel<AT, BT, EPI, true>, grid, 256, smem_bytes, s, a)
+                                 : of_launch(of_gemm_w4m_kernel<AT, BT, EPI, false>, grid, 256, smem_bytes, s, a);
     if (rc || !of_gemm_has_dot(a)) return rc;
     return of_gemm_dot_finish(a, ntiles, s);
 }

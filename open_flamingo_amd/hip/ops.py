@@ -109,7 +109,8 @@ class Ops:
         sk = False
         if safe in (0, 17) and M % 256 == 0 and N % 256 == 0 and K % 64 == 0:
             tiles, grid = (M // 256) * (N // 256), ((self.cu_limit & ~7) or 256)
-            sk = safe == 17 or (tiles >= 128 and tiles % min(max(grid, 8), 256) != 0)
+            grid = min(max(grid, 8), 256)
+            sk = safe == 17 or (tiles >= 128 and K >= 4096 and (tiles % grid != 0 if self.cu_limit else tiles < grid))
         if epi == abi.EPI_ACC_F32 or dot is not None or sk:
             need = self.lib.of_gemm_workspace_bytes(C.byref(a))
             if need:

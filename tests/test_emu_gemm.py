@@ -439,25 +439,26 @@ def test_stream_k_epilogues(M, N, K, G):
         assert torch.equal(vals[0], vals[1])
 
 
-def test_stream_k_is_of_gemms_own_choice_when_the_workgroup_count_does_not_divide_the_tiles():
-    """safe = 0: with a workspace of of_gemm_workspace_bytes() a launch whose tile count the workgroup count does not divide goes
-    stream-K -- 144 tiles under cu_limit = 128 (one whole round + 16 tiles shared out over 128 workgroups) -- and equals the classic
-    launch; without the workspace the same call still works (one tile per workgroup).  An explicit cu_limit that divides the tile
-    count changes nothing."""
+def test_stream_k_selection_rules():
+    """safe = 0.  Sharing a tile costs a partial tile written and read back per workgroup: of_gemm goes stream-K only for K >= 4096
+    (64 stages per tile) -- at K = 128, 144 tiles under cu_limit = 128 stay one tile per workgroup (bits of the classic launch),
+    with or without a workspace; the workspace query names the stream-K region exactly when the launch would use it.  (of_gemm's
+    own stream-K choice at real K runs on the GPU: tests/test_gpu_kernels.py::test_stream_k_matches_classic_launch_...)"""
+    import ctypes
     M, N, K = 2304, 4096, 128            # 9 x 16 = 144 tiles
     A, B = _rand((M, K), 77), _rand((N, K), 78)
-    o_cl, o_sk, o_nw = torch.zeros(M, N), torch.zeros(M, N), torch.zeros(M, N)
+    o_cl, o_lim, o_nw = torch.zeros(M, N), torch.zeros(M, N), torch.zeros(M, N)
     H.gemm(A, B, epi=abi.EPI_ACC_F32, C_out=o_cl, safe=16)
-    H.gemm(A, B, epi=abi.EPI_ACC_F32, C_out=o_sk, cu_limit=128)
-    np.testing.assert_allclose(o_sk.numpy(), o_cl.numpy(), rtol=1e-6, atol=5e-5)
-    assert not torch.equal(o_sk, o_cl)          # the 16 shared tiles were summed in two parts
+    H.gemm(A, B, epi=abi.EPI_ACC_F32, C_out=o_lim, cu_limit=128)
+    assert torch.equal(o_lim, o_cl)
     a = abi.OfGemmArgs()
     a.A, a.B, a.M, a.N, a.K, a.lda, a.ldb, a.epi = A.data_ptr(), B.data_ptr(), M, N, K, K, K, abi.EPI_ACC_F32
     a.C, a.ldc, a.alpha, a.cu_limit = o_nw.data_ptr(), N, 1.0, 128
-    import ctypes
+    assert H.lib().of_gemm(ctypes.byref(a), None) == 0 and torch.equal(o_nw, o_cl)
+    assert H.lib().of_gemm_workspace_bytes(ctypes.byref(a)) == 0
+    a.K = a.lda = a.ldb = 8192           # (sizes only: nothing is launched)
     assert H.lib().of_gemm_workspace_bytes(ctypes.byref(a)) >= 128 * 256 * 256 * 4
-    assert H.lib().of_gemm(ctypes.byref(a), None) == 0
-    assert torch.equal(o_nw, o_cl)
-    o_div = torch.zeros(M, N)
-    H.gemm(A, B, epi=abi.EPI_ACC_F32, C_out=o_div, cu_limit=144)
-    assert torch.equal(o_div, o_cl)
+    a.cu_limit = 144                     # divides the tile count: whole rounds, nothing shared
+    assert H.lib().of_gemm_workspace_bytes(ctypes.byref(a)) == 0
+    a.cu_limit = 0                       # 144 tiles / 256 workgroups
+    assert H.lib().of_gemm_workspace_bytes(ctypes.byref(a)) >= 256 * 256 * 256 * 4

@@ -491,17 +491,18 @@ def test_big_tile_gemm_fused_epilogues_at_benchmark_shapes(ops, safe):
 
 # ---- stream-K schedule of the 16x16x32 big-tile kernel (csrc/gemm_w4m.hip): tile counts the workgroup count does not divide --------
 _SK_SHAPES = [  # (M, N, K, ta, tb, epi, cu_limit)   tiles / workgroups
-    (10240, 2560, 8192, True, True, abi.EPI_ACC_F32, 0),      # OF-4B ffn dW: 400 tiles / 256 -> 1.5625 tiles per workgroup
     (2048, 4096, 16384, False, True, abi.EPI_STORE_BF16, 0),  # OF-9B L = 256 dX: 128 tiles / 256 -> half a tile per workgroup
+    (4096, 2048, 16384, True, True, abi.EPI_ACC_F32, 0),      # the same tile count as a weight gradient (fp32 out)
+    (10240, 2560, 8192, True, True, abi.EPI_ACC_F32, 248),    # OF-4B ffn dW, 400 tiles / 248 workgroups: 1 round + 152 shared tiles
     (8192, 2048, 8192, False, False, abi.EPI_STORE_BF16, 192),   # 256 tiles next to a collective holding 64 CUs: 1 1/3 tiles each
-    (8192, 8192, 2048, False, True, abi.EPI_STORE_BF16, 224),    # 1024 tiles / 224 workgroups: 4 rounds + 128 shared tiles
-    (8192, 2560, 2560, False, False, abi.EPI_STORE_BF16, 0),  # OF-4B to-2560 projection shape class: 320 tiles
+    (8192, 8192, 4096, False, True, abi.EPI_STORE_BF16, 224),    # 1024 tiles / 224 workgroups: 4 rounds + 128 shared tiles
 ]
 
 
 @pytest.mark.parametrize("M,N,K,ta,tb,epi,cu", _SK_SHAPES)
 def test_stream_k_matches_classic_launch_and_is_bit_reproducible(ops, M, N, K, ta, tb, epi, cu):
-    """of_gemm's own selection (safe = 0) with the stream-K workspace vs the classic one-tile-per-workgroup launch (safe = 16) of the
+    """of_gemm's own selection (safe = 0: stream-K for fewer tiles than workgroups, or for a tile count an explicit cu_limit does not
+    divide; K >= 4096) with the stream-K workspace vs the classic one-tile-per-workgroup launch (safe = 16) of the
     same kernel and vs fp32 torch: same products, fp32 accumulation, a shared tile's sum split at workgroup boundaries.  Five
     launches of the stream-K form give ONE bit pattern (fixed-order fix-up through the workspace; this is also the race screen of
     the flag / partial-tile hand-off between workgroups on different XCDs)."""
@@ -533,22 +534,30 @@ def test_stream_k_matches_classic_launch_and_is_bit_reproducible(ops, M, N, K, t
 
 
 def test_stream_k_fused_epilogues_at_of4b_shapes(ops):
-    """The fused epilogues behind shared tiles at OF-4B's widths (d = 2560: 320- and 400-tile launches that round 3 ran as an
-    N-split or a partial second round): up-projection + GELU (two outputs), gate + residual on the fp32 stream, dGELU + gate dot,
-    accumulating weight gradient -- stream-K (of_gemm's choice) against fp32 torch."""
+    """The fused epilogues behind shared tiles at OF-4B's widths (d = 2560) under cu_limit = 192 (a collective holding 64 CUs):
+    1280 tiles = 6 rounds + 128 shared, 320 = 1 round + 128, 400 = 2 rounds + 16 -- up-projection + GELU (two outputs), gate +
+    residual on the fp32 stream, dGELU + gate dot, accumulating weight gradient, against fp32 torch."""
+    old_limit, ops.cu_limit = ops.cu_limit, 192
+    try:
+        _sk_epilogues_of4b(ops)
+    finally:
+        ops.cu_limit = old_limit
+
+
+def _sk_epilogues_of4b(ops):
     gate = torch.tensor([0.37], device="cuda")
     g = float(torch.tanh(gate))
     rows, d, hid = 8192, 2560, 10240
     u, W1 = _r((rows, d), 91), _r((hid, d), 92, d ** -0.5)
     acc = u.float() @ W1.float().t()
     b, a = torch.empty(rows, hid, device="cuda", dtype=torch.bfloat16), torch.empty(rows, hid, device="cuda", dtype=torch.bfloat16)
-    ops.gemm(u, W1, b, epi=abi.EPI_GELU, out2=a)                                   # 1280 tiles = 5 whole rounds
+    ops.gemm(u, W1, b, epi=abi.EPI_GELU, out2=a)                                   # K = 2560 < 4096: one tile per workgroup
     _close(a, acc, "pre-GELU")
     W2 = _r((d, hid), 93, hid ** -0.5)
     acc2 = b.float() @ W2.float().t()
     res = _r((rows, d), 94, dtype=torch.float32)
     y = torch.empty(rows, d, device="cuda")
-    ops.gemm(b, W2, y, epi=abi.EPI_GATE_RESID, aux=res, gate=gate)                   # 320 tiles: 1 round + 64 shared
+    ops.gemm(b, W2, y, epi=abi.EPI_GATE_RESID, aux=res, gate=gate)                   # 320 tiles / 192: 1 round + 128 shared
     _close(y, res + g * acc2, "GATE_RESID fp32 (320 tiles)", rtol=1e-5, atol_rms=1e-4, l2=1e-5)
     dy = _r((rows, d), 95)
     accd = dy.float() @ W2.float()
@@ -563,7 +572,7 @@ def test_stream_k_fused_epilogues_at_of4b_shapes(ops):
     assert abs(float(dot) - wdot) <= 1e-5 * ref_scale
     c = torch.randn(d, hid, device="cuda")
     want = c + g * (dy.float().t() @ b.float())
-    ops.gemm(dy, b, c, ta=True, tb=True, epi=abi.EPI_ACC_F32, gate=gate, beta=1.0)   # 400 tiles: 1 round + 144 shared
+    ops.gemm(dy, b, c, ta=True, tb=True, epi=abi.EPI_ACC_F32, gate=gate, beta=1.0)   # 400 tiles / 192: 2 rounds + 16 shared
     _close(c, want, "dW2 beta=1 (400 tiles)", rtol=1e-5, atol_rms=1e-4, l2=1e-5)
 
 
