@@ -1,7 +1,7 @@
 // Epilogue of the 4-wave 256x256 kernel (gemm_w4.hip; kept apart from its K loop: a second K loop on a ring of four half
 // stages shared it -- built, parity-green, 2-8 % slower, removed after commit dd27936): a wave owns 128 x 128 = 4 x 4 accumulators of 32 x 32 and sends them as eight 32 x 64 groups through a private LDS patch.
 // `ring_bytes` = size of the (now idle) operand ring at the start of dynamic LDS; the *_DOT epilogues keep one 4-KiB aux
-// buffer per wave behind it (requested before the K loop) and five inside it (>= 4 * PATCH_BYTES + 256 + 20 * 4 KiB = 116992 B).  ASMDMA: LDS-DMA form of the kernel (of_platform.h).
+// buffer per wave behind it (requested before the K loop) and one inside it.  ASMDMA: LDS-DMA form of the kernel (of_platform.h).
 #pragma once
 #include "gemm_tile256.h"
 
@@ -60,35 +60,26 @@ OF_DEV void w4_epilogue_with(const OfGemmArgs& p, ToPatch to_patch, char* smem, 
         else w4_epilogue_resid_dma<ASMDMA, false>(p, to_patch, smem, ring_bytes, m0, n0, wm, wn, wave, lane, gv, sc, patch);
         return;
     }
+    // (Round 4 tried the aux tiles SIX groups deep -- five more 4-KiB slots per wave inside the idle ring -- on the reading that every
+    // group waited out a global-load latency: no gain, DGELU_DOT +1..+6 % (profiles/r04b_*, r04h_*).  tools/probes/tile_phase_probe.py
+    // then showed what the 18 us of a DGELU_DOT epilogue are: ~9 us of VALU issue (erf-GELU and its derivative: two quarter-rate
+    // transcendentals + ~30 full-rate operations per element on ONE wave per SIMD) and ~5 us of dependent LDS round trips in
+    // the rolled row loop, on top of the 3.6 us of a plain store -- not memory latency.)
     if constexpr (AUXL) {
-        // *_DOT epilogues: the saved activation of a group (32 rows x 128 B = 4 KiB per wave) travels global -> LDS by DMA, SIX groups
-        // deep.  Round 3 kept one group in flight (two 4-KiB buffers per wave): every group then waited out a full global-load
-        // latency (~1.4 us under load) for ~0.5 us of work -- 11 of the 23 us a DGELU_DOT tile spent outside its K loop
-        // (profiles/r03_gemm_epilogue_ladder.jsonl).  The idle ring has room: slot 0 = behind the ring (group 0, requested before
-        // the K loop), slots 1..5 = behind the four patches inside the ring (groups 1..5, requested right here); groups 6 / 7 reuse
-        // slots 0 / 1 as soon as groups 0 / 1 have been read.  vmcnt is counted by hand (loads and stores retire in order on
-        // gfx950; a group issues 4 DMA pieces and 4 stores): the constant in front of group g = vector-memory operations issued
-        // after group g's pieces.
-        auto aux_slot = [&](int g) OF_INLINE_LAMBDA -> char* {
-            const int sl = g < 6 ? g : g - 6;
-            return sl == 0 ? smem + ring_bytes + wave * ofg::AUX_LDS_BYTES
-                           : smem + 4 * ofg::PATCH_BYTES + 256 + ((sl - 1) * 4 + wave) * ofg::AUX_LDS_BYTES;
-        };
-        auto aux_request = [&](int g) OF_INLINE_LAMBDA {
-            ofg::epilogue_group_aux_dma<ASMDMA>(p, m0 + wm * 128 + (g >> 1) * 32, n0 + wn * 128 + (g & 1) * 64, lane, aux_slot(g));
-        };
+        // *_DOT epilogues: aux tiles by DMA, alternating between two 4-KiB buffers per wave -- E behind the ring (group 0 was
+        // requested before the K loop) and R inside the idle ring; vmcnt counted by hand (a group issues 4 stores): gemm_pp.hip
+        char* bufE = smem + ring_bytes + wave * ofg::AUX_LDS_BYTES;
+        char* bufR = smem + 4 * ofg::PATCH_BYTES + 256 + wave * ofg::AUX_LDS_BYTES;
         of_wait_vm<0>();
-#pragma unroll
-        for (int g = 1; g < 6; ++g) aux_request(g);
+        ofg::epilogue_group_aux_dma<ASMDMA>(p, m0 + wm * 128, n0 + wn * 128 + 64, lane, bufR);
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             const int mt = g >> 1, np = g & 1;
-            if (g == 1 || g == 6) of_wait_vm<24>();
-            if (g >= 2 && g <= 5) of_wait_vm<28>();
-            if (g == 7) of_wait_vm<20>();
+            if (g >= 1 && g < 7) ofg::epilogue_group_aux_dma<ASMDMA>(p, m0 + wm * 128 + ((g + 1) >> 1) * 32, n0 + wn * 128 + ((g + 1) & 1) * 64, lane, (g & 1) ? bufE : bufR);
+            if (g >= 1 && g < 7) of_wait_vm<8>();
+            if (g == 7) of_wait_vm<4>();
             to_patch(g, patch);
-            ofg::epilogue_group_rows_auxlds<EPI>(p, patch, aux_slot(g), m0 + wm * 128 + mt * 32, n0 + wn * 128 + np * 64, lane, gv, sc, dot);
-            if (g < 2) aux_request(g + 6);      // slot g is free: every read of it is behind the row passes' stores
+            ofg::epilogue_group_rows_auxlds<EPI>(p, patch, (g & 1) ? bufR : bufE, m0 + wm * 128 + mt * 32, n0 + wn * 128 + np * 64, lane, gv, sc, dot);
         }
     } else {
         ofg::AuxPre pre[2][4];
