@@ -132,7 +132,11 @@ OF_DEV void epilogue_row8(const OfGemmArgs& p, const float (&a)[8], int m, int n
     } else if (EPI == OF_EPI_GELU) {
         if (p.C2) *(u32x4*)((bf16_t*)p.C2 + off) = pack8(a);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = of_gelu(a[e]);
+        for (int e = 0; e < 8; e += 2) {          // packed fp32 math, two elements per instruction (of_platform.h)
+            const f32x2 g = of_gelu2(f32x2{a[e], a[e + 1]});
+            o[e] = g[0];
+            o[e + 1] = g[1];
+        }
         *(u32x4*)((bf16_t*)p.C + off) = pack8(o);
     } else if (EPI == OF_EPI_GATE_RESID) {
         const size_t aoff = (size_t)m * p.ldaux + n;
@@ -151,14 +155,22 @@ OF_DEV void epilogue_row8(const OfGemmArgs& p, const float (&a)[8], int m, int n
     } else if (EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) {
         float x[8];
         unpack8(pre ? pre->lo : *(const u32x4*)((const bf16_t*)p.aux + (size_t)m * p.ldaux + n), x);
+        if (EPI == OF_EPI_DGELU_DOT) {
+            f32x2 d2 = {0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            if (EPI == OF_EPI_DGELU_DOT) {
-                float ge, dg;
-                of_gelu_both(x[e], ge, dg);
-                dot += ge * a[e];
-                o[e] = sc * a[e] * dg;
-            } else {
+            for (int e = 0; e < 8; e += 2) {      // packed fp32 math, two elements per instruction (of_platform.h)
+                f32x2 ge, dg;
+                of_gelu_both2(f32x2{x[e], x[e + 1]}, ge, dg);
+                const f32x2 av = {a[e], a[e + 1]};
+                d2 = of_fma2(ge, av, d2);
+                const f32x2 ov = av * dg * sc;
+                o[e] = ov[0];
+                o[e + 1] = ov[1];
+            }
+            dot += d2[0] + d2[1];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
                 dot += x[e] * a[e];
                 o[e] = sc * a[e];
             }

@@ -360,3 +360,46 @@ OF_DEV void of_gelu_both(float a, float& gelu, float& dgelu) {
     gelu = a * cdf;
     dgelu = cdf + a * 0.39894228040143268f * e;
 }
+// ---- the same for TWO elements per lane in packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32: two results per instruction at the
+// full issue rate) -- the big-tile GEMM epilogues.  Round 4's tile phase probe showed the erf-GELU epilogues to be bound by VALU
+// issue of the one wave a SIMD holds (~90 cycles per element through the scalar forms above, 9 of the 12.6 us a GELU
+// tile spends behind its K loop), and the quarter-rate transcendentals to be a third of that.
+//   forward (Phi only): Abramowitz-Stegun 7.1.28, erf(x) = 1 - (1 + a1 x + .. + a6 x^6)^-16, |error| <= 3e-7: ONE transcendental
+//     (v_rcp_f32) instead of two, 7 packed fma + 4 packed squarings per pair;
+//   backward (Phi and phi): 7.1.26 as above with 0.5 folded into the polynomial and exp(-a^2/2) as a bare v_exp_f32 of a
+//     pre-scaled square.
+// |gelu - exact| <= 9e-7, |gelu' - exact| <= 6e-7 over [-10, 10] in fp32 (tests/test_emu_gemm.py::test_fast_erf_gelu_accuracy).
+OF_DEV f32x2 of_fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+OF_DEV f32x2 of_splat2(float v) { return f32x2{v, v}; }
+OF_DEV f32x2 of_gelu2(f32x2 a) {
+    const f32x2 x = __builtin_elementwise_abs(a) * 0.70710678118654752f;
+    f32x2 p = of_fma2(x, of_splat2(0.0000430638f), of_splat2(0.0002765672f));
+    p = of_fma2(x, p, of_splat2(0.0001520143f));
+    p = of_fma2(x, p, of_splat2(0.0092705272f));
+    p = of_fma2(x, p, of_splat2(0.0422820123f));
+    p = of_fma2(x, p, of_splat2(0.0705230784f));
+    p = of_fma2(x, p, of_splat2(1.0f));
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    const f32x2 r = {of_rcp(p[0]), of_rcp(p[1])};
+    const f32x2 h = of_fma2(r, of_splat2(-0.5f), of_splat2(0.5f));      // 0.5 erf(|a| / sqrt 2)
+    return a * (of_splat2(0.5f) + __builtin_elementwise_copysign(h, a));
+}
+OF_DEV void of_gelu_both2(f32x2 a, f32x2& gelu, f32x2& dgelu) {
+    const f32x2 s = a * 0.84932180028801904f;            // a sqrt(log2(e) / 2): exp2(-s^2) = exp(-a^2 / 2)
+    const f32x2 m = s * s;
+    const f32x2 e = {of_exp2(-m[0]), of_exp2(-m[1])};
+    const f32x2 u = of_fma2(__builtin_elementwise_abs(a), of_splat2(0.23164189f), of_splat2(1.0f));     // 1 + 0.3275911 |a| / sqrt 2
+    const f32x2 t = {of_rcp(u[0]), of_rcp(u[1])};
+    f32x2 q = of_fma2(t, of_splat2(0.5f * 1.061405429f), of_splat2(0.5f * -1.453152027f));
+    q = of_fma2(t, q, of_splat2(0.5f * 1.421413741f));
+    q = of_fma2(t, q, of_splat2(0.5f * -0.284496736f));
+    q = of_fma2(t, q, of_splat2(0.5f * 0.254829592f));
+    q = q * t;
+    const f32x2 h = of_fma2(-q, e, of_splat2(0.5f));      // 0.5 erf(|a| / sqrt 2)
+    const f32x2 cdf = of_splat2(0.5f) + __builtin_elementwise_copysign(h, a);
+    gelu = a * cdf;
+    dgelu = of_fma2(a * 0.39894228040143268f, e, cdf);
+}

@@ -263,19 +263,36 @@ def test_gemm_pingpong_epilogues(big):
 
 
 def test_fast_erf_gelu_accuracy():
-    """The epilogue's Abramowitz-Stegun erf: |gelu - exact| and |gelu' - exact| stay below bf16 resolution."""
+    """The epilogues' erf-GELU: |gelu - exact| and |gelu' - exact| stay below bf16 resolution -- the scalar form of the general kernel
+    (K = 32: Abramowitz-Stegun 7.1.26) and the packed-math forms of the tiled kernels (K = 64 -> the 128x128 LDS-DMA kernel: 7.1.28
+    forward, 7.1.26 with a folded polynomial backward; of_platform.h)."""
     x = torch.linspace(-8, 8, 4001).to(torch.bfloat16)
     M = 4096
-    A = torch.zeros(M, 32, dtype=torch.bfloat16)
-    A[:4001, 0] = x
-    B = torch.zeros(256, 32, dtype=torch.bfloat16)
-    B[:, 0] = 1
-    out = torch.zeros(M, 256, dtype=torch.bfloat16)
-    H.gemm(A, B, epi=abi.EPI_GELU, C_out=out)
     want = torch.nn.functional.gelu(x.double())
-    got = out[:4001, 0].double()
-    # one bf16 rounding of the result (2^-8 relative) + the 1.5e-7 absolute error of the erf polynomial (x |a|)
-    assert ((got - want).abs() <= 2.0 ** -8 * want.abs() + 2e-6).all()
+    for K in (32, 64):
+        A = torch.zeros(M, K, dtype=torch.bfloat16)
+        A[:4001, 0] = x
+        B = torch.zeros(256, K, dtype=torch.bfloat16)
+        B[:, 0] = 1
+        out = torch.zeros(M, 256, dtype=torch.bfloat16)
+        H.gemm(A, B, epi=abi.EPI_GELU, C_out=out)
+        got = out[:4001, 0].double()
+        # one bf16 rounding of the result (2^-8 relative) + the <= 1e-6 absolute error of the erf approximations (x |a|)
+        assert ((got - want).abs() <= 2.0 ** -8 * want.abs() + 2e-6).all(), K
+    # the derivative through the DGELU_DOT epilogue: acc = 1 everywhere, aux = x  ->  out = gelu'(x)
+    A1 = torch.zeros(M, 64, dtype=torch.bfloat16)
+    A1[:, 0] = 1
+    W = torch.zeros(64, 256, dtype=torch.bfloat16)
+    W[0, :] = 1
+    aux = torch.zeros(M, 256, dtype=torch.bfloat16)
+    aux[:4001, :] = x[:, None]
+    out, dot = torch.zeros(M, 256, dtype=torch.bfloat16), torch.zeros(1)
+    H.gemm(A1, W, b_trans=1, epi=abi.EPI_DGELU_DOT, C_out=out, aux=aux, dot_out=dot)
+    xd = x.double().requires_grad_(True)
+    torch.nn.functional.gelu(xd).sum().backward()
+    got = out[:4001, 7].double()
+    assert ((got - xd.grad).abs() <= 2.0 ** -8 * xd.grad.abs() + 2e-6).all()
+    # (the gate-gradient dot of these values is checked by test_gemm_dot_epilogues & co.: without a gate its factor 1 - tanh^2 is 0)
 
 
 _SKINNY = [(M, 4, 8) for M in (1, 16)] + [(M, 36, 520) for M in (1, 2, 3, 5, 8, 13, 16)] + \
