@@ -288,7 +288,9 @@ def test_grouped_media_projections_match_per_block_projections(on_emulator, monk
     assert abs(l0 - l1) <= 2e-5 * abs(l0), (l0, l1)      # other GEMM kernel (fp32 summation order) before the bf16 rounding of k|v
     assert g0.keys() == g1.keys()
     for k in g0:
-        assert _rel(g1[k], g0[k]) < 2e-2, (k, _rel(g1[k], g0[k]))     # Perceiver grads: dmedia summed in fp32 once vs 4 bf16->fp32 partial sums
+        # Perceiver grads: dmedia summed in fp32 once vs 4 bf16->fp32 partial sums.  The (1,)-shaped gate gradients of this
+        # random-upstream loss are nearly cancelling sums (|value| ~ 3e-3 of their term mass): 5e-2 for those
+        assert _rel(g1[k], g0[k]) < (5e-2 if k.endswith("_gate") else 2e-2), (k, _rel(g1[k], g0[k]))
 
 
 def test_bf16_twins_travel_between_backwards_and_change_nothing(on_emulator, monkeypatch):
