@@ -385,7 +385,8 @@ def main():
         fl, ms, n = groups[key]
         sym = {"w4m256": "of_gemm_w4m_kernel", "w4dma256": "of_gemm_w4_kernel", "pingpong256": "of_gemm_pp_kernel", "mid128": "of_gemm_mid_kernel",
                "general128": "of_gemm_kernel", "skinny": "of_gemm_skinny_kernel"}[key[3]]
-        sym += f"<{str(bool(key[0])).lower()}, {str(bool(key[1])).lower()}, {key[2]}" + (">" if key[3] in ("w4m256", "mid128") else ", ...>")
+        sym += f"<{str(bool(key[0])).lower()}, {str(bool(key[1])).lower()}, {key[2]}" + (
+            ", false>" if key[3] == "w4m256" else ">" if key[3] == "mid128" else ", ...>")       # w4m256: <AT, BT, EPI, SK = false> (one tile per workgroup)
         shapes = {}
         for k2, _, shape, _, _ in timing:
             if k2 == key:

@@ -785,7 +785,8 @@ def _rccl_rank(rank, world, port, q, same_device=False):
     red.time_waits = True
     opt = step.build_optimizer(model, lr=1e-3, reducer=red)
     batch = synthetic.make_batch(2, 2, 24, info, dev, seed=5 + rank)
-    losses = [float(step.train_step(model, red, opt, batch, info)) for _ in range(3)]
+    # (next_vision_x: the vision-tower prefetch on its side stream next to the collectives, as bench.py runs the step)
+    losses = [float(step.train_step(model, red, opt, batch, info, next_vision_x=batch["vision_x"])) for _ in range(3)]
     stats = red.overlap_stats()
     chk = torch.cat([p.detach().flatten()[:256].float() for p in model.parameters() if p.requires_grad]).double()
     gathered = [torch.zeros_like(chk) for _ in range(world)]
