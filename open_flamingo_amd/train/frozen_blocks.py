@@ -36,6 +36,8 @@ _DX_PRETRANSPOSED = True
 # (constants, set from measurements: DESIGN.md 4.9; tools/ab_frozen_mlp.py flips them for the same-box A/B)
 _MLP_FUSED_UP = False      # up_proj + erf-GELU (OF_EPI_GELU; the pre-activation is kept for the backward)
 _MLP_FUSED_DOWN = False    # down_proj + residual add into the fp32 stream (OF_EPI_GATE_RESID without a gate)
+_MLP_FUSED_DGELU = False   # backward: (dY Wdown) * gelu'(h) as ONE NN launch (OF_EPI_DGELU_DOT without a gate / dot) instead of
+                           # vendor GEMM + of_gelu_bwd pass -- round 4, after the packed-math dGELU epilogue
 
 
 def _ops():
@@ -131,9 +133,14 @@ class _FrozenMptBlockFn(torch.autograd.Function):
         dy2 = dy.reshape(rows, d)
         if dy2.dtype != F32 or not dy2.is_contiguous():
             dy2 = dy2.to(F32).contiguous()
-        dact = _mm_dx(_path.bf16_of(ops, dy2, ctx.scope), Wdown, td)            # (rows, 4d); the bf16 copy the backward above left, or a cast
-        dh = ops.gelu_bwd(dact, h, out=dact)                         # in place: dact * gelu'(h)
-        del dact
+        if _MLP_FUSED_DGELU:
+            from ..hip import abi
+            dh = torch.empty(rows, Wdown.shape[1], dtype=BF16, device=dev)
+            ops.gemm(_path.bf16_of(ops, dy2, ctx.scope), Wdown, dh, tb=True, epi=abi.EPI_DGELU_DOT, aux=h)     # (dY Wdown) * gelu'(h)
+        else:
+            dact = _mm_dx(_path.bf16_of(ops, dy2, ctx.scope), Wdown, td)        # (rows, 4d); the bf16 copy the backward above left, or a cast
+            dh = ops.gelu_bwd(dact, h, out=dact)                     # in place: dact * gelu'(h)
+            del dact
         dm = _mm_dx(dh, Wup, tu)                                     # (rows, d)
         del dh
         dx1 = torch.empty(rows, d, dtype=F32, device=dev)

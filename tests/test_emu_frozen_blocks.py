@@ -71,11 +71,12 @@ def test_layernorm_bwd_without_parameter_gradients_matches_with(on_emulator):
 
 @pytest.mark.parametrize("d,heads,mlp_fused", [(128, 2, False), (256, 2, False), (256, 2, True)])      # head dim 64 and 128
 def test_fused_frozen_mpt_block_matches_hf_eager(on_emulator, d, heads, mlp_fused, monkeypatch):
-    """mlp_fused: the block's two MLP GEMMs as of_gemm launches with fused GELU / residual epilogues (frozen_blocks._MLP_FUSED_*:
+    """mlp_fused: the block's MLP GEMMs (up, down, and the backward's dGELU) as of_gemm launches with fused epilogues (frozen_blocks._MLP_FUSED_*:
     off in the product on measurement, DESIGN.md 4.9 -- the route must stay correct for the next A/B)."""
     from transformers import MptConfig, MptForCausalLM
     monkeypatch.setattr(frozen_blocks, "_MLP_FUSED_UP", mlp_fused)
     monkeypatch.setattr(frozen_blocks, "_MLP_FUSED_DOWN", mlp_fused)
+    monkeypatch.setattr(frozen_blocks, "_MLP_FUSED_DGELU", mlp_fused)
     torch.manual_seed(0)
     lm = MptForCausalLM(MptConfig(d_model=d, n_heads=heads, n_layers=2, vocab_size=128, max_seq_len=64))
     lm.requires_grad_(False)

@@ -351,7 +351,7 @@ def test_block_module_against_reference_goldens_at_dim_head_64(on_emulator, case
 def test_vision_prefetch_changes_no_bit_and_runs_the_tower_once_per_forward(on_emulator, monkeypatch):
     """train_step(next_vision_x=...): the next step's frozen vision-tower forward is enqueued between this
     step's backward and its step epilogue (Flamingo.prefetch_vision; on the GPU: a side stream).  Same arithmetic -> the losses of
-    three steps on alternating batches are bit-identical with and without it; the tower runs exactly once per forward either way;
+    two steps on alternating batches (the second consumes prefetched tokens) are bit-identical with and without it; the tower runs exactly once per forward either way;
     a forward with ANOTHER tensor (or a changed one) ignores the prefetched tokens."""
     def run(prefetch):
         model, info = _tiny()
@@ -363,7 +363,7 @@ def test_vision_prefetch_changes_no_bit_and_runs_the_tower_once_per_forward(on_e
         orig = vis.forward
         monkeypatch.setattr(vis, "forward", lambda x: (calls.append(tuple(x.shape)), orig(x))[1])
         losses = []
-        for i in range(3):
+        for i in range(2):
             nxt = batches[(i + 1) % 2]["vision_x"] if prefetch else None
             losses.append(float(step.train_step(model, red, opt, batches[i % 2], info, amp=False, next_vision_x=nxt)))
         return losses, len(calls), model, info, batches
@@ -371,7 +371,7 @@ def test_vision_prefetch_changes_no_bit_and_runs_the_tower_once_per_forward(on_e
     l1, n1, model, info, batches = run(True)
     l0, n0, *_ = run(False)
     assert l1 == l0, (l1, l0)
-    assert n0 == 3 and n1 == 4            # three forwards; with prefetch one more tower run is waiting for a fourth step
+    assert n0 == 2 and n1 == 3            # two forwards; with prefetch one more tower run is waiting for a third step
     assert "_of_vision_prefetch" in model.__dict__
     # the waiting tokens belong to batches[1]'s tensor: a forward on another tensor must not take them ...
     other = batches[0]["vision_x"].clone()
