@@ -36,8 +36,9 @@ _DX_PRETRANSPOSED = True
 # (constants, set from measurements: DESIGN.md 4.9; tools/ab_frozen_mlp.py flips them for the same-box A/B)
 _MLP_FUSED_UP = False      # up_proj + erf-GELU (OF_EPI_GELU; the pre-activation is kept for the backward)
 _MLP_FUSED_DOWN = False    # down_proj + residual add into the fp32 stream (OF_EPI_GATE_RESID without a gate)
-_MLP_FUSED_DGELU = False   # backward: (dY Wdown) * gelu'(h) as ONE NN launch (OF_EPI_DGELU_DOT without a gate / dot) instead of
-                           # vendor GEMM + of_gelu_bwd pass -- round 4, after the packed-math dGELU epilogue
+_MLP_FUSED_DGELU = True    # backward: (dY Wdown) * gelu'(h) as ONE NN launch (OF_EPI_DGELU_DOT without a gate / dot) instead of
+                           # vendor GEMM + of_gelu_bwd pass -- round 4, after the packed-math dGELU epilogue: same box 109.75 / 110.02
+                           # -> 109.61 / 109.72 ms per step; up fused +0.7, down fused +0.1, all three +1.2 (profiles/r04k_ab_frozen_mlp.txt)
 
 
 def _ops():
