@@ -36,9 +36,11 @@ _DX_PRETRANSPOSED = True
 # (constants, set from measurements: DESIGN.md 4.9; tools/ab_frozen_mlp.py flips them for the same-box A/B)
 _MLP_FUSED_UP = False      # up_proj + erf-GELU (OF_EPI_GELU; the pre-activation is kept for the backward)
 _MLP_FUSED_DOWN = False    # down_proj + residual add into the fp32 stream (OF_EPI_GATE_RESID without a gate)
-_MLP_FUSED_DGELU = True    # backward: (dY Wdown) * gelu'(h) as ONE NN launch (OF_EPI_DGELU_DOT without a gate / dot) instead of
-                           # vendor GEMM + of_gelu_bwd pass -- round 4, after the packed-math dGELU epilogue: same box 109.75 / 110.02
-                           # -> 109.61 / 109.72 ms per step; up fused +0.7, down fused +0.1, all three +1.2 (profiles/r04k_ab_frozen_mlp.txt)
+_MLP_FUSED_DGELU = False   # backward: (dY Wdown) * gelu'(h) as ONE NN launch (OF_EPI_DGELU_DOT without a gate / dot) instead of
+                           # vendor GEMM + of_gelu_bwd pass -- round 4, after the packed-math dGELU epilogue: step-level a wash
+                           # (same box: 109.75 / 110.02 -> 109.61 / 109.72 ms on one box, 111.16 / 111.22 -> 111.21 / 111.23 on
+                           # another; up fused +0.7..1.0, down fused +0.1..0.6, all three +1.1..1.2: profiles/r04k_ab_frozen_mlp.txt,
+                           # r04_final_ab_frozen_mlp.txt) -- the vendor route stays
 
 
 def _ops():
