@@ -267,6 +267,10 @@ def main():
     ap.add_argument("--reserve-cus", type=int, default=0,
                     help="multi-GPU: CUs to leave to RCCL's kernels while gradient collectives are in flight -- the libofhip GEMMs of the "
                          "backward are then laid out stream-K for 256 - R workgroups (GradReducer.reserve_cus; default 0 = off)")
+    ap.add_argument("--optimizer-cus", type=int, default=0,
+                    help="run the step epilogue's streaming passes (global norm, AdamW) as narrow launches on this many CUs (fat "
+                         "workgroups, one per CU; identical results) so that the prefetched vision-tower forward on the side stream "
+                         "finds whole CUs free; 0 = launches that cover the chip")
     ap.add_argument("--no-vision-prefetch", action="store_true",
                     help="run the frozen vision tower at the start of each step (as the reference does) instead of enqueuing the NEXT "
                          "step's tower forward on a side stream next to the step epilogue (train/step.py: next_vision_x)")
@@ -309,6 +313,8 @@ def main():
                           embedding_rows=[info["media_token_id"], info["eoc_token_id"]], reserve_cus=args.reserve_cus)
     reducer.broadcast_parameters()
     opt = step.build_optimizer(model, reducer=None if args.torch_optimizer else reducer)
+    if args.optimizer_cus and not args.torch_optimizer:
+        opt.narrow_cus = args.optimizer_cus
     batch = synthetic.make_batch(args.batch, args.T, args.L, info, device, seed=1 + rank)
     laion = synthetic.make_batch(args.laion_batch, 1, 32, info, device, seed=101 + rank) if args.laion_batch > 0 else None
     step_kw = dict(batch_laion=laion, loss_multiplier_laion=0.2) if laion is not None else {}
@@ -435,6 +441,7 @@ def main():
                           "vendor_gemm_table": f"TunableOp table, {n_tuned} shapes, tuning off" if n_tuned else "library defaults",
                           "grad_wire_dtype": "bf16" if args.wire_bf16 else "fp32", "reserve_cus": args.reserve_cus,
                           "embedding_row_gradient": "sparse taps" if args.sparse_embedding_rows else "dense, masked",
+                          "step_epilogue_launch": (f"narrow: {args.optimizer_cus} fat workgroups" if args.optimizer_cus else "covers the chip"),
                           "vision_tower_schedule": ("at the start of the step" if args.no_vision_prefetch else
                                                     "next step's tower forward on a side stream next to the step epilogue"),
                           "laion_pass": (f"B={args.laion_batch} T=1 L=32, loss x0.2, same optimizer step" if args.laion_batch else "off")},

@@ -274,6 +274,14 @@ int of_adamw_clip(float* p, float* g, float* m, float* v, uint16_t* p_bf16, long
                   float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                   int step, int zero_grad, const int* applied_steps, void* stream);
 int of_step_advance(const float* sumsq, int* applied_steps, void* stream);
+/* ABI v8: the two streaming passes as NARROW launches -- max_workgroups fat workgroups (1024 threads, one per CU) instead of a grid
+ * that covers the chip, so that the pass holds that many CUs and leaves the others to work on another stream (the next step's frozen
+ * vision-tower forward, train/step.py: next_vision_x).  Same arithmetic per element and per partial slot: bit-identical results;
+ * max_workgroups = 0 is the plain launch. */
+int of_sumsq_partial_w(const float* g, long n, float* partials, int max_workgroups, void* stream);
+int of_adamw_clip_w(float* p, float* g, float* m, float* v, uint16_t* p_bf16, long n, const float* sumsq,
+                    float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                    int step, int zero_grad, const int* applied_steps, int max_workgroups, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Token-level cross entropy of the causal-LM loss (the reference's Flamingo.forward passes `labels` to the HF language

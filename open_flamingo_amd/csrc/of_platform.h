@@ -38,6 +38,7 @@ OF_DEV int of_bid_x() { return blockIdx.x; }
 OF_DEV int of_bid_y() { return blockIdx.y; }
 OF_DEV int of_bid_z() { return blockIdx.z; }
 OF_DEV int of_gdim_x() { return gridDim.x; }
+OF_DEV int of_bdim_x() { return blockDim.x; }
 OF_DEV char* of_smem() {
     extern __shared__ __attribute__((aligned(16))) char of_smem_[];
     return of_smem_;

@@ -27,36 +27,46 @@ struct OptArgs {
 
 constexpr int OPT_GRID_CAP = 4096;
 
+// One VIRTUAL workgroup of 256 threads per partial slot (OF_SUMSQ_PARTS of them: the slot -> element assignment depends on n alone).
+// The classic launch has one physical workgroup per slot; the narrow launch (of_sumsq_partial_w: a few fat workgroups, so that the
+// pass occupies only that many CUs and leaves the rest to another stream) walks the slots with 256-thread sub-blocks -- the same
+// threads' sums in the same order per slot: bit-identical partials.
 OF_GLOBAL void of_sumsq_kernel(OptArgs a) {
     float* red = (float*)of_smem();
     const long nv = a.n >> 2;
-    const long stride = (long)of_gdim_x() * 256;
-    float s = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
-    long i = (long)of_bid_x() * 256 + of_tid();
-    for (; i + 7 * stride < nv; i += 8 * stride) {   // eight independent 16-byte loads in flight per lane (the grid is
-        f32x4 g[8];                                   // capped at OF_SUMSQ_PARTS workgroups: depth, not width, hides latency)
+    const long stride = (long)OF_SUMSQ_PARTS * 256;
+    const int nsub = of_bdim_x() >> 8, sub = of_tid() >> 8, tid = of_tid() & 255;
+    for (int base = of_bid_x() * nsub; base < OF_SUMSQ_PARTS; base += of_gdim_x() * nsub) {
+        const int part = base + sub;
+        float s = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+        if (part < OF_SUMSQ_PARTS) {
+            long i = (long)part * 256 + tid;
+            for (; i + 7 * stride < nv; i += 8 * stride) {   // eight independent 16-byte loads in flight per lane (the grid is
+                f32x4 g[8];                                   // capped at OF_SUMSQ_PARTS workgroups: depth, not width, hides latency)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) g[u] = *(const f32x4*)(a.g + (i + u * stride) * 4);
+                for (int u = 0; u < 8; ++u) g[u] = *(const f32x4*)(a.g + (i + u * stride) * 4);
 #pragma unroll
-        for (int u = 0; u < 8; u += 4) {
-            s += g[u][0] * g[u][0] + g[u][1] * g[u][1] + g[u][2] * g[u][2] + g[u][3] * g[u][3];
-            s2 += g[u + 1][0] * g[u + 1][0] + g[u + 1][1] * g[u + 1][1] + g[u + 1][2] * g[u + 1][2] + g[u + 1][3] * g[u + 1][3];
-            s3 += g[u + 2][0] * g[u + 2][0] + g[u + 2][1] * g[u + 2][1] + g[u + 2][2] * g[u + 2][2] + g[u + 2][3] * g[u + 2][3];
-            s4 += g[u + 3][0] * g[u + 3][0] + g[u + 3][1] * g[u + 3][1] + g[u + 3][2] * g[u + 3][2] + g[u + 3][3] * g[u + 3][3];
+                for (int u = 0; u < 8; u += 4) {
+                    s += g[u][0] * g[u][0] + g[u][1] * g[u][1] + g[u][2] * g[u][2] + g[u][3] * g[u][3];
+                    s2 += g[u + 1][0] * g[u + 1][0] + g[u + 1][1] * g[u + 1][1] + g[u + 1][2] * g[u + 1][2] + g[u + 1][3] * g[u + 1][3];
+                    s3 += g[u + 2][0] * g[u + 2][0] + g[u + 2][1] * g[u + 2][1] + g[u + 2][2] * g[u + 2][2] + g[u + 2][3] * g[u + 2][3];
+                    s4 += g[u + 3][0] * g[u + 3][0] + g[u + 3][1] * g[u + 3][1] + g[u + 3][2] * g[u + 3][2] + g[u + 3][3] * g[u + 3][3];
+                }
+            }
+            for (; i < nv; i += stride) {
+                const f32x4 g = *(const f32x4*)(a.g + i * 4);
+                s += g[0] * g[0] + g[1] * g[1] + g[2] * g[2] + g[3] * g[3];
+            }
+            s += s2 + s3 + s4;
+            if (part == 0)
+                for (long i = (nv << 2) + tid; i < a.n; i += 256) s += a.g[i] * a.g[i];
         }
+        s = of_wave_sum(s);
+        if ((tid & 63) == 0) red[sub * 4 + (tid >> 6)] = s;
+        of_sync();
+        if (tid == 0 && part < OF_SUMSQ_PARTS) a.acc[part] = (red[sub * 4] + red[sub * 4 + 1]) + (red[sub * 4 + 2] + red[sub * 4 + 3]);   // slots without work store 0
+        of_sync();          // red is reused by the next round of slots
     }
-    for (; i < nv; i += stride) {
-        const f32x4 g = *(const f32x4*)(a.g + i * 4);
-        s += g[0] * g[0] + g[1] * g[1] + g[2] * g[2] + g[3] * g[3];
-    }
-    s += s2 + s3 + s4;
-    if (of_bid_x() == 0)
-        for (long i = (nv << 2) + of_tid(); i < a.n; i += 256) s += a.g[i] * a.g[i];
-    s = of_wave_sum(s);
-    const int tid = of_tid();
-    if ((tid & 63) == 0) red[tid >> 6] = s;
-    of_sync();
-    if (tid == 0) a.acc[of_bid_x()] = (red[0] + red[1]) + (red[2] + red[3]);   // workgroups without work store 0
 }
 
 // one workgroup: lane t sums slots t, t+256, ... in index order, then the fixed wave/LDS tree
@@ -93,10 +103,10 @@ OF_GLOBAL void of_adamw_kernel(OptArgs a) {
     // cleared are still cleared.
     if (!(norm < 3.0e38f)) {
         if (a.zero_grad) {
-            const long nvz = a.n >> 2, strz = (long)of_gdim_x() * 256;
-            for (long i = (long)of_bid_x() * 256 + of_tid(); i < nvz; i += strz) *(f32x4*)(a.g + i * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            const long nvz = a.n >> 2, strz = (long)of_gdim_x() * of_bdim_x();
+            for (long i = (long)of_bid_x() * of_bdim_x() + of_tid(); i < nvz; i += strz) *(f32x4*)(a.g + i * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
             if (of_bid_x() == 0)
-                for (long i = (nvz << 2) + of_tid(); i < a.n; i += 256) a.g[i] = 0.f;
+                for (long i = (nvz << 2) + of_tid(); i < a.n; i += of_bdim_x()) a.g[i] = 0.f;
         }
         return;
     }
@@ -110,7 +120,7 @@ OF_GLOBAL void of_adamw_kernel(OptArgs a) {
     }
     const float step_size = a.lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2), decay = 1.0f - a.lr * a.wd;
     const long nv = a.n >> 2;
-    const long stride = (long)of_gdim_x() * 256;
+    const long stride = (long)of_gdim_x() * of_bdim_x();      // element-wise: any grid gives the same results
     auto one = [&](long i, f32x4 p, f32x4 m, f32x4 v, const f32x4 g) OF_INLINE_LAMBDA {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -124,7 +134,7 @@ OF_GLOBAL void of_adamw_kernel(OptArgs a) {
         if (a.p_bf16) *(u32x2*)(a.p_bf16 + i * 4) = u32x2{of_pack_bf16(p[0], p[1]), of_pack_bf16(p[2], p[3])};
         if (a.zero_grad) *(f32x4*)(a.g + i * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    long i = (long)of_bid_x() * 256 + of_tid();
+    long i = (long)of_bid_x() * of_bdim_x() + of_tid();
     for (; i + stride < nv; i += 2 * stride) {       // two vectors of each stream per lane: eight 16-byte loads in flight
         const long j = i + stride;
         const f32x4 p0 = *(const f32x4*)(a.p + i * 4), m0 = *(const f32x4*)(a.m + i * 4), v0 = *(const f32x4*)(a.v + i * 4);
@@ -137,7 +147,7 @@ OF_GLOBAL void of_adamw_kernel(OptArgs a) {
     for (; i < nv; i += stride)
         one(i, *(const f32x4*)(a.p + i * 4), *(const f32x4*)(a.m + i * 4), *(const f32x4*)(a.v + i * 4), *(const f32x4*)(a.g + i * 4));
     if (of_bid_x() == 0) {
-        for (long i = (nv << 2) + of_tid(); i < a.n; i += 256) {
+        for (long i = (nv << 2) + of_tid(); i < a.n; i += of_bdim_x()) {
             float pe = a.p[i], me = a.m[i], ve = a.v[i];
             adamw_one(a, coef, step_size, inv_sqrt_bc2, decay, pe, a.g[i], me, ve);
             a.p[i] = pe; a.m[i] = me; a.v[i] = ve;
@@ -160,6 +170,30 @@ unsigned opt_grid(long n) {
 }
 
 }  // namespace
+
+// Narrow launches (max_workgroups > 0): that many FAT workgroups (1024 threads: one per CU) instead of a grid that covers the chip --
+// the pass then holds max_workgroups CUs and leaves the others to whatever runs on another stream (train/optim.py: the next step's
+// vision-tower forward).  HBM-bound passes need depth, not width: ~96 CUs with 16 waves of eight 16-byte loads each keep the memory
+// pipes as full as 256 do.  Same arithmetic per element / per partial slot: bit-identical results.
+#ifdef OF_HOST_EMU
+constexpr int OPT_FAT_BLOCK = 512;       // the emulator runs at most 512 fibers per workgroup
+#else
+constexpr int OPT_FAT_BLOCK = 1024;
+#endif
+
+extern "C" int of_sumsq_partial_w(const float* g, long n, float* partials, int max_workgroups, void* stream) {
+    if (!g || !partials || n <= 0 || max_workgroups < 0) return OF_E_ARG;
+    if ((uintptr_t)g & 15) return OF_E_ALIGN;
+    OptArgs a{};
+    a.g = const_cast<float*>(g); a.n = n; a.acc = partials;
+    if (max_workgroups > 0) {
+        constexpr int nsub = OPT_FAT_BLOCK / 256;
+        int wg = (OF_SUMSQ_PARTS + nsub - 1) / nsub;
+        if (wg > max_workgroups) wg = max_workgroups;
+        return of_launch(of_sumsq_kernel, of_dim3{(unsigned)wg, 1, 1}, OPT_FAT_BLOCK, 4 * nsub * sizeof(float), (of_stream_t)stream, a);
+    }
+    return of_launch(of_sumsq_kernel, of_dim3{OF_SUMSQ_PARTS, 1, 1}, 256, 4 * sizeof(float), (of_stream_t)stream, a);
+}
 
 extern "C" int of_sumsq_partial(const float* g, long n, float* partials, void* stream) {
     if (!g || !partials || n <= 0) return OF_E_ARG;
@@ -186,9 +220,21 @@ extern "C" int of_step_advance(const float* sumsq, int* applied_steps, void* str
     return of_launch(of_step_advance_kernel, of_dim3{1, 1, 1}, 64, 0, (of_stream_t)stream, a);
 }
 
+extern "C" int of_adamw_clip_w(float* p, float* g, float* m, float* v, uint16_t* p_bf16, long n, const float* sumsq,
+                               float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                               float grad_scale, int step, int zero_grad, const int* applied_steps, int max_workgroups, void* stream);
+
 extern "C" int of_adamw_clip(float* p, float* g, float* m, float* v, uint16_t* p_bf16, long n, const float* sumsq,
                              float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
                              float grad_scale, int step, int zero_grad, const int* applied_steps, void* stream) {
+    return of_adamw_clip_w(p, g, m, v, p_bf16, n, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, grad_scale, step, zero_grad,
+                           applied_steps, 0, stream);
+}
+
+extern "C" int of_adamw_clip_w(float* p, float* g, float* m, float* v, uint16_t* p_bf16, long n, const float* sumsq,
+                               float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                               float grad_scale, int step, int zero_grad, const int* applied_steps, int max_workgroups, void* stream) {
+    if (max_workgroups < 0) return OF_E_ARG;
     if (!p || !g || !m || !v || !sumsq || n <= 0 || (step <= 0 && !applied_steps)) return OF_E_ARG;
     if (((uintptr_t)p & 15) || ((uintptr_t)g & 15) || ((uintptr_t)m & 15) || ((uintptr_t)v & 15) || ((uintptr_t)p_bf16 & 7))
         return OF_E_ALIGN;
@@ -199,5 +245,11 @@ extern "C" int of_adamw_clip(float* p, float* g, float* m, float* v, uint16_t* p
     a.bc2 = 1.0f - powf(beta2, (float)(step > 0 ? step : 1));
     a.zero_grad = zero_grad;
     a.applied = const_cast<int*>(applied_steps);
+    if (max_workgroups > 0) {
+        long need = ((n >> 2) + OPT_FAT_BLOCK - 1) / OPT_FAT_BLOCK;
+        if (need < 1) need = 1;
+        const unsigned wg = (unsigned)(need < max_workgroups ? need : max_workgroups);
+        return of_launch(of_adamw_kernel, of_dim3{wg, 1, 1}, OPT_FAT_BLOCK, 0, (of_stream_t)stream, a);
+    }
     return of_launch(of_adamw_kernel, of_dim3{opt_grid(n), 1, 1}, 256, 0, (of_stream_t)stream, a);
 }

@@ -80,6 +80,9 @@ PROTOTYPES = {
     "of_adamw_clip": (C.c_int, [vp, vp, vp, vp, vp, C.c_long, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_float, C.c_float, C.c_int, C.c_int, vp, vp]),
     "of_step_advance": (C.c_int, [vp, vp, vp]),
+    "of_sumsq_partial_w": (C.c_int, [vp, C.c_long, vp, C.c_int, vp]),
+    "of_adamw_clip_w": (C.c_int, [vp, vp, vp, vp, vp, C.c_long, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                  C.c_float, C.c_float, C.c_int, C.c_int, vp, C.c_int, vp]),
     "of_rotary_neox": (C.c_int, [vp, C.c_long, vp, vp, C.c_long, vp, vp, vp, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, vp]),
     "of_head_repack": (C.c_int, [vp, C.c_long, vp, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, vp]),

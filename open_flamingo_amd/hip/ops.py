@@ -287,24 +287,26 @@ class Ops:
     # ------------------------------------------------------------------ step epilogue
     SUMSQ_PARTS = abi.OF_SUMSQ_PARTS
 
-    def sumsq_partial(self, g, partials):
-        """partials[0:SUMSQ_PARTS] = per-workgroup sums of g*g (deterministic: no floating-point atomics)."""
+    def sumsq_partial(self, g, partials, max_workgroups=0):
+        """partials[0:SUMSQ_PARTS] = per-workgroup sums of g*g (deterministic: no floating-point atomics).  max_workgroups > 0: a
+        narrow launch of that many fat workgroups (one per CU; the same bits)."""
         assert g.dtype == F32 and g.is_contiguous() and partials.dtype == F32 and partials.is_contiguous()
         assert partials.numel() >= self.SUMSQ_PARTS
-        self._chk(self.lib.of_sumsq_partial(g.data_ptr(), g.numel(), partials.data_ptr(), self._stream()), "of_sumsq_partial")
+        self._chk(self.lib.of_sumsq_partial_w(g.data_ptr(), g.numel(), partials.data_ptr(), int(max_workgroups), self._stream()),
+                  "of_sumsq_partial")
 
     def sumsq_finish(self, partials, acc):
         """acc[0] = sum(partials) in a fixed order."""
         assert partials.dtype == F32 and partials.is_contiguous() and acc.dtype == F32
         self._chk(self.lib.of_sumsq_finish(partials.data_ptr(), partials.numel(), acc.data_ptr(), self._stream()), "of_sumsq_finish")
 
-    def sumsq(self, bufs, acc, scratch=None):
+    def sumsq(self, bufs, acc, scratch=None, max_workgroups=0):
         """acc[0] = sum over the buffers of sum(g*g): one partial launch per buffer + one finish."""
         bufs = list(bufs)
         if scratch is None or scratch.numel() < len(bufs) * self.SUMSQ_PARTS:
             scratch = torch.empty(len(bufs) * self.SUMSQ_PARTS, dtype=F32, device=acc.device)
         for i, g in enumerate(bufs):
-            self.sumsq_partial(g, scratch[i * self.SUMSQ_PARTS:(i + 1) * self.SUMSQ_PARTS])
+            self.sumsq_partial(g, scratch[i * self.SUMSQ_PARTS:(i + 1) * self.SUMSQ_PARTS], max_workgroups)
         self.sumsq_finish(scratch[:len(bufs) * self.SUMSQ_PARTS], acc)
         return scratch
 
@@ -314,13 +316,15 @@ class Ops:
         self._chk(self.lib.of_step_advance(sumsq.data_ptr(), applied.data_ptr(), self._stream()), "of_step_advance")
 
     def adamw_clip(self, p, g, m, v, sumsq, *, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=1.0,
-                   p_bf16=None, zero_grad=True, grad_scale=1.0, applied=None):
-        """applied: optional device int32 count of applied updates (step_advance) that replaces ``step`` in the bias correction."""
+                   p_bf16=None, zero_grad=True, grad_scale=1.0, applied=None, max_workgroups=0):
+        """applied: optional device int32 count of applied updates (step_advance) that replaces ``step`` in the bias correction.
+        max_workgroups > 0: a narrow launch of that many fat workgroups (one per CU; the same bits)."""
         n = p.numel()
         assert all(t.dtype == F32 and t.is_contiguous() and t.numel() == n for t in (p, g, m, v))
-        self._chk(self.lib.of_adamw_clip(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(p_bf16), n,
-                                         sumsq.data_ptr(), max_norm, lr, betas[0], betas[1], eps, weight_decay,
-                                         grad_scale, step, int(zero_grad), _p(applied), self._stream()), "of_adamw_clip")
+        self._chk(self.lib.of_adamw_clip_w(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(p_bf16), n,
+                                           sumsq.data_ptr(), max_norm, lr, betas[0], betas[1], eps, weight_decay,
+                                           grad_scale, step, int(zero_grad), _p(applied), int(max_workgroups), self._stream()),
+                  "of_adamw_clip")
 
     # ------------------------------------------------------------------ causal-LM loss
     def ce_fwd(self, logits, labels, lse, loss_rows, ignore_index=-100):

@@ -116,8 +116,11 @@ class FlatAdamW(torch.optim.Optimizer):
             g_rows = self.embedding.grad.index_select(0, self._emb["rows"]).contiguous()
         # global norm without floating-point atomics (of_sumsq_partial / of_sumsq_finish): every rank computes the same
         # bits from the same all-reduced buffers, so the clip coefficient cannot differ between replicas
+        # narrow_cus > 0: both streaming passes as narrow launches (that many fat workgroups, one per CU: the same bits) so that
+        # work on another stream -- the next step's vision-tower forward, train/step.py -- finds whole CUs free
+        nw = int(getattr(self, "narrow_cus", 0))
         self._parts = ops.sumsq([b["flat"] for b in self.reducer.buckets] + ([g_rows] if g_rows is not None else []),
-                                self._sumsq, getattr(self, "_parts", None))
+                                self._sumsq, getattr(self, "_parts", None), max_workgroups=nw)
         # Adam's step = the number of updates actually APPLIED, counted on the device: a step skipped for a non-finite norm
         # (the reference `continue`s before optimizer.step(), train_utils.py:161-169) does not advance the bias correction.
         # (step_count, the host's count of step() calls, only seeds the counter and names checkpoints' "step" after a sync.)
@@ -134,7 +137,7 @@ class FlatAdamW(torch.optim.Optimizer):
                     ops.adamw_clip(b["flat_p"][lo:hi], b["flat"][lo:hi], b["m"][lo:hi], b["v"][lo:hi], self._sumsq,
                                    step=self.step_count, lr=lr, betas=self.betas, eps=self.eps, weight_decay=b["wd"],
                                    max_norm=self.max_norm, p_bf16=b["flat_bf16"][lo:hi], zero_grad=zero, grad_scale=gs,
-                                   applied=self._applied)
+                                   applied=self._applied, max_workgroups=nw)
             for p in b.get("overwritable", ()):
                 p._of_grad_fresh = True
         if g_rows is not None:

@@ -146,6 +146,7 @@ OF_DEV int of_bid_x() { return (int)of_emu::g_blk->bid.x; }
 OF_DEV int of_bid_y() { return (int)of_emu::g_blk->bid.y; }
 OF_DEV int of_bid_z() { return (int)of_emu::g_blk->bid.z; }
 OF_DEV int of_gdim_x() { return (int)of_emu::g_blk->gdim.x; }
+OF_DEV int of_bdim_x() { return of_emu::g_blk->nthreads; }
 OF_DEV char* of_smem() { return of_emu::g_blk->smem; }
 OF_DEV void of_sync() { of_emu::block_barrier(); }
 

@@ -231,3 +231,30 @@ def test_fused_cross_entropy_matches_torch():
         tol = 1e-6 if dt == torch.float32 else 4e-3
         assert (d.float() - xf.grad).abs().max() <= tol * xf.grad.abs().max() + 1e-9
         assert (d[[3, 11, 36]] == 0).all()
+
+
+def test_narrow_step_epilogue_launches_give_the_same_bits():
+    """of_sumsq_partial_w / of_adamw_clip_w (ABI v8): a few fat workgroups instead of a grid that covers the chip (so that the step
+    epilogue leaves whole CUs to the prefetched vision tower on its side stream).  Every partial slot is summed by the same 256
+    virtual threads in the same order, AdamW is element-wise: partial slots, parameters, moments and bf16 copies are bit-identical
+    to the plain launches -- sizes with a vector body and a scalar tail, fewer elements than slots, and several slots per workgroup."""
+    ops = H.emu_ops()
+    g = torch.Generator().manual_seed(5)
+    for n in (1027, 70001, 300):
+        grad = torch.randn(n, generator=g)
+        wide, narrow = torch.full((ops.SUMSQ_PARTS,), -1.0), torch.full((ops.SUMSQ_PARTS,), -2.0)
+        ops.sumsq_partial(grad, wide)
+        for cus in (3, 96):
+            ops.sumsq_partial(grad, narrow, max_workgroups=cus)
+            assert torch.equal(wide, narrow), (n, cus)
+        acc = torch.zeros(1)
+        ops.sumsq_finish(wide, acc)
+        p0, m0, v0 = torch.randn(n, generator=g), torch.rand(n, generator=g) * 0.1, torch.rand(n, generator=g) * 0.1
+        outs = []
+        for cus in (0, 2, 96):
+            p, gb, m, v, b16 = p0.clone(), grad.clone(), m0.clone(), v0.clone(), torch.zeros(n, dtype=torch.bfloat16)
+            ops.adamw_clip(p, gb, m, v, acc, step=2, lr=1e-2, weight_decay=0.1, max_norm=1.0, p_bf16=b16, zero_grad=True, max_workgroups=cus)
+            assert float(gb.abs().max()) == 0.0
+            outs.append((p, m, v, b16))
+        for o in outs[1:]:
+            assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
