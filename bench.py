@@ -267,6 +267,8 @@ def main():
     ap.add_argument("--reserve-cus", type=int, default=0,
                     help="multi-GPU: CUs to leave to RCCL's kernels while gradient collectives are in flight -- the libofhip GEMMs of the "
                          "backward are then laid out stream-K for 256 - R workgroups (GradReducer.reserve_cus; default 0 = off)")
+    ap.add_argument("--no-batched-dw", action="store_true",
+                    help="A/B: the three 512-wide weight gradients of a gated block as separate split-K launches instead of one batched launch")
     ap.add_argument("--optimizer-cus", type=int, default=0,
                     help="run the step epilogue's streaming passes (global norm, AdamW) as narrow launches on this many CUs (fat "
                          "workgroups, one per CU; identical results) so that the prefetched vision-tower forward on the side stream "
@@ -321,6 +323,7 @@ def main():
     if not args.no_vision_prefetch:       # the next step's first forward sees this tensor (a loader is one batch ahead anyway)
         step_kw["next_vision_x"] = (laion if laion is not None else batch)["vision_x"]
     ops = Ops.default()
+    ops.batch_dw = not args.no_batched_dw
     nan_check = "device" if (args.nan_check == "device" and not args.torch_optimizer) else True
 
     def sync():
@@ -390,9 +393,9 @@ def main():
         key = max(groups, key=lambda k: groups[k][1])
         fl, ms, n = groups[key]
         sym = {"w4m256": "of_gemm_w4m_kernel", "w4dma256": "of_gemm_w4_kernel", "pingpong256": "of_gemm_pp_kernel", "mid128": "of_gemm_mid_kernel",
-               "general128": "of_gemm_kernel", "skinny": "of_gemm_skinny_kernel"}[key[3]]
+               "general128": "of_gemm_kernel", "skinny": "of_gemm_skinny_kernel", "mid128batch": "of_gemm_mid_batch_kernel"}[key[3]]
         sym += f"<{str(bool(key[0])).lower()}, {str(bool(key[1])).lower()}, {key[2]}" + (
-            ", false>" if key[3] == "w4m256" else ">" if key[3] == "mid128" else ", ...>")       # w4m256: <AT, BT, EPI, SK = false> (one tile per workgroup)
+            ", false>" if key[3] == "w4m256" else ">" if key[3] in ("mid128", "mid128batch") else ", ...>")       # w4m256: <AT, BT, EPI, SK = false> (one tile per workgroup)
         shapes = {}
         for k2, _, shape, _, _ in timing:
             if k2 == key:

@@ -114,6 +114,11 @@ typedef struct OfGemmArgs {
 } OfGemmArgs;
 
 int of_gemm(const OfGemmArgs* args, void* stream);
+/* n independent problems in ONE launch (ABI v8).  For 2..4 weight-gradient problems (a_trans = b_trans = 1, OF_EPI_ACC_F32) that
+ * of_gemm would each run split along K on the 128x128 kernel -- the 512-wide projections' gradients of a gated block: to_q, to_out,
+ * to_kv -- and whose `workspace` fields each hold of_gemm_workspace_bytes() bytes (distinct regions), the problems share one GEMM grid
+ * and one reduce grid: the bits of the separate launches without their launch boundaries.  Everything else runs as n of_gemm calls. */
+int of_gemm_batch(const OfGemmArgs* args, int n, void* stream);
 /* Bytes of workspace of_gemm would use for these arguments: split-K slabs (optional, see `workspace`), the per-workgroup
  * partials of a *_DOT launch with dot_out (required), the stream-K partial tiles + flags of a big-tile launch whose tile count
  * is not a multiple of its workgroup count (optional, see cu_limit), else 0. */

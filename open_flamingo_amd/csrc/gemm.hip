@@ -208,6 +208,40 @@ OF_GLOBAL void of_splitk_reduce_kernel(OfGemmArgs p) {
     }
 }
 
+// the same for the problems of an of_gemm_batch launch in ONE grid: workgroups [wg_end[i-1], wg_end[i]) combine problem i's slabs
+OF_GLOBAL void of_splitk_reduce_batch_kernel(OfGemmBatchArgs m) {
+    const int bid = of_bid_x();
+    int i = 0, first = 0;
+#pragma unroll
+    for (int j = 0; j + 1 < OF_GEMM_BATCH_MAX; ++j)
+        if (j + 1 < m.n && bid >= m.wg_end[j]) {
+            i = j + 1;
+            first = m.wg_end[j];
+        }
+    OfGemmArgs p = m.a[0];
+    if (i == 1) p = m.a[1];
+    if (i == 2) p = m.a[2];
+    if (i == 3) p = m.a[3];
+    const int nblk = m.wg_end[i] - first;
+    const long nv = ((long)p.M * p.N) >> 2;
+    const long stride = (long)nblk * 256;
+    const float* ws = (const float*)p.workspace;
+    for (long e4 = (long)(bid - first) * 256 + of_tid(); e4 < nv; e4 += stride) {
+        const long e = e4 * 4, mm = e / p.N, nn = e - mm * p.N;
+        f32x4 s = *(const f32x4*)(ws + e);
+        for (int k = 1; k < p.ksplit; ++k) {
+            const f32x4 t = *(const f32x4*)(ws + (size_t)k * p.M * p.N + e);
+            s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+        }
+        float* c = (float*)p.C + (size_t)mm * p.ldc + nn;
+        if (p.beta != 0.f) {
+            const f32x4 o = *(const f32x4*)c;
+            s[0] += p.beta * o[0]; s[1] += p.beta * o[1]; s[2] += p.beta * o[2]; s[3] += p.beta * o[3];
+        }
+        *(f32x4*)c = s;
+    }
+}
+
 // *dot_out += (1 - tanh(gate)^2) * (partials[0] + ... + partials[n-1]), one workgroup, fixed order (ofg::epilogue_finish)
 struct OfDotFinishArgs {
     const float* partials;
@@ -492,4 +526,58 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
         return dispatch(b, grid, s, true);
     }
     return dispatch(b, grid, s);
+}
+
+
+// Several independent weight-gradient GEMMs (TN, OF_EPI_ACC_F32) as ONE grid on the 128x128 LDS-DMA kernel + ONE reduce grid: every
+// problem is split along K as of_gemm would split it alone (fp32 slabs in ITS workspace, combined in slice order: the bits of the
+// separate launches), the launch boundaries -- where the chip runs half empty -- are gone.  Anything the batch form does not cover
+// (other layouts / epilogues, shapes the 128x128 kernel does not take, a missing workspace, more than OF_GEMM_BATCH_MAX problems)
+// runs as the separate of_gemm launches: same results either way.
+extern "C" int of_gemm_batch(const OfGemmArgs* args, int n, void* stream) {
+    if (!args || n <= 0) return OF_E_ARG;
+    of_stream_t s = (of_stream_t)stream;
+    bool batched = n >= 2 && n <= OF_GEMM_BATCH_MAX;
+    OfGemmBatchArgs m{};
+    OfGemmBatchArgs r{};
+    int total = 0, rtotal = 0;
+    for (int i = 0; batched && i < n; ++i) {
+        const OfGemmArgs& a = args[i];
+        if (!a.A || !a.B || !a.C || a.group_kind || a.safe || !(a.a_trans && a.b_trans) || a.epi != OF_EPI_ACC_F32) batched = false;
+        else if ((a.lda & 7) || (a.ldb & 7) || (a.ldc & 3) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15) || ((uintptr_t)a.C & 15)) batched = false;
+        else {
+            OfGemmArgs b = a;
+            b.ksplit = pick_ksplit(a, true);
+            const size_t need = b.ksplit > 1 ? (size_t)b.ksplit * a.M * a.N * sizeof(float) : 0;
+            const long tiles256 = (long)(a.M / 256) * (a.N / 256);
+            const bool big = !(a.M % 256) && !(a.N % 256) && !(a.K % 64) && tiles256 >= 128;       // of_gemm would take the big tile
+            if (big || b.ksplit < 2 || !a.workspace || a.workspace_bytes < need || ((uintptr_t)a.workspace & 15) || !of_gemm_mid_eligible(b))
+                batched = false;
+            else {
+                m.a[i] = b;
+                total += (b.M / 128) * (b.N / 128) * b.ksplit;
+                m.wg_end[i] = total;
+                r.a[i] = b;
+                long blocks = (((long)a.M * a.N >> 2) + 255) / 256;
+                if (blocks > 1024) blocks = 1024;
+                rtotal += (int)blocks;
+                r.wg_end[i] = rtotal;
+            }
+        }
+    }
+    if (!batched) {
+        for (int i = 0; i < n; ++i) {
+            const int rc = of_gemm(&args[i], stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    m.n = r.n = n;
+    for (int i = n; i < OF_GEMM_BATCH_MAX; ++i) {
+        m.wg_end[i] = total;
+        r.wg_end[i] = rtotal;
+    }
+    int rc = of_gemm_mid_batch_launch(m, total, s);
+    if (rc) return rc;
+    return of_launch(of_splitk_reduce_batch_kernel, of_dim3{(unsigned)rtotal, 1, 1}, 256, 0, s, r);
 }

@@ -393,6 +393,14 @@ OF_HOSTDEV size_t of_gemm_dot_bytes(const OfGemmArgs& a) {
     return of_gemm_has_dot(a) ? ((of_gemm_dot_slots(a) * sizeof(float) + 255) & ~(size_t)255) : 0;
 }
 constexpr int OF_NUM_CUS = 256;      // MI355X
+// several problems in one grid (gemm_mid.hip: of_gemm_mid_batch_kernel; gemm.hip: of_gemm_batch, of_splitk_reduce_batch_kernel)
+constexpr int OF_GEMM_BATCH_MAX = 4;
+struct OfGemmBatchArgs {
+    int n;
+    int wg_end[OF_GEMM_BATCH_MAX];      // cumulative workgroup counts: problem i owns workgroups [wg_end[i-1], wg_end[i])
+    OfGemmArgs a[OF_GEMM_BATCH_MAX];
+};
+int of_gemm_mid_batch_launch(const OfGemmBatchArgs& m, int total_wg, of_stream_t s);
 // implemented in gemm_mid.hip (8 waves, 128x128 tile, 4-slot LDS-DMA ring); OF_E_SHAPE when not eligible
 int of_gemm_mid_try(const OfGemmArgs& a, of_stream_t s);
 bool of_gemm_mid_eligible(const OfGemmArgs& a);     // what of_gemm_mid_try would accept, without launching

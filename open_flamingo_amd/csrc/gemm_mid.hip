@@ -29,21 +29,23 @@ constexpr int MID_NS = 4;                       // ring slots
 constexpr int MID_PD = MID_NS - 1;              // stages in flight
 constexpr int SMEM_MID = MID_NS * MID_STAGE;    // 128 KiB
 
+// One workgroup's work: tile `tile_id` of `ntiles` (the XCD-aware tile map takes the pair like a block id / grid size), K slice
+// `slice` of p.ksplit.  Called by the plain kernel (block ids) and by the batch kernel (several problems in one grid).
 template <bool AT, bool BT, int EPI>
-OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_mid_kernel(OfGemmArgs p) {
+OF_DEV void mid_tile(const OfGemmArgs& p, const int tile_id, const int ntiles, const int slice) {
     char* smem = of_smem();
     const int tid = of_tid(), lane = tid & 63;
     const int wave = of_uniform(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_m = p.M / MT, tiles_n = p.N / MN;
     int pm, pn;
-    ofg::tile_coords(of_bid_x(), of_gdim_x(), tiles_m, tiles_n, pm, pn);
+    ofg::tile_coords(tile_id, ntiles, tiles_m, tiles_n, pm, pn);
     const int m0 = pm * MT, n0 = pn * MN;
 
-    // K range of this slice (p.ksplit > 1: OF_EPI_ACC_F32 only, slice of_bid_y() of the K stages)
+    // K range of this slice (p.ksplit > 1: OF_EPI_ACC_F32 only, slice `slice` of the K stages)
     const int nk_all = p.K / DK;
     const int per = (nk_all + p.ksplit - 1) / p.ksplit;
-    const int kt0 = of_bid_y() * per;
+    const int kt0 = slice * per;
     const int nk = nk_all - kt0 < per ? nk_all - kt0 : per;
     if (nk <= 0) return;
 
@@ -129,14 +131,41 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_mid_kernel(OfGemmArgs p) {
     char* patch = smem + wave * ofg::PATCH_BYTES;
     if (sliced) {                    // this slice's partial tile -> its fp32 slab (combined by of_splitk_reduce_kernel)
         OfGemmArgs q = p;
-        q.C = (float*)p.workspace + (size_t)of_bid_y() * p.M * p.N;
+        q.C = (float*)p.workspace + (size_t)slice * p.M * p.N;
         q.ldc = p.N;
         q.beta = 0.f;
         ofg::epilogue_group<EPI>(q, acc[0], acc[1], patch, m0 + wm * 32, n0 + wn * 64, lane, gv, sc, dot, pre);
         return;
     }
     ofg::epilogue_group<EPI>(p, acc[0], acc[1], patch, m0 + wm * 32, n0 + wn * 64, lane, gv, sc, dot, pre);
-    ofg::epilogue_finish<EPI>(p, dot, lane, wave, 8, (float*)(smem + 8 * ofg::PATCH_BYTES), of_bid_x());
+    ofg::epilogue_finish<EPI>(p, dot, lane, wave, 8, (float*)(smem + 8 * ofg::PATCH_BYTES), tile_id);
+}
+
+template <bool AT, bool BT, int EPI>
+OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_mid_kernel(OfGemmArgs p) {
+    mid_tile<AT, BT, EPI>(p, of_bid_x(), of_gdim_x(), of_bid_y());
+}
+
+// Several independent problems of one (layout, epilogue) in ONE grid (of_gemm_batch: the three 512-wide weight gradients of a gated
+// block -- to_q, to_out, to_kv: off the critical path, 64 tiles each -- were three split-K launches + three reduce launches with the
+// chip half empty at every launch boundary).  Workgroup b belongs to the problem whose cumulative range holds b; inside a problem
+// the workgroups are (K slice, tile), slices of a tile far apart in the grid.
+template <bool AT, bool BT, int EPI>
+OF_GLOBAL void OF_BOUNDS(512, 2) of_gemm_mid_batch_kernel(OfGemmBatchArgs m) {
+    const int bid = of_bid_x();
+    int i = 0, first = 0;
+#pragma unroll
+    for (int j = 0; j + 1 < OF_GEMM_BATCH_MAX; ++j)
+        if (j + 1 < m.n && bid >= m.wg_end[j]) {
+            i = j + 1;
+            first = m.wg_end[j];
+        }
+    OfGemmArgs p = m.a[0];            // (selected by uniform branches: a dynamic index into the kernel-argument struct would go through scratch)
+    if (i == 1) p = m.a[1];
+    if (i == 2) p = m.a[2];
+    if (i == 3) p = m.a[3];
+    const int tiles = (p.M / MT) * (p.N / MN), local = bid - first;
+    mid_tile<AT, BT, EPI>(p, local % tiles, tiles, local / tiles);
 }
 
 template <bool AT, bool BT, int EPI>
@@ -147,6 +176,11 @@ int launch_mid(const OfGemmArgs& a, of_stream_t s) {
     return of_gemm_dot_finish(a, (int)grid.x, s);
 }
 }  // namespace
+
+// the weight-gradient form only (TN, fp32 accumulate): what of_gemm_batch is for
+int of_gemm_mid_batch_launch(const OfGemmBatchArgs& m, int total_wg, of_stream_t s) {
+    return of_launch(of_gemm_mid_batch_kernel<true, true, OF_EPI_ACC_F32>, of_dim3{(unsigned)total_wg, 1, 1}, 512, SMEM_MID, s, m);
+}
 
 // Eligibility: M, N multiples of 128, K a multiple of 64; split-K (a.ksplit > 1) only with OF_EPI_ACC_F32 and fp32 slabs in
 // a.workspace (the caller, of_gemm, has checked their size).  Byte offsets are 32-bit: operands up to 4 GiB.

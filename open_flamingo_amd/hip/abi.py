@@ -53,6 +53,7 @@ PROTOTYPES = {
     "of_build_kind": (C.c_int, []),
     "of_gemm": (C.c_int, [C.POINTER(OfGemmArgs), vp]),
     "of_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(OfGemmArgs)]),
+    "of_gemm_batch": (C.c_int, [C.POINTER(OfGemmArgs), C.c_int, vp]),
     "of_layernorm_fwd": (C.c_int, [vp, C.c_int, C.c_long, vp, vp, vp, C.c_long, vp, C.c_long, C.c_int, vp]),
     "of_layernorm_fwd_out": (C.c_int, [vp, C.c_int, C.c_long, vp, vp, vp, C.c_int, C.c_long, vp, C.c_long,
                                        C.c_int, vp]),

@@ -35,6 +35,7 @@ class Ops:
         # CUs a big-tile GEMM launch may count on (OfGemmArgs.cu_limit; 0 = all): train/reducer.py lowers it while its collectives
         # hold CUs on the side stream, so that the GEMMs of the backward are laid out (stream-K) for the CUs that are left
         self.cu_limit = 0
+        self.batch_dw = True      # gemm_batch_dw really batches (bench.py --no-batched-dw clears it for the same-box A/B)
         self.gemm_timing = None   # bench.py sets this to a list to collect (key, flops, start_evt, end_evt) per launch
         self.gemm_timing_only = None   # optional set of (ta, tb, epi, kernel label) keys: only those launches are bracketed by events
 
@@ -130,6 +131,50 @@ class Ops:
                 return out
         self._chk(self.lib.of_gemm(C.byref(a), self._stream()), "of_gemm")
         return out
+
+    def gemm_batch_dw(self, problems):
+        """Several independent weight-gradient GEMMs out_i (M_i, N_i) = [gate_i] A_i^T B_i (+ beta_i out_i) in ONE launch
+        (of_gemm_batch: the 512-wide projections' gradients of a gated block).  problems: [(A (K, M), B (K, N), out fp32 (M, N), beta,
+        gate or None)].  Same bits as the separate ``gemm(A, B, out, ta=True, tb=True, epi=EPI_ACC_F32, ...)`` calls."""
+        if not self.batch_dw:          # (constant True; A/B tooling clears it: the separate launches)
+            for A, B, out, beta, gate in problems:
+                self.gemm(A, B, out, ta=True, tb=True, epi=abi.EPI_ACC_F32, gate=gate, beta=beta)
+            return
+        n = len(problems)
+        arr = (abi.OfGemmArgs * n)()
+        need = []
+        for a, (A, B, out, beta, gate) in zip(arr, problems):
+            assert A.dtype == BF16 and B.dtype == BF16 and out.dtype == F32 and A.stride(1) == 1 and B.stride(1) == 1 and out.stride(1) == 1
+            assert A.shape[0] == B.shape[0] and tuple(out.shape) == (A.shape[1], B.shape[1])
+            a.A, a.B = A.data_ptr(), B.data_ptr()
+            a.M, a.N, a.K = A.shape[1], B.shape[1], A.shape[0]
+            a.lda, a.ldb = A.stride(0), B.stride(0)
+            a.a_trans, a.b_trans, a.epi = 1, 1, abi.EPI_ACC_F32
+            a.C, a.ldc = out.data_ptr(), out.stride(0)
+            a.gate = _p(gate)
+            a.alpha, a.beta = 1.0, float(beta)
+            need.append((self.lib.of_gemm_workspace_bytes(C.byref(a)) + 255) // 256 * 256)
+        total = sum(need)
+        if total:
+            ws = self.__dict__.get("_gemm_ws")
+            if ws is None or ws.numel() * 4 < total or ws.device != problems[0][2].device:
+                ws = torch.empty((total + 3) // 4, dtype=F32, device=problems[0][2].device)
+                self._gemm_ws = ws
+            off = 0
+            for a, nb in zip(arr, need):
+                if nb:
+                    a.workspace, a.workspace_bytes = ws.data_ptr() + off, nb
+                off += nb
+        if self.gemm_timing is not None:
+            key = (1, 1, abi.EPI_ACC_F32, "mid128batch")
+            if self.gemm_timing_only is None or key in self.gemm_timing_only:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self._chk(self.lib.of_gemm_batch(arr, n, self._stream()), "of_gemm_batch")
+                e1.record()
+                self.gemm_timing.append((key, sum(2.0 * a.M * a.N * a.K for a in arr), tuple((a.M, a.N, a.K) for a in arr), e0, e1))
+                return
+        self._chk(self.lib.of_gemm_batch(arr, n, self._stream()), "of_gemm_batch")
 
     def gemm_grouped(self, A, Bs, table, out, *, kind, epi=abi.EPI_STORE_BF16, beta=0.0):
         """One launch over several B matrices (OfGemmArgs.group_kind): kind 1 -- out[:, gE:(g+1)E] = A @ Bs[g]^T with

@@ -237,8 +237,12 @@ def masked_cross_attention_bwd(ops, P, W, S, media_bf, tt, dy, dyb, G, *, B, L, 
     dO = _e((rows, inner), BF16, dev)
     ops.gemm(dyb, W[prefix + "to_out.weight"], dO, tb=True, epi=EPI_SCALE_DOT, aux=S["o"], gate=gate,
              dot=G.acc(gate_name, (1,)) if gate_name else None)
+    # The three 512-wide weight gradients of the branch (to_out, to_q, to_kv: off the critical path, 64 tiles of 128 x 128 each) go
+    # out as ONE batched launch at the end (ops.gemm_batch_dw -> of_gemm_batch): separately they were three split-K launches + three
+    # reduce launches, 103 us per block in-step for 43 GFLOP (profiles/r04_final_default_gemm_report.jsonl)
+    dw_batch = []
     t, beta = G.mat(prefix + "to_out.weight", (d, inner))
-    ops.gemm(dyb, S["o"], t, ta=True, tb=True, epi=EPI_ACC_F32, gate=gate, beta=beta)
+    dw_batch.append((dyb, S["o"], t, beta, gate))
     dq = _e((rows, inner), BF16, dev)
     dkv = _e((B * T * n, 2 * inner), BF16, dev) if dkv_out is None else dkv_out
     delta = _e((B, heads, L), F32, dev)
@@ -249,7 +253,7 @@ def masked_cross_attention_bwd(ops, P, W, S, media_bf, tt, dy, dyb, G, *, B, L, 
     dxn = _e((rows, d), BF16, dev)
     ops.gemm(dq, W[prefix + "to_q.weight"], dxn, tb=True)
     t, beta = G.mat(prefix + "to_q.weight", (inner, d))
-    ops.gemm(dq, S["xn"], t, ta=True, tb=True, epi=EPI_ACC_F32, beta=beta)
+    dw_batch.append((dq, S["xn"], t, beta, None))
     dx = torch.empty_like(dy)
     dxb = _e((rows, d), BF16, dev) if (offer_twin and TWINS and dy.dtype == F32) else None     # for the next backward down the stream
     ops.ln_bwd(dxn, S["x"], S["st"], P[prefix + "norm.weight"], resid=dy if residual else None, dx=dx, dx_bf16=dxb,
@@ -257,7 +261,8 @@ def masked_cross_attention_bwd(ops, P, W, S, media_bf, tt, dy, dyb, G, *, B, L, 
     if dxb is not None:
         offer_bf16_twin(dx, dxb, scope)
     t, beta = G.mat(prefix + "to_kv.weight", (2 * inner, Dv))
-    ops.gemm(dkv, media_bf, t, ta=True, tb=True, epi=EPI_ACC_F32, beta=beta)
+    dw_batch.append((dkv, media_bf, t, beta, None))
+    ops.gemm_batch_dw(dw_batch)
     dmedia = None
     if need_dmedia:
         dmedia = _e((B * T * n, Dv), F32, dev)

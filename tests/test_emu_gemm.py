@@ -479,3 +479,34 @@ def test_stream_k_selection_rules():
     assert H.lib().of_gemm_workspace_bytes(ctypes.byref(a)) == 0
     a.cu_limit = 0                       # 144 tiles / 256 workgroups
     assert H.lib().of_gemm_workspace_bytes(ctypes.byref(a)) >= 256 * 256 * 256 * 4
+
+
+def test_gemm_batch_of_weight_gradients_equals_the_separate_launches():
+    """of_gemm_batch (ABI v8): the three 512-wide weight gradients of a gated block -- to_q (512 x d), to_out (d x 512), to_kv (1024 x
+    1024 over the media rows) -- as ONE GEMM grid + ONE reduce grid on the 128x128 kernel.  Every problem keeps the K split and the
+    slab order of its own of_gemm launch: bit-identical results, beta = 0 and beta = 1, with a gate on one problem; a batch the form
+    does not cover (a problem without a workspace) runs as separate launches with the same bits."""
+    from open_flamingo_amd.hip.ops import BF16      # noqa: F401
+    ops = H.emu_ops()
+    rows, d, inner, mrows = 2048, 256, 128, 1024
+    dq, xn = _rand((rows, inner), 81), _rand((rows, d), 82)
+    dy, o = _rand((rows, d), 83), _rand((rows, inner), 84)
+    dkv, media = _rand((mrows, 256), 85), _rand((mrows, 128), 86)
+    gate = torch.tensor([0.4])
+    probs = [(dq, xn, 0.0, None), (dy, o, 1.0, gate), (dkv, media, 0.0, None)]
+    want = []
+    for A, B, beta, g in probs:
+        c = torch.ones(A.shape[1], B.shape[1])
+        ws = torch.empty(16 * c.numel())
+        H.gemm(A, B, a_trans=1, b_trans=1, epi=abi.EPI_ACC_F32, C_out=c, beta=beta, gate=g, workspace=ws)
+        want.append(c)
+    got = [torch.ones_like(w) for w in want]
+    ops.gemm_batch_dw([(A, B, c, beta, g) for (A, B, beta, g), c in zip(probs, got)])
+    for g_, w in zip(got, want):
+        assert torch.equal(g_, w)
+    np.testing.assert_allclose(got[0].double().numpy(), _ref(dq, xn, 1, 1).numpy(), rtol=1e-5, atol=2e-4)
+    # not coverable as a batch (one problem is big-tile material): separate launches, same interface
+    Abig, Bbig = _rand((64, 4096), 87), _rand((64, 8192), 88)
+    cb, cs = torch.zeros(4096, 8192), torch.zeros(inner, d)
+    ops.gemm_batch_dw([(Abig, Bbig, cb, 0.0, None), (dq, xn, cs, 0.0, None)])
+    assert torch.equal(cs, want[0] * 0 + got[0]) and torch.allclose(cb.double(), _ref(Abig, Bbig, 1, 1), rtol=1e-5, atol=2e-4)

@@ -597,3 +597,26 @@ def test_stream_k_partial_tiles_are_never_stale(ops):
         if i % 2 in first:
             assert torch.equal(o, first[i % 2]), i
         first.setdefault(i % 2, o)
+
+
+def test_gemm_batch_of_weight_gradients_at_benchmark_shapes(ops):
+    """of_gemm_batch: to_out dW (2048 x 512), to_q dW (512 x 2048) over 8192 token rows and to_kv dW (1024 x 1024) over 4096 media rows
+    (a strided column block of the grouped d(k|v) buffer) in one launch -- bit-identical to the three separate split-K launches,
+    beta 0 and 1, gate on the first."""
+    rows, d, inner, mrows = 8192, 2048, 512, 4096
+    gate = torch.tensor([0.37], device="cuda")
+    dy, o, dq, xn = _r((rows, d), 111), _r((rows, inner), 112), _r((rows, inner), 113), _r((rows, d), 114)
+    dkv_all, media = _r((mrows, 24 * 1024), 115), _r((mrows, 1024), 116)
+    dkv = dkv_all[:, 5 * 1024:6 * 1024]
+    probs = [(dy, o, 1.0, gate), (dq, xn, 0.0, None), (dkv, media, 0.0, None)]
+    want = []
+    for A, B, beta, g in probs:
+        c = torch.ones(A.shape[1], B.shape[1], device="cuda")
+        ops.gemm(A, B, c, ta=True, tb=True, epi=abi.EPI_ACC_F32, beta=beta, gate=g)
+        want.append(c)
+    got = [torch.ones_like(w) for w in want]
+    ops.gemm_batch_dw([(A, B, c, beta, g) for (A, B, beta, g), c in zip(probs, got)])
+    for g_, w in zip(got, want):
+        assert torch.equal(g_, w)
+    ref = float(torch.tanh(gate)) * (dy.float().t() @ o.float()) + 1.0
+    _close(got[0], ref, "to_out dW", rtol=1e-5, atol_rms=1e-4, l2=1e-5)
