@@ -62,39 +62,94 @@ OF_DEV void store8(void* base, int is_f32, size_t off, const float (&v)[8]) {
 // chunks per lane, dim <= CPL*512), so x / dy / resid are read from HBM exactly once, with all of a row's loads in
 // flight together.  RPW rows per wave; the backward accumulates its dw/db column partials in registers across those
 // rows and reduces them once per workgroup (LDS, one add per wave per column) and once per grid (global atomics).
-template <int CPL>
-OF_GLOBAL void OF_BOUNDS(256, 2) of_ln_fwd_kernel(LnArgs a) {
-    const int rpw = a.rpw;
-    const int tid = of_tid(), lane = tid & 63, wave = tid >> 6;
-    const int nchunk = a.dim >> 3;
-    const float inv_dim = 1.0f / (float)a.dim;
-    f32x4 wv[CPL][2], bv[CPL][2];
+// Forward.  gamma / beta are staged once per workgroup in LDS (2 * dim floats) AFTER the first row's loads have been issued and are
+// read back at the point of use: held in registers (rounds 1-3) they cost 16 * CPL registers -- the kernel ran at 2-4 waves per
+// SIMD -- and every wave pulled 2 * dim floats through its CU's vector cache ahead of its 1 * dim of x.  With them in LDS a row's
+// working set is 8 * CPL + ~16 registers: eight waves per SIMD, i.e. at 8192 x 2048 every row of the tensor has its loads in flight
+// at once; with more rows than that a wave walks rpw rows and (PF) has row r + 1's loads out before it reduces and stores row r.
+// Cold (input not in the 256-MB infinity cache: the step's case) 8192 x 2048 fp32 -> bf16: see profiles/r04o_ln_in_step_probe.jsonl.
+// A row's addresses are a wave-uniform row pointer (SGPRs) + ONE per-lane element offset + a compile-time chunk stride: 64-bit
+// per-chunk addresses of five arrays were 40 of the old kernel's registers.
+OF_DEV void ln_load8(const void* rowp, int is_f32, unsigned eo, float (&v)[8]) {
+    if (is_f32) {
+        const f32x4 a = *(const f32x4*)((const float*)rowp + eo);
+        const f32x4 b = *(const f32x4*)((const float*)rowp + eo + 4);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+        v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    } else {
+        const u32x4 r = *(const u32x4*)((const bf16_t*)rowp + eo);
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) {
-        const int c = lane + j * 64;
-        if (c < nchunk) {
-            wv[j][0] = *(const f32x4*)(a.w + c * 8); wv[j][1] = *(const f32x4*)(a.w + c * 8 + 4);
-            bv[j][0] = *(const f32x4*)(a.b + c * 8); bv[j][1] = *(const f32x4*)(a.b + c * 8 + 4);
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] = of_bf16_to_f32((bf16_t)(r[e] & 0xffff));
+            v[2 * e + 1] = of_bf16_to_f32((bf16_t)(r[e] >> 16));
         }
     }
+}
+OF_DEV void ln_store8(void* rowp, int is_f32, unsigned eo, const float (&v)[8]) {
+    if (is_f32) {
+        *(f32x4*)((float*)rowp + eo) = f32x4{v[0], v[1], v[2], v[3]};
+        *(f32x4*)((float*)rowp + eo + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    } else {
+        u32x4 r = {of_pack_bf16(v[0], v[1]), of_pack_bf16(v[2], v[3]), of_pack_bf16(v[4], v[5]), of_pack_bf16(v[6], v[7])};
+        *(u32x4*)((bf16_t*)rowp + eo) = r;
+    }
+}
+OF_DEV const void* ln_row(const void* base, int is_f32, size_t elem_off) {
+    return of_uniform_ptr((const char*)base + elem_off * (is_f32 ? 4 : 2));
+}
+
+template <int CPL, bool PF>
+OF_GLOBAL void OF_BOUNDS(256, (PF ? (CPL <= 2 ? 6 : CPL <= 4 ? 4 : 2) : (CPL <= 2 ? 8 : CPL <= 4 ? 5 : CPL <= 5 ? 4 : 3))) of_ln_fwd_kernel(LnArgs a) {
+    const int rpw = a.rpw;
+    float* sw = (float*)of_smem();
+    float* sb = sw + a.dim;
+    const int tid = of_tid(), lane = tid & 63, wave = tid >> 6;
+    const unsigned lo = (unsigned)lane * 8, dim = (unsigned)a.dim;
+    const float inv_dim = 1.0f / (float)a.dim;
+    const long row0 = ((long)of_bid_x() * 4 + wave) * rpw;
+    float v[CPL][8];
+    auto load_row = [&](long row, auto& d) {
+        if (row >= a.rows) return;      // wave-uniform
+        const void* xr = ln_row(a.x, a.x_f32, (size_t)row * a.ldx);
+#pragma unroll
+        for (int j = 0; j < CPL; ++j)
+            if (lo + j * 512 < dim) ln_load8(xr, a.x_f32, lo + j * 512, d[j]);
+        if (a.add) {
+            const void* ar = ln_row(a.add, 0, (size_t)row * a.ldadd);
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                if (lo + j * 512 < dim) {
+                    float t[8];
+                    ln_load8(ar, 0, lo + j * 512, t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) d[j][e] += t[e];
+                }
+            }
+        }
+    };
+    load_row(row0, v);
+    for (unsigned c = tid * 4; c < dim; c += 1024) {
+        *(f32x4*)(sw + c) = *(const f32x4*)(a.w + c);
+        *(f32x4*)(sb + c) = *(const f32x4*)(a.b + c);
+    }
+    of_sync();
     for (int rr = 0; rr < rpw; ++rr) {
-        const long row = ((long)of_bid_x() * 4 + wave) * rpw + rr;
-        if (row >= a.rows) return;  // wave-uniform
-        const size_t xo = (size_t)row * a.ldx;
-        float v[CPL][8];
+        const long row = row0 + rr;
+        if (row >= a.rows) return;  // wave-uniform; after the workgroup's only barrier
+        float nx[PF ? CPL : 1][8];
+        if constexpr (PF) {
+            if (rr + 1 < rpw) load_row(row + 1, nx);
+        }
+        if (a.add) {
+            void* sr = (void*)ln_row(a.xsum, a.x_f32, (size_t)row * a.ldsum);
+#pragma unroll
+            for (int j = 0; j < CPL; ++j)
+                if (lo + j * 512 < dim) ln_store8(sr, a.x_f32, lo + j * 512, v[j]);
+        }
         float sum = 0.f;
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
-            const int c = lane + j * 64;
-            if (c < nchunk) {
-                load8(a.x, a.x_f32, xo + c * 8, v[j]);
-                if (a.add) {
-                    float t[8];
-                    load8(a.add, 0, (size_t)row * a.ldadd + c * 8, t);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[j][e] += t[e];
-                    store8(a.xsum, a.x_f32, (size_t)row * a.ldsum + c * 8, v[j]);
-                }
+            if (lo + j * 512 < dim) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) sum += v[j][e];
             }
@@ -103,7 +158,7 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_ln_fwd_kernel(LnArgs a) {
         float sq = 0.f;
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
-            if (lane + j * 64 < nchunk) {
+            if (lo + j * 512 < dim) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) sq += (v[j][e] - mean) * (v[j][e] - mean);
             }
@@ -115,18 +170,30 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_ln_fwd_kernel(LnArgs a) {
         }
         const size_t yo = a.y_grp_rows > 0 ? (size_t)(row / a.y_grp_rows) * a.y_grp_stride + (size_t)(row % a.y_grp_rows) * a.ldy
                                            : (size_t)row * a.ldy;
+        void* yr = (void*)ln_row(a.y, a.y_f32, yo);
+        void* y2r = a.y2 ? (void*)ln_row(a.y2, 0, (size_t)row * a.dim) : nullptr;
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
-            const int c = lane + j * 64;
-            if (c < nchunk) {
+            const unsigned eo = lo + j * 512;
+            if (eo < dim) {
+                const f32x4 w0 = *(const f32x4*)(sw + eo), w1 = *(const f32x4*)(sw + eo + 4);
+                const f32x4 b0 = *(const f32x4*)(sb + eo), b1 = *(const f32x4*)(sb + eo + 4);
                 float o[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    o[e] = (v[j][e] - mean) * rstd * wv[j][0][e] + bv[j][0][e];
-                    o[4 + e] = (v[j][4 + e] - mean) * rstd * wv[j][1][e] + bv[j][1][e];
+                    o[e] = (v[j][e] - mean) * rstd * w0[e] + b0[e];
+                    o[4 + e] = (v[j][4 + e] - mean) * rstd * w1[e] + b1[e];
                 }
-                store8(a.y, a.y_f32, yo + c * 8, o);
-                if (a.y2) store8(a.y2, 0, (size_t)row * a.dim + c * 8, o);
+                ln_store8(yr, a.y_f32, eo, o);
+                if (y2r) ln_store8(y2r, 0, eo, o);
+            }
+        }
+        if constexpr (PF) {
+            if (rr + 1 < rpw) {
+#pragma unroll
+                for (int j = 0; j < CPL; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[j][e] = nx[j][e];
             }
         }
     }
@@ -420,11 +487,17 @@ int pick_rpw(long rows, int cap) {
     return OF_E_SHAPE;
 
 int launch_fwd(LnArgs a, of_stream_t s) {
-    const int rpw = a.rpw = pick_rpw(a.rows, 4);
+    // eight resident waves per SIMD take 8192 rows at once; beyond that a wave walks rpw rows with the next row's loads in flight
+    int rpw = 1;
+    while (rpw < 4 && a.rows > 8192L * rpw) rpw *= 2;
+    a.rpw = rpw;
     const long rows_per_block = 4L * rpw;
     of_dim3 grid{(unsigned)((a.rows + rows_per_block - 1) / rows_per_block), 1, 1};
-    const size_t smem = 0;
-    OF_LN_DISPATCH(of_ln_fwd_kernel)
+    const size_t smem = (size_t)a.dim * 2 * sizeof(float);
+    if (rpw > 1) {
+        OF_LN_DISPATCH(of_ln_fwd_kernel, , true)
+    }
+    OF_LN_DISPATCH(of_ln_fwd_kernel, , false)
 }
 constexpr int WG_ROWS = 16;          // rows per workgroup of of_ln_bwd_wg_kernel
 bool use_wg_bwd(long rows, int dim, bool red) { return red && dim >= 1536 && dim <= 4096 && rows >= 4 * WG_ROWS; }

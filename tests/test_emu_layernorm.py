@@ -57,6 +57,28 @@ def test_layernorm_fwd_bwd(x_f32, rows, dim):
     np.testing.assert_allclose((db - db0).double().numpy(), bd.grad.numpy(), rtol=1e-3, atol=1e-3)
 
 
+def test_layernorm_fwd_many_rows_walks_rows_with_the_next_row_in_flight():
+    """More rows than the chip holds waves (> 8192): a wave walks 2 / 4 consecutive rows with the next row's loads issued before the
+    current row is reduced and stored (of_ln_fwd_kernel<CPL, true>); ragged last wave; fused residual add writing the sum IN PLACE."""
+    ops = H.emu_ops()
+    for rows, dim in ((8192 + 5, 16), (2 * 8192 + 7, 8)):
+        g = torch.Generator().manual_seed(rows)
+        x = torch.randn(rows, dim, generator=g) * 2 + 0.5
+        add = torch.randn(rows, dim, generator=g).to(torch.bfloat16)
+        w, b = 1 + 0.1 * torch.randn(dim, generator=g), 0.1 * torch.randn(dim, generator=g)
+        y, st = torch.zeros(rows, dim, dtype=torch.bfloat16), torch.zeros(rows, 2)
+        ops.ln_fwd(x, w, b, y, st)
+        ref = _ln_ref(x.double(), w.double(), b.double())
+        np.testing.assert_allclose(y.double().numpy(), ref.numpy(), rtol=1e-2, atol=2e-2)
+        xs = x.clone()
+        y2, st2 = torch.zeros(rows, dim, dtype=torch.bfloat16), torch.zeros(rows, 2)
+        ops.ln_fwd_add(xs, add, xs, w, b, y2, st2)
+        want = x + add.float()
+        assert torch.equal(xs, want)
+        np.testing.assert_allclose(y2.double().numpy(), _ln_ref(want.double(), w.double(), b.double()).numpy(), rtol=1e-2, atol=2e-2)
+        np.testing.assert_allclose(st2[:, 0].double().numpy(), want.double().mean(-1).numpy(), rtol=1e-5, atol=1e-6)
+
+
 def test_elementwise_helpers():
     L = H.lib()
     g = torch.Generator().manual_seed(5)
