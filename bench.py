@@ -273,6 +273,10 @@ def main():
                     help="run the step epilogue's streaming passes (global norm, AdamW) as narrow launches on this many CUs (fat "
                          "workgroups, one per CU; identical results) so that the prefetched vision-tower forward on the side stream "
                          "finds whole CUs free; 0 = launches that cover the chip")
+    ap.add_argument("--early-norm", action="store_true",
+                    help="A/B: compute every bucket's share of the global gradient norm on the reducer's side stream as soon as the bucket's "
+                         "gradient is final (behind its all-reduce) instead of in the step epilogue (train/optim.py: early_norm; same bits; "
+                         "measured +0.5 ms per step on one GPU, hence off)")
     ap.add_argument("--no-vision-prefetch", action="store_true",
                     help="run the frozen vision tower at the start of each step (as the reference does) instead of enqueuing the NEXT "
                          "step's tower forward on a side stream next to the step epilogue (train/step.py: next_vision_x)")
@@ -317,6 +321,8 @@ def main():
     opt = step.build_optimizer(model, reducer=None if args.torch_optimizer else reducer)
     if args.optimizer_cus and not args.torch_optimizer:
         opt.narrow_cus = args.optimizer_cus
+    if args.early_norm and not args.torch_optimizer:
+        opt.early_norm = True
     batch = synthetic.make_batch(args.batch, args.T, args.L, info, device, seed=1 + rank)
     laion = synthetic.make_batch(args.laion_batch, 1, 32, info, device, seed=101 + rank) if args.laion_batch > 0 else None
     step_kw = dict(batch_laion=laion, loss_multiplier_laion=0.2) if laion is not None else {}

@@ -59,7 +59,17 @@ class FlatAdamW(torch.optim.Optimizer):
                                  have.get(False, dict(groups[1], betas=tuple(betas), eps=eps))]
         self._sumsq = None
         self._applied = None          # device int32: updates applied so far (NaN-skipped steps do not count)
+        # Early norm partials: a bucket's per-workgroup sums of squares are computed as soon as its gradient is final (GradReducer
+        # calls back on its side stream, right behind the bucket's all-reduce), under the remaining backward, instead of in step():
+        # the same kernel over the same values into the same slots -- the same bits -- and 25 HBM passes less at the serial end.
+        # OFF by default: on one GPU the concurrent passes cost the GEMMs they run next to more than the 1.4 ms they save at the end
+        # (same box, alternating: 109.5 / 109.6 ms per step with it, 109.1 / 109.0 without; profiles/r04p_*) -- like every other
+        # overlap of HBM-bound with MFMA-bound work tried on this chip.  Whether the balance differs when the
+        # step's end also waits for the last all-reduce is a measurement a multi-GPU node has to make: bench.py --early-norm.
+        self._parts = None
+        self.early_norm = False
         self.refresh_bf16()
+        self._parts_for(len(reducer.buckets) + 1)     # allocated here, on the construction stream, not inside a side-stream callback
         model = reducer.module
         for mod in [model.perceiver] + [b for b in model.lang_encoder.gated_cross_attn_layers if b is not None]:
             mod.__dict__["_w_bf16_provider"] = self
@@ -86,6 +96,31 @@ class FlatAdamW(torch.optim.Optimizer):
         if ent is None or ent[1] != p._version or ent[2] != p.numel():
             return None
         return ent[0]
+
+    def _parts_for(self, nbufs):
+        ops = self._ops()
+        need = nbufs * ops.SUMSQ_PARTS
+        if self._parts is None or self._parts.numel() < need:
+            old = self._parts
+            self._parts = torch.empty(need, dtype=F32, device=self.reducer.buckets[0]["flat"].device)
+            if old is not None:
+                self._parts[:old.numel()].copy_(old)
+        return self._parts
+
+    @property
+    def early_norm(self):
+        return self.reducer.on_bucket_final is not None
+
+    @early_norm.setter
+    def early_norm(self, on):          # off: the reducer does not touch its side stream for this at all
+        self.reducer.on_bucket_final = self._early_partial if on else None
+
+    @torch.no_grad()
+    def _early_partial(self, bi):
+        ops, P = self._ops(), self._ops().SUMSQ_PARTS
+        parts = self._parts_for(len(self.reducer.buckets) + 1)
+        ops.sumsq_partial(self.reducer.buckets[bi]["flat"], parts[bi * P:(bi + 1) * P], int(getattr(self, "narrow_cus", 0)))
+        self.reducer.buckets[bi]["early_gen"] = self.reducer.generation
 
     # ------------------------------------------------------------------ optimizer API subset used by train_step
     @torch.no_grad()
@@ -119,8 +154,22 @@ class FlatAdamW(torch.optim.Optimizer):
         # narrow_cus > 0: both streaming passes as narrow launches (that many fat workgroups, one per CU: the same bits) so that
         # work on another stream -- the next step's vision-tower forward, train/step.py -- finds whole CUs free
         nw = int(getattr(self, "narrow_cus", 0))
-        self._parts = ops.sumsq([b["flat"] for b in self.reducer.buckets] + ([g_rows] if g_rows is not None else []),
-                                self._sumsq, getattr(self, "_parts", None), max_workgroups=nw)
+        bufs = [b["flat"] for b in self.reducer.buckets] + ([g_rows] if g_rows is not None else [])
+        P = ops.SUMSQ_PARTS
+        parts = self._parts_for(len(self.reducer.buckets) + 1)
+        side = getattr(self.reducer, "_stream", None)
+        gen = self.reducer.generation
+        early = [i for i, b in enumerate(self.reducer.buckets) if b.get("early_gen") == gen and self.early_norm]
+        if early and side is not None:               # GradReducer.finish() has already made this stream wait; a caller that skipped it must not race
+            torch.cuda.current_stream(dev).wait_stream(side)
+        for i, g in enumerate(bufs):
+            if i in early:
+                continue                             # this step's partial sums of the bucket are in their slots already
+            ops.sumsq_partial(g, parts[i * P:(i + 1) * P], nw)
+        for b in self.reducer.buckets:
+            b["early_gen"] = None
+        self.early_partials_used = len(early)        # (tests, tools)
+        ops.sumsq_finish(parts[:len(bufs) * P], self._sumsq)
         # Adam's step = the number of updates actually APPLIED, counted on the device: a step skipped for a non-finite norm
         # (the reference `continue`s before optimizer.step(), train_utils.py:161-169) does not advance the bias correction.
         # (step_count, the host's count of step() calls, only seeds the counter and names checkpoints' "step" after a sync.)

@@ -51,6 +51,13 @@ class GradReducer:
         self._sync = True
         self._pending = []
         self._stream = None
+        # on_bucket_final(bucket_index): set by the fused step epilogue (train/optim.py).  Called once per bucket and optimizer step,
+        # on the stream on which the bucket's FINAL values (all-reduced, or complete on one GPU) are ordered -- the side stream -- so
+        # that the bucket's share of the global gradient norm is computed under the rest of the backward instead of at the serial end
+        # of the step.  The callback's result is valid while bucket["early_gen"] == self.generation: ``generation`` counts zero_grad()
+        # calls, and any later gradient write into the bucket (a parameter hook) resets early_gen.
+        self.on_bucket_final = None
+        self.generation = 0
         self.stats = dict(collectives=0, bytes=0, steps=0)
         self.time_waits, self._wait_events = False, []
         lm = model.lang_encoder
@@ -140,9 +147,10 @@ class GradReducer:
         return self._stream
 
     def _launch(self, flat):
-        """all-reduce(avg) of one flat buffer on the side stream (or inline on CPU/gloo)."""
+        """all-reduce(avg) of one flat buffer on the side stream (or inline on CPU/gloo).  Returns the collective's work handle when
+        the reduced values land in ``flat`` itself (None: no collective, or a wire copy that finish() writes back)."""
         if self.world == 1 and not self.force_collectives:
-            return
+            return None
         side = self._side_stream(flat.device)
         if self.reserve_cus > 0 and side is not None:          # GEMMs enqueued from here on count on the CUs RCCL leaves
             from ..hip.ops import Ops
@@ -163,25 +171,49 @@ class GradReducer:
                     wire.record_stream(compute)      # allocated on the side stream, read back on the compute stream in finish()
                 work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 self._pending.append((work, flat, wire))
-            else:
-                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                self._pending.append((work, flat, None))
+                return None
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._pending.append((work, flat, None))
+            return work
+
+    def _bucket_final(self, bi, work):
+        """The bucket's final values exist (after ``work``, if there was a collective): let the step epilogue take its share of the
+        global norm now, on the side stream, under the rest of the backward (on_bucket_final, see __init__)."""
+        early = self.on_bucket_final
+        collective = self.world > 1 or self.force_collectives
+        if early is None or (collective and work is None):       # wire copy: the reduced values reach the bucket in finish()
+            return
+        flat = self.buckets[bi]["flat"]
+        side = self._side_stream(flat.device)
+        if side is None:                                         # CPU / gloo: inline
+            if work is not None:
+                work.wait()
+            early(bi)
+            return
+        if work is None:
+            side.wait_stream(torch.cuda.current_stream(flat.device))
+        with torch.cuda.stream(side):
+            if work is not None:
+                work.wait()          # orders the side stream behind the collective (a stream wait with RCCL, no host block)
+            early(bi)
 
     def _hook_inplace(self, p):
         """Called by the libofhip backward for a parameter whose gradient it accumulated in place.  torch's engine still
         runs the parameter's post-accumulate hook afterwards although the Function returned None for it (observed on
         torch 2.10: 91 + 91 calls for 91 parameters) -- counted twice, a bucket would be exchanged when only half of its
         gradients exist, and once more at the end.  The mark makes the engine's call for the same backward a no-op."""
+        self.buckets[self._param_bucket[p]]["early_gen"] = None      # the bucket changed: an earlier partial norm of it is void
         if not self._sync:
             return
         p._of_notified = True
         self._count(p)
 
     def _hook(self, p):
-        if not self._sync:
-            return
-        if getattr(p, "_of_notified", False):       # already counted by _hook_inplace in this backward
+        if self._sync and getattr(p, "_of_notified", False):       # already counted by _hook_inplace in this backward
             p._of_notified = False
+            return
+        self.buckets[self._param_bucket[p]]["early_gen"] = None
+        if not self._sync:
             return
         self._count(p)
 
@@ -190,7 +222,7 @@ class GradReducer:
         b["ready"] += 1
         if b["ready"] == len(b["params"]):
             b["ready"] = 0
-            self._launch(b["flat"])
+            self._bucket_final(self._param_bucket[p], self._launch(b["flat"]))
 
     def _sparse_hook(self, leaf):
         if self._sync:
@@ -236,6 +268,9 @@ class GradReducer:
                 flat.copy_(wire)
             if self.world > 1 and average:
                 flat.div_(self.world)
+        if self.world > 1 and average:
+            for b in self.buckets:
+                b["early_gen"] = None            # the buckets were rescaled after their partial norms were taken
         self._pending.clear()
         for b in self.buckets:                       # a torch build whose engine skips the hook of a None gradient
             for p in b["params"]:                    # would leave the marks set: never carry them into the next step
@@ -276,6 +311,7 @@ class GradReducer:
     def zero_grad(self, flat_already_zero=False):
         """Zero in place (the .grad views must stay attached to the buckets).  ``flat_already_zero``: the fused step
         epilogue (train/optim.py) cleared the buckets in its AdamW pass."""
+        self.generation += 1
         for b in self.buckets:
             if not flat_already_zero:
                 b["flat"].zero_()

@@ -229,6 +229,52 @@ def test_step_epilogue_leaves_weight_gradients_for_the_backward_to_overwrite(on_
         assert torch.allclose(opt._moments_of(p)[0], 0.9 * m0, rtol=1e-5, atol=1e-12)
 
 
+def test_early_norm_partials_change_no_bit_and_are_voided_by_later_gradient_writes(on_emulator):
+    """A bucket's share of the global gradient norm is computed when its gradient becomes final (the reducer's callback), not in
+    step(): same kernel, same values, same slots -- the slots hold exactly what the late form computes from the finished buckets.
+    A gradient written into a bucket AFTER its partial sums were taken (a second backward before the step, with or without
+    no_sync) voids them: step() recomputes.  (Parameters of two separate runs are not compared bit for bit here: the emulator's
+    workgroups run on parallel host threads and the LayerNorm column sums add in arrival order.)"""
+    ops = H.emu_ops()
+    P = ops.SUMSQ_PARTS
+    for early in (True, False):
+        model, info = _tiny()
+        red = GradReducer(model, embedding_rows=[info["media_token_id"], info["eoc_token_id"]])
+        opt = FlatAdamW(red, lr=1e-3, ops=ops)
+        opt.early_norm = early
+        b1 = synthetic.make_batch(2, 1, 16, info, "cpu", seed=6, image_size=56)
+        b2 = synthetic.make_batch(2, 2, 24, info, "cpu", seed=5, image_size=56)
+        used = []
+        for _ in range(2):
+            step.train_step(model, red, opt, b2, info, amp=False)
+            used.append(opt.early_partials_used)
+        assert used == ([len(red.buckets)] * 2 if early else [0, 0])
+        # the slots against the late form, on the finished buckets of a third backward
+        step.forward_loss(model, b1, info, amp=False).backward()
+        red.finish(average=False)
+        if early:
+            assert all(b["early_gen"] == red.generation for b in red.buckets)
+            for i, b in enumerate(red.buckets):
+                late = torch.empty(P)
+                ops.sumsq_partial(b["flat"], late)
+                assert torch.equal(late, opt._parts[i * P:(i + 1) * P]), i
+        # a second synchronised backward recomputes; one under no_sync after it voids: step() computes every share itself
+        step.forward_loss(model, b2, info, amp=False).backward()
+        if early:
+            assert all(b["early_gen"] == red.generation for b in red.buckets)
+        with red.no_sync():
+            step.forward_loss(model, b1, info, amp=False).backward()
+        assert all(b.get("early_gen") is None for b in red.buckets)
+        red.finish(average=False)
+        want = torch.zeros(1)
+        ops.sumsq([b["flat"] for b in red.buckets] + [model.lang_encoder.get_input_embeddings().weight.grad.index_select(
+            0, torch.as_tensor([info["media_token_id"], info["eoc_token_id"]])).contiguous()], want)
+        opt.step()
+        assert opt.early_partials_used == 0
+        assert torch.equal(opt._sumsq, want)
+        red.zero_grad(flat_already_zero=True)
+
+
 def test_nan_loss_skips_the_step_on_the_device(on_emulator, monkeypatch):
     """train_step(nan_check="device"): no host-side isnan; a NaN loss makes every gradient NaN, the fused step epilogue sees a
     non-finite global norm and leaves every trainable parameter (and AdamW moment) as it was -- the reference's skip

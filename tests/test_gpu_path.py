@@ -784,10 +784,25 @@ def _rccl_rank(rank, world, port, q, same_device=False):
     red.broadcast_parameters()
     red.time_waits = True
     opt = step.build_optimizer(model, lr=1e-3, reducer=red)
+    opt.early_norm = True            # opt-in (train/optim.py): exercised here behind real collectives
     batch = synthetic.make_batch(2, 2, 24, info, dev, seed=5 + rank)
     # (next_vision_x: the vision-tower prefetch on its side stream next to the collectives, as bench.py runs the step)
     losses = [float(step.train_step(model, red, opt, batch, info, next_vision_x=batch["vision_x"])) for _ in range(3)]
     stats = red.overlap_stats()
+    # early norm partials (train/optim.py): every bucket's share was taken on the side stream behind its all-reduce, and holds
+    # the bits the late form computes from the finished buckets
+    stats["early_partials_used"] = getattr(opt, "early_partials_used", None)
+    step.forward_loss(model, batch, info).backward()
+    red.finish(average=False)
+    ops, P = opt._ops(), opt._ops().SUMSQ_PARTS
+    late = torch.empty(len(red.buckets) * P, device=dev)
+    for i, b in enumerate(red.buckets):
+        ops.sumsq_partial(b["flat"], late[i * P:(i + 1) * P])
+    torch.cuda.synchronize()
+    stats["early_slots_equal"] = (all(b.get("early_gen") == red.generation for b in red.buckets)
+                                  and torch.equal(late, opt._parts[:late.numel()]))
+    stats["buckets"] = len(red.buckets)
+    red.zero_grad()
     chk = torch.cat([p.detach().flatten()[:256].float() for p in model.parameters() if p.requires_grad]).double()
     gathered = [torch.zeros_like(chk) for _ in range(world)]
     dist.all_gather(gathered, chk)
@@ -850,6 +865,7 @@ def test_two_rank_rccl_train_step_on_one_gpu_over_loopback():
         assert same, f"rank {rank}: replicas diverged"
         assert all(l == l for l in losses)
         assert stats["collectives_per_step"] >= 3 and stats["exposed_wait_ms_per_step"] is not None
+        assert stats["early_partials_used"] == stats["buckets"] and stats["early_slots_equal"], stats
     assert res[0][1] != res[1][1], "the ranks trained on different batches"
 
 
@@ -988,3 +1004,48 @@ def test_vision_prefetch_on_a_side_stream_changes_no_bit():
     for k in p0:          # GEMM-made gradients are deterministic (fixed-order reductions)
         if "latents" not in k and "embs" not in k:
             assert torch.equal(p1[k], p0[k]), k
+
+
+def test_early_norm_partials_on_the_side_stream_change_no_bit():
+    """One GPU, no collective: each bucket's share of the global gradient norm is taken on the reducer's side stream as soon as the
+    bucket is complete (under the rest of the backward), not in the step epilogue.  The slots hold the bits of the late form, every
+    bucket is served early, and two steps with and without it end in bit-identical weight matrices."""
+    from open_flamingo_amd.train import sparse_rows, step, synthetic, towers
+    from open_flamingo_amd.train.reducer import GradReducer
+
+    def run(early):
+        model, info = towers.build_flamingo("OF-tiny", device="cuda", seed=0, gates=0.5, frozen_bf16=True, fused_lm_attention="libofhip",
+                                            tower_layernorm="libofhip", lm_loss="libofhip", fused_lm_blocks=True, fused_vision="libofhip")
+        model.train()
+        rows = [info["media_token_id"], info["eoc_token_id"]]
+        sparse_rows.enable(model, rows)
+        red = GradReducer(model, embedding_rows=rows)
+        opt = step.build_optimizer(model, lr=1e-3, reducer=red)
+        opt.early_norm = early
+        batch = synthetic.make_batch(2, 2, 24, info, "cuda", seed=5)
+        losses = [float(step.train_step(model, red, opt, batch, info, nan_check="device"))]
+        used = opt.early_partials_used
+        norm = float(opt.grad_norm())
+        mats = {k: p.detach().clone() for k, p in model.named_parameters() if p.requires_grad and p.dim() == 2 and "latents" not in k and "embs" not in k}
+        step.forward_loss(model, batch, info).backward()
+        red.finish(average=False)
+        ops, P = opt._ops(), opt._ops().SUMSQ_PARTS
+        late = torch.empty(len(red.buckets) * P, device="cuda")
+        for i, b in enumerate(red.buckets):
+            ops.sumsq_partial(b["flat"], late[i * P:(i + 1) * P])
+        torch.cuda.synchronize()
+        slots = torch.equal(late, opt._parts[:late.numel()]) if early else None
+        return losses, used, norm, mats, slots, len(red.buckets)
+
+    l1, used1, n1, m1, slots1, nb = run(True)
+    l0, used0, n0, m0, _, _ = run(False)
+    assert used1 == nb and used0 == 0 and slots1
+    assert l1 == l0
+    # GEMM-made gradients are deterministic; the clip coefficient enters every update.  (Two RUNS can differ by an ulp of the norm with
+    # or without this feature: below dim 1536 the LayerNorm backward sums dw / db with LDS atomics.  Then the matrices differ by ulps.)
+    assert abs(n1 - n0) <= 1e-6 * n0
+    for k in m0:
+        if n1 == n0:
+            assert torch.equal(m1[k], m0[k]), k
+        else:
+            assert torch.allclose(m1[k], m0[k], rtol=1e-5, atol=1e-7), k
