@@ -437,6 +437,9 @@ def main():
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "bf16", "data": "synthetic",
+               # the training loss of the last timed step (read after the timed region): a run whose arithmetic broke -- NaN or garbage
+               # activations draw less power and time FASTER on this chip -- shows here (a same-box A/B of round 4 was void for that reason)
+               "loss_last_step": round(float(loss), 4) if loss is not None else None,
                "config": {"baseline_config": cfg_name,
                           "workload": f"{args.family} (ViT-L/14 + {'MPT-1B' if args.family == 'OF-3B' else args.family}, "
                                       f"xattn_every={info['every']}) full train step, amp_bf16, per-GPU B={args.batch} "
