@@ -237,42 +237,37 @@ def test_early_norm_partials_change_no_bit_and_are_voided_by_later_gradient_writ
     workgroups run on parallel host threads and the LayerNorm column sums add in arrival order.)"""
     ops = H.emu_ops()
     P = ops.SUMSQ_PARTS
-    for early in (True, False):
-        model, info = _tiny()
-        red = GradReducer(model, embedding_rows=[info["media_token_id"], info["eoc_token_id"]])
-        opt = FlatAdamW(red, lr=1e-3, ops=ops)
-        opt.early_norm = early
-        b1 = synthetic.make_batch(2, 1, 16, info, "cpu", seed=6, image_size=56)
-        b2 = synthetic.make_batch(2, 2, 24, info, "cpu", seed=5, image_size=56)
-        used = []
-        for _ in range(2):
-            step.train_step(model, red, opt, b2, info, amp=False)
-            used.append(opt.early_partials_used)
-        assert used == ([len(red.buckets)] * 2 if early else [0, 0])
-        # the slots against the late form, on the finished buckets of a third backward
-        step.forward_loss(model, b1, info, amp=False).backward()
-        red.finish(average=False)
-        if early:
-            assert all(b["early_gen"] == red.generation for b in red.buckets)
-            for i, b in enumerate(red.buckets):
-                late = torch.empty(P)
-                ops.sumsq_partial(b["flat"], late)
-                assert torch.equal(late, opt._parts[i * P:(i + 1) * P]), i
-        # a second synchronised backward recomputes; one under no_sync after it voids: step() computes every share itself
+    model, info = _tiny()
+    red = GradReducer(model, embedding_rows=[info["media_token_id"], info["eoc_token_id"]])
+    opt = FlatAdamW(red, lr=1e-3, ops=ops)
+    assert not opt.early_norm                   # opt-in (measured +0.5 ms per step on one GPU)
+    opt.early_norm = True
+    b1 = synthetic.make_batch(2, 1, 16, info, "cpu", seed=6, image_size=56)
+    b2 = synthetic.make_batch(2, 2, 24, info, "cpu", seed=5, image_size=56)
+    step.train_step(model, red, opt, b2, info, amp=False)
+    assert opt.early_partials_used == len(red.buckets)
+    # the slots against the late form, on the finished buckets of another backward
+    step.forward_loss(model, b1, info, amp=False).backward()
+    red.finish(average=False)
+    assert all(b["early_gen"] == red.generation for b in red.buckets)
+    for i, b in enumerate(red.buckets):
+        late = torch.empty(P)
+        ops.sumsq_partial(b["flat"], late)
+        assert torch.equal(late, opt._parts[i * P:(i + 1) * P]), i
+    # one more backward under no_sync voids them: step() computes every share itself
+    with red.no_sync():
         step.forward_loss(model, b2, info, amp=False).backward()
-        if early:
-            assert all(b["early_gen"] == red.generation for b in red.buckets)
-        with red.no_sync():
-            step.forward_loss(model, b1, info, amp=False).backward()
-        assert all(b.get("early_gen") is None for b in red.buckets)
-        red.finish(average=False)
-        want = torch.zeros(1)
-        ops.sumsq([b["flat"] for b in red.buckets] + [model.lang_encoder.get_input_embeddings().weight.grad.index_select(
-            0, torch.as_tensor([info["media_token_id"], info["eoc_token_id"]])).contiguous()], want)
-        opt.step()
-        assert opt.early_partials_used == 0
-        assert torch.equal(opt._sumsq, want)
-        red.zero_grad(flat_already_zero=True)
+    assert all(b.get("early_gen") is None for b in red.buckets)
+    red.finish(average=False)
+    want = torch.zeros(1)
+    ops.sumsq([b["flat"] for b in red.buckets] + [model.lang_encoder.get_input_embeddings().weight.grad.index_select(
+        0, torch.as_tensor([info["media_token_id"], info["eoc_token_id"]])).contiguous()], want)
+    opt.step()
+    assert opt.early_partials_used == 0
+    assert torch.equal(opt._sumsq, want)
+    red.zero_grad(flat_already_zero=True)
+    opt.early_norm = False                      # off again: the reducer's callback is gone
+    assert red.on_bucket_final is None
 
 
 def test_nan_loss_skips_the_step_on_the_device(on_emulator, monkeypatch):
