@@ -1,5 +1,8 @@
-"""Which host-side call sites produce the eager glue kernels (copies, fills, casts) of a train step?  torch.profiler over two
-steps, grouped by operator + python stack.  PROFILING TOOL."""
+"""Call sites of the small eager kernels of a train step (fills, dtype copies): torch.profiler events of two steps, grouped by operator,
+input shapes and (where the profiler recorded one) the innermost non-torch Python frames.  Only operators launched INSIDE train_step
+are counted -- a rocprofv3 kernel table of a whole bench.py run also holds the model's random initialisation, the reference-eager leg and
+the GEMM report's buffers.  PROFILING TOOL."""
+import collections
 import os
 import sys
 
@@ -10,37 +13,37 @@ from torch.profiler import ProfilerActivity, profile
 from open_flamingo_amd.train import sparse_rows, step, synthetic, towers
 from open_flamingo_amd.train.reducer import GradReducer
 
-
-def main():
-    fam = sys.argv[1] if len(sys.argv) > 1 else "OF-3B"
-    model, info = towers.build_flamingo(fam, device="cuda", seed=0, gates=0.5, frozen_bf16=True, fused_lm_attention="libofhip",
-                                        tower_layernorm="libofhip", lm_loss="libofhip", fused_lm_blocks=True, fused_vision="libofhip")
-    model.train()
-    towers.use_tuned_vendor_gemms()
-    sparse_rows.enable(model, [info["media_token_id"], info["eoc_token_id"]])
-    red = GradReducer(model, embedding_rows=[info["media_token_id"], info["eoc_token_id"]])
-    opt = step.build_optimizer(model, reducer=red)
-    batch = synthetic.make_batch(32, 2, 256, info, "cuda", seed=1)
+model, info = towers.build_flamingo("OF-3B", device="cuda", seed=0, gates=0.5, frozen_bf16=True, fused_lm_attention="libofhip",
+                                    tower_layernorm="libofhip", lm_loss="libofhip", fused_lm_blocks=True, fused_vision="libofhip")
+model.train()
+towers.use_tuned_vendor_gemms()
+rows = [info["media_token_id"], info["eoc_token_id"]]
+sparse_rows.enable(model, rows)
+red = GradReducer(model, embedding_rows=rows)
+opt = step.build_optimizer(model, reducer=red)
+batch = synthetic.make_batch(32, 2, 256, info, "cuda", seed=1)
+kw = dict(nan_check="device", next_vision_x=batch["vision_x"])
+for _ in range(3):
+    step.train_step(model, red, opt, batch, info, **kw)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     for _ in range(2):
-        step.train_step(model, red, opt, batch, info, nan_check="device")
+        step.train_step(model, red, opt, batch, info, **kw)
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-        for _ in range(2):
-            step.train_step(model, red, opt, batch, info, nan_check="device")
-        torch.cuda.synchronize()
-    rows = []
-    for e in prof.key_averages(group_by_stack_n=6):
-        dev = getattr(e, "device_time_total", 0) or getattr(e, "cuda_time_total", 0)
-        if dev > 0 and e.key.startswith("aten::") and not any(k in e.key for k in ("mm", "addmm", "matmul", "linear")):
-            stack = [s for s in e.stack if "open_flamingo_amd" in s or "transformers" in s][:3]
-            rows.append((dev / 2e3, e.count // 2, e.key, " <- ".join(s.split("/")[-1] for s in stack)))
-    rows.sort(reverse=True)
-    tot = 0
-    for ms, n, key, stack in rows[:40]:
-        tot += ms
-        print(f"{ms:7.3f} ms/step {n:5d}x {key:28s} {stack[:200]}")
-    print("listed total", round(tot, 2), "ms/step")
-
-
-if __name__ == "__main__":
-    main()
+agg = collections.defaultdict(lambda: [0.0, 0])
+for e in prof.events():
+    if not e.name.startswith("aten::") or e.name in ("aten::mm", "aten::addmm", "aten::matmul", "aten::linear"):
+        continue
+    dev = getattr(e, "self_device_time_total", 0)
+    if dev <= 0:
+        continue
+    frames = [f for f in (e.stack or []) if "site-packages/torch" not in f and "dist-packages/torch" not in f and "<built-in" not in f]
+    where = " <- ".join(f.split("/")[-1][:70] for f in frames[:3]) or "-"
+    key = (e.name, str(e.input_shapes)[:80], where)
+    agg[key][0] += dev / 2e3
+    agg[key][1] += 1
+tot = 0.0
+for (name, shapes, where), (ms, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:45]:
+    tot += ms
+    print(f"{ms:7.3f} ms/step {n // 2:4d}x {name:24s} {shapes:80s} {where}")
+print("listed total", round(tot, 2), "ms/step")
