@@ -399,9 +399,10 @@ def main():
         key = max(groups, key=lambda k: groups[k][1])
         fl, ms, n = groups[key]
         sym = {"w4m256": "of_gemm_w4m_kernel", "w4dma256": "of_gemm_w4_kernel", "pingpong256": "of_gemm_pp_kernel", "mid128": "of_gemm_mid_kernel",
-               "general128": "of_gemm_kernel", "skinny": "of_gemm_skinny_kernel", "mid128batch": "of_gemm_mid_batch_kernel"}[key[3]]
+               "general128": "of_gemm_kernel", "skinny": "of_gemm_skinny_kernel", "mid128batch": "of_gemm_mid_batch_kernel",
+               "w4h256x128": "of_gemm_w4h_kernel"}[key[3]]
         sym += f"<{str(bool(key[0])).lower()}, {str(bool(key[1])).lower()}, {key[2]}" + (
-            ", false>" if key[3] == "w4m256" else ">" if key[3] in ("mid128", "mid128batch") else ", ...>")       # w4m256: <AT, BT, EPI, SK = false> (one tile per workgroup)
+            ", false>" if key[3] == "w4m256" else ">" if key[3] in ("mid128", "mid128batch") else ", 0>" if key[3] == "w4h256x128" else ", ...>")       # w4m256: <AT, BT, EPI, SK = false> (one tile per workgroup)
         shapes = {}
         for k2, _, shape, _, _ in timing:
             if k2 == key:

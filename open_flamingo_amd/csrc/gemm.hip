@@ -462,7 +462,11 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
         const int rc = of_gemm_w4m_try(w, s);
         if (rc != OF_E_SHAPE) return rc;
     }
-    if (a.safe >= 18) return OF_E_ARG;
+    if (a.safe == 18) {                            // force the two-workgroups-per-CU 256x128 kernel (gemm_w4h.hip)
+        const int rc = of_gemm_w4h_try(a, s);
+        if (rc != OF_E_SHAPE) return rc;
+    }
+    if (a.safe >= 19) return OF_E_ARG;
     const bool pp_forced = a.safe == 4;
     // Big-tile selection (measured on MI355X, random operands, same box): every layout -> the 4-wave LDS-DMA kernel ON 16x16x32
     // MFMAs (gemm_w4m.hip).  With every CU busy the K loop is bound by the chip's power budget and the 16x16x32 shape spends
@@ -472,6 +476,14 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
     // layouts with a K-strided operand to the ping-pong kernel because the 4-wave DMA schedule lost 15-25 % there -- that was
     // hipcc draining the DMA ring in front of every transposed-fragment read (of_platform.h).
     if (a.safe == 0 && pp_ok) {
+        // *_DOT epilogues (aux tile + erf-GELU derivative + gate-gradient dot: 10-17 us of VALU / LDS issue per 256x256 tile behind a
+        // K loop of 32 stages) over >= 4 rounds of big tiles: two workgroups per CU on 256x128 tiles (gemm_w4h.hip) -- one runs its
+        // epilogue under the other one's K loop.  Same box, interleaved, four boxes: NN 8192 x 8192 x 2048 DGELU_DOT -2.4..-3.6 %,
+        // SCALE_DOT -3.8..-4.8 %, bit-identical outputs; the plain-store and GELU launches do NOT gain (a K loop alone on a CU runs at
+        // 68 % of the MFMA rate there, and the erf-GELU epilogue takes the K loop's issue slots) and stay on the 256x256 kernel
+        // (profiles/r05a..d_w4h_probe.jsonl).  K = 4096 (OF-9B): +-2 % -> the 256x256 kernel (profiles/r05e_w4h_family_probe.jsonl).
+        if ((a.epi == OF_EPI_DGELU_DOT || a.epi == OF_EPI_SCALE_DOT) && tiles256 >= 1024 && a.K <= 3072 && a.cu_limit <= 0 && of_gemm_w4h_eligible(a))
+            return of_gemm_w4h_try(a, s);
         // Stream-K first: a tile count the workgroup count does not divide is shared out evenly (needs the workspace; without
         // it the N-split / partial-round forms below).
         const int G = sk_grid_for(a, tiles256);

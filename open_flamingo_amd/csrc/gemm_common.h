@@ -408,6 +408,9 @@ bool of_gemm_mid_eligible(const OfGemmArgs& a);     // what of_gemm_mid_try woul
 int of_gemm_w4m_try(const OfGemmArgs& a, of_stream_t s);
 bool of_gemm_w4m_eligible(const OfGemmArgs& a);
 size_t of_gemm_w4m_sk_bytes(const OfGemmArgs& a, int grid);      // workspace of a stream-K launch over `grid` workgroups (0: none needed)
+// implemented in gemm_w4h.hip: 256x128 tile, 4 waves x (128x64), two workgroups per CU (a tile's epilogue under the other's K loop)
+int of_gemm_w4h_try(const OfGemmArgs& a, of_stream_t s);
+bool of_gemm_w4h_eligible(const OfGemmArgs& a);
 // implemented in gemm_skinny.hip: M <= 16 rows (decode step), HBM-bound weight streaming; OF_E_SHAPE when not eligible
 int of_gemm_skinny_try(const OfGemmArgs& a, of_stream_t s);
 inline bool of_gemm_is_skinny(const OfGemmArgs& a) {

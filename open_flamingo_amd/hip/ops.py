@@ -61,12 +61,15 @@ class Ops:
 
     # ------------------------------------------------------------------ GEMM
     @staticmethod
-    def kernel_label(M, N, K, ta, tb):
+    def kernel_label(M, N, K, ta, tb, epi=None, cu_limit=0):
         """Mirror of of_gemm's kernel selection (csrc/gemm.hip): which HIP kernel a launch ends up in -- only used to label
         timing records (bench.py's roofline names ONE kernel so that it can be checked against rocprofv3)."""
         if M <= 16 and not ta and not tb:
             return "skinny"
         if M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and (M // 256) * (N // 256) >= 128:
+            if (epi in (abi.EPI_DGELU_DOT, abi.EPI_SCALE_DOT) and not ta and tb and (M // 256) * (N // 256) >= 1024 and K <= 3072
+                    and cu_limit <= 0):
+                return "w4h256x128"       # two workgroups per CU (csrc/gemm_w4h.hip)
             return "w4m256"
         if M % 128 == 0 and N % 128 == 0 and K % 64 == 0:
             return "mid128"
@@ -121,7 +124,7 @@ class Ops:
                     self._gemm_ws = ws
                 a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
         if self.gemm_timing is not None:
-            key = (int(ta), int(tb), epi, self.kernel_label(M, N, K, ta, tb))
+            key = (int(ta), int(tb), epi, self.kernel_label(M, N, K, ta, tb, epi, self.cu_limit))
             if self.gemm_timing_only is None or key in self.gemm_timing_only:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()

@@ -510,3 +510,104 @@ def test_gemm_batch_of_weight_gradients_equals_the_separate_launches():
     cb, cs = torch.zeros(4096, 8192), torch.zeros(inner, d)
     ops.gemm_batch_dw([(Abig, Bbig, cb, 0.0, None), (dq, xn, cs, 0.0, None)])
     assert torch.equal(cs, want[0] * 0 + got[0]) and torch.allclose(cb.double(), _ref(Abig, Bbig, 1, 1), rtol=1e-5, atol=2e-4)
+
+
+# ---- the two-workgroups-per-CU 256 x 128 kernel (gemm_w4h.hip; OfGemmArgs.safe = 18 forces it) ----------------------------------
+@pytest.mark.parametrize("bt", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (256, 128, 128), (256, 256, 192), (512, 128, 256), (256, 384, 320), (256, 128, 448),
+                                   (256, 128, 704)])
+def test_half_tile_kernel_matches_the_big_tile_and_general_kernels(bt, M, N, K):
+    """Ring of five 16-KiB units, a stage = three of them (B, A rows 0-63, A rows 64-127 of both wave rows): K = 64 ... 704 = 1 ... 11
+    stages -- prologue only, each tail form, the steady state, and the unit -> slot map wrapped twice (period: 5 stages).  fp32
+    accumulation in the big-tile kernel's order: equal to the general kernel up to summation order inside a stage, and BIT-EQUAL to
+    the 256 x 256 kernel on 16x16x32 MFMAs (safe = 16) where that one takes the shape."""
+    A = _rand((M, K), 81)
+    B = _rand((K, N) if bt else (N, K), 82)
+    ref = _ref(A, B, 0, bt)
+    o_h, o_gen = torch.zeros(M, N), torch.zeros(M, N)
+    H.gemm(A, B, b_trans=bt, epi=abi.EPI_ACC_F32, C_out=o_h, safe=18)
+    H.gemm(A, B, b_trans=bt, epi=abi.EPI_ACC_F32, C_out=o_gen, safe=2)
+    np.testing.assert_allclose(o_h.double().numpy(), ref.numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(o_h.numpy(), o_gen.numpy(), rtol=1e-6, atol=1e-5)
+    if N % 256 == 0:
+        o_big = torch.zeros(M, N)
+        H.gemm(A, B, b_trans=bt, epi=abi.EPI_ACC_F32, C_out=o_big, safe=16)
+        assert torch.equal(o_h, o_big)
+    ob = torch.zeros(M, N, dtype=torch.bfloat16)
+    H.gemm(A, B, b_trans=bt, epi=abi.EPI_STORE_BF16, C_out=ob, alpha=0.5, safe=18)
+    np.testing.assert_allclose(ob.double().numpy(), 0.5 * ref.numpy(), rtol=1e-2, atol=2e-2)
+
+
+def test_half_tile_kernel_strided_operands_and_tile_order():
+    """Leading dimensions larger than the extents (views into wider buffers) and a grid of 4 x 3 tiles through the XCD-aware order."""
+    M, N, K = 1024, 384, 128
+    Aw, Bw, Cw = _rand((M, K + 64), 83), _rand((N, K + 128), 84), torch.zeros(M, N + 32)
+    A, B, C = Aw[:, 64:], Bw[:, 128:], Cw[:, 32:]
+    H.gemm(A, B, epi=abi.EPI_ACC_F32, C_out=C, safe=18)
+    np.testing.assert_allclose(C.double().numpy(), _ref(A, B, 0, 0).numpy(), rtol=1e-5, atol=1e-4)
+    assert float(Cw[:, :32].abs().max()) == 0.0
+    Wt = _rand((K, N + 256), 85)
+    W = Wt[:, 128:128 + N]
+    C2 = torch.zeros(M, N)
+    H.gemm(A, W, b_trans=1, epi=abi.EPI_ACC_F32, C_out=C2, safe=18)
+    np.testing.assert_allclose(C2.double().numpy(), (A.double() @ W.double()).numpy(), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (512, 256, 384)])
+def test_half_tile_kernel_epilogues(M, N, K):
+    """Every fused epilogue of the half-tile kernel: four 32 x 64 groups per wave through the LDS patch, aux tiles of the *_DOT
+    forms by LDS-DMA two groups deep, one gate-gradient partial per tile (deterministic), bit-equal to the 256 x 256 kernel's."""
+    A, B = _rand((M, K), 86), _rand((N, K), 87) * 0.1
+    acc = _ref(A, B, 0, 0)
+    gate = torch.tensor([0.37])
+    g = float(torch.tanh(gate))
+    kw = dict(safe=18)
+    big = N % 256 == 0
+    b_out, a_out = torch.zeros(M, N, dtype=torch.bfloat16), torch.zeros(M, N, dtype=torch.bfloat16)
+    H.gemm(A, B, epi=abi.EPI_GELU, C_out=b_out, C2=a_out, **kw)
+    np.testing.assert_allclose(a_out.double().numpy(), acc.numpy(), rtol=1e-2, atol=1e-2)
+    np.testing.assert_allclose(b_out.double().numpy(), torch.nn.functional.gelu(acc).numpy(), rtol=1e-2, atol=1e-2)
+    if big:
+        b16, a16 = torch.zeros(M, N, dtype=torch.bfloat16), torch.zeros(M, N, dtype=torch.bfloat16)
+        H.gemm(A, B, epi=abi.EPI_GELU, C_out=b16, C2=a16, safe=16)
+        assert torch.equal(b16, b_out) and torch.equal(a16, a_out)
+    b_only = torch.zeros(M, N, dtype=torch.bfloat16)
+    H.gemm(A, B, epi=abi.EPI_GELU, C_out=b_only, **kw)          # no pre-activation output
+    assert torch.equal(b_only, b_out)
+    res = torch.randn(M, N)
+    out = torch.zeros(M, N)
+    H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=out, aux=res, gate=gate, io_f32=1, **kw)
+    np.testing.assert_allclose(out.double().numpy(), (res.double() + g * acc).numpy(), rtol=1e-5, atol=1e-4)
+    y = res.clone()
+    H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=y, aux=y, gate=gate, io_f32=1, **kw)          # in place
+    assert torch.equal(y, out)
+    resb, outb = res.to(torch.bfloat16), torch.zeros(M, N, dtype=torch.bfloat16)
+    H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=outb, aux=resb, gate=gate, io_f32=0, **kw)
+    np.testing.assert_allclose(outb.double().numpy(), (resb.double() + g * acc).numpy(), rtol=1e-2, atol=2e-2)
+    c = torch.randn(M, N)
+    c0 = c.clone()
+    H.gemm(A, B, epi=abi.EPI_ACC_F32, C_out=c, alpha=0.5, beta=1.0, gate=gate, **kw)
+    np.testing.assert_allclose(c.double().numpy(), (c0.double() + 0.5 * g * acc).numpy(), rtol=1e-5, atol=1e-4)
+    W = _rand((K, N), 88) * 0.2
+    acc2 = A.double() @ W.double()
+    aux = _rand((M, N), 89)
+    for epi in (abi.EPI_DGELU_DOT, abi.EPI_SCALE_DOT):
+        vals = []
+        for _ in range(2):
+            o, dot = torch.zeros(M, N, dtype=torch.bfloat16), torch.full((1,), 3.0)
+            H.gemm(A, W, b_trans=1, epi=epi, C_out=o, aux=aux, gate=gate, dot_out=dot, **kw)
+            vals.append(dot.clone())
+        x = aux.double()
+        if epi == abi.EPI_DGELU_DOT:
+            xx = x.clone().requires_grad_(True)
+            torch.nn.functional.gelu(xx).sum().backward()
+            want, wdot = g * acc2 * xx.grad, (1 - g * g) * (torch.nn.functional.gelu(x) * acc2).sum()
+        else:
+            want, wdot = g * acc2, (1 - g * g) * (x * acc2).sum()
+        np.testing.assert_allclose(o.double().numpy(), want.numpy(), rtol=1e-2, atol=2e-2)
+        assert abs(float(dot) - 3.0 - float(wdot)) <= 1e-3 * abs(float(wdot)) + 1e-2
+        assert torch.equal(vals[0], vals[1])
+        if big:
+            o16, d16 = torch.zeros(M, N, dtype=torch.bfloat16), torch.full((1,), 3.0)
+            H.gemm(A, W, b_trans=1, epi=epi, C_out=o16, aux=aux, gate=gate, dot_out=d16, safe=16)
+            assert torch.equal(o16, o)

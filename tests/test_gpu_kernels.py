@@ -423,7 +423,7 @@ def _close(got, want, name, rtol=1e-2, atol_rms=2e-3, l2=4e-3):
     assert e <= l2, f"{name}: rel L2 {e:.3e}"
 
 
-@pytest.mark.parametrize("safe", [0, 4, 6, 7, 16, 17])
+@pytest.mark.parametrize("safe", [0, 4, 6, 7, 16, 17, 18])
 def test_big_tile_gemm_fused_epilogues_at_benchmark_shapes(ops, safe):
     """The launches bench.py times at BASELINE config 2 (per gated block: rows = B*L = 8192, d = 2048, hidden 8192) run the
     256x256 kernel with FUSED epilogues; small-batch tests select the 128x128 kernel.  Every (layout, epilogue) pair the
@@ -434,6 +434,9 @@ def test_big_tile_gemm_fused_epilogues_at_benchmark_shapes(ops, safe):
     g = float(torch.tanh(gate))
     rows, d, hid, inner = 8192, 2048, 8192, 512
     assert Ops.kernel_label(rows, hid, d, False, False) == "w4m256" and Ops.kernel_label(rows, d, hid, False, True) == "w4m256"
+    # (safe = 18: the two-workgroups-per-CU 256x128 kernel, of_gemm's own selection for the *_DOT launches over >= 1024 big tiles;
+    #  it does not take the TN weight gradient below, which then runs the general kernel)
+    assert Ops.kernel_label(rows, hid, d, False, True, abi.EPI_DGELU_DOT) == "w4h256x128"
     # ---- up-projection + erf-GELU, two outputs (pre-activation kept for the backward): NT 8192 x 8192 x 2048
     u, W1 = _r((rows, d), 41), _r((hid, d), 42, d ** -0.5)
     acc = u.float() @ W1.float().t()
@@ -487,6 +490,65 @@ def test_big_tile_gemm_fused_epilogues_at_benchmark_shapes(ops, safe):
     du = torch.empty(rows, d, device="cuda", dtype=torch.bfloat16)
     ops.gemm(da, W1, du, tb=True, safe=safe)
     _close(du, da.float() @ W1.float(), "dU")
+
+
+# ---- the two-workgroups-per-CU 256 x 128 kernel (csrc/gemm_w4h.hip, safe = 18) -------------------------------------------------------
+@pytest.mark.parametrize("tb", [False, True])
+@pytest.mark.parametrize("K", [64, 128, 192, 256, 320, 704, 1088])
+def test_half_tile_kernel_ring_tails_and_wraps_on_hardware(ops, tb, K):
+    """1 ... 17 K stages through the ring of five 16-KiB units (prologue only, every tail form, the unit -> slot map wrapped three
+    times) with every CU holding two workgroups: bit-equal to the 256x256 kernel on the same MFMAs (safe = 16), five launches one
+    bit pattern (the race screen of the slot reuse: a piece landing in a slot that is still being read shows up here)."""
+    M, N = 4096, 4096          # 512 half tiles: one full round of two workgroups per CU
+    A = _r((M, K), 91)
+    B = _r((K, N) if tb else (N, K), 92, K ** -0.5)
+    want = torch.empty(M, N, device="cuda")
+    ops.gemm(A, B, want, tb=tb, epi=abi.EPI_ACC_F32, safe=16)
+    ref = A.float() @ (B.float() if tb else B.float().t())
+    _close(want, ref, "256x256", rtol=1e-5, atol_rms=1e-4, l2=1e-5)
+    for _ in range(5):
+        got = torch.zeros(M, N, device="cuda")
+        ops.gemm(A, B, got, tb=tb, epi=abi.EPI_ACC_F32, safe=18)
+        assert torch.equal(got, want)
+
+
+def test_half_tile_kernel_is_bit_equal_to_the_big_tile_kernel_at_benchmark_shapes(ops):
+    """The launches of_gemm sends to the half-tile kernel (NN *_DOT over >= 1024 big tiles) and the ones it could take (GELU with two
+    outputs, gate + residual): outputs bit-equal to the 256x256 kernel's, the gate-gradient dot equal up to the order of the
+    per-tile partials (twice as many) and bit-reproducible over five launches."""
+    rows, d, hid = 8192, 2048, 8192
+    gate = torch.tensor([0.37], device="cuda")
+    u, W1 = _r((rows, d), 41), _r((hid, d), 42, d ** -0.5)
+    outs = {}
+    for safe in (16, 18):
+        b, a = torch.empty(rows, hid, device="cuda", dtype=torch.bfloat16), torch.empty(rows, hid, device="cuda", dtype=torch.bfloat16)
+        ops.gemm(u, W1, b, epi=abi.EPI_GELU, out2=a, safe=safe)
+        outs[safe] = (b, a)
+    assert torch.equal(outs[16][0], outs[18][0]) and torch.equal(outs[16][1], outs[18][1])
+    a = outs[16][1]
+    W2, dy = _r((d, hid), 43, hid ** -0.5), _r((rows, d), 45)
+    for epi in (abi.EPI_DGELU_DOT, abi.EPI_SCALE_DOT):
+        res = {}
+        for safe in (16, 18, 0):
+            das, dots = [], []
+            for _ in range(5 if safe == 18 else 1):
+                da, dot = torch.empty(rows, hid, device="cuda", dtype=torch.bfloat16), torch.zeros(1, device="cuda")
+                ops.gemm(dy, W2, da, tb=True, epi=epi, aux=a, gate=gate, dot=dot, safe=safe)
+                das.append(da)
+                dots.append(dot)
+            assert all(torch.equal(das[0], x) for x in das) and all(torch.equal(dots[0], x) for x in dots)
+            res[safe] = (das[0], dots[0])
+        assert torch.equal(res[16][0], res[18][0]) and torch.equal(res[0][0], res[18][0])
+        assert torch.equal(res[0][1], res[18][1])          # safe = 0 IS the half-tile kernel here
+        assert abs(float(res[16][1]) - float(res[18][1])) <= 2e-6 * abs(float(res[16][1])) + 1e-6
+    res32 = _r((rows, d), 44, dtype=torch.float32)
+    bb = outs[16][0]
+    ys = []
+    for safe in (16, 18):
+        y = torch.empty(rows, d, device="cuda")
+        ops.gemm(bb, W2, y, epi=abi.EPI_GATE_RESID, aux=res32, gate=gate, safe=safe)
+        ys.append(y)
+    assert torch.equal(ys[0], ys[1])
 
 
 # ---- stream-K schedule of the 16x16x32 big-tile kernel (csrc/gemm_w4m.hip): tile counts the workgroup count does not divide --------

@@ -23,10 +23,14 @@ def _regs(tok):
     return None
 
 
+ASM_MFMA_SOURCES = [("gemm_w4m.hip", 10000), ("gemm_w4h.hip", 3000)]      # (file, at least this many v_mfma in its ISA)
+
+
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc to cross-compile")
-def test_no_valu_write_right_in_front_of_an_asm_mfma(tmp_path):
-    out = tmp_path / "gemm_w4m.s"
-    _compile_to_asm("gemm_w4m.hip", out)
+@pytest.mark.parametrize("src,min_mfma", ASM_MFMA_SOURCES)
+def test_no_valu_write_right_in_front_of_an_asm_mfma(tmp_path, src, min_mfma):
+    out = tmp_path / (src + ".s")
+    _compile_to_asm(src, out)
     window = []          # the last four instructions: (mnemonic, written register set or None)
     n_mfma, bad = 0, []
     for ln, raw in enumerate(open(out), 1):
@@ -52,7 +56,7 @@ def test_no_valu_write_right_in_front_of_an_asm_mfma(tmp_path):
         else:
             window.append((op, None))
         window = window[-4:]
-    assert n_mfma > 10000, n_mfma             # twenty instantiations (classic + stream-K) x several unrolled stage bodies
+    assert n_mfma > min_mfma, n_mfma          # gemm_w4m.hip: twenty instantiations (classic + stream-K) x several unrolled stage bodies
     assert not bad, bad[:5]
 
 
@@ -80,13 +84,14 @@ def _instructions(path):
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc to cross-compile")
-def test_accumulators_of_asm_mfmas_are_read_only_after_the_settle_wait(tmp_path):
+@pytest.mark.parametrize("src", [s for s, _ in ASM_MFMA_SOURCES])
+def test_accumulators_of_asm_mfmas_are_read_only_after_the_settle_wait(tmp_path, src):
     """The other direction of the same blind spot: of_mfma_acc_settle() is an asm statement with no operand tie to the
     accumulators, so nothing formally stops hipcc from moving a read of an accumulation register (v_accvgpr_read / an `a` source
     operand of a store) above its s_nops.  An 8-pass MFMA (16x16x32 bf16) needs 11 wait states between its issue and a VALU /
     memory read of its result: count them in the cross-compiled ISA (s_nop n = n + 1 wait states, any other instruction 1)."""
-    out = tmp_path / "gemm_w4m.s"
-    _compile_to_asm("gemm_w4m.hip", out)
+    out = tmp_path / (src + ".s")
+    _compile_to_asm(src, out)
     # Per basic block, conservatively: a label that follows an MFMA of the same kernel in the listing counts as "an MFMA was just
     # issued" (the block may be entered from the K loop).  Registers (re)written by v_accvgpr_write / v_accvgpr_mov inside the
     # block are exempt -- the accumulator zero-fill blocks read those right away.
@@ -133,7 +138,7 @@ def test_accumulators_of_asm_mfmas_are_read_only_after_the_settle_wait(tmp_path)
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc to cross-compile")
-@pytest.mark.parametrize("src", ["gemm_w4m.hip", "gemm_mid.hip", "gemm_pp.hip", "attention.hip"])
+@pytest.mark.parametrize("src", ["gemm_w4m.hip", "gemm_w4h.hip", "gemm_mid.hip", "gemm_pp.hip", "attention.hip"])
 def test_m0_is_only_ever_the_lds_dma_destination(tmp_path, src):
     """The inline-asm LDS-DMA (of_platform.h) writes M0 without declaring it: hipcc reserves M0 and refuses it in a clobber list
     ("inline asm clobber list contains reserved registers").  That is sound as long as the compiler itself never keeps a value in M0
