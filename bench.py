@@ -185,6 +185,9 @@ def pmc_traffic(key, shape):
         ent = table["kernels"][name]
     except (OSError, KeyError, ValueError):
         return None, f"no PMC pass on record for this launch ({name}; profiles/pmc_traffic.json)"
+    if table.get("libofhip_sha16") != _lib_sha16():       # the record is of another build of the library: not this line's bytes
+        return None, (f"the PMC passes on record ran libofhip {table.get('libofhip_sha16')}, this line {_lib_sha16()} "
+                      f"(profiles/pmc_traffic.json; regenerate: tools/gpu_pmc_traffic.sh + tools/make_pmc_traffic_json.py)")
     return ent["fetch_bytes"] + ent["write_bytes"], (
         f"bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE; fetches include "
         f"Infinity-Cache hits), not collected in this run: {ent['launch']}; algorithmic bytes {ent['algorithmic_bytes']}; "
@@ -429,6 +432,8 @@ def main():
                     "launches_per_step": n // args.steps, "avg_launch_ms": round(ms / n, 4),
                     "gflop_per_launch": round(fl / n / 1e9, 2),
                     "all_gemm_tflops": round(all_fl / all_ms / 1e9, 1),
+                    # the time-weighted figure over EVERY of_gemm launch of a step: what describes the path (`frac` is its best big family)
+                    "all_gemm_frac": round(all_fl / all_ms / 1e9 / MFMA_PEAK_TFLOPS, 4),
                     "all_gemm_ms_per_step": round(all_ms / args.steps, 2),
                     "note": "achieved/avg_launch_ms: HIP events around every launch of this family inside the timed region; "
                             "all_gemm_*: every of_gemm launch of the last warm-up step"}

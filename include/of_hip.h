@@ -81,7 +81,9 @@ typedef struct OfGemmArgs {
                           transposed-fragment path; 2 = general kernel; 3 = general kernel with 128 x 64 tiles; 4 = 8-wave ping-pong big-tile kernel;
                           5 = 8-wave LDS-DMA 128x128 kernel; 6 / 7 = 4-wave
                           big-tile kernel on 32x32x16 MFMAs (register-staged / LDS-DMA operands); 8..15 = general kernel with
-                          2^(safe-8) K slices; 16 = 4-wave LDS-DMA big-tile kernel on 16x16x32 MFMAs (what 0 selects).  Every value the product library accepts gives correct results; anything else returns
+                          2^(safe-8) K slices; 16 = 4-wave LDS-DMA big-tile kernel on 16x16x32 MFMAs (what 0 selects for most big launches);
+                          17 = its persistent stream-K schedule; 18 = the 256x128 kernel with two workgroups per CU (what 0 selects
+                          for the *_DOT launches over >= 1024 big tiles with K <= 3072).  Every value the product library accepts gives correct results; anything else returns
                           OF_E_ARG (timing ablations live in tools/libofhip_tools.so, built with -DOF_TOOLS_BUILD, never
                           shipped). */
     int ksplit;        /* internal: filled in by of_gemm (number of K slices of a split-K launch); callers pass 0 */

@@ -7,7 +7,7 @@ for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $c | tr ' ' '_')
   timeout 300 rocprofv3 --pmc $c --kernel-trace -d $OUT/$n -o run --output-format csv -- python tools/prof_gemm_shapes.py > $OUT/$n.log 2>&1
 done
-python - <<'PY'
+python - <<'PY' | tee gpurun_out/pmc_traffic_$TAG.txt
 import csv, glob, collections
 res = collections.OrderedDict()
 for f in sorted(glob.glob("gpurun_out/pmc_traffic_*/*/run_counter_collection.csv")):
@@ -17,3 +17,4 @@ for f in sorted(glob.glob("gpurun_out/pmc_traffic_*/*/run_counter_collection.csv
 for k, v in res.items():
     print(k, [round(x) for x in v[:4]])
 PY
+sha256sum open_flamingo_amd/csrc/libofhip.so | cut -c1-16 > gpurun_out/pmc_traffic_$TAG.sha16
