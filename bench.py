@@ -284,6 +284,12 @@ def main():
                     help="run the frozen vision tower at the start of each step (as the reference does) instead of enqueuing the NEXT "
                          "step's tower forward on a side stream next to the step epilogue (train/step.py: next_vision_x)")
     ap.add_argument("--gemm-report", default=None, help="write a per-(layout,epilogue,shape) GEMM time table (JSON lines)")
+    ap.add_argument("--one-gpu-loopback", action="store_true",
+                    help="REHEARSAL of the multi-rank path on a one-GPU box: every rank of --gpus N uses device 0 and the ranks talk "
+                         "through RCCL's socket transport over `lo` (each rank claims its own NCCL_HOSTID: RCCL refuses two ranks of one "
+                         "host on one device).  Rank spawning, the NCCL-backend process group, the side-stream all-reduces, finish(), "
+                         "max-over-ranks timing and the overlap record are the multi-GPU ones; the wire is a socket and N replicas share "
+                         "one chip, so the THROUGHPUT IS MEANINGLESS (config.one_gpu_loopback says so on the line)")
     args = ap.parse_args()
     cfg_family, cfg_batch, cfg_T, cfg_L, cfg_name = CONFIGS[args.config]
     overridden = any(v is not None for v in (args.family, args.batch, args.T, args.L))
@@ -298,6 +304,15 @@ def main():
     from open_flamingo_amd.train import distributed, step, synthetic, towers
     from open_flamingo_amd.train.reducer import GradReducer
 
+    if args.one_gpu_loopback and args.gpus > 1:
+        r = os.environ.get("RANK", "0")
+        os.environ.update(NCCL_HOSTID=f"of-one-gpu-rank{r}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_NET_GDR_LEVEL="0",
+                          NCCL_SHM_DISABLE="1", NCCL_P2P_DISABLE="1", LOCAL_RANK="0")
+    # RCCL prints a version banner on STDOUT when its first communicator comes up; the contract is ONE JSON line there.  Until the
+    # line is printed, file descriptor 1 points at stderr (C-level writes included).
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     device = distributed.init_distributed_device()
     assert device.type == "cuda", "bench.py needs an AMD GPU"
     local_rank, rank, world = distributed.world_info_from_env()
@@ -450,6 +465,8 @@ def main():
                           "workload": f"{args.family} (ViT-L/14 + {'MPT-1B' if args.family == 'OF-3B' else args.family}, "
                                       f"xattn_every={info['every']}) full train step, amp_bf16, per-GPU B={args.batch} "
                                       f"T={args.T} F=1 L={args.L} synthetic MMC4-style batch, random-init weights",
+                          **({"one_gpu_loopback": f"REHEARSAL: {world} ranks on ONE device over RCCL's socket transport -- the value "
+                                                      "on this line is not a throughput"} if args.one_gpu_loopback and world > 1 else {}),
                           "global_batch": args.batch * world, "images_per_step": images, "seq_len": args.L,
                           "parallelism": f"dp{world}",
                           "frozen_tower_weights": "fp32 (re-cast by autocast)" if args.frozen_fp32 else "bf16 copies held",
@@ -517,6 +534,8 @@ def main():
                     out["vs_reference_stock_towers"] = round(stock["ms_per_step"] / ms_per_step, 3)
             except Exception as exc:
                 out["reference_eager"] = {"error": repr(exc)}
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

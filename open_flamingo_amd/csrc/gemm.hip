@@ -381,6 +381,7 @@ static int gemm_grouped(const OfGemmArgs& a, of_stream_t s) {
     if (a.group_kind == 1) {              // y[:, gE:(g+1)E] = x W_g^T
         if (a.b_trans || (a.group_extent % 256) || (a.N % a.group_extent)) return OF_E_SHAPE;
         OfGemmArgs w = a;
+        w.sk_grid = 0;                    // internal field: a caller's value is ignored
         return of_gemm_w4m_try(w, s);
     }
     if (a.group_kind == 2) {              // dX = sum_g dY[:, gE:(g+1)E] W_g
@@ -394,7 +395,9 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
     if (!args || !args->A || !args->C) return OF_E_ARG;
     if (args->group_kind) return gemm_grouped(*args, (of_stream_t)stream);
     if (!args->B) return OF_E_ARG;
-    const OfGemmArgs& a = *args;
+    OfGemmArgs a_own = *args;
+    a_own.sk_grid = 0;                 // internal field ("callers pass 0"): only the stream-K branches below set it, a caller's value is ignored
+    const OfGemmArgs& a = a_own;
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return OF_E_ARG;
     // vector-loaded (contiguous) extents must be multiples of 8 elements; outputs are written 4 wide
     const int a_vec = a.a_trans ? a.M : a.K, b_vec = a.b_trans ? a.N : a.K;
@@ -466,7 +469,11 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
         const int rc = of_gemm_w4h_try(a, s);
         if (rc != OF_E_SHAPE) return rc;
     }
-    if (a.safe >= 19) return OF_E_ARG;
+    if (a.safe == 19) {                            // force the persistent software-pipelined 256x128 kernel (gemm_w4p.hip)
+        const int rc = of_gemm_w4p_try(a, s);
+        if (rc != OF_E_SHAPE) return rc;
+    }
+    if (a.safe >= 20) return OF_E_ARG;
     const bool pp_forced = a.safe == 4;
     // Big-tile selection (measured on MI355X, random operands, same box): every layout -> the 4-wave LDS-DMA kernel ON 16x16x32
     // MFMAs (gemm_w4m.hip).  With every CU busy the K loop is bound by the chip's power budget and the 16x16x32 shape spends

@@ -59,6 +59,7 @@ class Flamingo(nn.Module):
             if side is None or side.device != vision_x.device:
                 side = self.__dict__["_of_vision_stream"] = torch.cuda.Stream(device=vision_x.device)
             side.wait_stream(main)
+            vision_x.record_stream(side)       # allocated on the main stream, read on the side one: its memory must outlive the tower
             with torch.cuda.stream(side), torch.no_grad(), ac:
                 tokens = self.vision_encoder(vision_x.flatten(0, 2))[1]
             done = torch.cuda.Event()
@@ -67,12 +68,16 @@ class Flamingo(nn.Module):
             with torch.no_grad(), ac:
                 tokens = self.vision_encoder(vision_x.flatten(0, 2))[1]
             done = None
-        self.__dict__["_of_vision_prefetch"] = (vision_x, vision_x._version, tokens, done)
+        self.__dict__["_of_vision_prefetch"] = (vision_x, vision_x._version, tokens, done, amp_dtype)
 
     def _take_prefetched_vision(self, vision_x):
         hit = self.__dict__.pop("_of_vision_prefetch", None)
-        if hit is None or hit[0] is not vision_x or hit[1] != vision_x._version:
+        if hit is None:
             return None
+        # the consumer's autocast state must be the producer's (tokens of another dtype otherwise)
+        amp_now = torch.get_autocast_dtype(vision_x.device.type) if torch.is_autocast_enabled(vision_x.device.type) else None
+        if hit[0] is not vision_x or hit[1] != vision_x._version or hit[4] != amp_now:
+            return None                        # a miss: the tokens were allocated on the side stream and go back to its pool
         tokens, done = hit[2], hit[3]
         if done is not None:
             main = torch.cuda.current_stream(vision_x.device)

@@ -160,7 +160,10 @@ class FlatAdamW(torch.optim.Optimizer):
         side = getattr(self.reducer, "_stream", None)
         gen = self.reducer.generation
         early = [i for i, b in enumerate(self.reducer.buckets) if b.get("early_gen") == gen and self.early_norm]
-        if early and side is not None:               # GradReducer.finish() has already made this stream wait; a caller that skipped it must not race
+        # finish() waits for the COLLECTIVES, not for the of_sumsq kernels queued behind them on the side stream: wait for that stream
+        # whenever early partials may have been launched this step -- also when every one of them was voided since (a stale side-stream
+        # pass would otherwise write the slots after the main-stream pass below: a wrong, or rank-divergent, clip norm)
+        if self.early_norm and side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)
         for i, g in enumerate(bufs):
             if i in early:

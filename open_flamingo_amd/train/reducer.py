@@ -154,7 +154,7 @@ class GradReducer:
         side = self._side_stream(flat.device)
         if self.reserve_cus > 0 and side is not None:          # GEMMs enqueued from here on count on the CUs RCCL leaves
             from ..hip.ops import Ops
-            Ops.default().cu_limit = 256 - self.reserve_cus
+            Ops.default().cu_limit = 256 - self.reserve_cus      # process-wide: released in finish() AND in zero_grad() / no_sync()
         compute = None
         if side is not None:
             compute = torch.cuda.current_stream(flat.device)
@@ -240,10 +240,19 @@ class GradReducer:
         self._emb_rows = (rows, kept)
         self._launch(kept)
 
+    def _release_cus(self):
+        """Give the CUs reserved for collectives (reserve_cus -> the process-wide Ops.cu_limit, set by the first bucket's launch) back
+        to the GEMMs.  finish() does it; so do zero_grad() and no_sync(), so that a step that raised between its first bucket and
+        finish() cannot leave every later GEMM of the process -- forwards, other models -- laid out for fewer CUs."""
+        if self.reserve_cus > 0 and self._stream is not None:
+            from ..hip.ops import Ops
+            Ops.default().cu_limit = 0
+
     @contextlib.contextmanager
     def no_sync(self):
         """Skip the exchange for backward passes that are not the last of the optimizer step."""
         old, self._sync = self._sync, False
+        self._release_cus()
         try:
             yield
         finally:
@@ -258,11 +267,11 @@ class GradReducer:
         # collectives run in issue order on one RCCL stream -- true for today's defaults, not a contract: a group configured with
         # several streams, or a bucket launched through another group, would have let the step epilogue read a bucket still in
         # flight.  On CPU / gloo the waits complete on the host.
-        for work, _, _ in self._pending:
-            work.wait()
-        if self.reserve_cus > 0 and self._stream is not None:
-            from ..hip.ops import Ops
-            Ops.default().cu_limit = 0
+        try:
+            for work, _, _ in self._pending:
+                work.wait()
+        finally:
+            self._release_cus()
         for _, flat, wire in self._pending:
             if wire is not None:
                 flat.copy_(wire)
@@ -312,6 +321,7 @@ class GradReducer:
         """Zero in place (the .grad views must stay attached to the buckets).  ``flat_already_zero``: the fused step
         epilogue (train/optim.py) cleared the buckets in its AdamW pass."""
         self.generation += 1
+        self._release_cus()
         for b in self.buckets:
             if not flat_already_zero:
                 b["flat"].zero_()

@@ -139,8 +139,6 @@ OF_DEV void of_flag_await(const int* flag, int value) {
         std::this_thread::yield();
     }
 }
-OF_DEV void of_fence_release_device() { std::atomic_thread_fence(std::memory_order_release); }
-OF_DEV void of_fence_acquire_device() { std::atomic_thread_fence(std::memory_order_acquire); }
 OF_DEV int of_tid() { return of_emu::g_blk->cur; }
 OF_DEV int of_bid_x() { return (int)of_emu::g_blk->bid.x; }
 OF_DEV int of_bid_y() { return (int)of_emu::g_blk->bid.y; }
