@@ -271,8 +271,11 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4p_kernel(OfGemmArgs p) {
 template <bool BT, int EPI>
 int launch_w4p(const OfGemmArgs& a, of_stream_t s) {
     const int ntiles = (a.M / PT_M) * (a.N / PT_N);
-    int grid = ntiles < OF_NUM_CUS ? (ntiles & ~7) : OF_NUM_CUS;
-    if (grid < 8) grid = ntiles;
+    // one workgroup per CU the caller lets the launch count on (OfGemmArgs.cu_limit; 0 = all), whole groups of 8 for the XCD-aware tile
+    // order where there are that many
+    int grid = a.cu_limit > 0 && a.cu_limit < OF_NUM_CUS ? a.cu_limit : OF_NUM_CUS;
+    if (grid > ntiles) grid = ntiles;
+    if (grid >= 8) grid &= ~7;
     return of_launch(of_gemm_w4p_kernel<BT, EPI>, of_dim3{(unsigned)grid, 1, 1}, 256, SMEM_W4P, s, a);
 }
 }  // namespace

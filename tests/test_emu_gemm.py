@@ -611,3 +611,40 @@ def test_half_tile_kernel_epilogues(M, N, K):
             o16, d16 = torch.zeros(M, N, dtype=torch.bfloat16), torch.full((1,), 3.0)
             H.gemm(A, W, b_trans=1, epi=epi, C_out=o16, aux=aux, gate=gate, dot_out=d16, safe=16)
             assert torch.equal(o16, o)
+
+
+# ---- the persistent software-pipelined 256 x 128 kernel (gemm_w4p.hip; OfGemmArgs.safe = 19 forces it) ---------------------------
+@pytest.mark.parametrize("bt", [0, 1])
+@pytest.mark.parametrize("M,N,K,cus", [(256, 128, 1152, 0), (256, 256, 1216, 1), (512, 256, 1152, 3), (256, 384, 1280, 2)])
+def test_pipelined_kernel_plain_store_is_bit_equal_to_the_big_tile_kernel(bt, M, N, K, cus):
+    """One workgroup walks several tiles (cu_limit = workgroups): a tile's accumulators are rounded to bf16 into the wave's LDS image
+    at the end of its K loop and stored, 8 rows per stage, during the first 16 stages of the NEXT tile's K loop (the last tile's by
+    a drain loop).  K = 1152 / 1216 / 1280: 18 (the minimum: 16 chunk stages + both tail forms), 19 and 20 stages."""
+    A = _rand((M, K), 91)
+    B = _rand((K, N) if bt else (N, K), 92)
+    ref = _ref(A, B, 0, bt)
+    o_p = torch.zeros(M, N, dtype=torch.bfloat16)
+    H.gemm(A, B, b_trans=bt, epi=abi.EPI_STORE_BF16, C_out=o_p, alpha=0.5, safe=19, cu_limit=cus)
+    np.testing.assert_allclose(o_p.double().numpy(), 0.5 * ref.numpy(), rtol=1e-2, atol=2e-2)
+    o_gen = torch.zeros(M, N, dtype=torch.bfloat16)
+    H.gemm(A, B, b_trans=bt, epi=abi.EPI_STORE_BF16, C_out=o_gen, alpha=0.5, safe=18)
+    assert torch.equal(o_p, o_gen)
+
+
+def test_pipelined_kernel_gelu_and_strided_outputs():
+    M, N, K = 512, 256, 1152
+    A, B = _rand((M, K), 93), _rand((N, K), 94) * 0.05
+    acc = _ref(A, B, 0, 0)
+    wide_b, wide_a = torch.zeros(M, N + 64, dtype=torch.bfloat16), torch.zeros(M, N + 64, dtype=torch.bfloat16)
+    b_out, a_out = wide_b[:, 32:32 + N], wide_a[:, 32:32 + N]
+    H.gemm(A, B, epi=abi.EPI_GELU, C_out=b_out, C2=a_out, safe=19, cu_limit=3)
+    a16, b16 = torch.zeros(M, N, dtype=torch.bfloat16), torch.zeros(M, N, dtype=torch.bfloat16)
+    H.gemm(A, B, epi=abi.EPI_GELU, C_out=b16, C2=a16, safe=16)
+    assert torch.equal(a_out, a16)                      # the pre-activation: the rounded product, bit for bit
+    # GELU of the ROUNDED product (the reference's order under autocast) vs the 256x256 kernel's GELU of the fp32 product: one bf16 ulp
+    np.testing.assert_allclose(b_out.double().numpy(), torch.nn.functional.gelu(a_out.double()).numpy(), rtol=1e-2, atol=1e-3)
+    np.testing.assert_allclose(b_out.double().numpy(), b16.double().numpy(), rtol=2e-2, atol=2e-3)
+    assert float(wide_b[:, :32].abs().max()) == 0.0 and float(wide_b[:, 32 + N:].abs().max()) == 0.0
+    b_only = torch.zeros(M, N, dtype=torch.bfloat16)
+    H.gemm(A, B, epi=abi.EPI_GELU, C_out=b_only, safe=19, cu_limit=1)          # no pre-activation output, one workgroup, four tiles
+    assert torch.equal(b_only, b_out.contiguous())

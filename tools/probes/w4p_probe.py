@@ -1,0 +1,78 @@
+"""The persistent software-pipelined 256 x 128 kernel (csrc/gemm_w4p.hip, OfGemmArgs.safe = 19) against the 256 x 256 kernel (16), the
+two-workgroups-per-CU kernel (18) and the vendor library (torch.mm: hipBLASLt) on the launches of a train step: same box, interleaved
+rounds, random operands.  One JSON line per case; first a parity screen (plain store: bit-equal; GELU: pre-activation bit-equal, output
+within one bf16 ulp of the 256 x 256 kernel's, five launches one bit pattern).  PROFILING TOOL."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from open_flamingo_amd.hip import abi
+from open_flamingo_amd.hip.ops import Ops
+from bench_gemm_ab import make, timed
+
+ops = Ops.default()
+E = abi
+CASES = [("NT store_bf16", 8192, 8192, 2048, 0, 0, E.EPI_STORE_BF16), ("NT gelu 2 outputs", 8192, 8192, 2048, 0, 0, E.EPI_GELU),
+         ("NN store_bf16", 8192, 8192, 2048, 0, 1, E.EPI_STORE_BF16), ("NN dgelu_dot", 8192, 8192, 2048, 0, 1, E.EPI_DGELU_DOT),
+         ("NN scale_dot", 8192, 8192, 2048, 0, 1, E.EPI_SCALE_DOT),
+         ("NT Wqkv store", 8192, 6144, 2048, 0, 0, E.EPI_STORE_BF16), ("NT out_proj store", 8192, 2048, 2048, 0, 0, E.EPI_STORE_BF16),
+         ("NT down_proj store K=8192", 8192, 2048, 8192, 0, 0, E.EPI_STORE_BF16), ("NN dX K=8192", 8192, 2048, 8192, 0, 1, E.EPI_STORE_BF16),
+         ("NT store 8192^3", 8192, 8192, 8192, 0, 0, E.EPI_STORE_BF16), ("NT OF-4B up gelu", 8192, 10240, 2560, 0, 0, E.EPI_GELU)]
+if os.environ.get("W4P_CASES"):
+    keep = os.environ["W4P_CASES"].split(",")
+    CASES = [c for c in CASES if any(k in c[0] for k in keep)]
+
+
+def run(A, B, C, kw, ta, tb, epi, safe):
+    if "dot" in kw:
+        kw["dot"].zero_()
+    ops.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=safe, **kw)
+
+
+for name, M, N, K, ta, tb, epi in CASES:
+    A, B, C, kw = make(M, N, K, ta, tb, epi)
+    eligible = ops.lib.of_gemm is not None
+    run(A, B, C, kw, ta, tb, epi, 16)
+    want = [C.clone()] + ([kw["out2"].clone()] if "out2" in kw else []) + ([kw["dot"].clone()] if "dot" in kw else [])
+    rec = dict(parity=name, MNK=[M, N, K])
+    try:
+        outs = []
+        for _ in range(5):
+            C.zero_()
+            if "out2" in kw:
+                kw["out2"].zero_()
+            run(A, B, C, kw, ta, tb, epi, 19)
+            outs.append([C.clone()] + ([kw["out2"].clone()] if "out2" in kw else []) + ([kw["dot"].clone()] if "dot" in kw else []))
+        rec["repeatable"] = all(all(torch.equal(x, y) for x, y in zip(outs[0], o)) for o in outs[1:])
+        rec["C_bit_equal_to_256x256"] = bool(torch.equal(outs[0][0], want[0]))
+        d = (outs[0][0].float() - want[0].float()).abs()
+        rec["C_max_abs_diff"] = float(d.max())
+        rec["C_rel_l2"] = float(d.norm() / (want[0].float().norm() + 1e-30))
+        if "out2" in kw:
+            rec["C2_bit_equal"] = bool(torch.equal(outs[0][1], want[1]))
+        if "dot" in kw:
+            rec["dot_rel_diff"] = abs(float(outs[0][-1]) - float(want[-1])) / (abs(float(want[-1])) + 1e-30)
+    except RuntimeError as exc:
+        rec["w4p"] = "not eligible: " + str(exc)[:80]
+    print(json.dumps(rec), flush=True)
+    arms = {"w4m256": lambda: run(A, B, C, kw, ta, tb, epi, 16), "w4h": lambda: run(A, B, C, kw, ta, tb, epi, 18)}
+    if "w4p" not in rec:
+        arms["w4p"] = lambda: run(A, B, C, kw, ta, tb, epi, 19)
+    if epi == E.EPI_STORE_BF16:
+        Bv = B if tb else B.t()          # torch.mm(A, Bv): the vendor library on the same operands (NT: B^T view, NN: B)
+        arms["vendor"] = lambda: torch.mm(A, Bv, out=C)
+    best = {k: 1e9 for k in arms}
+    for fn in arms.values():
+        for _ in range(3):
+            fn()
+    torch.cuda.synchronize()
+    for _ in range(4):
+        for k, fn in arms.items():
+            best[k] = min(best[k], timed(fn, 10))
+    rec = dict(case=name, MNK=[M, N, K])
+    for k, ms in best.items():
+        rec[k + "_us"] = round(ms * 1e3, 1)
+    for k, ms in best.items():
+        rec[k + "_tflops"] = round(2.0 * M * N * K / ms / 1e9, 1)
+    print(json.dumps(rec), flush=True)
+    del A, B, C, kw
