@@ -469,8 +469,8 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
         const int rc = of_gemm_w4h_try(a, s);
         if (rc != OF_E_SHAPE) return rc;
     }
-    if (a.safe == 19) {                            // force the persistent software-pipelined 256x128 kernel (gemm_w4p.hip)
-        const int rc = of_gemm_w4p_try(a, s);
+    if (a.safe == 19) {                            // force the persistent wave-specialised 256x128 kernel (gemm_w4s.hip)
+        const int rc = of_gemm_w4s_try(a, s);
         if (rc != OF_E_SHAPE) return rc;
     }
     if (a.safe >= 20) return OF_E_ARG;

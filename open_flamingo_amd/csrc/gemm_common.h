@@ -411,9 +411,10 @@ size_t of_gemm_w4m_sk_bytes(const OfGemmArgs& a, int grid);      // workspace of
 // implemented in gemm_w4h.hip: 256x128 tile, 4 waves x (128x64), two workgroups per CU (a tile's epilogue under the other's K loop)
 int of_gemm_w4h_try(const OfGemmArgs& a, of_stream_t s);
 bool of_gemm_w4h_eligible(const OfGemmArgs& a);
-// implemented in gemm_w4p.hip: the same tile, ONE persistent workgroup per CU, a tile's epilogue inside the next tile's K loop
-int of_gemm_w4p_try(const OfGemmArgs& a, of_stream_t s);
-bool of_gemm_w4p_eligible(const OfGemmArgs& a);
+// implemented in gemm_w4s.hip: the same tile, ONE persistent workgroup of 8 waves per CU -- 4 MFMA waves + 4 waves that issue the LDS-DMA
+// and run the previous tile's epilogue under the K loop
+int of_gemm_w4s_try(const OfGemmArgs& a, of_stream_t s);
+bool of_gemm_w4s_eligible(const OfGemmArgs& a);
 // implemented in gemm_skinny.hip: M <= 16 rows (decode step), HBM-bound weight streaming; OF_E_SHAPE when not eligible
 int of_gemm_skinny_try(const OfGemmArgs& a, of_stream_t s);
 inline bool of_gemm_is_skinny(const OfGemmArgs& a) {

@@ -76,6 +76,95 @@ OF_DEV f32x16 of_mfma32(s16x8 a, s16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(of_bf16x8n, a),
                                                    __builtin_bit_cast(of_bf16x8n, b), c, 0, 0, 0);
 }
+// ---- a bank of 32 accumulators (16x16 fp32 MFMA results) in FIXED accumulation registers a[4k : 4k + 3], outside hipcc's register
+// allocation (gemm_w4s.hip).  With the accumulators as C++ values ("+a" operands of of_mfma_acc) a kernel whose accumulators live
+// across a loop over tiles had hipcc permute them between registers with v_accvgpr_mov in the middle of the MFMA stream -- moves it
+// does not know to be reads of MFMA results, issued without the wait states: wrong values on hardware (two registers of 128), nothing
+// on the emulator.  Here no C++ value ever is an accumulator: every statement that touches the bank names its registers and lists
+// all 128 as clobbered, so hipcc keeps nothing of its own in them across those statements (and counts them into the kernel's
+// register budget).  k is a compile-time constant after unrolling (the switch folds).  Reads need of_mfma_acc_settle() first.
+#define OF_ACCBANK_CLOBBERS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
+struct of_accbank_t {};
+OF_DEV void of_accbank_mfma(of_accbank_t&, int k, s16x8 a, s16x8 b) {
+    switch (k) {
+        case 0: asm volatile("v_mfma_f32_16x16x32_bf16 a[0:3], %0, %1, a[0:3]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 1: asm volatile("v_mfma_f32_16x16x32_bf16 a[4:7], %0, %1, a[4:7]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 2: asm volatile("v_mfma_f32_16x16x32_bf16 a[8:11], %0, %1, a[8:11]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 3: asm volatile("v_mfma_f32_16x16x32_bf16 a[12:15], %0, %1, a[12:15]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 4: asm volatile("v_mfma_f32_16x16x32_bf16 a[16:19], %0, %1, a[16:19]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 5: asm volatile("v_mfma_f32_16x16x32_bf16 a[20:23], %0, %1, a[20:23]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 6: asm volatile("v_mfma_f32_16x16x32_bf16 a[24:27], %0, %1, a[24:27]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 7: asm volatile("v_mfma_f32_16x16x32_bf16 a[28:31], %0, %1, a[28:31]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 8: asm volatile("v_mfma_f32_16x16x32_bf16 a[32:35], %0, %1, a[32:35]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 9: asm volatile("v_mfma_f32_16x16x32_bf16 a[36:39], %0, %1, a[36:39]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 10: asm volatile("v_mfma_f32_16x16x32_bf16 a[40:43], %0, %1, a[40:43]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 11: asm volatile("v_mfma_f32_16x16x32_bf16 a[44:47], %0, %1, a[44:47]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 12: asm volatile("v_mfma_f32_16x16x32_bf16 a[48:51], %0, %1, a[48:51]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 13: asm volatile("v_mfma_f32_16x16x32_bf16 a[52:55], %0, %1, a[52:55]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 14: asm volatile("v_mfma_f32_16x16x32_bf16 a[56:59], %0, %1, a[56:59]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 15: asm volatile("v_mfma_f32_16x16x32_bf16 a[60:63], %0, %1, a[60:63]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 16: asm volatile("v_mfma_f32_16x16x32_bf16 a[64:67], %0, %1, a[64:67]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 17: asm volatile("v_mfma_f32_16x16x32_bf16 a[68:71], %0, %1, a[68:71]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 18: asm volatile("v_mfma_f32_16x16x32_bf16 a[72:75], %0, %1, a[72:75]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 19: asm volatile("v_mfma_f32_16x16x32_bf16 a[76:79], %0, %1, a[76:79]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 20: asm volatile("v_mfma_f32_16x16x32_bf16 a[80:83], %0, %1, a[80:83]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 21: asm volatile("v_mfma_f32_16x16x32_bf16 a[84:87], %0, %1, a[84:87]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 22: asm volatile("v_mfma_f32_16x16x32_bf16 a[88:91], %0, %1, a[88:91]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 23: asm volatile("v_mfma_f32_16x16x32_bf16 a[92:95], %0, %1, a[92:95]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 24: asm volatile("v_mfma_f32_16x16x32_bf16 a[96:99], %0, %1, a[96:99]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 25: asm volatile("v_mfma_f32_16x16x32_bf16 a[100:103], %0, %1, a[100:103]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 26: asm volatile("v_mfma_f32_16x16x32_bf16 a[104:107], %0, %1, a[104:107]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 27: asm volatile("v_mfma_f32_16x16x32_bf16 a[108:111], %0, %1, a[108:111]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 28: asm volatile("v_mfma_f32_16x16x32_bf16 a[112:115], %0, %1, a[112:115]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 29: asm volatile("v_mfma_f32_16x16x32_bf16 a[116:119], %0, %1, a[116:119]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 30: asm volatile("v_mfma_f32_16x16x32_bf16 a[120:123], %0, %1, a[120:123]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+        case 31: asm volatile("v_mfma_f32_16x16x32_bf16 a[124:127], %0, %1, a[124:127]" ::"v"(a), "v"(b) : OF_ACCBANK_CLOBBERS); break;
+    }
+}
+OF_DEV void of_accbank_zero(of_accbank_t&) {
+    asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tv_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0\n\tv_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\tv_accvgpr_write_b32 a10, 0\n\tv_accvgpr_write_b32 a11, 0\n\tv_accvgpr_write_b32 a12, 0\n\tv_accvgpr_write_b32 a13, 0\n\tv_accvgpr_write_b32 a14, 0\n\tv_accvgpr_write_b32 a15, 0\n\tv_accvgpr_write_b32 a16, 0\n\tv_accvgpr_write_b32 a17, 0\n\tv_accvgpr_write_b32 a18, 0\n\tv_accvgpr_write_b32 a19, 0\n\tv_accvgpr_write_b32 a20, 0\n\tv_accvgpr_write_b32 a21, 0\n\tv_accvgpr_write_b32 a22, 0\n\tv_accvgpr_write_b32 a23, 0\n\tv_accvgpr_write_b32 a24, 0\n\tv_accvgpr_write_b32 a25, 0\n\tv_accvgpr_write_b32 a26, 0\n\tv_accvgpr_write_b32 a27, 0\n\tv_accvgpr_write_b32 a28, 0\n\tv_accvgpr_write_b32 a29, 0\n\tv_accvgpr_write_b32 a30, 0\n\tv_accvgpr_write_b32 a31, 0" ::: OF_ACCBANK_CLOBBERS);
+    asm volatile("v_accvgpr_write_b32 a32, 0\n\tv_accvgpr_write_b32 a33, 0\n\tv_accvgpr_write_b32 a34, 0\n\tv_accvgpr_write_b32 a35, 0\n\tv_accvgpr_write_b32 a36, 0\n\tv_accvgpr_write_b32 a37, 0\n\tv_accvgpr_write_b32 a38, 0\n\tv_accvgpr_write_b32 a39, 0\n\tv_accvgpr_write_b32 a40, 0\n\tv_accvgpr_write_b32 a41, 0\n\tv_accvgpr_write_b32 a42, 0\n\tv_accvgpr_write_b32 a43, 0\n\tv_accvgpr_write_b32 a44, 0\n\tv_accvgpr_write_b32 a45, 0\n\tv_accvgpr_write_b32 a46, 0\n\tv_accvgpr_write_b32 a47, 0\n\tv_accvgpr_write_b32 a48, 0\n\tv_accvgpr_write_b32 a49, 0\n\tv_accvgpr_write_b32 a50, 0\n\tv_accvgpr_write_b32 a51, 0\n\tv_accvgpr_write_b32 a52, 0\n\tv_accvgpr_write_b32 a53, 0\n\tv_accvgpr_write_b32 a54, 0\n\tv_accvgpr_write_b32 a55, 0\n\tv_accvgpr_write_b32 a56, 0\n\tv_accvgpr_write_b32 a57, 0\n\tv_accvgpr_write_b32 a58, 0\n\tv_accvgpr_write_b32 a59, 0\n\tv_accvgpr_write_b32 a60, 0\n\tv_accvgpr_write_b32 a61, 0\n\tv_accvgpr_write_b32 a62, 0\n\tv_accvgpr_write_b32 a63, 0" ::: OF_ACCBANK_CLOBBERS);
+    asm volatile("v_accvgpr_write_b32 a64, 0\n\tv_accvgpr_write_b32 a65, 0\n\tv_accvgpr_write_b32 a66, 0\n\tv_accvgpr_write_b32 a67, 0\n\tv_accvgpr_write_b32 a68, 0\n\tv_accvgpr_write_b32 a69, 0\n\tv_accvgpr_write_b32 a70, 0\n\tv_accvgpr_write_b32 a71, 0\n\tv_accvgpr_write_b32 a72, 0\n\tv_accvgpr_write_b32 a73, 0\n\tv_accvgpr_write_b32 a74, 0\n\tv_accvgpr_write_b32 a75, 0\n\tv_accvgpr_write_b32 a76, 0\n\tv_accvgpr_write_b32 a77, 0\n\tv_accvgpr_write_b32 a78, 0\n\tv_accvgpr_write_b32 a79, 0\n\tv_accvgpr_write_b32 a80, 0\n\tv_accvgpr_write_b32 a81, 0\n\tv_accvgpr_write_b32 a82, 0\n\tv_accvgpr_write_b32 a83, 0\n\tv_accvgpr_write_b32 a84, 0\n\tv_accvgpr_write_b32 a85, 0\n\tv_accvgpr_write_b32 a86, 0\n\tv_accvgpr_write_b32 a87, 0\n\tv_accvgpr_write_b32 a88, 0\n\tv_accvgpr_write_b32 a89, 0\n\tv_accvgpr_write_b32 a90, 0\n\tv_accvgpr_write_b32 a91, 0\n\tv_accvgpr_write_b32 a92, 0\n\tv_accvgpr_write_b32 a93, 0\n\tv_accvgpr_write_b32 a94, 0\n\tv_accvgpr_write_b32 a95, 0" ::: OF_ACCBANK_CLOBBERS);
+    asm volatile("v_accvgpr_write_b32 a96, 0\n\tv_accvgpr_write_b32 a97, 0\n\tv_accvgpr_write_b32 a98, 0\n\tv_accvgpr_write_b32 a99, 0\n\tv_accvgpr_write_b32 a100, 0\n\tv_accvgpr_write_b32 a101, 0\n\tv_accvgpr_write_b32 a102, 0\n\tv_accvgpr_write_b32 a103, 0\n\tv_accvgpr_write_b32 a104, 0\n\tv_accvgpr_write_b32 a105, 0\n\tv_accvgpr_write_b32 a106, 0\n\tv_accvgpr_write_b32 a107, 0\n\tv_accvgpr_write_b32 a108, 0\n\tv_accvgpr_write_b32 a109, 0\n\tv_accvgpr_write_b32 a110, 0\n\tv_accvgpr_write_b32 a111, 0\n\tv_accvgpr_write_b32 a112, 0\n\tv_accvgpr_write_b32 a113, 0\n\tv_accvgpr_write_b32 a114, 0\n\tv_accvgpr_write_b32 a115, 0\n\tv_accvgpr_write_b32 a116, 0\n\tv_accvgpr_write_b32 a117, 0\n\tv_accvgpr_write_b32 a118, 0\n\tv_accvgpr_write_b32 a119, 0\n\tv_accvgpr_write_b32 a120, 0\n\tv_accvgpr_write_b32 a121, 0\n\tv_accvgpr_write_b32 a122, 0\n\tv_accvgpr_write_b32 a123, 0\n\tv_accvgpr_write_b32 a124, 0\n\tv_accvgpr_write_b32 a125, 0\n\tv_accvgpr_write_b32 a126, 0\n\tv_accvgpr_write_b32 a127, 0" ::: OF_ACCBANK_CLOBBERS);
+}
+OF_DEV f32x4 of_accbank_read(of_accbank_t&, int k) {
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+    switch (k) {
+        case 0: asm volatile("v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\tv_accvgpr_read_b32 %3, a3" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 1: asm volatile("v_accvgpr_read_b32 %0, a4\n\tv_accvgpr_read_b32 %1, a5\n\tv_accvgpr_read_b32 %2, a6\n\tv_accvgpr_read_b32 %3, a7" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 2: asm volatile("v_accvgpr_read_b32 %0, a8\n\tv_accvgpr_read_b32 %1, a9\n\tv_accvgpr_read_b32 %2, a10\n\tv_accvgpr_read_b32 %3, a11" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 3: asm volatile("v_accvgpr_read_b32 %0, a12\n\tv_accvgpr_read_b32 %1, a13\n\tv_accvgpr_read_b32 %2, a14\n\tv_accvgpr_read_b32 %3, a15" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 4: asm volatile("v_accvgpr_read_b32 %0, a16\n\tv_accvgpr_read_b32 %1, a17\n\tv_accvgpr_read_b32 %2, a18\n\tv_accvgpr_read_b32 %3, a19" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 5: asm volatile("v_accvgpr_read_b32 %0, a20\n\tv_accvgpr_read_b32 %1, a21\n\tv_accvgpr_read_b32 %2, a22\n\tv_accvgpr_read_b32 %3, a23" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 6: asm volatile("v_accvgpr_read_b32 %0, a24\n\tv_accvgpr_read_b32 %1, a25\n\tv_accvgpr_read_b32 %2, a26\n\tv_accvgpr_read_b32 %3, a27" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 7: asm volatile("v_accvgpr_read_b32 %0, a28\n\tv_accvgpr_read_b32 %1, a29\n\tv_accvgpr_read_b32 %2, a30\n\tv_accvgpr_read_b32 %3, a31" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 8: asm volatile("v_accvgpr_read_b32 %0, a32\n\tv_accvgpr_read_b32 %1, a33\n\tv_accvgpr_read_b32 %2, a34\n\tv_accvgpr_read_b32 %3, a35" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 9: asm volatile("v_accvgpr_read_b32 %0, a36\n\tv_accvgpr_read_b32 %1, a37\n\tv_accvgpr_read_b32 %2, a38\n\tv_accvgpr_read_b32 %3, a39" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 10: asm volatile("v_accvgpr_read_b32 %0, a40\n\tv_accvgpr_read_b32 %1, a41\n\tv_accvgpr_read_b32 %2, a42\n\tv_accvgpr_read_b32 %3, a43" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 11: asm volatile("v_accvgpr_read_b32 %0, a44\n\tv_accvgpr_read_b32 %1, a45\n\tv_accvgpr_read_b32 %2, a46\n\tv_accvgpr_read_b32 %3, a47" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 12: asm volatile("v_accvgpr_read_b32 %0, a48\n\tv_accvgpr_read_b32 %1, a49\n\tv_accvgpr_read_b32 %2, a50\n\tv_accvgpr_read_b32 %3, a51" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 13: asm volatile("v_accvgpr_read_b32 %0, a52\n\tv_accvgpr_read_b32 %1, a53\n\tv_accvgpr_read_b32 %2, a54\n\tv_accvgpr_read_b32 %3, a55" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 14: asm volatile("v_accvgpr_read_b32 %0, a56\n\tv_accvgpr_read_b32 %1, a57\n\tv_accvgpr_read_b32 %2, a58\n\tv_accvgpr_read_b32 %3, a59" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 15: asm volatile("v_accvgpr_read_b32 %0, a60\n\tv_accvgpr_read_b32 %1, a61\n\tv_accvgpr_read_b32 %2, a62\n\tv_accvgpr_read_b32 %3, a63" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 16: asm volatile("v_accvgpr_read_b32 %0, a64\n\tv_accvgpr_read_b32 %1, a65\n\tv_accvgpr_read_b32 %2, a66\n\tv_accvgpr_read_b32 %3, a67" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 17: asm volatile("v_accvgpr_read_b32 %0, a68\n\tv_accvgpr_read_b32 %1, a69\n\tv_accvgpr_read_b32 %2, a70\n\tv_accvgpr_read_b32 %3, a71" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 18: asm volatile("v_accvgpr_read_b32 %0, a72\n\tv_accvgpr_read_b32 %1, a73\n\tv_accvgpr_read_b32 %2, a74\n\tv_accvgpr_read_b32 %3, a75" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 19: asm volatile("v_accvgpr_read_b32 %0, a76\n\tv_accvgpr_read_b32 %1, a77\n\tv_accvgpr_read_b32 %2, a78\n\tv_accvgpr_read_b32 %3, a79" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 20: asm volatile("v_accvgpr_read_b32 %0, a80\n\tv_accvgpr_read_b32 %1, a81\n\tv_accvgpr_read_b32 %2, a82\n\tv_accvgpr_read_b32 %3, a83" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 21: asm volatile("v_accvgpr_read_b32 %0, a84\n\tv_accvgpr_read_b32 %1, a85\n\tv_accvgpr_read_b32 %2, a86\n\tv_accvgpr_read_b32 %3, a87" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 22: asm volatile("v_accvgpr_read_b32 %0, a88\n\tv_accvgpr_read_b32 %1, a89\n\tv_accvgpr_read_b32 %2, a90\n\tv_accvgpr_read_b32 %3, a91" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 23: asm volatile("v_accvgpr_read_b32 %0, a92\n\tv_accvgpr_read_b32 %1, a93\n\tv_accvgpr_read_b32 %2, a94\n\tv_accvgpr_read_b32 %3, a95" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 24: asm volatile("v_accvgpr_read_b32 %0, a96\n\tv_accvgpr_read_b32 %1, a97\n\tv_accvgpr_read_b32 %2, a98\n\tv_accvgpr_read_b32 %3, a99" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 25: asm volatile("v_accvgpr_read_b32 %0, a100\n\tv_accvgpr_read_b32 %1, a101\n\tv_accvgpr_read_b32 %2, a102\n\tv_accvgpr_read_b32 %3, a103" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 26: asm volatile("v_accvgpr_read_b32 %0, a104\n\tv_accvgpr_read_b32 %1, a105\n\tv_accvgpr_read_b32 %2, a106\n\tv_accvgpr_read_b32 %3, a107" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 27: asm volatile("v_accvgpr_read_b32 %0, a108\n\tv_accvgpr_read_b32 %1, a109\n\tv_accvgpr_read_b32 %2, a110\n\tv_accvgpr_read_b32 %3, a111" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 28: asm volatile("v_accvgpr_read_b32 %0, a112\n\tv_accvgpr_read_b32 %1, a113\n\tv_accvgpr_read_b32 %2, a114\n\tv_accvgpr_read_b32 %3, a115" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 29: asm volatile("v_accvgpr_read_b32 %0, a116\n\tv_accvgpr_read_b32 %1, a117\n\tv_accvgpr_read_b32 %2, a118\n\tv_accvgpr_read_b32 %3, a119" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 30: asm volatile("v_accvgpr_read_b32 %0, a120\n\tv_accvgpr_read_b32 %1, a121\n\tv_accvgpr_read_b32 %2, a122\n\tv_accvgpr_read_b32 %3, a123" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+        case 31: asm volatile("v_accvgpr_read_b32 %0, a124\n\tv_accvgpr_read_b32 %1, a125\n\tv_accvgpr_read_b32 %2, a126\n\tv_accvgpr_read_b32 %3, a127" : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : : OF_ACCBANK_CLOBBERS); break;
+    }
+    return r;
+}
 // shader clock (s_memtime; timing aid of the ablation builds).  The value returns through the scalar-memory counter,
 // so reading it also waits for the wave's outstanding LDS operations (lgkmcnt is shared).
 OF_DEV unsigned of_cycles() {

@@ -178,6 +178,15 @@ OF_DEV f32x4 of_mfma(s16x8 a, s16x8 b, f32x4 c) {
 }
 OF_DEV void of_mfma_acc(s16x8 a, s16x8 b, f32x4& c) { c = of_mfma(a, b, c); }
 OF_DEV void of_mfma_acc_settle() {}
+// the fixed-register accumulator bank of the device build (of_platform.h): here just 32 values
+struct of_accbank_t {
+    f32x4 v[32];
+};
+OF_DEV void of_accbank_mfma(of_accbank_t& bank, int k, s16x8 a, s16x8 b) { bank.v[k] = of_mfma(a, b, bank.v[k]); }
+OF_DEV void of_accbank_zero(of_accbank_t& bank) {
+    for (int k = 0; k < 32; ++k) bank.v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+OF_DEV f32x4 of_accbank_read(of_accbank_t& bank, int k) { return bank.v[k]; }
 OF_DEV void of_acc_pin(f32x4&) {}
 OF_DEV void of_mfma_acc_guard() {}
 OF_DEV f32x16 of_mfma32(s16x8 a, s16x8 b, f32x16 c) {

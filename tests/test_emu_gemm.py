@@ -613,13 +613,14 @@ def test_half_tile_kernel_epilogues(M, N, K):
             assert torch.equal(o16, o)
 
 
-# ---- the persistent software-pipelined 256 x 128 kernel (gemm_w4p.hip; OfGemmArgs.safe = 19 forces it) ---------------------------
+# ---- the persistent wave-specialised 256 x 128 kernel (gemm_w4s.hip; OfGemmArgs.safe = 19 forces it) -----------------------------
 @pytest.mark.parametrize("bt", [0, 1])
 @pytest.mark.parametrize("M,N,K,cus", [(256, 128, 1152, 0), (256, 256, 1216, 1), (512, 256, 1152, 3), (256, 384, 1280, 2)])
-def test_pipelined_kernel_plain_store_is_bit_equal_to_the_big_tile_kernel(bt, M, N, K, cus):
-    """One workgroup walks several tiles (cu_limit = workgroups): a tile's accumulators are rounded to bf16 into the wave's LDS image
-    at the end of its K loop and stored, 8 rows per stage, during the first 16 stages of the NEXT tile's K loop (the last tile's by
-    a drain loop).  K = 1152 / 1216 / 1280: 18 (the minimum: 16 chunk stages + both tail forms), 19 and 20 stages."""
+def test_specialised_kernel_plain_store_is_bit_equal_to_the_big_tile_kernel(bt, M, N, K, cus):
+    """Four MFMA waves + four producer waves per workgroup; one workgroup walks several tiles (cu_limit = workgroups): a tile's
+    accumulators are rounded to bf16 into the consumer's LDS image at the end of its K loop and stored by its producer, 8 rows per
+    stage, during the first 16 stages of the NEXT tile's K loop (the last tile's by a drain loop).  K = 1152 / 1216 / 1280: 18 (the
+    minimum: 16 chunk stages + both tail forms), 19 and 20 stages through the two-stage ring of six units."""
     A = _rand((M, K), 91)
     B = _rand((K, N) if bt else (N, K), 92)
     ref = _ref(A, B, 0, bt)
@@ -631,10 +632,9 @@ def test_pipelined_kernel_plain_store_is_bit_equal_to_the_big_tile_kernel(bt, M,
     assert torch.equal(o_p, o_gen)
 
 
-def test_pipelined_kernel_gelu_and_strided_outputs():
+def test_specialised_kernel_gelu_and_strided_outputs():
     M, N, K = 512, 256, 1152
     A, B = _rand((M, K), 93), _rand((N, K), 94) * 0.05
-    acc = _ref(A, B, 0, 0)
     wide_b, wide_a = torch.zeros(M, N + 64, dtype=torch.bfloat16), torch.zeros(M, N + 64, dtype=torch.bfloat16)
     b_out, a_out = wide_b[:, 32:32 + N], wide_a[:, 32:32 + N]
     H.gemm(A, B, epi=abi.EPI_GELU, C_out=b_out, C2=a_out, safe=19, cu_limit=3)
@@ -648,3 +648,38 @@ def test_pipelined_kernel_gelu_and_strided_outputs():
     b_only = torch.zeros(M, N, dtype=torch.bfloat16)
     H.gemm(A, B, epi=abi.EPI_GELU, C_out=b_only, safe=19, cu_limit=1)          # no pre-activation output, one workgroup, four tiles
     assert torch.equal(b_only, b_out.contiguous())
+
+
+def test_specialised_kernel_dot_epilogues():
+    """*_DOT: the producer reads the saved activation chunk by chunk, the gate-gradient partial is per (tile, wave) -- deterministic,
+    equal to the 256x256 kernel's up to the order of the partials; SCALE_DOT's output is bit-equal (one rounding less matters only
+    where the scale is not a power of two: gate = atanh(0.5), alpha = 1)."""
+    M, N, K = 512, 256, 1152
+    A, W = _rand((M, K), 95), _rand((K, N), 96) * 0.1
+    acc2 = A.double() @ W.double()
+    aux = _rand((M, N), 97)
+    gate = torch.tensor([0.37])
+    g = float(torch.tanh(gate))
+    for epi in (abi.EPI_DGELU_DOT, abi.EPI_SCALE_DOT):
+        vals, outs = [], []
+        for cus in (3, 1):
+            o, dot = torch.zeros(M, N, dtype=torch.bfloat16), torch.full((1,), 3.0)
+            H.gemm(A, W, b_trans=1, epi=epi, C_out=o, aux=aux, gate=gate, dot_out=dot, safe=19, cu_limit=cus)
+            vals.append(dot.clone())
+            outs.append(o)
+        assert torch.equal(vals[0], vals[1]) and torch.equal(outs[0], outs[1])
+        x = aux.double()
+        if epi == abi.EPI_DGELU_DOT:
+            xx = x.clone().requires_grad_(True)
+            torch.nn.functional.gelu(xx).sum().backward()
+            want, wdot = g * acc2 * xx.grad, (1 - g * g) * (torch.nn.functional.gelu(x) * acc2).sum()
+        else:
+            want, wdot = g * acc2, (1 - g * g) * (x * acc2).sum()
+        np.testing.assert_allclose(outs[0].double().numpy(), want.numpy(), rtol=2e-2, atol=2e-2)
+        # the dot is taken of the bf16-ROUNDED product (what the reference's autocast matmul hands its autograd): 2^-9 relative noise
+        # per term, random sign -> ~2^-9 |term| sqrt(n) in the sum; the bound is on the terms' mass, as in tests/test_gpu_kernels.py
+        terms = ((torch.nn.functional.gelu(x) if epi == abi.EPI_DGELU_DOT else x) * acc2).abs().sum()
+        assert abs(float(vals[0]) - 3.0 - float(wdot)) <= 3e-5 * (1 - g * g) * float(terms) + 1e-2
+        o16, d16 = torch.zeros(M, N, dtype=torch.bfloat16), torch.full((1,), 3.0)
+        H.gemm(A, W, b_trans=1, epi=epi, C_out=o16, aux=aux, gate=gate, dot_out=d16, safe=16)
+        np.testing.assert_allclose(outs[0].double().numpy(), o16.double().numpy(), rtol=2e-2, atol=2e-3)

@@ -551,6 +551,70 @@ def test_half_tile_kernel_is_bit_equal_to_the_big_tile_kernel_at_benchmark_shape
     assert torch.equal(ys[0], ys[1])
 
 
+# ---- the persistent wave-specialised 256 x 128 kernel (csrc/gemm_w4s.hip, safe = 19; built and measured in round 5, not selected) ---------
+@pytest.mark.parametrize("tb", [False, True])
+@pytest.mark.parametrize("K,cus", [(1152, 0), (1216, 8), (1280, 64), (2048, 0)])
+def test_specialised_kernel_plain_store_is_bit_equal_on_hardware(ops, tb, K, cus):
+    """Four MFMA waves + four producer waves per workgroup, one workgroup per CU walking its tiles (cu_limit = workgroups: 512 half
+    tiles over 512 / 8 / 64 / 256 workgroups -- one, 64, 8 and two tiles each): the bf16 store is bit-equal to the 256x256 kernel's and
+    five launches give one bit pattern (the race screen of the six-unit ring, of the image hand-over between a consumer and its
+    producer, and of the accumulator bank in fixed registers -- round 5 found hipcc permuting C++ accumulators with v_accvgpr_mov
+    among the MFMAs on hardware only)."""
+    M, N = 4096, 4096
+    A = _r((M, K), 93)
+    B = _r((K, N) if tb else (N, K), 94, K ** -0.5)
+    want = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(A, B, want, tb=tb, alpha=0.5, safe=16)
+    old = ops.cu_limit
+    try:
+        ops.cu_limit = cus
+        for _ in range(5):
+            got = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+            ops.gemm(A, B, got, tb=tb, alpha=0.5, safe=19)
+            assert torch.equal(got, want)
+    finally:
+        ops.cu_limit = old
+
+
+def test_specialised_kernel_fused_epilogues_at_benchmark_shapes(ops):
+    """GELU with two outputs and both *_DOT epilogues drained by the producer waves under the next tile's K loop, at the shapes of a
+    gated block's FFN: the pre-activation is the rounded product bit for bit, GELU / dGELU are taken of the ROUNDED product (the
+    reference's own order under autocast) -- compared with fp32 torch by the tolerances of the 256x256 kernel's test."""
+    rows, d, hid = 8192, 2048, 8192
+    gate = torch.tensor([0.37], device="cuda")
+    g = float(torch.tanh(gate))
+    u, W1 = _r((rows, d), 41), _r((hid, d), 42, d ** -0.5)
+    acc = u.float() @ W1.float().t()
+    b, a = torch.empty(rows, hid, device="cuda", dtype=torch.bfloat16), torch.empty(rows, hid, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(u, W1, b, epi=abi.EPI_GELU, out2=a, safe=19)
+    a16 = torch.empty_like(a)
+    ops.gemm(u, W1, torch.empty_like(b), epi=abi.EPI_GELU, out2=a16, safe=16)
+    assert torch.equal(a, a16)
+    _close(a, acc, "pre-GELU")
+    _close(b, torch.nn.functional.gelu(a.float()), "GELU of the rounded product")
+    _close(b, torch.nn.functional.gelu(acc), "GELU", rtol=2e-2)
+    W2, dy = _r((d, hid), 43, hid ** -0.5), _r((rows, d), 45)
+    accd = dy.float() @ W2.float()
+    for epi in (abi.EPI_DGELU_DOT, abi.EPI_SCALE_DOT):
+        das, dots = [], []
+        for _ in range(3):
+            da, dot = torch.empty(rows, hid, device="cuda", dtype=torch.bfloat16), torch.zeros(1, device="cuda")
+            ops.gemm(dy, W2, da, tb=True, epi=epi, aux=a, gate=gate, dot=dot, safe=19)
+            das.append(da)
+            dots.append(dot)
+        assert all(torch.equal(das[0], x) for x in das) and all(torch.equal(dots[0], x) for x in dots)
+        ad = a.double().requires_grad_(True)
+        ge = torch.nn.functional.gelu(ad)
+        ge.sum().backward()
+        if epi == abi.EPI_DGELU_DOT:
+            want, terms = g * accd.double() * ad.grad, ge.detach() * accd.double()
+        else:
+            want, terms = g * accd.double(), a.double() * accd.double()
+        _close(das[0], want, "dX", rtol=2e-2)
+        wdot, ref_scale = (1 - g * g) * terms.sum().item(), (1 - g * g) * terms.abs().sum().item()
+        assert abs(float(dots[0]) - wdot) <= 1e-5 * ref_scale, (float(dots[0]), wdot, ref_scale)
+
+
 # ---- stream-K schedule of the 16x16x32 big-tile kernel (csrc/gemm_w4m.hip): tile counts the workgroup count does not divide --------
 _SK_SHAPES = [  # (M, N, K, ta, tb, epi, cu_limit)   tiles / workgroups
     (2048, 4096, 16384, False, True, abi.EPI_STORE_BF16, 0),  # OF-9B L = 256 dX: 128 tiles / 256 -> half a tile per workgroup

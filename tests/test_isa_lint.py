@@ -23,7 +23,7 @@ def _regs(tok):
     return None
 
 
-ASM_MFMA_SOURCES = [("gemm_w4m.hip", 10000), ("gemm_w4h.hip", 3000)]      # (file, at least this many v_mfma in its ISA)
+ASM_MFMA_SOURCES = [("gemm_w4m.hip", 10000), ("gemm_w4h.hip", 3000), ("gemm_w4s.hip", 500)]      # (file, at least this many v_mfma in its ISA)
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc to cross-compile")
@@ -138,7 +138,7 @@ def test_accumulators_of_asm_mfmas_are_read_only_after_the_settle_wait(tmp_path,
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc to cross-compile")
-@pytest.mark.parametrize("src", ["gemm_w4m.hip", "gemm_w4h.hip", "gemm_mid.hip", "gemm_pp.hip", "attention.hip"])
+@pytest.mark.parametrize("src", ["gemm_w4m.hip", "gemm_w4h.hip", "gemm_w4s.hip", "gemm_mid.hip", "gemm_pp.hip", "attention.hip"])
 def test_m0_is_only_ever_the_lds_dma_destination(tmp_path, src):
     """The inline-asm LDS-DMA (of_platform.h) writes M0 without declaring it: hipcc reserves M0 and refuses it in a clobber list
     ("inline asm clobber list contains reserved registers").  That is sound as long as the compiler itself never keeps a value in M0

@@ -1,4 +1,4 @@
-"""The persistent software-pipelined 256 x 128 kernel (csrc/gemm_w4p.hip, OfGemmArgs.safe = 19) against the 256 x 256 kernel (16), the
+"""The persistent wave-specialised 256 x 128 kernel (csrc/gemm_w4s.hip, OfGemmArgs.safe = 19) against the 256 x 256 kernel (16), the
 two-workgroups-per-CU kernel (18) and the vendor library (torch.mm: hipBLASLt) on the launches of a train step: same box, interleaved
 rounds, random operands.  One JSON line per case; first a parity screen (plain store: bit-equal; GELU: pre-activation bit-equal, output
 within one bf16 ulp of the 256 x 256 kernel's, five launches one bit pattern).  PROFILING TOOL."""
@@ -18,8 +18,8 @@ CASES = [("NT store_bf16", 8192, 8192, 2048, 0, 0, E.EPI_STORE_BF16), ("NT gelu 
          ("NT Wqkv store", 8192, 6144, 2048, 0, 0, E.EPI_STORE_BF16), ("NT out_proj store", 8192, 2048, 2048, 0, 0, E.EPI_STORE_BF16),
          ("NT down_proj store K=8192", 8192, 2048, 8192, 0, 0, E.EPI_STORE_BF16), ("NN dX K=8192", 8192, 2048, 8192, 0, 1, E.EPI_STORE_BF16),
          ("NT store 8192^3", 8192, 8192, 8192, 0, 0, E.EPI_STORE_BF16), ("NT OF-4B up gelu", 8192, 10240, 2560, 0, 0, E.EPI_GELU)]
-if os.environ.get("W4P_CASES"):
-    keep = os.environ["W4P_CASES"].split(",")
+if os.environ.get("W4S_CASES"):
+    keep = os.environ["W4S_CASES"].split(",")
     CASES = [c for c in CASES if any(k in c[0] for k in keep)]
 
 
@@ -53,11 +53,11 @@ for name, M, N, K, ta, tb, epi in CASES:
         if "dot" in kw:
             rec["dot_rel_diff"] = abs(float(outs[0][-1]) - float(want[-1])) / (abs(float(want[-1])) + 1e-30)
     except RuntimeError as exc:
-        rec["w4p"] = "not eligible: " + str(exc)[:80]
+        rec["w4s"] = "not eligible: " + str(exc)[:80]
     print(json.dumps(rec), flush=True)
     arms = {"w4m256": lambda: run(A, B, C, kw, ta, tb, epi, 16), "w4h": lambda: run(A, B, C, kw, ta, tb, epi, 18)}
-    if "w4p" not in rec:
-        arms["w4p"] = lambda: run(A, B, C, kw, ta, tb, epi, 19)
+    if "w4s" not in rec:
+        arms["w4s"] = lambda: run(A, B, C, kw, ta, tb, epi, 19)
     if epi == E.EPI_STORE_BF16:
         Bv = B if tb else B.t()          # torch.mm(A, Bv): the vendor library on the same operands (NT: B^T view, NN: B)
         arms["vendor"] = lambda: torch.mm(A, Bv, out=C)
