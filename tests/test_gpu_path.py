@@ -975,7 +975,10 @@ def test_vision_prefetch_on_a_side_stream_changes_no_bit():
     model, info = build()
     x = synthetic.make_batch(2, 2, 24, info, "cuda", seed=5)["vision_x"]
     model.prefetch_vision(x, amp_dtype=torch.bfloat16)
-    got = model._take_prefetched_vision(x)
+    assert model._take_prefetched_vision(x) is None        # a consumer WITHOUT the producer's autocast state does not get the tokens ...
+    model.prefetch_vision(x, amp_dtype=torch.bfloat16)
+    with torch.autocast("cuda", dtype=torch.bfloat16):      # ... the forward under the same autocast does
+        got = model._take_prefetched_vision(x)
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         want = model.vision_encoder(x.flatten(0, 2))[1]
     torch.cuda.synchronize()
