@@ -440,6 +440,8 @@ def main():
                 if t2 is not None:
                     traffic, traffic_note = t2, n2
                     break
+                if "ran libofhip" in n2:          # a record exists, of another build of the library: say THAT
+                    traffic_note = n2
         roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "kernel": f"{sym}  = of_gemm {LAYOUT_NAMES[key[:2]]}, epilogue {EPI_NAMES[key[2]]}",

@@ -25,6 +25,21 @@ def timeit(fn, iters=20, warm=3):
     return s.elapsed_time(e) / iters
 
 
+def timeit_cold(fn_of_set, nsets, iters=24, warm=None):
+    """the same over `nsets` rotating buffer sets (together > the 256-MB infinity cache: what a launch sees inside a train step --
+    round 4 found the same-buffer loop 20-40 % flattering for the streaming kernels)"""
+    for i in range(warm if warm is not None else nsets):
+        fn_of_set(i % nsets)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for i in range(iters):
+        fn_of_set(i % nsets)
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
 def main():
     ops = Ops.default()
     dev = "cuda"
@@ -69,38 +84,65 @@ def main():
                         general128_tflops=round(fl / ms_v1 / 1e9, 1), torch_ms=round(ms_t, 4), torch_tflops=round(fl / ms_t / 1e9, 1)))
         print(json.dumps(out[-1]), flush=True)
     # LayerNorm (HBM bound)
-    x = torch.randn(8192, 2048, device=dev)
+    NS = 6          # rotating sets for the cold figures: 6 x (100 ... 270 MB)
+    xs_ = [torch.randn(8192, 2048, device=dev) for _ in range(NS)]
+    x = xs_[0]
     w, b = torch.ones(2048, device=dev), torch.zeros(2048, device=dev)
-    y = torch.empty(8192, 2048, device=dev, dtype=torch.bfloat16)
+    ys_ = [torch.empty(8192, 2048, device=dev, dtype=torch.bfloat16) for _ in range(NS)]
+    y = ys_[0]
     st = torch.empty(8192, 2, device=dev)
     ms = timeit(lambda: ops.ln_fwd(x, w, b, y, st))
+    cold = timeit_cold(lambda i: ops.ln_fwd(xs_[i], w, b, ys_[i], st), NS)
     by = 8192 * 2048 * (4 + 2)
-    print(json.dumps(dict(kernel="ln_fwd", rows=8192, dim=2048, ms=round(ms, 4), GBps=round(by / ms / 1e6, 1))), flush=True)
-    dy = torch.randn(8192, 2048, device=dev).to(torch.bfloat16)
-    dx = torch.empty_like(x)
-    dxb = torch.empty_like(y)
+    print(json.dumps(dict(kernel="ln_fwd", rows=8192, dim=2048, ms=round(ms, 4), GBps=round(by / ms / 1e6, 1), cold_ms=round(cold, 4),
+                          cold_GBps=round(by / cold / 1e6, 1))), flush=True)
+    dys_ = [torch.randn(8192, 2048, device=dev).to(torch.bfloat16) for _ in range(NS)]
+    dy = dys_[0]
+    dxs_ = [torch.empty_like(x) for _ in range(NS)]
+    dx = dxs_[0]
+    dxbs_ = [torch.empty_like(y) for _ in range(NS)]
+    dxb = dxbs_[0]
     dw, db = torch.zeros(2048, device=dev), torch.zeros(2048, device=dev)
-    ms = timeit(lambda: ops.ln_bwd(dy, x, st, w, resid=x, dx=dx, dx_bf16=dxb, dw=dw, db=db))
     by = 8192 * 2048 * (2 + 4 + 4 + 4 + 2)
-    print(json.dumps(dict(kernel="ln_bwd", rows=8192, dim=2048, ms=round(ms, 4), GBps=round(by / ms / 1e6, 1))), flush=True)
-    ms = timeit(lambda: ops.ln_bwd(dy, x, st, w, resid=x, dx=dx, dx_bf16=dxb))
-    print(json.dumps(dict(kernel="ln_bwd_no_dw (frozen towers)", rows=8192, dim=2048, ms=round(ms, 4), GBps=round(by / ms / 1e6, 1))), flush=True)
-    ms = timeit(lambda: ops.ln_bwd(dy, x, st, w, resid=x, dx=dx))
-    print(json.dumps(dict(kernel="ln_bwd_no_dw_no_bf16_copy", rows=8192, dim=2048, ms=round(ms, 4), GBps=round((by - 8192 * 2048 * 2) / ms / 1e6, 1))), flush=True)
-    xs = torch.empty_like(x)
-    ms = timeit(lambda: ops.ln_fwd_add(x, dy, xs, w, b, y, st))
-    print(json.dumps(dict(kernel="ln_fwd_add", rows=8192, dim=2048, ms=round(ms, 4), GBps=round(8192 * 2048 * (4 + 2 + 4 + 2) / ms / 1e6, 1))), flush=True)
+    for name, kwf, nbytes in (("ln_bwd", lambda i: dict(resid=xs_[i], dx=dxs_[i], dx_bf16=dxbs_[i], dw=dw, db=db), by),
+                              ("ln_bwd_no_dw (frozen towers)", lambda i: dict(resid=xs_[i], dx=dxs_[i], dx_bf16=dxbs_[i]), by),
+                              ("ln_bwd_no_dw_no_bf16_copy", lambda i: dict(resid=xs_[i], dx=dxs_[i]), by - 8192 * 2048 * 2)):
+        ms = timeit(lambda: ops.ln_bwd(dy, x, st, w, **kwf(0)))
+        cold = timeit_cold(lambda i: ops.ln_bwd(dys_[i], xs_[i], st, w, **kwf(i)), NS)
+        print(json.dumps(dict(kernel=name, rows=8192, dim=2048, ms=round(ms, 4), GBps=round(nbytes / ms / 1e6, 1), cold_ms=round(cold, 4),
+                              cold_GBps=round(nbytes / cold / 1e6, 1))), flush=True)
+    sums_ = [torch.empty_like(x) for _ in range(NS)]
+    ms = timeit(lambda: ops.ln_fwd_add(x, dy, sums_[0], w, b, y, st))
+    cold = timeit_cold(lambda i: ops.ln_fwd_add(xs_[i], dys_[i], sums_[i], w, b, ys_[i], st), NS)
+    by = 8192 * 2048 * (4 + 2 + 4 + 2)
+    print(json.dumps(dict(kernel="ln_fwd_add", rows=8192, dim=2048, ms=round(ms, 4), GBps=round(by / ms / 1e6, 1), cold_ms=round(cold, 4),
+                          cold_GBps=round(by / cold / 1e6, 1))), flush=True)
+    # the frozen towers' element-wise passes (8192 x 8192 bf16), warm and cold
+    ga_ = [torch.randn(8192, 8192, device=dev).to(torch.bfloat16) for _ in range(4)]
+    gb_ = [torch.empty_like(t) for t in ga_]
+    for name, fn, nbytes in (("gelu_fwd", lambda i: ops.gelu_fwd(ga_[i], out=gb_[i]), 8192 * 8192 * 4),
+                             ("gelu_bwd", lambda i: ops.gelu_bwd(ga_[i], ga_[(i + 1) % 4], out=gb_[i]), 8192 * 8192 * 6)):
+        ms = timeit(lambda: fn(0))
+        cold = timeit_cold(fn, 4)
+        print(json.dumps(dict(kernel=name, elements=8192 * 8192, ms=round(ms, 4), GBps=round(nbytes / ms / 1e6, 1), cold_ms=round(cold, 4),
+                              cold_GBps=round(nbytes / cold / 1e6, 1))), flush=True)
+    del xs_, ys_, dys_, dxs_, dxbs_, sums_, ga_, gb_
     g = torch.randn(36_700_000, device=dev)
     parts = torch.empty(ops.SUMSQ_PARTS, device=dev)
     pp_, mm_, vv_ = torch.randn_like(g), torch.zeros_like(g), torch.zeros_like(g)
     pb_ = torch.empty(g.numel(), dtype=torch.bfloat16, device=dev)
     acc_ = torch.ones(1, device=dev)
+    # (one bucket's four fp32 arrays + the bf16 copy are 660 MB: the same-buffer loop is already cold in the infinity cache;
+    #  sumsq over one 147-MB array is not -- rotate it)
     ms = timeit(lambda: ops.adamw_clip(pp_, g, mm_, vv_, acc_, step=3, lr=1e-4, weight_decay=0.1, p_bf16=pb_, zero_grad=False))
     print(json.dumps(dict(kernel="adamw_clip (one gated-block bucket, bf16 copy, no zero)", n=g.numel(), ms=round(ms, 4),
-                          GBps=round(g.numel() * 30 / ms / 1e6, 1))), flush=True)
+                          GBps=round(g.numel() * 30 / ms / 1e6, 1), cold_ms=round(ms, 4), note="660 MB per launch: cold as it is")), flush=True)
     ms = timeit(lambda: ops.sumsq_partial(g, parts))
-    print(json.dumps(dict(kernel="sumsq_partial (one gated-block bucket)", n=g.numel(), ms=round(ms, 4), GBps=round(g.numel() * 4 / ms / 1e6, 1))), flush=True)
-    del g
+    gs_ = [g, pp_, mm_, vv_]
+    cold = timeit_cold(lambda i: ops.sumsq_partial(gs_[i], parts), 4)
+    print(json.dumps(dict(kernel="sumsq_partial (one gated-block bucket)", n=g.numel(), ms=round(ms, 4), GBps=round(g.numel() * 4 / ms / 1e6, 1),
+                          cold_ms=round(cold, 4), cold_GBps=round(g.numel() * 4 / cold / 1e6, 1))), flush=True)
+    del g, gs_
     # causal-LM loss at cfg-2: 8192 rows x 50435 logits (odd vocabulary: rows start at 2-byte alignment)
     lg = torch.randn(8192, 50435, device=dev).to(torch.bfloat16)
     lab = torch.randint(0, 50435, (8192,), device=dev)
