@@ -19,6 +19,9 @@ LAUNCHES = {
         2 * (8192 * 8192 + 2048 * 8192) + 2 * 4 * 8192 * 2048),
     "of_gemm_w4m_kernel<false, false, 1, false>": ("0 0 1 w4m256 8192 8192 2048", 0, "ffn up + GELU (a and b), 8192x8192x2048",
         2 * (8192 * 2048 + 8192 * 2048) + 2 * 2 * 8192 * 8192),
+    "of_gemm_w4h_kernel<true, 3, 0>": ("0 1 3 w4h256x128 8192 8192 2048", 0,
+        "ffn dX * gate * gelu'(a) + gate-gradient dot, 8192x8192x2048 (two workgroups per CU, 256x128 tiles)",
+        2 * (8192 * 2048 + 2048 * 8192) + 2 * 8192 * 8192 + 2 * 8192 * 8192),
 }
 
 

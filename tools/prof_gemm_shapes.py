@@ -20,4 +20,8 @@ for _ in range(2): ops.gemm(A, W, out, epi=abi.EPI_GATE_RESID, aux=res, gate=g)
 # ffn up + gelu : (NT) M=8192 N=8192 K=2048
 A, W, b, a = r(8192, 2048), r(8192, 2048), torch.empty(8192, 8192, device="cuda", dtype=torch.bfloat16), torch.empty(8192, 8192, device="cuda", dtype=torch.bfloat16)
 for _ in range(2): ops.gemm(A, W, b, epi=abi.EPI_GELU, out2=a)
+# ffn dX with the gate-gradient dot : (NN) M=8192 N=8192 K=2048, erf-GELU derivative -- of_gemm's selection: the two-workgroups-per-CU kernel
+dy, W2, x = r(8192, 2048), r(2048, 8192), r(8192, 8192)
+da, dot = torch.empty(8192, 8192, device="cuda", dtype=torch.bfloat16), torch.zeros(1, device="cuda")
+for _ in range(2): ops.gemm(dy, W2, da, tb=True, epi=abi.EPI_DGELU_DOT, aux=x, gate=g, dot=dot)
 torch.cuda.synchronize()
