@@ -201,8 +201,13 @@ def xattn_project_media(ops, W, media_bf, heads, out=None, prefix="attn.", dim_h
     return kv
 
 
+def _softmax_scale(scale, dim_head):
+    """the reference's dim_head ** -0.5 (helpers.py:28,140) -- given explicitly when the heads are zero-padded to a kernel size"""
+    return dim_head ** -0.5 if scale is None else float(scale)
+
+
 def masked_cross_attention_fwd(ops, P, W, x, media_bf, tt, *, B, L, T, n, heads, only_immediate, prefix="attn.", gate=None,
-                               residual=False, safe=0, kv=None, dim_head=64):
+                               residual=False, safe=0, kv=None, dim_head=64, scale=None):
     """x (B*L, d) stream dtype; media_bf (B*T*n, Dv) bf16; tt (B, L) int32 or None.  Returns (y, saved)."""
     dev = x.device
     rows, d = x.shape
@@ -218,14 +223,14 @@ def masked_cross_attention_fwd(ops, P, W, x, media_bf, tt, *, B, L, T, n, heads,
     lse = _e((B, heads, L), F32, dev)
     ops.attn_fwd(q, kv[:, :inner], kv[:, inner:], o, lse, batch=B, Lq=L, Lk=T * n, heads=heads, text_time=tt,
                  n_per_media=n, T_img=T, only_immediate=only_immediate, safe=safe, head_dim=dim_head,
-                 scale=dim_head ** -0.5)
+                 scale=_softmax_scale(scale, dim_head))
     y = _branch_out(ops, o, W[prefix + "to_out.weight"], x, x if residual else None, gate)   # to_out [, *tanh(gate), +x]
     return y, dict(x=x, xn=xn, st=st, q=q, kv=kv, o=o, lse=lse)
 
 
 def masked_cross_attention_bwd(ops, P, W, S, media_bf, tt, dy, dyb, G, *, B, L, T, n, heads, only_immediate,
                                prefix="attn.", gate=None, gate_name=None, residual=False, need_dmedia=True, safe=0,
-                               dim_head=64, dkv_out=None, offer_twin=False, scope=None):
+                               dim_head=64, dkv_out=None, offer_twin=False, scope=None, scale=None):
     """dy stream dtype + its bf16 copy dyb.  Returns (dx, dmedia fp32 or None).
     dkv_out: (B*T*n, 2*inner) bf16 destination of d(k|v) owned by the caller (a column block of the buffer shared by all
     blocks when their to_kv projections are grouped); the caller then forms the media gradient of all
@@ -249,7 +254,7 @@ def masked_cross_attention_bwd(ops, P, W, S, media_bf, tt, dy, dyb, G, *, B, L, 
     kv = S["kv"]
     ops.attn_bwd(S["q"], kv[:, :inner], kv[:, inner:], S["o"], S["lse"], dO, dq, dkv[:, :inner], dkv[:, inner:], delta,
                  batch=B, Lq=L, Lk=T * n, heads=heads, text_time=tt, n_per_media=n, T_img=T,
-                 only_immediate=only_immediate, safe=safe, head_dim=dim_head, scale=dim_head ** -0.5)
+                 only_immediate=only_immediate, safe=safe, head_dim=dim_head, scale=_softmax_scale(scale, dim_head))
     dxn = _e((rows, d), BF16, dev)
     ops.gemm(dq, W[prefix + "to_q.weight"], dxn, tb=True)
     t, beta = G.mat(prefix + "to_q.weight", (inner, d))
@@ -274,13 +279,13 @@ def masked_cross_attention_bwd(ops, P, W, S, media_bf, tt, dy, dyb, G, *, B, L, 
 # GatedCrossAttentionBlock (helpers.py:260-279) = the two gated branches with fused residuals
 # =================================================================================================
 def xattn_block_fwd(ops, P, W, x, media_bf, tt, *, B, L, T, n, heads, only_immediate, safe=0, kv=None, keep=True,
-                    dim_head=64):
+                    dim_head=64, scale=None):
     """x (B*L, d) stream dtype; media_bf (B*T*n, Dv) bf16; tt (B, L) int32 or None.  Returns (y, saved).
     kv: projected media from xattn_project_media (else computed here).  keep=False (inference): nothing is saved for a
     backward -- the pre-GELU activations are not written -- and saved is None."""
     y1, Sa = masked_cross_attention_fwd(ops, P, W, x, media_bf, tt, B=B, L=L, T=T, n=n, heads=heads,
                                         only_immediate=only_immediate, gate=P["attn_gate"], residual=True, safe=safe,
-                                        kv=kv, dim_head=dim_head)
+                                        kv=kv, dim_head=dim_head, scale=scale)
     y2, Sf = feed_forward_fwd(ops, P, W, y1, prefix="ff.", gate=P["ff_gate"], residual=True, keep=keep)
     if not keep:
         return y2, None
@@ -288,7 +293,7 @@ def xattn_block_fwd(ops, P, W, x, media_bf, tt, *, B, L, T, n, heads, only_immed
 
 
 def xattn_block_bwd(ops, P, W, S, media_bf, tt, dy, *, B, L, T, n, heads, only_immediate, need_dmedia=True, safe=0,
-                    sinks=None, dim_head=64, fresh=(), dkv_out=None, scope=None):
+                    sinks=None, dim_head=64, fresh=(), dkv_out=None, scope=None, scale=None):
     """Returns (dx, dmedia fp32 (B*T*n, Dv) or None, grads dict keyed like P).  sinks / fresh: see _GradOut."""
     G = _GradOut(sinks, dy.device, fresh)
     dy = dy.contiguous()
@@ -299,14 +304,14 @@ def xattn_block_bwd(ops, P, W, S, media_bf, tt, dy, *, B, L, T, n, heads, only_i
     dx, dmedia = masked_cross_attention_bwd(ops, P, W, S["attn"], media_bf, tt, dy1, dy1b, G, B=B, L=L, T=T, n=n,
                                             heads=heads, only_immediate=only_immediate, gate=P["attn_gate"],
                                             gate_name="attn_gate", residual=True, need_dmedia=need_dmedia, safe=safe,
-                                            dim_head=dim_head, dkv_out=dkv_out, offer_twin=True, scope=scope)
+                                            dim_head=dim_head, dkv_out=dkv_out, offer_twin=True, scope=scope, scale=scale)
     return dx, dmedia, G.g
 
 
 # =================================================================================================
 # PerceiverResampler
 # =================================================================================================
-def perceiver_attention_fwd(ops, P, W, x, lat, *, N, Fv, n, heads, prefix, residual=False, safe=0, dim_head=64):
+def perceiver_attention_fwd(ops, P, W, x, lat, *, N, Fv, n, heads, prefix, residual=False, safe=0, dim_head=64, scale=None):
     """PerceiverAttention.forward (helpers.py:39-65).  x (N*Fv, D) media rows, lat (N*n, D) latents, both stream dtype.
     Returns (out (N*n, D) = attn(x, latents) [+ latents], saved)."""
     dev = x.device
@@ -327,13 +332,13 @@ def perceiver_attention_fwd(ops, P, W, x, lat, *, N, Fv, n, heads, prefix, resid
     o = _e((N * n, inner), BF16, dev)
     lse = _e((N, heads, n), F32, dev)
     ops.attn_fwd(q, kv[:, :inner], kv[:, inner:], o, lse, batch=N, Lq=n, Lk=S_, heads=heads, safe=safe, head_dim=dim_head,
-                 scale=dim_head ** -0.5)
+                 scale=_softmax_scale(scale, dim_head))
     out = _branch_out(ops, o, W[prefix + "to_out.weight"], lat, lat if residual else None, None)
     return out, dict(x=x, lat=lat, kvin=kvin, st_m=st_m, st_l=st_l, ltn=ltn, q=q, kv=kv, o=o, lse=lse)
 
 
 def perceiver_attention_bwd(ops, P, W, S, dout, doutb, G, *, N, Fv, n, heads, prefix, residual=False, need_dx=False,
-                            dx_acc=None, safe=0, dim_head=64):
+                            dx_acc=None, safe=0, dim_head=64, scale=None):
     """dout (N*n, D) stream dtype (+ bf16 copy).  Returns (dlat, dx): dlat = [dout +] gradient through norm_latents;
     dx = (dx_acc or 0) + gradient through norm_media when need_dx, else None (norm_media's dw/db are always produced)."""
     dev = dout.device
@@ -350,7 +355,7 @@ def perceiver_attention_bwd(ops, P, W, S, dout, doutb, G, *, N, Fv, n, heads, pr
     delta = _e((N, heads, n), F32, dev)
     kv = S["kv"]
     ops.attn_bwd(S["q"], kv[:, :inner], kv[:, inner:], S["o"], S["lse"], dO, dq, dkv[:, :inner], dkv[:, inner:],
-                 delta, batch=N, Lq=n, Lk=S_, heads=heads, safe=safe, head_dim=dim_head, scale=dim_head ** -0.5)
+                 delta, batch=N, Lq=n, Lk=S_, heads=heads, safe=safe, head_dim=dim_head, scale=_softmax_scale(scale, dim_head))
     dltn = _e((N * n, D), BF16, dev)
     ops.gemm(dq, W[prefix + "to_q.weight"], dltn, tb=True)                      # through to_q
     t, beta = G.mat(prefix + "to_q.weight", (inner, D))
@@ -373,7 +378,7 @@ def perceiver_attention_bwd(ops, P, W, S, dout, doutb, G, *, N, Fv, n, heads, pr
     return dlat, dx_new
 
 
-def perceiver_fwd(ops, P, W, x, *, N, Fv, n, heads, depth, T=1, frames=1, safe=0, keep=True, dim_head=64):
+def perceiver_fwd(ops, P, W, x, *, N, Fv, n, heads, depth, T=1, frames=1, safe=0, keep=True, dim_head=64, scale=None):
     """x (N*Fv, D) stream dtype (already flattened 'b T (F v) d' rows, N = b*T, Fv = frames*v); returns
     (out (N*n, D) stream, saved).  frame_embs / media_time_embs (helpers.py:117-119,123-124) are added when present
     in P; T and frames give the row structure they index."""
@@ -390,7 +395,7 @@ def perceiver_fwd(ops, P, W, x, *, N, Fv, n, heads, depth, T=1, frames=1, safe=0
     layers = []
     for i in range(depth):
         lat1, Sa = perceiver_attention_fwd(ops, P, W, x, lat, N=N, Fv=Fv, n=n, heads=heads, prefix=f"layers.{i}.0.",
-                                           residual=True, safe=safe, dim_head=dim_head)   # attn(x, latents) + latents
+                                           residual=True, safe=safe, dim_head=dim_head, scale=scale)   # attn(x, latents) + latents
         lat, Sf = feed_forward_fwd(ops, P, W, lat1, prefix=f"layers.{i}.1.", residual=True, keep=keep)   # ff + latents
         if keep:
             layers.append(dict(attn=Sa, ff=Sf))
@@ -403,7 +408,7 @@ def perceiver_fwd(ops, P, W, x, *, N, Fv, n, heads, depth, T=1, frames=1, safe=0
 
 
 def perceiver_bwd(ops, P, W, S, dout, *, N, Fv, n, heads, depth, T=1, frames=1, need_dx=False, safe=0, sinks=None,
-                  on_ready=None, dim_head=64, fresh=()):
+                  on_ready=None, dim_head=64, fresh=(), scale=None):
     """Returns (dx (N*Fv, D) stream dtype or None, grads dict keyed like P).  sinks: see _GradOut.
     on_ready(names): called as soon as the kernels producing the FINAL value of those parameters' gradients are enqueued
     (per layer, last layer first) -- the gradient exchange of a layer can then start while the earlier layers' backward
@@ -427,7 +432,7 @@ def perceiver_bwd(ops, P, W, S, dout, *, N, Fv, n, heads, depth, T=1, frames=1, 
         dlat1, dlat1b = feed_forward_bwd(ops, P, W, Lr["ff"], dlat, G, prefix=pf, residual=True)   # ff(latents) + latents
         dlat, dx = perceiver_attention_bwd(ops, P, W, Lr["attn"], dlat1, dlat1b, G, N=N, Fv=Fv, n=n, heads=heads,
                                            prefix=pa, residual=True, need_dx=need_dx, dx_acc=dx, safe=safe,
-                                           dim_head=dim_head)                                        # attn + latents
+                                           dim_head=dim_head, scale=scale)                           # attn + latents
         ready([k for k in P if k.startswith(pa) or k.startswith(pf)])
     ops.reduce_rows(dlat, G.acc("latents", tuple(P["latents"].shape)))           # sum over (b, T) of the repeat
     if S.get("embs", False):

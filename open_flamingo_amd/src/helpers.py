@@ -187,7 +187,7 @@ class _PerceiverAttentionFn(torch.autograd.Function):
         n2 = latents.shape[2]
         xr = x.detach().reshape(b * T * n1, D).contiguous()
         lr = latents.detach().reshape(b * T * n2, D).to(xr.dtype).contiguous()
-        dims = dict(N=b * T, Fv=n1, n=n2, heads=mod.heads, prefix="", dim_head=mod.dim_head)
+        dims = dict(N=b * T, Fv=n1, n=n2, heads=mod.heads, prefix="", dim_head=_kernel_dim_head(mod.dim_head), scale=mod.dim_head ** -0.5)
         out, S = _path.perceiver_attention_fwd(ops, P, W, xr, lr, **dims)
         ctx.S, ctx.P, ctx.W, ctx.dims, ctx.params, ctx.param_dtypes = S, P, W, dims, params, tuple(p.dtype for p in params)
         ctx.xshape, ctx.lshape = tuple(x.shape), tuple(latents.shape)
@@ -207,9 +207,39 @@ class _PerceiverAttentionFn(torch.autograd.Function):
 
 
 def _check_dim_head(dim_head, who):
-    if dim_head not in (64, 128):
-        raise NotImplementedError(f"{who}: the libofhip attention kernels exist for dim_head 64 (every released OpenFlamingo "
-                                  f"model) and 128; got dim_head={dim_head}")
+    if not (isinstance(dim_head, int) and 1 <= dim_head <= 128):
+        raise NotImplementedError(f"{who}: the libofhip attention kernels take heads of up to 128 columns; got dim_head={dim_head}")
+
+
+def _kernel_dim_head(dim_head):
+    """The attention kernels exist for head sizes 64 (every released OpenFlamingo model) and 128.  The reference accepts ANY
+    dim_head (helpers.py:26-30,137-149): other sizes run with every head ZERO-PADDED to the next kernel size -- zero query / key
+    columns add nothing to a score, zero value columns give zero output columns, which meet zero columns of to_out -- and the softmax
+    scale of the TRUE size (``_pad_heads``: the padded weights are differentiable views of the parameters, so their gradients are the
+    true parameters' through autograd's slicing; the same arithmetic on more columns, not a fast path)."""
+    return 64 if dim_head <= 64 else 128
+
+
+def _pad_heads(names, params, heads, dim_head):
+    """to_q / to_kv rows and to_out columns of every attention in ``names`` padded per head from dim_head to the kernel size."""
+    dhp = _kernel_dim_head(dim_head)
+    if dhp == dim_head:
+        return list(params)
+    out = []
+    for k, p in zip(names, params):
+        if k.endswith(("to_q.weight", "to_kv.weight", "to_out.weight")) and getattr(p, "_of_grad_fresh", False):
+            # the step epilogue left this gradient stale for a backward that OVERWRITES it (train/optim.py); the padded view's
+            # gradient reaches the parameter through autograd's AccumulateGrad, which adds: clear the stale content now
+            if p.grad is not None:
+                p.grad.zero_()
+            p._of_grad_fresh = False
+        if k.endswith("to_q.weight") or k.endswith("to_kv.weight"):          # (groups * dim_head, D): groups = heads | k heads + v heads
+            g = p.shape[0] // dim_head
+            p = torch.nn.functional.pad(p.view(g, dim_head, p.shape[1]), (0, 0, 0, dhp - dim_head)).reshape(g * dhp, p.shape[1])
+        elif k.endswith("to_out.weight"):                                     # (D, heads * dim_head)
+            p = torch.nn.functional.pad(p.view(p.shape[0], heads, dim_head), (0, dhp - dim_head)).reshape(p.shape[0], heads * dhp)
+        out.append(p)
+    return out
 
 
 class PerceiverAttention(_HipParamModule):
@@ -235,6 +265,7 @@ class PerceiverAttention(_HipParamModule):
         _require_hip(latents, "PerceiverAttention(latents)")
         params = [self.norm_media.weight, self.norm_media.bias, self.norm_latents.weight, self.norm_latents.bias,
                   self.to_q.weight, self.to_kv.weight, self.to_out.weight]
+        params = _pad_heads(_PATTN_NAMES, params, self.heads, self.dim_head)
         return _PerceiverAttentionFn.apply(self, x, latents, *params)
 
 
@@ -250,7 +281,7 @@ def _perceiver_operands(mod, names, x, params):
     assert ("frame_embs" not in P or Fr <= P["frame_embs"].shape[0]) and \
         ("media_time_embs" not in P or T <= P["media_time_embs"].shape[0]), "more frames/media than embedding rows"
     dims = dict(N=b * T, Fv=Fr * v, n=P["latents"].shape[0], heads=mod.heads, depth=mod.depth, T=T, frames=Fr,
-                dim_head=mod.dim_head)
+                dim_head=_kernel_dim_head(mod.dim_head), scale=mod.dim_head ** -0.5)
     return ops, P, W, xr, dims
 
 
@@ -310,11 +341,12 @@ class PerceiverResampler(_HipParamModule):
         assert x.dim() == 5 and x.shape[-1] == self.dim, f"expected (b,T,F,v,{self.dim}), got {tuple(x.shape)}"
         named = list(self.named_parameters())
         names = tuple(k for k, _ in named)
+        params = _pad_heads(names, [p for _, p in named], self.heads, self.dim_head)
         if not torch.is_grad_enabled():          # inference: nothing kept for a backward
-            ops, P, W, xr, dims = _perceiver_operands(self, names, x, [p for _, p in named])
+            ops, P, W, xr, dims = _perceiver_operands(self, names, x, params)
             out, _ = _path.perceiver_fwd(ops, P, W, xr, keep=False, **dims)
             return out.view(x.shape[0], x.shape[1], dims["n"], x.shape[-1])
-        return _PerceiverFn.apply(self, names, x, *[p for _, p in named])
+        return _PerceiverFn.apply(self, names, x, *params)
 
 
 _MCA_NAMES = ("norm.weight", "norm.bias", "to_q.weight", "to_kv.weight", "to_out.weight")
@@ -345,6 +377,7 @@ class MaskedCrossAttention(_HipParamModule):
             assert media_locations is None or media_locations.shape[1] == x.shape[1], (
                 f"media_location.shape is {media_locations.shape} but x.shape is {x.shape}")
         params = [self.norm.weight, self.norm.bias, self.to_q.weight, self.to_kv.weight, self.to_out.weight]
+        params = _pad_heads(_MCA_NAMES, params, self.heads, self.dim_head)
         return _MaskedCrossAttentionFn.apply(self, x, media, media_locations, use_cached_media, *params)
 
 
@@ -386,7 +419,7 @@ def _xattn_operands(mod, x, media, media_locations, use_cached_media, params, na
             return out
         tt = shared.get(media_locations, ("tt", L, bool(use_cached_media)), _tt)
     dims = dict(B=B, L=L, T=T, n=n, heads=attn.heads, only_immediate=attn.only_attend_immediate_media,
-                dim_head=attn.dim_head)
+                dim_head=_kernel_dim_head(attn.dim_head), scale=attn.dim_head ** -0.5)
     return ops, P, W, xr, media_bf, tt, dims
 
 
@@ -460,6 +493,8 @@ def group_media_projections(blocks, media):
         return None
     a0 = blocks[0].attn
     E = a0.to_kv.weight.shape[0]
+    if any(_kernel_dim_head(b.attn.dim_head) != b.attn.dim_head for b in blocks):
+        return None                       # zero-padded heads: the blocks project their padded weights on their own
     if any(b.attn.to_kv.weight.shape != a0.to_kv.weight.shape for b in blocks) or E % 256 or media.shape[-1] % 256 \
             or (media.shape[0] * media.shape[1] * media.shape[2]) % 256:
         return None                       # not big-tile eligible (forward: N = E, K = D_img; backward: N = D_img, K = E
@@ -577,6 +612,7 @@ class GatedCrossAttentionBlock(_HipParamModule):
         a, f = self.attn, self.ff                        # the parameters in _XATTN_NAMES order
         params = [self.attn_gate, self.ff_gate, a.norm.weight, a.norm.bias, a.to_q.weight, a.to_kv.weight,
                   a.to_out.weight, f[0].weight, f[0].bias, f[1].weight, f[3].weight]
+        params = _pad_heads(_XATTN_NAMES, params, a.heads, a.dim_head)
         if not torch.is_grad_enabled():
             return self._forward_inference(x, media, media_locations, use_cached_media, params)
         grp = _media_group_of(self, media)
@@ -628,7 +664,7 @@ class GatedCrossAttentionBlock(_HipParamModule):
         The graph owns static input buffers (token, text_time, projected media) and its split-K workspace; it is
         captured the second time a shape is seen (the first call runs kernel by kernel, which also warms every lazily
         initialised piece outside the capture), and dropped with the weight copies (``invalidate_weight_cache``)."""
-        if not self.decode_graphs or tt is None or not xr.is_cuda:
+        if not self.decode_graphs or tt is None or not xr.is_cuda or _kernel_dim_head(self.attn.dim_head) != self.attn.dim_head:
             return None
         sig = (dims["B"], dims["T"], dims["n"], xr.dtype, tt.shape,
                tuple((w.data_ptr(), w._version) for w in W.values()),

@@ -152,8 +152,8 @@ def test_submodules_run_stand_alone_like_the_reference(on_emulator):
     assert _rel(y.detach(), ref[0]) < 1e-2 and _rel(xi.grad, ref[1]) < 3e-2
     for k, p in ff.named_parameters():
         assert _rel(p.grad, ref[2][k]) < 3e-2, k
-    # ---- MaskedCrossAttention (dim_head 64 and 128)
-    for dh in (64, 128):
+    # ---- MaskedCrossAttention (dim_head 64 and 128: the kernels' sizes; 32 and 80: zero-padded heads, the true softmax scale)
+    for dh in (64, 128, 32, 80):
         att = helpers.MaskedCrossAttention(dim=64, dim_visual=32, dim_head=dh, heads=2)
         media = w_(2, 2, 64, 32)
         locs = torch.zeros(2, 10, dtype=torch.bool)
@@ -170,22 +170,23 @@ def test_submodules_run_stand_alone_like_the_reference(on_emulator):
         assert _rel(y.detach(), ref[0]) < 1e-2 and _rel(xi.grad, ref[1]) < 3e-2 and _rel(mi.grad, ref[2]) < 3e-2, dh
         for k, p in att.named_parameters():
             assert _rel(p.grad, ref[3][k]) < 3e-2, (dh, k)
-    # ---- PerceiverAttention
-    pa = helpers.PerceiverAttention(dim=64, dim_head=64, heads=2)
-    feats, lat = w_(1, 2, 24, 64), w_(1, 2, 16, 64)
-    P = {k: v for k, v in pa.named_parameters()}
-    fo, lo = feats.clone().requires_grad_(True), lat.clone().requires_grad_(True)
-    yo = O.perceiver_attention(fo, lo, P, heads=2, quant=O.bf16_round)
-    wl = w_(1, 2, 16, 64)
-    (yo * wl).sum().backward()
-    ref = (yo.detach(), fo.grad, lo.grad, {k: p.grad.clone() for k, p in P.items()})
-    pa.zero_grad()
-    fi, li = feats.clone().requires_grad_(True), lat.clone().requires_grad_(True)
-    y = pa(fi, li)
-    (y * wl).sum().backward()
-    assert _rel(y.detach(), ref[0]) < 1e-2 and _rel(fi.grad, ref[1]) < 3e-2 and _rel(li.grad, ref[2]) < 3e-2
-    for k, p in pa.named_parameters():
-        assert _rel(p.grad, ref[3][k]) < 3e-2, k
+    # ---- PerceiverAttention (dim_head 64; 48: zero-padded heads)
+    for dh in (64, 48):
+        pa = helpers.PerceiverAttention(dim=64, dim_head=dh, heads=2)
+        feats, lat = w_(1, 2, 24, 64), w_(1, 2, 16, 64)
+        P = {k: v for k, v in pa.named_parameters()}
+        fo, lo = feats.clone().requires_grad_(True), lat.clone().requires_grad_(True)
+        yo = O.perceiver_attention(fo, lo, P, heads=2, quant=O.bf16_round)
+        wl = w_(1, 2, 16, 64)
+        (yo * wl).sum().backward()
+        ref = (yo.detach(), fo.grad, lo.grad, {k: p.grad.clone() for k, p in P.items()})
+        pa.zero_grad()
+        fi, li = feats.clone().requires_grad_(True), lat.clone().requires_grad_(True)
+        y = pa(fi, li)
+        (y * wl).sum().backward()
+        assert _rel(y.detach(), ref[0]) < 1e-2 and _rel(fi.grad, ref[1]) < 3e-2 and _rel(li.grad, ref[2]) < 3e-2, dh
+        for k, p in pa.named_parameters():
+            assert _rel(p.grad, ref[3][k]) < 3e-2, (dh, k)
     # a whole block with dim_head = 128 (the reference accepts any dim_head; the kernels exist for 64 and 128)
     blk = helpers.GatedCrossAttentionBlock(dim=64, dim_visual=32, dim_head=128, heads=2)
     refb = O.OracleGatedCrossAttentionBlock(dim=64, dim_visual=32, dim_head=128, heads=2)
@@ -195,6 +196,37 @@ def test_submodules_run_stand_alone_like_the_reference(on_emulator):
     refb.load_state_dict(blk.state_dict(), strict=True)
     yb = blk(x, media, media_locations=locs)
     assert _rel(yb.detach(), refb(x, media, media_locations=locs, quant=O.bf16_round).detach()) < 1e-2
+    # ... and with dim_head = 80 (OF-4B's language model uses that head size; the reference's helpers accept it): forward, every
+    # gradient, the no-grad path, and a PerceiverResampler with dim_head = 32
+    blk = helpers.GatedCrossAttentionBlock(dim=64, dim_visual=32, dim_head=80, heads=2)
+    refb = O.OracleGatedCrossAttentionBlock(dim=64, dim_visual=32, dim_head=80, heads=2)
+    with torch.no_grad():
+        blk.attn_gate.fill_(0.5)
+        blk.ff_gate.fill_(0.5)
+    refb.load_state_dict(blk.state_dict(), strict=True)
+    xo, mo = x.clone().requires_grad_(True), media.clone().requires_grad_(True)
+    yo = refb(xo, mo, media_locations=locs, quant=O.bf16_round)
+    (yo * wt).sum().backward()
+    xi, mi = x.clone().requires_grad_(True), media.clone().requires_grad_(True)
+    yb = blk(xi, mi, media_locations=locs)
+    (yb * wt).sum().backward()
+    assert _rel(yb.detach(), yo.detach()) < 1e-2 and _rel(xi.grad, xo.grad) < 3e-2 and _rel(mi.grad, mo.grad) < 3e-2
+    for (k, p), (_, q) in zip(blk.named_parameters(), refb.named_parameters()):
+        assert p.grad.shape == q.grad.shape and _rel(p.grad, q.grad) < 3e-2 + 1e-3, k
+    with torch.no_grad():
+        assert _rel(blk(x, media, media_locations=locs), yo.detach()) < 1e-2
+    pr = helpers.PerceiverResampler(dim=64, depth=2, dim_head=32, heads=2, num_latents=16)
+    pro = O.OraclePerceiverResampler(dim=64, depth=2, dim_head=32, heads=2, num_latents=16)
+    pro.load_state_dict(pr.state_dict(), strict=True)
+    feats = w_(1, 2, 1, 24, 64)
+    wl = w_(1, 2, 16, 64)
+    yo = pro(feats, quant=O.bf16_round)
+    (yo * wl).sum().backward()
+    yp = pr(feats)
+    (yp * wl).sum().backward()
+    assert _rel(yp.detach(), yo.detach()) < 1e-2
+    for (k, p), (_, q) in zip(pr.named_parameters(), pro.named_parameters()):
+        assert _rel(p.grad, q.grad) < 3e-2 + 1e-3, k
 
 
 def test_step_epilogue_leaves_weight_gradients_for_the_backward_to_overwrite(on_emulator):
@@ -421,3 +453,29 @@ def test_vision_prefetch_changes_no_bit_and_runs_the_tower_once_per_forward(on_e
     model.prefetch_vision(batches[1]["vision_x"])
     batches[1]["vision_x"].add_(1.0)
     assert model._take_prefetched_vision(batches[1]["vision_x"]) is None
+
+
+def test_padded_heads_do_not_add_to_gradients_the_step_epilogue_left_stale(on_emulator):
+    """dim_head outside {64, 128}: the attention projections reach the kernels as zero-padded differentiable views, so their gradients
+    arrive through autograd's AccumulateGrad (which ADDS) instead of the overwrite-with-beta-0 protocol of train/optim.py -- a
+    gradient marked `_of_grad_fresh` (stale content, to be overwritten) is cleared in the forward."""
+    torch.manual_seed(1)
+    blk = helpers.GatedCrossAttentionBlock(dim=64, dim_visual=32, dim_head=80, heads=2)
+    with torch.no_grad():
+        blk.attn_gate.fill_(0.5)
+        blk.ff_gate.fill_(0.5)
+    x, media = torch.randn(2, 10, 64), torch.randn(2, 2, 64, 32)
+    locs = torch.zeros(2, 10, dtype=torch.bool)
+    locs[:, 1] = True
+    blk(x, media, media_locations=locs).square().sum().backward()
+    want = {k: p.grad.clone() for k, p in blk.named_parameters()}
+    for k, p in blk.named_parameters():
+        if k.endswith(("to_q.weight", "to_kv.weight", "to_out.weight")):
+            p.grad.fill_(7.0)                   # what an optimizer step leaves behind
+            p._of_grad_fresh = True
+        else:
+            p.grad.zero_()
+    blk(x, media, media_locations=locs).square().sum().backward()
+    for k, p in blk.named_parameters():
+        assert torch.allclose(p.grad, want[k], rtol=1e-5, atol=1e-6), k
+        assert not getattr(p, "_of_grad_fresh", False)

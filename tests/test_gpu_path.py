@@ -1052,3 +1052,44 @@ def test_early_norm_partials_on_the_side_stream_change_no_bit():
             assert torch.equal(m1[k], m0[k]), k
         else:
             assert torch.allclose(m1[k], m0[k], rtol=1e-5, atol=1e-7), k
+
+
+@pytest.mark.parametrize("dh", [32, 80, 96])
+def test_modules_accept_any_dim_head_up_to_128(dh):
+    """The reference's helpers take any dim_head (helpers.py:26-30,137-149); the attention kernels exist for 64 and 128.  Other sizes
+    run with every head zero-padded to the next kernel size and the TRUE softmax scale: product modules on the GPU against the
+    oracle (fp32, rounding points of the bf16 path), forward and every gradient, gated block and Perceiver."""
+    from oracle import flamingo_oracle as O
+    from open_flamingo_amd.src.helpers import GatedCrossAttentionBlock, PerceiverResampler
+    torch.manual_seed(dh)
+    blk = GatedCrossAttentionBlock(dim=256, dim_visual=128, dim_head=dh, heads=4).cuda()
+    ref = O.OracleGatedCrossAttentionBlock(dim=256, dim_visual=128, dim_head=dh, heads=4)
+    with torch.no_grad():
+        blk.attn_gate.fill_(0.5)
+        blk.ff_gate.fill_(0.5)
+    ref.load_state_dict({k: v.cpu() for k, v in blk.state_dict().items()}, strict=True)
+    x, media = torch.randn(2, 48, 256), torch.randn(2, 2, 64, 128)
+    locs = torch.zeros(2, 48, dtype=torch.bool)
+    locs[:, 2] = locs[0, 20] = True
+    w = torch.randn(2, 48, 256)
+    xo, mo = x.clone().requires_grad_(True), media.clone().requires_grad_(True)
+    yo = ref(xo, mo, media_locations=locs, quant=O.bf16_round)
+    (yo * w).sum().backward()
+    xi, mi = x.cuda().requires_grad_(True), media.cuda().requires_grad_(True)
+    y = blk(xi, mi, media_locations=locs.cuda())
+    (y * w.cuda()).sum().backward()
+    assert PC.rel_l2(y.detach().cpu(), yo.detach()) < 1e-2
+    assert PC.rel_l2(xi.grad.cpu(), xo.grad) < 2e-2 and PC.rel_l2(mi.grad.cpu(), mo.grad) < 2e-2
+    for (k, p), (_, q) in zip(blk.named_parameters(), ref.named_parameters()):
+        assert p.grad.shape == q.grad.shape and PC.rel_l2(p.grad.cpu(), q.grad) < 2e-2, k
+    pr = PerceiverResampler(dim=128, depth=2, dim_head=dh, heads=4, num_latents=32).cuda()
+    pro = O.OraclePerceiverResampler(dim=128, depth=2, dim_head=dh, heads=4, num_latents=32)
+    pro.load_state_dict({k: v.cpu() for k, v in pr.state_dict().items()}, strict=True)
+    feats, wl = torch.randn(1, 2, 1, 64, 128), torch.randn(1, 2, 32, 128)
+    yo = pro(feats, quant=O.bf16_round)
+    (yo * wl).sum().backward()
+    yp = pr(feats.cuda())
+    (yp * wl.cuda()).sum().backward()
+    assert PC.rel_l2(yp.detach().cpu(), yo.detach()) < 1e-2
+    for (k, p), (_, q) in zip(pr.named_parameters(), pro.named_parameters()):
+        assert PC.rel_l2(p.grad.cpu(), q.grad) < 2e-2, k

@@ -89,8 +89,9 @@ def test_modules_have_reference_state_dict_and_fail_loudly_on_cpu():
         b(torch.zeros(1, 4, 128), torch.zeros(1, 1, 64, 64), torch.zeros(1, 4, dtype=torch.bool))
     with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
         p(torch.zeros(1, 1, 1, 8, 64))
+    GatedCrossAttentionBlock(dim=128, dim_visual=64, dim_head=32)           # any head size up to 128 (zero-padded to a kernel size)
     with pytest.raises(NotImplementedError):
-        GatedCrossAttentionBlock(dim=128, dim_visual=64, dim_head=32)
+        GatedCrossAttentionBlock(dim=128, dim_visual=64, dim_head=160)
 
 
 def test_golden_state_dict_names():
