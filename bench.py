@@ -280,6 +280,10 @@ def main():
                     help="A/B: compute every bucket's share of the global gradient norm on the reducer's side stream as soon as the bucket's "
                          "gradient is final (behind its all-reduce) instead of in the step epilogue (train/optim.py: early_norm; same bits; "
                          "measured +0.5 ms per step on one GPU, hence off)")
+    ap.add_argument("--no-norm-taps", action="store_true",
+                    help="A/B (one GPU): take the FFN weight gradients' share of the global gradient norm in the step epilogue's pass "
+                         "over the gradients instead of in their dW GEMMs' epilogues (train/optim.py: tap_norm; same norm up to the "
+                         "order of the partial sums)")
     ap.add_argument("--no-vision-prefetch", action="store_true",
                     help="run the frozen vision tower at the start of each step (as the reference does) instead of enqueuing the NEXT "
                          "step's tower forward on a side stream next to the step epilogue (train/step.py: next_vision_x)")
@@ -341,6 +345,8 @@ def main():
         opt.narrow_cus = args.optimizer_cus
     if args.early_norm and not args.torch_optimizer:
         opt.early_norm = True
+    if args.no_norm_taps and not args.torch_optimizer:
+        opt.tap_norm = False
     batch = synthetic.make_batch(args.batch, args.T, args.L, info, device, seed=1 + rank)
     laion = synthetic.make_batch(args.laion_batch, 1, 32, info, device, seed=101 + rank) if args.laion_batch > 0 else None
     step_kw = dict(batch_laion=laion, loss_multiplier_laion=0.2) if laion is not None else {}
@@ -478,6 +484,9 @@ def main():
                           "vendor_gemm_table": f"TunableOp table, {n_tuned} shapes, tuning off" if n_tuned else "library defaults",
                           "grad_wire_dtype": "bf16" if args.wire_bf16 else "fp32", "reserve_cus": args.reserve_cus,
                           "embedding_row_gradient": "sparse taps" if args.sparse_embedding_rows else "dense, masked",
+                          "global_norm": ("torch clip_grad_norm_" if args.torch_optimizer else
+                                          f"FFN weight gradients' share from their dW GEMM epilogues ({getattr(opt, 'tapped_buckets', 0)} buckets), "
+                                          "the rest in one pass" if getattr(opt, "tapped_buckets", 0) else "one pass over the gradients"),
                           "step_epilogue_launch": (f"narrow: {args.optimizer_cus} fat workgroups" if args.optimizer_cus else "covers the chip"),
                           "vision_tower_schedule": ("at the start of the step" if args.no_vision_prefetch else
                                                     "next step's tower forward on a side stream next to the step epilogue"),

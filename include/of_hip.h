@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OF_ABI_VERSION 8
+#define OF_ABI_VERSION 9
 #define OF_E_ARG (-1)      /* null pointer / negative size */
 #define OF_E_SHAPE (-2)    /* shape not supported by the kernels (see each function) */
 #define OF_E_ALIGN (-3)    /* pointer or leading dimension not 16-byte aligned */
@@ -113,6 +113,12 @@ typedef struct OfGemmArgs {
      * workgroup.  sk_grid: internal, filled in by of_gemm; callers pass 0. */
     int cu_limit;
     int sk_grid;
+    /* OF_EPI_ACC_F32 (ABI v9): optional sum of squares of the FINAL output values (after alpha, gate and beta), one fp32 partial per
+     * 256x256 output tile, m-major tile order, WRITTEN (not added) to sumsq_out[tile]: a weight gradient's share of the global gradient
+     * norm (train_utils.py:199: clip_grad_norm_) leaves with the GEMM that produces the gradient instead of in another pass over it.
+     * Honoured only where of_gemm_sumsq_slots(args) > 0 -- a single launch of the 256x256 kernel: no split along K or N -- and ignored
+     * elsewhere (the slots stay untouched): callers ask first.  NULL = off. */
+    float* sumsq_out;
 } OfGemmArgs;
 
 int of_gemm(const OfGemmArgs* args, void* stream);
@@ -125,6 +131,9 @@ int of_gemm_batch(const OfGemmArgs* args, int n, void* stream);
  * partials of a *_DOT launch with dot_out (required), the stream-K partial tiles + flags of a big-tile launch whose tile count
  * is not a multiple of its workgroup count (optional, see cu_limit), else 0. */
 size_t of_gemm_workspace_bytes(const OfGemmArgs* args);
+/* Number of fp32 slots of_gemm would write to args->sumsq_out for these arguments (the launch's 256x256 tiles), or 0 if the launch
+ * does not take the form that honours it (ABI v9). */
+size_t of_gemm_sumsq_slots(const OfGemmArgs* args);
 
 /* ---------------------------------------------------------------------------------------------------
  * LayerNorm (eps 1e-5, affine) -- nn.LayerNorm in helpers.py:18,33-34,105,152.

@@ -373,8 +373,34 @@ extern "C" size_t of_gemm_workspace_bytes(const OfGemmArgs* args) {
     return slabs > need ? slabs : need;
 }
 
+// Mirror of of_gemm's selection for OfGemmArgs.sumsq_out: the launch is ONE launch of the 256x256 kernel (classic or stream-K) --
+// not the skinny kernel, not grouped, not split along K, not split along N (tile quantisation), no forced kernel.
+extern "C" size_t of_gemm_sumsq_slots(const OfGemmArgs* args) {
+    if (!args || !args->A || !args->B || !args->C || args->M <= 0 || args->N <= 0 || args->K <= 0) return 0;
+    OfGemmArgs a = *args;
+    a.sk_grid = 0;
+    if (a.epi != OF_EPI_ACC_F32 || a.group_kind || a.safe != 0 || of_gemm_is_skinny(a)) return 0;
+    const long tiles256 = (long)(a.M / 256) * (a.N / 256);
+    const bool pp_ok = !(a.M % 256) && !(a.N % 256) && !(a.K % 64) && tiles256 >= 128;
+    if (!pp_ok || !of_gemm_w4m_eligible(a) || pick_ksplit(a, true) > 1 || pick_ksplit(a, false) > 1) return 0;
+    const int G = sk_grid_for(a, tiles256);
+    if (G > 0 && sk_usable(a, G)) return (size_t)tiles256;
+    const int tm = a.M / 256, tn = a.N / 256;
+    if (tiles256 > 256 && tiles256 % 256)
+        for (int n = tn - 1; n >= 1; --n)
+            if (((long)tm * n) % 256 == 0) {
+                const bool mid_ok = !(a.M % 128) && !(a.N % 128) && !(a.K % 64);
+                if ((long)tm * (tn - n) <= 128 && mid_ok) return 0;      // (of_gemm would try the N-split: two launches)
+                break;
+            }
+    return (size_t)tiles256;
+}
+
 // grouped-B launches (OfGemmArgs.group_kind): big-tile kernels only
-static int gemm_grouped(const OfGemmArgs& a, of_stream_t s) {
+static int gemm_grouped(const OfGemmArgs& a_in, of_stream_t s) {
+    OfGemmArgs a_own = a_in;
+    a_own.sumsq_out = nullptr;            // (single-matrix weight gradients only: of_gemm_sumsq_slots)
+    const OfGemmArgs& a = a_own;
     if (!a.groups || a.group_extent <= 0) return OF_E_ARG;
     if ((a.M % 256) || (a.N % 256) || (a.K % 64) || a.a_trans) return OF_E_SHAPE;
     if ((a.lda & 7) || (a.ldb & 7) || (a.ldc & 3) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.C & 15)) return OF_E_ALIGN;
@@ -397,6 +423,8 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
     if (!args->B) return OF_E_ARG;
     OfGemmArgs a_own = *args;
     a_own.sk_grid = 0;                 // internal field ("callers pass 0"): only the stream-K branches below set it, a caller's value is ignored
+    float* const sumsq = a_own.sumsq_out;
+    a_own.sumsq_out = nullptr;         // honoured by the single big-tile launch only (of_gemm_sumsq_slots): every other kernel must not see it
     const OfGemmArgs& a = a_own;
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return OF_E_ARG;
     // vector-loaded (contiguous) extents must be multiples of 8 elements; outputs are written 4 wide
@@ -497,6 +525,7 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
         if (G > 0 && sk_usable(a, G)) {
             OfGemmArgs w = a;
             w.sk_grid = G;
+            if (a.epi == OF_EPI_ACC_F32) w.sumsq_out = sumsq;      // a shared tile is finished -- and summed -- by exactly one workgroup
             return of_gemm_w4m_try(w, s);
         }
         // Tile quantisation: a grid whose last round of 256x256 tiles would be under half full (OF-4B: M = 8192, N = 2560 ->
@@ -527,7 +556,9 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
                 return rc ? rc : of_gemm_mid_try(right, s);
             }
         }
-        const int rc = of_gemm_w4m_try(a, s);
+        OfGemmArgs w = a;
+        if (a.epi == OF_EPI_ACC_F32) w.sumsq_out = sumsq;
+        const int rc = of_gemm_w4m_try(w, s);
         if (rc != OF_E_SHAPE) return rc;
     }
     if ((a.safe == 0 && pp_ok) || pp_forced) {   // 4 = force the ping-pong kernel whenever the shape is eligible
@@ -566,6 +597,7 @@ extern "C" int of_gemm_batch(const OfGemmArgs* args, int n, void* stream) {
         else if ((a.lda & 7) || (a.ldb & 7) || (a.ldc & 3) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15) || ((uintptr_t)a.C & 15)) batched = false;
         else {
             OfGemmArgs b = a;
+            b.sumsq_out = nullptr;
             b.ksplit = pick_ksplit(a, true);
             const size_t need = b.ksplit > 1 ? (size_t)b.ksplit * a.M * a.N * sizeof(float) : 0;
             const long tiles256 = (long)(a.M / 256) * (a.N / 256);

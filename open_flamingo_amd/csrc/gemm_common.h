@@ -189,6 +189,10 @@ OF_DEV void epilogue_row8(const OfGemmArgs& p, const float (&a)[8], int m, int n
         }
         *(f32x4*)c = o0;
         *(f32x4*)(c + hi) = o1;
+        if (p.sumsq_out) {      // the gradient norm's share of these eight values (OfGemmArgs.sumsq_out; `dot` is the lane's running sum)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dot = __builtin_fmaf(o0[e], o0[e], __builtin_fmaf(o1[e], o1[e], dot));
+        }
     }
 }
 
@@ -374,6 +378,17 @@ OF_DEV void epilogue_finish(const OfGemmArgs& p, float dot, int lane, int wave, 
                 float s = 0.f;
                 for (int w = 0; w < nwaves; ++w) s += red[w];
                 ((float*)p.workspace)[slot] = s;
+            }
+        }
+    } else if (EPI == OF_EPI_ACC_F32) {      // OfGemmArgs.sumsq_out: the tile's sum of squares, waves added in a fixed order
+        if (p.sumsq_out) {
+            dot = of_wave_sum(dot);
+            if (lane == 0) red[wave] = dot;
+            of_sync();
+            if (wave == 0 && lane == 0) {
+                float s = 0.f;
+                for (int w = 0; w < nwaves; ++w) s += red[w];
+                p.sumsq_out[slot] = s;
             }
         }
     }

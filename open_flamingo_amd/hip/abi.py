@@ -5,7 +5,7 @@ Pure declarations: nothing here loads a library.  ``open_flamingo_amd.hip.lib`` 
 """
 import ctypes as C
 
-OF_ABI_VERSION = 8
+OF_ABI_VERSION = 9
 OF_SUMSQ_PARTS = 512
 EPI_STORE_BF16, EPI_GELU, EPI_GATE_RESID, EPI_DGELU_DOT, EPI_SCALE_DOT, EPI_ACC_F32 = range(6)
 
@@ -29,6 +29,7 @@ class OfGemmArgs(C.Structure):
         ("workspace", vp), ("workspace_bytes", C.c_size_t),
         ("groups", vp), ("group_kind", C.c_int), ("group_extent", C.c_int),
         ("cu_limit", C.c_int), ("sk_grid", C.c_int),
+        ("sumsq_out", vp),
     ]
 
 
@@ -53,6 +54,7 @@ PROTOTYPES = {
     "of_build_kind": (C.c_int, []),
     "of_gemm": (C.c_int, [C.POINTER(OfGemmArgs), vp]),
     "of_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(OfGemmArgs)]),
+    "of_gemm_sumsq_slots": (C.c_size_t, [C.POINTER(OfGemmArgs)]),
     "of_gemm_batch": (C.c_int, [C.POINTER(OfGemmArgs), C.c_int, vp]),
     "of_layernorm_fwd": (C.c_int, [vp, C.c_int, C.c_long, vp, vp, vp, C.c_long, vp, C.c_long, C.c_int, vp]),
     "of_layernorm_fwd_out": (C.c_int, [vp, C.c_int, C.c_long, vp, vp, vp, C.c_int, C.c_long, vp, C.c_long,

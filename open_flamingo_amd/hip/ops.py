@@ -76,8 +76,10 @@ class Ops:
         return "general128"
 
     def gemm(self, A, B, out, *, ta=False, tb=False, epi=abi.EPI_STORE_BF16, out2=None, aux=None, gate=None,
-             alpha=1.0, beta=0.0, dot=None, safe=0):
-        """acc[m][n] = sum_k A(m,k) B(n,k); A is (M,K) or, with ta, (K,M); B is (N,K) or, with tb, (K,N)."""
+             alpha=1.0, beta=0.0, dot=None, safe=0, sumsq=None):
+        """acc[m][n] = sum_k A(m,k) B(n,k); A is (M,K) or, with ta, (K,M); B is (N,K) or, with tb, (K,N).
+        sumsq (EPI_ACC_F32): fp32 tensor that receives the sum of squares of the final output, one partial per 256x256 tile
+        (OfGemmArgs.sumsq_out) -- returns True iff the launch honoured it (it is left untouched otherwise)."""
         assert A.dim() == 2 and B.dim() == 2 and out.dim() == 2
         assert A.dtype == BF16 and B.dtype == BF16 and A.stride(1) == 1 and B.stride(1) == 1 and out.stride(1) == 1
         M, K = (A.shape[1], A.shape[0]) if ta else (A.shape[0], A.shape[1])
@@ -107,6 +109,12 @@ class Ops:
             assert out.dtype == BF16
         a.safe = safe
         a.cu_limit = self.cu_limit
+        took_sumsq = False
+        if sumsq is not None and epi == abi.EPI_ACC_F32:
+            need = self.lib.of_gemm_sumsq_slots(C.byref(a))
+            if need and sumsq.dtype == F32 and sumsq.is_contiguous() and sumsq.numel() >= need and sumsq.device == out.device:
+                a.sumsq_out = sumsq.data_ptr()
+                took_sumsq = True
         # scratch: split-K fp32 slabs (EPI_ACC_F32), the per-workgroup gate-gradient partials of a *_DOT launch (summed in
         # a fixed order by a second launch: deterministic), or the partial tiles + flags of a stream-K big-tile launch (tile count
         # not a multiple of the workgroup count: csrc/gemm.hip sk_grid_for); one grow-only buffer, reused in stream order
@@ -131,9 +139,9 @@ class Ops:
                 self._chk(self.lib.of_gemm(C.byref(a), self._stream()), "of_gemm")
                 e1.record()
                 self.gemm_timing.append((key, 2.0 * M * N * K, (M, N, K), e0, e1))
-                return out
+                return took_sumsq if sumsq is not None else out
         self._chk(self.lib.of_gemm(C.byref(a), self._stream()), "of_gemm")
-        return out
+        return took_sumsq if sumsq is not None else out
 
     def gemm_batch_dw(self, problems):
         """Several independent weight-gradient GEMMs out_i (M_i, N_i) = [gate_i] A_i^T B_i (+ beta_i out_i) in ONE launch

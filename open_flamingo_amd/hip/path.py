@@ -29,8 +29,24 @@ class _GradOut:
     existing fp32 ``.grad``, e.g. a view into a GradReducer bucket) the kernels accumulate into it directly: the dW
     GEMMs run with beta = 1, the LayerNorm / gate / table reductions already add into their output."""
 
-    def __init__(self, sinks, dev, fresh=()):
+    def __init__(self, sinks, dev, fresh=(), sumsq=None):
         self.sinks, self.dev, self.g, self.fresh = (sinks or {}), dev, {}, fresh
+        # sumsq: name -> fp32 slots that take the gradient's sum of squares from the dW GEMM's epilogue (OfGemmArgs.sumsq_out; the
+        # step epilogue then skips that matrix in its global-norm pass, train/optim.py).  Only for gradients that go straight into
+        # their sink; sumsq_done[name] says whether the launch honoured it.
+        self.sumsq, self.sumsq_done = (sumsq or {}), {}
+
+    def dw_gemm(self, ops, name, shape, A, B, **kw):
+        """The weight gradient `name` = A^T B (TN, fp32) into its buffer, with its sum of squares into its slots where it has some."""
+        t, beta = self.mat(name, shape)
+        slots = self.sumsq.get(name) if name in self.sinks else None
+        if slots is None:
+            ops.gemm(A, B, t, ta=True, tb=True, epi=EPI_ACC_F32, beta=beta, **kw)
+            if name in self.sumsq:
+                self.sumsq_done[name] = False
+        else:
+            self.sumsq_done[name] = bool(ops.gemm(A, B, t, ta=True, tb=True, epi=EPI_ACC_F32, beta=beta, sumsq=slots, **kw))
+        return t
 
     def mat(self, name, shape):
         """Buffer for a GEMM-produced gradient and the beta to use with it (0 for a sink in ``fresh``: its content is
@@ -177,12 +193,10 @@ def feed_forward_bwd(ops, P, W, S, dy, G, *, prefix="", gate=None, gate_name=Non
     da = _e((rows, hid), BF16, dev)
     ops.gemm(dyb, W[prefix + "3.weight"], da, tb=True, epi=EPI_DGELU_DOT, aux=S["a"], gate=gate,
              dot=G.acc(gate_name, (1,)) if gate_name else None)
-    t, beta = G.mat(prefix + "3.weight", (d, hid))
-    ops.gemm(dyb, S["b"], t, ta=True, tb=True, epi=EPI_ACC_F32, gate=gate, beta=beta)         # dW2
+    G.dw_gemm(ops, prefix + "3.weight", (d, hid), dyb, S["b"], gate=gate)                    # dW2
     du = _e((rows, d), BF16, dev)
     ops.gemm(da, W[prefix + "1.weight"], du, tb=True)
-    t, beta = G.mat(prefix + "1.weight", (hid, d))
-    ops.gemm(da, S["u"], t, ta=True, tb=True, epi=EPI_ACC_F32, beta=beta)                    # dW1
+    G.dw_gemm(ops, prefix + "1.weight", (hid, d), da, S["u"])                                # dW1
     dx = torch.empty_like(dy)
     dxb = _e((rows, d), BF16, dev) if dy.dtype == F32 else None
     ops.ln_bwd(du, S["x"], S["st"], P[prefix + "0.weight"], resid=dy if residual else None, dx=dx, dx_bf16=dxb,
@@ -293,9 +307,10 @@ def xattn_block_fwd(ops, P, W, x, media_bf, tt, *, B, L, T, n, heads, only_immed
 
 
 def xattn_block_bwd(ops, P, W, S, media_bf, tt, dy, *, B, L, T, n, heads, only_immediate, need_dmedia=True, safe=0,
-                    sinks=None, dim_head=64, fresh=(), dkv_out=None, scope=None, scale=None):
-    """Returns (dx, dmedia fp32 (B*T*n, Dv) or None, grads dict keyed like P).  sinks / fresh: see _GradOut."""
-    G = _GradOut(sinks, dy.device, fresh)
+                    sinks=None, dim_head=64, fresh=(), dkv_out=None, scope=None, scale=None, sumsq=None):
+    """Returns (dx, dmedia fp32 (B*T*n, Dv) or None, grads dict keyed like P).  sinks / fresh / sumsq: see _GradOut
+    (the grads dict carries `sumsq_done` under the key "__sumsq_done__" when sumsq was given)."""
+    G = _GradOut(sinks, dy.device, fresh, sumsq)
     dy = dy.contiguous()
     # ---- feed forward branch: y2 = y1 + tanh(gf) * F(y1)
     dy1, dy1b = feed_forward_bwd(ops, P, W, S["ff"], dy, G, prefix="ff.", gate=P["ff_gate"], gate_name="ff_gate",
@@ -305,6 +320,8 @@ def xattn_block_bwd(ops, P, W, S, media_bf, tt, dy, *, B, L, T, n, heads, only_i
                                             heads=heads, only_immediate=only_immediate, gate=P["attn_gate"],
                                             gate_name="attn_gate", residual=True, need_dmedia=need_dmedia, safe=safe,
                                             dim_head=dim_head, dkv_out=dkv_out, offer_twin=True, scope=scope, scale=scale)
+    if sumsq:
+        G.g["__sumsq_done__"] = G.sumsq_done
     return dx, dmedia, G.g
 
 

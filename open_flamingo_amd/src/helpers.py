@@ -575,10 +575,16 @@ class _GatedXAttnFn(torch.autograd.Function):
         grp = ctx.grp
         need_dmedia = ctx.needs_input_grad[2] and grp is None      # grouped: the group's node forms the media gradient
         sinks, fresh = _grad_sinks(_XATTN_NAMES, ctx.params)
+        # norm taps (train/optim.py): parameters whose owner registered slots for the sum of squares of their gradient
+        taps = {k: p._of_sumsq_slots for k, p in zip(_XATTN_NAMES, ctx.params) if getattr(p, "_of_sumsq_slots", None) is not None}
         dx, dmedia, g = _path.xattn_block_bwd(ops, ctx.P, ctx.W, ctx.S, ctx.media_bf, ctx.tt, dy.reshape(-1, d),
                                               need_dmedia=need_dmedia, sinks=sinks, fresh=fresh,
                                               dkv_out=grp.dkv_of(ctx.mod) if grp is not None else None,
-                                              scope=_path.scope_of(ctx.mod), **ctx.dims)
+                                              scope=_path.scope_of(ctx.mod), sumsq=taps, **ctx.dims)
+        done = g.pop("__sumsq_done__", {})
+        for k, p in zip(_XATTN_NAMES, ctx.params):
+            if k in taps:
+                p._of_sumsq_valid = bool(done.get(k, False))
         ctx.S = None
         if dmedia is not None:
             dmedia = (dmedia if ctx.mdtype == F32 else ops.to_bf16(dmedia)).view(ctx.mshape)

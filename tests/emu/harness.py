@@ -33,7 +33,7 @@ def bf16(t):
 
 
 def gemm(A, B, *, a_trans=0, b_trans=0, epi=abi.EPI_STORE_BF16, C_out=None, C2=None, aux=None, gate=None,
-         alpha=1.0, beta=0.0, dot_out=None, io_f32=0, safe=0, M=None, N=None, K=None, workspace=None, cu_limit=0):
+         alpha=1.0, beta=0.0, dot_out=None, io_f32=0, safe=0, M=None, N=None, K=None, workspace=None, cu_limit=0, sumsq=None):
     if M is None:
         M = A.shape[1] if a_trans else A.shape[0]
         K = A.shape[0] if a_trans else A.shape[1]
@@ -51,6 +51,9 @@ def gemm(A, B, *, a_trans=0, b_trans=0, epi=abi.EPI_STORE_BF16, C_out=None, C2=N
     a.alpha, a.beta = alpha, beta
     a.dot_out = dot_out.data_ptr() if dot_out is not None else None
     a.io_f32, a.safe, a.cu_limit = io_f32, safe, cu_limit
+    if sumsq is not None:
+        assert lib().of_gemm_sumsq_slots(C.byref(a)) <= sumsq.numel()
+        a.sumsq_out = sumsq.data_ptr()
     if workspace is None and (dot_out is not None or cu_limit or safe == 17):
         # per-workgroup gate-gradient partials (deterministic finish); stream-K partial tiles + flags
         workspace = torch.empty(max(1, lib().of_gemm_workspace_bytes(C.byref(a)) // 4))

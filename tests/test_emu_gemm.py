@@ -683,3 +683,32 @@ def test_specialised_kernel_dot_epilogues():
         o16, d16 = torch.zeros(M, N, dtype=torch.bfloat16), torch.full((1,), 3.0)
         H.gemm(A, W, b_trans=1, epi=epi, C_out=o16, aux=aux, gate=gate, dot_out=d16, safe=16)
         np.testing.assert_allclose(outs[0].double().numpy(), o16.double().numpy(), rtol=2e-2, atol=2e-3)
+
+
+# ---- OfGemmArgs.sumsq_out (ABI v9): a weight gradient's share of the global gradient norm leaves with the GEMM that produces it -------
+def test_weight_gradient_gemm_emits_its_sum_of_squares_per_tile():
+    """TN, OF_EPI_ACC_F32, 128 big tiles (the smallest launch of_gemm gives to the 256x256 kernel): one fp32 partial per tile = the sum
+    of squares of the FINAL values (alpha, tanh(gate) and beta * old applied), written not added; launches that are not a single
+    big-tile launch leave the slots untouched and of_gemm_sumsq_slots() says so beforehand."""
+    import ctypes as C
+    M, N, K = 2048, 4096, 64
+    A, B = _rand((K, M), 101), _rand((K, N), 102)
+    gate = torch.tensor([0.37])
+    c = torch.randn(M, N)
+    want = c.double() + 0.5 * float(torch.tanh(gate)) * _ref(A, B, 1, 1)
+    slots = torch.full((200,), -1.0)
+    H.gemm(A, B, a_trans=1, b_trans=1, epi=abi.EPI_ACC_F32, C_out=c, alpha=0.5, beta=1.0, gate=gate, sumsq=slots)
+    np.testing.assert_allclose(c.double().numpy(), want.numpy(), rtol=1e-5, atol=1e-4)
+    per_tile = c.double().view(M // 256, 256, N // 256, 256).pow(2).sum((1, 3)).reshape(-1)        # m-major tile order
+    np.testing.assert_allclose(slots[:128].double().numpy(), per_tile.numpy(), rtol=1e-5)
+    assert bool((slots[128:] == -1.0).all())
+    # not honoured: split along K (small output), a bf16-store launch, a forced kernel -- the query says 0 and nothing is written
+    a = abi.OfGemmArgs()
+    A2, B2, c2 = _rand((512, 256), 103), _rand((512, 256), 104), torch.zeros(256, 256)
+    a.A, a.B, a.C, a.M, a.N, a.K, a.lda, a.ldb, a.ldc = A2.data_ptr(), B2.data_ptr(), c2.data_ptr(), 256, 256, 512, 256, 256, 256
+    a.a_trans, a.b_trans, a.epi = 1, 1, abi.EPI_ACC_F32
+    assert H.lib().of_gemm_sumsq_slots(C.byref(a)) == 0
+    s2 = torch.full((4,), -1.0)
+    H.gemm(A2, B2, a_trans=1, b_trans=1, epi=abi.EPI_ACC_F32, C_out=c2, sumsq=s2)
+    assert bool((s2 == -1.0).all())
+    np.testing.assert_allclose(c2.double().numpy(), _ref(A2, B2, 1, 1).numpy(), rtol=1e-5, atol=1e-4)

@@ -1096,3 +1096,69 @@ def test_modules_accept_any_dim_head_up_to_128(dh):
     assert PC.rel_l2(yp.detach().cpu(), yo.detach()) < 1e-2
     for (k, p), (_, q) in zip(pr.named_parameters(), pro.named_parameters()):
         assert PC.rel_l2(p.grad.cpu(), q.grad) < 2e-2, k
+
+
+def test_norm_taps_give_the_full_pass_norm_and_the_same_training():
+    """FlatAdamW's norm taps (one GPU): the FFN weight gradients' sums of squares come out of their dW GEMMs' epilogues
+    (OfGemmArgs.sumsq_out) and the global-norm pass skips those matrices.  A model with OF-3B's block width (d = 2048: the 8192 x 2048
+    gradients are 256 big tiles each) but two layers: (1) the norm the step epilogue ends up with equals the sum of squares of every
+    gradient taken by torch before the step; (2) three optimizer steps with and without the taps give the same losses and weights up to
+    the summation order of the norm (1e-6); (3) a two-pass step (LAION + MMC4: the second backward accumulates with beta = 1) taps the
+    FINAL gradient; (4) a step whose FFN gradient did not come out of a tapped GEMM falls back to the full pass."""
+    from open_flamingo_amd.train import sparse_rows, step, synthetic, towers
+    from open_flamingo_amd.train.reducer import GradReducer
+    towers.FAMILY["OF-wide-test"] = dict(lm="mpt", d=2048, layers=2, heads=16, vocab=1000, every=1)
+    vkw = dict(width=64, layers=2, heads=2, patch=14, image=224)
+
+    def build(tap):
+        model, info = towers.build_flamingo("OF-wide-test", device="cuda", seed=0, gates=0.5, vision_kw=vkw, frozen_bf16=True,
+                                            fused_lm_attention="libofhip", tower_layernorm="libofhip", lm_loss="libofhip",
+                                            fused_lm_blocks=True, perceiver_depth=1)
+        model.train()
+        rows = [info["media_token_id"], info["eoc_token_id"]]
+        sparse_rows.enable(model, rows)
+        red = GradReducer(model, embedding_rows=rows)
+        opt = step.build_optimizer(model, lr=1e-3, reducer=red)
+        opt.tap_norm = tap
+        return model, info, red, opt
+
+    runs = {}
+    for tap in (True, False):
+        model, info, red, opt = build(tap)
+        assert opt._tap_groups >= 1 and sum(len(b["taps"]) for b in red.buckets) == 4
+        batch = synthetic.make_batch(2, 2, 64, info, "cuda", seed=5)
+        small = synthetic.make_batch(4, 1, 32, info, "cuda", seed=6)
+        losses = []
+        for i in range(3):
+            losses.append(float(step.train_step(model, red, opt, batch, info, nan_check="device")))
+            assert opt.tapped_buckets == (2 if tap else 0), (i, opt.tapped_buckets)
+        # (1) + (3): a two-pass step; the norm against torch's over the finished buckets
+        with red.no_sync():
+            (0.2 * step.forward_loss(model, small, info)).backward()
+        step.forward_loss(model, batch, info).backward()
+        red.finish(average=False)
+        want = sum(float(b["flat"].double().pow(2).sum()) for b in red.buckets)
+        rows_g = red.sparse.grad_rows()
+        want += float(rows_g.double().pow(2).sum()) if rows_g is not None else 0.0
+        opt.step()
+        torch.cuda.synchronize()
+        assert opt.tapped_buckets == (2 if tap else 0)
+        assert abs(float(opt._sumsq) - want) <= 2e-6 * want, (float(opt._sumsq), want)
+        red.zero_grad(flat_already_zero=True)
+        runs[tap] = (losses, {k: p.detach().clone() for k, p in model.named_parameters() if p.requires_grad and p.dim() == 2})
+        if tap:      # (4) the gradient of one tapped matrix arrives by another route: no tap for its bucket, the full pass counts it
+            step.forward_loss(model, batch, info).backward()
+            blk = [b for b in model.lang_encoder.gated_cross_attn_layers if b is not None][0]
+            blk.ff[3].weight._of_sumsq_valid = False
+            red.finish(average=False)
+            want = sum(float(b["flat"].double().pow(2).sum()) for b in red.buckets)
+            rows_g = red.sparse.grad_rows()
+            want += float(rows_g.double().pow(2).sum()) if rows_g is not None else 0.0
+            opt.step()
+            torch.cuda.synchronize()
+            assert opt.tapped_buckets == 1 and abs(float(opt._sumsq) - want) <= 2e-6 * want
+        del model, red, opt
+    (l1, p1), (l0, p0) = runs[True], runs[False]
+    assert all(abs(a - b) <= 1e-5 * abs(b) for a, b in zip(l1, l0)), (l1, l0)
+    for k in p0:
+        assert (p1[k] - p0[k]).norm().item() <= 1e-4 * p0[k].norm().item() + 1e-7, k
