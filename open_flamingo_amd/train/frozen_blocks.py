@@ -36,11 +36,12 @@ _DX_PRETRANSPOSED = True
 # (constants, set from measurements: DESIGN.md 4.9; tools/ab_frozen_mlp.py flips them for the same-box A/B)
 _MLP_FUSED_UP = False      # up_proj + erf-GELU (OF_EPI_GELU; the pre-activation is kept for the backward)
 _MLP_FUSED_DOWN = False    # down_proj + residual add into the fp32 stream (OF_EPI_GATE_RESID without a gate)
-_MLP_FUSED_DGELU = False   # backward: (dY Wdown) * gelu'(h) as ONE NN launch (OF_EPI_DGELU_DOT without a gate / dot) instead of
-                           # vendor GEMM + of_gelu_bwd pass -- round 4, after the packed-math dGELU epilogue: step-level a wash
-                           # (same box: 109.75 / 110.02 -> 109.61 / 109.72 ms on one box, 111.16 / 111.22 -> 111.21 / 111.23 on
-                           # another; up fused +0.7..1.0, down fused +0.1..0.6, all three +1.1..1.2: profiles/r04k_ab_frozen_mlp.txt,
-                           # r04_final_ab_frozen_mlp.txt) -- the vendor route stays
+_MLP_FUSED_DGELU = True    # backward: (dY Wdown) * gelu'(h) as ONE NN launch (OF_EPI_DGELU_DOT without a gate / dot) instead of
+                           # vendor GEMM + of_gelu_bwd pass.  Round 4 (256x256 kernel): a wash at step level (profiles/r04k_*, r04_final_ab_frozen_mlp.txt).
+                           # Round 5: of_gemm sends this launch to the two-workgroups-per-CU kernel (gemm_w4h.hip) -- same box, alternating:
+                           # 120.13 / 119.98 -> 118.40 / 118.62 ms per step (-1.5 ms: the of_gelu_bwd pass is gone and the fused launch
+                           # costs less than vendor GEMM + pass); up fused +2.0, down fused 0.0, all three +1.5 (profiles/r05o_ab_frozen_mlp.txt)
+                           # -> ON; the other two stay off
 
 
 def _ops():
@@ -413,9 +414,14 @@ class _FrozenNeoXBlockFn(torch.autograd.Function):
         if dy2.dtype != F32 or not dy2.is_contiguous():
             dy2 = dy2.to(F32).contiguous()
         dyb = _path.bf16_of(ops, dy2, ctx.scope)
-        dact = _mm_dx(dyb, Wdown, tdn)                                   # (rows, 4d)
-        dh = ops.gelu_bwd(dact, h, out=dact)
-        del dact
+        if _MLP_FUSED_DGELU:
+            from ..hip import abi
+            dh = torch.empty(rows, Wdown.shape[1], dtype=BF16, device=dev)
+            ops.gemm(dyb, Wdown, dh, tb=True, epi=abi.EPI_DGELU_DOT, aux=h)        # (dY Wdown) * gelu'(h): one launch (see _MLP_FUSED_DGELU)
+        else:
+            dact = _mm_dx(dyb, Wdown, tdn)                               # (rows, 4d)
+            dh = ops.gelu_bwd(dact, h, out=dact)
+            del dact
         dm = _mm_dx(dh, Wup, tu)
         del dh
         dx1 = torch.empty(rows, d, dtype=F32, device=dev)
