@@ -425,8 +425,11 @@ def main():
         sym = {"w4m256": "of_gemm_w4m_kernel", "w4dma256": "of_gemm_w4_kernel", "pingpong256": "of_gemm_pp_kernel", "mid128": "of_gemm_mid_kernel",
                "general128": "of_gemm_kernel", "skinny": "of_gemm_skinny_kernel", "mid128batch": "of_gemm_mid_batch_kernel",
                "w4h256x128": "of_gemm_w4h_kernel"}[key[3]]
-        sym += f"<{str(bool(key[0])).lower()}, {str(bool(key[1])).lower()}, {key[2]}" + (
-            ", false>" if key[3] == "w4m256" else ">" if key[3] in ("mid128", "mid128batch") else ", 0>" if key[3] == "w4h256x128" else ", ...>")       # w4m256: <AT, BT, EPI, SK = false> (one tile per workgroup)
+        if key[3] == "w4h256x128":          # <BT, EPI, VAR = 0> (A is never transposed on this kernel)
+            sym += f"<{str(bool(key[1])).lower()}, {key[2]}, 0>"
+        else:                               # w4m256: <AT, BT, EPI, SK = false> (one tile per workgroup)
+            sym += f"<{str(bool(key[0])).lower()}, {str(bool(key[1])).lower()}, {key[2]}" + (
+                ", false>" if key[3] == "w4m256" else ">" if key[3] in ("mid128", "mid128batch") else ", ...>")
         shapes = {}
         for k2, _, shape, _, _ in timing:
             if k2 == key:
@@ -438,6 +441,15 @@ def main():
         else:
             all_fl = sum(v[0] for v in groups.values())
             all_ms = sum(v[1] for v in groups.values())
+        fam = {}
+        for k2, f2, _, e0, e1 in (survey or []):
+            v = fam.setdefault(k2, [0.0, 0.0, 0])
+            v[0] += f2
+            v[1] += e0.elapsed_time(e1)
+            v[2] += 1
+        families = [{"kernel": k[3], "layout": LAYOUT_NAMES[k[:2]], "epi": EPI_NAMES[k[2]], "launches_per_step": v[2],
+                     "ms_per_step": round(v[1], 2), "frac": round(v[0] / v[1] / 1e9 / MFMA_PEAK_TFLOPS, 4)}
+                    for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])[:4]]
         ach = fl / ms / 1e9
         traffic, traffic_note = pmc_traffic(key, top_shape)
         if traffic is None:          # a family can hold two launch shapes of equal count (dW1 / dW2): quote the one on record
@@ -454,8 +466,10 @@ def main():
                     "shapes_MNK": {"x".join(map(str, sh)): c // args.steps for sh, c in shapes.items()},
                     "launches_per_step": n // args.steps, "avg_launch_ms": round(ms / n, 4),
                     "gflop_per_launch": round(fl / n / 1e9, 2),
+                    # the four (layout, epilogue, kernel) families that take the most time in the surveyed warm-up step
+                    "families": families,
                     "all_gemm_tflops": round(all_fl / all_ms / 1e9, 1),
-                    # the time-weighted figure over EVERY of_gemm launch of a step: what describes the path (`frac` is its best big family)
+                    # the time-weighted figure over EVERY of_gemm launch of a step: what describes the path (`frac` is the ONE family that takes the most time)
                     "all_gemm_frac": round(all_fl / all_ms / 1e9 / MFMA_PEAK_TFLOPS, 4),
                     "all_gemm_ms_per_step": round(all_ms / args.steps, 2),
                     "note": "achieved/avg_launch_ms: HIP events around every launch of this family inside the timed region; "

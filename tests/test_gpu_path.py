@@ -1102,9 +1102,12 @@ def test_norm_taps_give_the_full_pass_norm_and_the_same_training():
     """FlatAdamW's norm taps (one GPU): the FFN weight gradients' sums of squares come out of their dW GEMMs' epilogues
     (OfGemmArgs.sumsq_out) and the global-norm pass skips those matrices.  A model with OF-3B's block width (d = 2048: the 8192 x 2048
     gradients are 256 big tiles each) but two layers: (1) the norm the step epilogue ends up with equals the sum of squares of every
-    gradient taken by torch before the step; (2) three optimizer steps with and without the taps give the same losses and weights up to
-    the summation order of the norm (1e-6); (3) a two-pass step (LAION + MMC4: the second backward accumulates with beta = 1) taps the
-    FINAL gradient; (4) a step whose FFN gradient did not come out of a tapped GEMM falls back to the full pass."""
+    gradient taken by torch before the step; (2) ONE set of gradients and optimizer state stepped twice, with the taps and with the full
+    pass, gives the same new weights (1e-5 of the update); a run of optimizer steps with the taps and a second run without give the same
+    losses and weights up to what two runs of the SAME configuration differ by on this stack -- the frozen blocks' vendor GEMMs are not
+    repeatable run to run at these small shapes (tools/probes/step_repeat_probe.py: 0 on most runs, 1.3e-4 of a weight's norm after four
+    steps on some), hence 1e-3 there; (3) a two-pass step (LAION + MMC4: the second backward accumulates with beta = 1) taps the FINAL
+    gradient; (4) a step whose FFN gradient did not come out of a tapped GEMM falls back to the full pass."""
     from open_flamingo_amd.train import sparse_rows, step, synthetic, towers
     from open_flamingo_amd.train.reducer import GradReducer
     towers.FAMILY["OF-wide-test"] = dict(lm="mpt", d=2048, layers=2, heads=16, vocab=1000, every=1)
@@ -1146,7 +1149,38 @@ def test_norm_taps_give_the_full_pass_norm_and_the_same_training():
         assert abs(float(opt._sumsq) - want) <= 2e-6 * want, (float(opt._sumsq), want)
         red.zero_grad(flat_already_zero=True)
         runs[tap] = (losses, {k: p.detach().clone() for k, p in model.named_parameters() if p.requires_grad and p.dim() == 2})
-        if tap:      # (4) the gradient of one tapped matrix arrives by another route: no tap for its bucket, the full pass counts it
+        if tap:      # (2) the same gradients, moments and weights through both routes
+            step.forward_loss(model, batch, info).backward()
+            red.finish(average=False)
+            names = ("flat", "flat_p", "m", "v")
+            keep = [[b[k].clone() for k in names] for b in red.buckets]
+            keep_rows = red.sparse.grad_rows().clone()
+            keep_emb = (opt.embedding.data.clone(), opt._emb["m"].clone(), opt._emb["v"].clone())
+            keep_applied, keep_count = opt._applied.clone(), opt.step_count
+            opt.step()
+            assert opt.tapped_buckets == 2
+            with_taps = [b["flat_p"].clone() for b in red.buckets]
+            for b, saved in zip(red.buckets, keep):
+                for k, t in zip(names, saved):
+                    b[k].copy_(t)
+                for q in b.get("overwritable", ()):
+                    q._of_grad_fresh = False          # the restored gradient is this step's, not a stale one to clear
+            red.sparse.leaf.grad = keep_rows
+            opt.embedding.data.copy_(keep_emb[0])
+            opt._emb["m"].copy_(keep_emb[1])
+            opt._emb["v"].copy_(keep_emb[2])
+            opt._applied.copy_(keep_applied)
+            opt.step_count = keep_count
+            opt.tap_norm = False
+            opt.step()
+            opt.tap_norm = True
+            torch.cuda.synchronize()
+            assert opt.tapped_buckets == 0
+            for a, b, saved in zip(with_taps, red.buckets, keep):
+                update = (b["flat_p"] - saved[1]).norm().item()
+                assert update > 0 and (a - b["flat_p"]).norm().item() <= 1e-5 * update
+            red.zero_grad(flat_already_zero=True)
+            # (4) the gradient of one tapped matrix arrives by another route: no tap for its bucket, the full pass counts it
             step.forward_loss(model, batch, info).backward()
             blk = [b for b in model.lang_encoder.gated_cross_attn_layers if b is not None][0]
             blk.ff[3].weight._of_sumsq_valid = False
@@ -1159,6 +1193,6 @@ def test_norm_taps_give_the_full_pass_norm_and_the_same_training():
             assert opt.tapped_buckets == 1 and abs(float(opt._sumsq) - want) <= 2e-6 * want
         del model, red, opt
     (l1, p1), (l0, p0) = runs[True], runs[False]
-    assert all(abs(a - b) <= 1e-5 * abs(b) for a, b in zip(l1, l0)), (l1, l0)
+    assert all(abs(a - b) <= 1e-4 * abs(b) for a, b in zip(l1, l0)), (l1, l0)
     for k in p0:
-        assert (p1[k] - p0[k]).norm().item() <= 1e-4 * p0[k].norm().item() + 1e-7, k
+        assert (p1[k] - p0[k]).norm().item() <= 1e-3 * p0[k].norm().item() + 1e-7, k
