@@ -21,6 +21,31 @@ OF_DEV void tile_coords(int bid, int nwg, int tiles_m, int tiles_n, int& pm, int
     pn = in / gsz;
 }
 
+#if defined(OF_TOOLS_BUILD)
+// tools/libofhip_tools.so only (tools/probes/interleaved_gemm_probe.py): the same walk with the group height and the XCD assignment
+// as knobs -- knob & 0xff = GM (0: 8); (knob >> 8) & 15: 0 = a contiguous run of ids per XCD (the product's), 1 = id = block id (tiles
+// round-robin over the XCDs), 2 = contiguous runs, groups of GM n-tiles swept along m
+OF_DEV void tile_coords_knob(int bid, int nwg, int tiles_m, int tiles_n, int& pm, int& pn, int knob) {
+    int GM = knob & 0xff;
+    if (!GM) GM = 8;
+    const int mode = (knob >> 8) & 15;
+    int id = bid;
+    if (mode != 1) {
+        int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int ta = mode == 2 ? tiles_n : tiles_m, tb = mode == 2 ? tiles_m : tiles_n;
+    int width = GM * tb;
+    int group = id / width;
+    int first = group * GM;
+    int gsz = ta - first < GM ? ta - first : GM;
+    int in = id - group * width;
+    const int a = first + in % gsz, b = in / gsz;
+    pm = mode == 2 ? b : a;
+    pn = mode == 2 ? a : b;
+}
+#endif
+
 OF_DEV void unpack4(u32x2 r, float (&x)[4]) {
     x[0] = of_bf16_to_f32((bf16_t)(r[0] & 0xffff));
     x[1] = of_bf16_to_f32((bf16_t)(r[0] >> 16));

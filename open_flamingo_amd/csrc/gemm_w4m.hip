@@ -16,6 +16,10 @@
 //     phase 3 reads the first fragments of stage d + 1 from the other slot -- the schedule of gemm_w4.hip: A of stage d + 2 is
 //     requested in phase 3 (into the slot the barrier freed), B of stage d + 1 in phase 0, eight pieces over the 32 MFMA gaps
 //     of the phase, odd waves two gaps after the even ones; one vmcnt(0) in front of the barrier covers both;
+//   * round 5, for operands that come from HBM instead of the Infinity Cache (a launch inside a train step): the
+//     epilogues that keep nothing in LDS during the K loop have a THIRD image of B behind the two slots (W4M_B3: B of stage d + 2
+//     requested in phase 0 of stage d, vmcnt(8) in front of the barrier), and launches of_gemm selected itself walk K rotated per
+//     XCD (w4m_rotation);
 //   * the MFMAs are inline asm accumulating in place (of_mfma_acc: through the builtin hipcc shuttled the 64 small accumulators
 //     between AGPRs and VGPRs, 390 v_accvgpr_* per 128 MFMAs).  The price: the compiler's hazard recognizer does not know them,
 //     so every K stage opens with of_mfma_acc_guard() and tests/test_isa_lint.py checks the cross-compiled ISA for a VALU write
@@ -27,6 +31,18 @@
 #include "gemm_tile256.h"
 #include "gemm_w4_epi.h"
 
+// K rotation of a tile's stage loop (see the kernel): the workgroups of XCD x (block id & 7) start at stage x * (stages / 8).  The 32
+// tiles an XCD runs at a time share A and B panels through its L2 and must walk K together; the eight XCDs need not -- measured on
+// operands that are NOT in the Infinity Cache (a launch behind a streaming pass, as in a train step: tools/probes/interleaved_gemm_probe.py,
+// profiles/r05q_*): NT 8192 x 2048 x 8192 241 -> 218 us, NN 235 -> 226, NT K = 2048 238 -> 230, hot-loop times unchanged; a rotation per
+// tile loses the L2 sharing (hot 199 -> 239 us), a window of rotations inside the XCD adds nothing.  K-strided operands (TN) gain
+// nothing: there a K offset moves the address by whole rows.
+#ifdef OF_W4M_NO_ROTATION          // tools/ab builds only (tools/build_ab_variant.sh): the other arm of the same-box A/B
+OF_DEV int w4m_rotation(int, int) { return 0; }
+#else
+OF_DEV int w4m_rotation(int bid, int nd) { return (bid & 7) * (nd >> 3); }
+#endif
+
 #if defined(OF_TOOLS_BUILD) && !defined(OF_HOST_EMU)
 // tools/libofhip_tools.so only (tools/probes/tile_phase_probe.py): where a tile's time goes.  Wave 0 of every workgroup stamps
 // the 100-MHz wall clock at kernel entry, after the prologue (stage 0 landed), after the K loop and after its last epilogue
@@ -35,6 +51,29 @@ __device__ unsigned long long* of_tools_stamps = nullptr;
 extern "C" int of_tools_set_stamp_buffer(void* p) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(of_tools_stamps), &p, sizeof(p));
 }
+__device__ int of_w4m_map_knob = 0;          // tile walk of the launch: ofg::tile_coords_knob
+extern "C" int of_tools_set_w4m_map_knob(int v) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(of_w4m_map_knob), &v, sizeof(v)); }
+#define OF_W4M_TILE_COORDS(vt, nt, tm, tn, pm, pn) ofg::tile_coords_knob(vt, nt, tm, tn, pm, pn, of_w4m_map_knob)
+// knob bits 12..15 = rotation rule, bits 16..23 = its multiplier m (0: 1)
+OF_DEV int w4m_rotation_knob(int vt, int bid, int pm, int pn, int tiles_m, int tiles_n, int nd) {
+    const int mode = (of_w4m_map_knob >> 12) & 15;
+    int m = (of_w4m_map_knob >> 16) & 255;
+    if (!m) m = 1;
+    int r = 0;
+    if (mode == 0) return w4m_rotation(bid, nd);          // the product's rule
+    if (mode == 15) return 0;                             // none (rounds 1-4)
+    if (mode == 1) r = vt * m;                            // per tile
+    else if (mode == 2) r = (bid & 7) * (nd / 8) * m;     // per XCD
+    else if (mode == 3) r = pm * m;                       // per tile row
+    else if (mode == 4) r = pn * m;                       // per tile column
+    else if (mode == 5) r = (pm + pn) * m;
+    else if (mode == 6) r = (bid >> 3) * m;               // per position inside the XCD's run
+    else if (mode == 7) r = (bid & 7) * (nd / 8) + ((bid >> 3) % m);          // per XCD + a window of m stages inside it (L2 keeps that much history)
+    else if (mode == 8) r = (bid & 7) * (nd / 8) + (pm % m);
+    else if (mode == 9) r = (bid & 7) * (nd / 8) + (pn % m) ;
+    return (int)((unsigned)r % (unsigned)nd);
+}
+#define OF_W4M_ROTATION(vt, bid, pm, pn, tm, tn, nd) w4m_rotation_knob(vt, bid, pm, pn, tm, tn, nd)
 #define OF_STAMP(i) (of_stamp_t[i] = wall_clock64())          /* wave-uniform: stays in SGPRs until the one store block at the end */
 #define OF_STAMP_DECL() unsigned long long of_stamp_t[5] = {0, 0, 0, 0, 0}
 #define OF_STAMP_FLUSH()                                                                                              \
@@ -55,12 +94,22 @@ extern "C" int of_tools_set_stamp_buffer(void* p) {
 #define OF_STAMP(i) ((void)0)
 #define OF_STAMP_DECL() ((void)0)
 #define OF_STAMP_FLUSH() ((void)0)
+#define OF_W4M_TILE_COORDS(vt, nt, tm, tn, pm, pn) ofg::tile_coords(vt, nt, tm, tn, pm, pn)
+#define OF_W4M_ROTATION(vt, bid, pm, pn, tm, tn, nd) w4m_rotation(bid, nd)
 #endif
 
 namespace {
 using namespace oft;
 
 constexpr int SMEM_W4M = NSLOT * STAGE_BYTES;    // 128 KiB
+template <int EPI>
+struct W4M_B3 {
+#ifdef OF_W4M_NO_B3          // tools/ab builds only: the other arm of the same-box A/B
+    static constexpr bool value = false;
+#else
+    static constexpr bool value = EPI == OF_EPI_STORE_BF16 || EPI == OF_EPI_GELU || EPI == OF_EPI_ACC_F32;
+#endif
+};
 
 // ---- stream-K layout of the optional workspace region behind the *_DOT partials (of_gemm fills p.sk_grid, gemm.hip):
 //   [ flags: one int per workgroup, zeroed by of_gemm in front of the launch ][ slabs: one 256 x 256 fp32 partial tile per workgroup ]
@@ -119,6 +168,12 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
     const unsigned stepB = 2u * (BT ? (unsigned)DK * (unsigned)p.ldb : (unsigned)DK);
     const unsigned smem_u = of_lds_base(smem) + (unsigned)wave * 1024u;
     constexpr bool AUXL = EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT;
+    // B3: a THIRD image of B behind the two slots (epilogues without an aux / residual tile in LDS leave 32 KiB of the CU's 160 free): B
+    // of stage d + 2 is requested in phase 0 of stage d -- six to seven phases before the barrier that needs it instead of two to three.
+    // A's images stay two: requested in phase 3, three to four phases ahead.  For operands that come from HBM, not from the Infinity
+    // Cache.
+    constexpr bool B3 = W4M_B3<EPI>::value;
+    constexpr unsigned B_OFF0 = OPER_BYTES, B_OFF1 = STAGE_BYTES + OPER_BYTES, B_OFF2 = B3 ? (unsigned)SMEM_W4M : B_OFF0;
 
     for (int seg = 0;; ++seg) {
         // ---- this segment: tile `vt` (virtual block id for the XCD-aware tile map), K stages [s0, s0 + nd)
@@ -143,7 +198,7 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
         }
         const bool last_k = !SK || s0 + nd == nd_all;       // this workgroup finishes the tile (epilogue), else it publishes a partial tile
         int pm, pn;
-        ofg::tile_coords(vt, ntiles, tiles_m, tiles_n, pm, pn);
+        OF_W4M_TILE_COORDS(vt, ntiles, tiles_m, tiles_n, pm, pn);
         const int m0 = pm * TM, n0 = pn * TN;
         if (SK && seg > 0) of_barrier_raw();          // the previous segment's epilogue is done with the ring
 
@@ -164,14 +219,36 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
             nB = n0 - grp * p.group_extent;
         }
         const of_buf_t gB = of_buf_make(chunk_base<BT>(Bmat, p.ldb, nB));
-        unsigned sA = (unsigned)s0 * stepA, sB = (unsigned)s0 * stepB;              // scalar byte offsets of the next stage to request
+        // K rotation: a workgroup that holds ALL K stages of its tile starts at stage `rot` and wraps around (same products, another
+        // order of the fp32 additions).  Without it every workgroup of the launch reads K offset 64 d of its panels at the same time;
+        // with a power-of-two row pitch those addresses differ in high bits only and land on the same few HBM channels.
+        int rot = 0;
+        // (only launches of_gemm selected itself: a kernel forced through OfGemmArgs.safe keeps stage order 0, 1, 2, ... -- the order of
+        // the general kernel, which the race screens of tests/test_gpu_kernels.py compare with bit for bit)
+        if (p.safe == 0 && (!SK || (s0 == 0 && nd == nd_all))) rot = OF_W4M_ROTATION(vt, bid, pm, pn, tiles_m, tiles_n, nd_all);
+        int kidx2 = rot + s0 + 1;                                                    // stage index of (sA2, sB2)
+        if (kidx2 >= nd_all) kidx2 -= nd_all;
+        unsigned sA = (unsigned)(rot + s0) * stepA, sB = (unsigned)(rot + s0) * stepB;          // scalar byte offsets of the next stage to request
+        unsigned sA2 = (unsigned)kidx2 * stepA, sB2 = (unsigned)kidx2 * stepB;       // ... and of the one after it (wraps to stage 0 behind the last)
+        auto next_stage = [&]() OF_INLINE_LAMBDA {
+            sA = sA2;
+            sB = sB2;
+            ++kidx2;
+            sA2 += stepA;
+            sB2 += stepB;
+            if (kidx2 == nd_all) {
+                kidx2 = 0;
+                sA2 = 0u;
+                sB2 = 0u;
+            }
+        };
         // piece j (0..15 = op * 8 + hf * 4 + jj) of the stage at (sA, sB) -- ahead = 1: of the stage after it -- into the slot at
         // byte offset slot_off
-        auto dma_piece = [&](unsigned slot_off, int j, int ahead) OF_INLINE_LAMBDA {
+        auto dma_piece = [&](unsigned a_off, unsigned b_off, int j, int ahead) OF_INLINE_LAMBDA {
             const int op = j >> 3, hf = (j >> 2) & 1, jj = j & 3;
-            const unsigned dst = smem_u + slot_off + (unsigned)(op * OPER_BYTES + hf * HALF_BYTES + jj * 4096);
-            if (op == 0) of_buf_load16_lds_at<ASMD>(gA, offA[hf][jj], sA + (ahead ? stepA : 0u), dst);
-            else of_buf_load16_lds_at<ASMD>(gB, offB[hf][jj], sB + (ahead ? stepB : 0u), dst);
+            const unsigned dst = smem_u + (op == 0 ? a_off : b_off) + (unsigned)(hf * HALF_BYTES + jj * 4096);
+            if (op == 0) of_buf_load16_lds_at<ASMD>(gA, offA[hf][jj], ahead ? sA2 : sA, dst);
+            else of_buf_load16_lds_at<ASMD>(gB, offB[hf][jj], ahead ? sB2 : sB, dst);
         };
 
         if (last_k) {      // the epilogue's first aux / residual tile travels during the K loop (gemm_w4_epi.h)
@@ -185,30 +262,37 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
         auto read_a = [&](const char* stage, int ks, int ah, int buf, int r) OF_INLINE_LAMBDA {
             fa[buf][r] = mfrag16<AT>(stage, wm * 128 + ah * 64 + r * 16, ks, lane);
         };
-        auto read_b = [&](const char* stage, int ks, int r) OF_INLINE_LAMBDA {
-            fb[ks][r] = mfrag16<BT>(stage + OPER_BYTES, wn * 128 + r * 16, ks, lane);
+        auto read_b = [&](const char* b_img, int ks, int r) OF_INLINE_LAMBDA {
+            fb[ks][r] = mfrag16<BT>(b_img, wn * 128 + r * 16, ks, lane);
         };
         // the 12 fragments a phase that starts a k-step needs, in the order of first use: fb0 fa0 fb1 .. fb7 fa1 fa2 fa3
-        auto read_kstep = [&](const char* stage, int ks, int abuf, int r) OF_INLINE_LAMBDA {
+        auto read_kstep = [&](const char* stage, const char* b_img, int ks, int abuf, int r) OF_INLINE_LAMBDA {
             if (r == 1) read_a(stage, ks, 0, abuf, 0);
-            else if (r < 9) read_b(stage, ks, r == 0 ? 0 : r - 1);
+            else if (r < 9) read_b(b_img, ks, r == 0 ? 0 : r - 1);
             else read_a(stage, ks, 0, abuf, r - 8);
         };
 
         // ---- prologue: stage 0 landed in slot 0; A of stage 1 requested into slot 1 (what phase 3 of "stage -1" would have done)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) dma_piece(0, j, 0);
-        sA += stepA;                       // (sA, sB) = stage 1 from here on: "the next stage"
-        sB += stepB;
-        of_wait_vm<0>();
-        if (nd > 1) {
+        for (int j = 0; j < 16; ++j) dma_piece(0u, B_OFF0, j, 0);
+        next_stage();                      // (sA, sB) = stage 1 from here on: "the next stage"
+        if (!B3) {
+            of_wait_vm<0>();
+            if (nd > 1) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dma_piece(STAGE_BYTES, j, 0);
+                for (int j = 0; j < 8; ++j) dma_piece(STAGE_BYTES, 0u, j, 0);
+            }
+        } else if (nd > 1) {               // three B images: all of stage 1 is requested here (its B in what phase 0 of "stage -1" would have done)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) dma_piece(STAGE_BYTES, B_OFF1, j, 0);
+            of_wait_vm<16>();              // stage 0 has landed, stage 1 is in flight
+        } else {
+            of_wait_vm<0>();
         }
         of_barrier_raw();
         OF_STAMP(1);
 #pragma unroll
-        for (int r = 0; r < 12; ++r) read_kstep(smem, 0, 0, r);
+        for (int r = 0; r < 12; ++r) read_kstep(smem, smem + B_OFF0, 0, 0, r);
 
         // The K loop, compiled once per wave parity (odd waves request their pieces two MFMA gaps after the even ones).
         auto main_loop = [&](auto parc) OF_INLINE_LAMBDA {
@@ -216,7 +300,7 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
             // One phase = 32 MFMAs: B fragments fb[ks] x A fragments fa[ph & 1] (rows 64 (ph & 1) .. of the wave's 128).  Its MFMA gaps
             // carry the fragment reads of the NEXT phase (4 or 12, from the gap after the previous read on, every other gap) and,
             // with `dma`, eight LDS-DMA pieces (gaps 4j + 2 PARC).
-            auto phase = [&](int ph, const char* rd_stage, bool rd, unsigned dma_slot, int dma0, bool dma, int ahead) OF_INLINE_LAMBDA {
+            auto phase = [&](int ph, const char* rd_stage, const char* rd_b, bool rd, unsigned dma_a, unsigned dma_b, int dma0, bool dma, int ahead) OF_INLINE_LAMBDA {
                 const int ks = ph >> 1, ah = ph & 1;
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
@@ -226,38 +310,54 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
                         if (ph == 0 || ph == 2) {          // next phase: same k-step, the other row half
                             if (r < 4) read_a(rd_stage, ks, 1, (ph + 1) & 1, r);
                         } else if (r < 12) {               // next phase starts a k-step (ph 1: k-step 1 of this stage; ph 3: k-step 0 of the next)
-                            read_kstep(rd_stage, ph == 1 ? 1 : 0, (ph + 1) & 1, r);
+                            read_kstep(rd_stage, rd_b, ph == 1 ? 1 : 0, (ph + 1) & 1, r);
                         }
                     }
-                    if (dma && (i & 3) == 2 * PARC) dma_piece(dma_slot, dma0 + (i >> 2), ahead);
+                    if (dma && (i & 3) == 2 * PARC) dma_piece(dma_a, dma_b, dma0 + (i >> 2), ahead);
                     of_sched_fence();
                 }
             };
-            // One K stage in slot `cur`.  WR: stage d + 1 exists, LD: stage d + 2 exists.  (sA, sB) = offsets of stage d + 1.
-            auto stage_body = [&](char* cur, char* nxt, const bool WR, const bool LD) OF_INLINE_LAMBDA {
-                const unsigned cur_u = (unsigned)(cur - smem), nxt_u = (unsigned)(nxt - smem);
+            // One K stage: A in slot `cur`, B in the image at b_cur.  WR: stage d + 1 exists, LD: stage d + 2 exists.  (sA, sB) = offsets
+            // of stage d + 1, (sA2, sB2) of stage d + 2.  b_nxt: B image of stage d + 1; b_ld (B3): the third image, free since the
+            // barrier of stage d - 1, takes B of stage d + 2.
+            auto stage_body = [&](char* cur, char* nxt, unsigned b_cur, unsigned b_nxt, unsigned b_ld, const bool WR, const bool LD) OF_INLINE_LAMBDA {
+                const unsigned cur_u = (unsigned)(cur - smem);
                 of_mfma_acc_guard();       // fragments may have been moved between registers on the way into this stage (of_platform.h)
-                phase(0, cur, true, nxt_u, 8, WR, 0);          // + B of stage d + 1 -> nxt (its A went there in phase 3 of stage d - 1)
-                phase(1, cur, true, 0u, 0, false, 0);
-                phase(2, cur, true, 0u, 0, false, 0);
-                of_wait_vm<0>();       // own pieces of stage d + 1 have landed ...
+                if (B3) phase(0, cur, smem + b_cur, true, 0u, b_ld, 8, LD, 1);          // + B of stage d + 2 -> the third image
+                else phase(0, cur, smem + b_cur, true, 0u, b_nxt, 8, WR, 0);           // + B of stage d + 1 -> nxt (its A went there in phase 3 of stage d - 1)
+                phase(1, cur, smem + b_cur, true, 0u, 0u, 0, false, 0);
+                phase(2, cur, smem + b_cur, true, 0u, 0u, 0, false, 0);
+                // own pieces of stage d + 1 have landed (B3: the eight pieces of B of stage d + 2 behind them may still fly -- loads retire
+                // in order) ...
+                if (B3 && LD) of_wait_vm<8>();
+                else of_wait_vm<0>();
                 of_wait_lgkm0();       // ... own reads of this slot are done ...
                 of_barrier_raw();      // ... and so are everybody else's
                 of_sched_fence();
-                phase(3, nxt, WR, cur_u, 0, LD, 1);            // + A of stage d + 2 -> cur (free since the barrier)
-                sA += stepA;
-                sB += stepB;
+                phase(3, nxt, smem + b_nxt, WR, cur_u, 0u, 0, LD, 1);            // + A of stage d + 2 -> cur (free since the barrier)
+                next_stage();
             };
             int d = 0;
+            unsigned bc = B_OFF0, bn = B_OFF1, bl = B_OFF2;          // B images of stage d, d + 1, d + 2 (two of them alternate unless B3)
+            auto rotate_b = [&]() OF_INLINE_LAMBDA {
+                const unsigned t = bc;
+                bc = bn;
+                bn = B3 ? bl : t;
+                bl = t;
+            };
             // (gemm_w4.hip unrolls its NT steady state by two stages for compile-time slot addresses; here that measured +-1 % and
             // is not done.  It is how the VALU-write -> asm-MFMA hazard of of_mfma_acc_guard() was found: the unrolled build moved stage
             // 0's fragments between registers right in front of the loop and lost half a k-step -- DESIGN.md 4.1.)
-            for (; d + 2 < nd; ++d) stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, true, true);
+            for (; d + 2 < nd; ++d) {
+                stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, bc, bn, bl, true, true);
+                rotate_b();
+            }
             if (d + 1 < nd) {
-                stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, true, false);
+                stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, bc, bn, bl, true, false);
+                rotate_b();
                 ++d;
             }
-            stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, false, false);
+            stage_body(smem + (d & 1) * STAGE_BYTES, smem + ((d + 1) & 1) * STAGE_BYTES, bc, bn, bl, false, false);
         };
         if (wave & 1) main_loop(std::integral_constant<int, 1>{});
         else main_loop(std::integral_constant<int, 0>{});
@@ -331,8 +431,9 @@ int launch_w4m(const OfGemmArgs& a, of_stream_t s) {
     of_dim3 grid{(unsigned)(a.sk_grid > 0 ? a.sk_grid : ntiles), 1, 1};
     // *_DOT epilogues: + 4 KiB per wave behind the ring for the first group's aux tile
     // GATE_RESID: + 8 KiB per wave for the first group's residual tile (160 KiB in all: the CU's whole LDS)
+    // plain-store / GELU / fp32 epilogues: + 32 KiB for the third image of B (also 160 KiB)
     constexpr int smem_bytes = SMEM_W4M + ((EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT) ? 4 * ofg::AUX_LDS_BYTES
-                                           : EPI == OF_EPI_GATE_RESID ? 4 * ofg::RESID_LDS_BYTES : 0);
+                                           : EPI == OF_EPI_GATE_RESID ? 4 * ofg::RESID_LDS_BYTES : W4M_B3<EPI>::value ? OPER_BYTES : 0);
     if (a.sk_grid > 0 && ntiles % a.sk_grid) {       // tiles will be shared: every workgroup's flag starts at 0
         const int rc = of_memset_async((char*)a.workspace + sk_dot_bytes(a), 0, sk_flags_bytes(a.sk_grid), s);
         if (rc) return rc;

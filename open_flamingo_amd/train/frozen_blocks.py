@@ -40,8 +40,16 @@ _MLP_FUSED_DGELU = True    # backward: (dY Wdown) * gelu'(h) as ONE NN launch (O
                            # vendor GEMM + of_gelu_bwd pass.  Round 4 (256x256 kernel): a wash at step level (profiles/r04k_*, r04_final_ab_frozen_mlp.txt).
                            # Round 5: of_gemm sends this launch to the two-workgroups-per-CU kernel (gemm_w4h.hip) -- same box, alternating:
                            # 120.13 / 119.98 -> 118.40 / 118.62 ms per step (-1.5 ms: the of_gelu_bwd pass is gone and the fused launch
-                           # costs less than vendor GEMM + pass); up fused +2.0, down fused 0.0, all three +1.5 (profiles/r05o_ab_frozen_mlp.txt)
+                           # costs less than vendor GEMM + pass); up fused +2.0, down fused 0.0, all three +1.5 (profiles/r05o_ab_frozen_mlp.txt;
+                           # with 20-step arms, r05s_*: up +0.55, down -0.1, up + down +1.15 on top of this one)
                            # -> ON; the other two stay off
+# Frozen MPT block (no biases): its plain GEMMs -- Wqkv, out_proj, up_proj, down_proj forward; the four dX backward -- as of_gemm launches
+# (NT forward, NN backward on the weight as it lies: no transposed copies) instead of torch.mm -> hipBLASLt.  Set from a same-box A/B
+# (tools/ab_frozen_mlp.py, fourth arm digit): 106.5 / 106.6 ms per step on the vendor library, 110.1-110.2 native (+3.6 ms;
+# profiles/r05s_ab_frozen_mpt_gemms_native.txt) -- in a hot loop the two libraries are within 0-6 % of each other on these shapes, behind
+# the streaming passes of a step (operands not in the Infinity Cache) this library's kernel loses 7-22 %, the vendor's 3-5 % (DESIGN.md
+# 4.12; the K rotation took back half) -> OFF.
+_MPT_GEMMS_NATIVE = False
 
 
 def _ops():
@@ -78,6 +86,24 @@ def _mm_dx(dy, w, wt):
     return torch.mm(dy, wt.t()) if wt is not None else torch.mm(dy, w)
 
 
+def _lin(ops, x, w):
+    """y = x W^T for a bias-free frozen nn.Linear (MPT): of_gemm's NT launch, or the vendor library."""
+    if not _MPT_GEMMS_NATIVE:
+        return torch.mm(x, w.t())
+    y = torch.empty(x.shape[0], w.shape[0], dtype=BF16, device=x.device)
+    ops.gemm(x, w, y)
+    return y
+
+
+def _lin_dx(ops, dy, w, wt):
+    """dX = dY W of the same layer: of_gemm's NN launch on W as it lies (no transposed copy), or the vendor library on the cached W^T."""
+    if not _MPT_GEMMS_NATIVE:
+        return _mm_dx(dy, w, wt)
+    dx = torch.empty(dy.shape[0], w.shape[1], dtype=BF16, device=dy.device)
+    ops.gemm(dy, w, dx, tb=True)
+    return dx
+
+
 class _FrozenMptBlockFn(torch.autograd.Function):
     """HF MptBlock (norm_1 -> Wqkv -> causal ALiBi attention -> out_proj -> + -> norm_2 -> up_proj -> GELU -> down_proj -> +)
     with frozen weights.  x: (B, L, d) fp32 residual stream; returns the new stream (fp32)."""
@@ -94,13 +120,13 @@ class _FrozenMptBlockFn(torch.autograd.Function):
         a = torch.empty(rows, d, dtype=BF16, device=dev)
         st1 = torch.empty(rows, 2, dtype=F32, device=dev)
         ops.ln_fwd(x2, w1, b1, a, st1)
-        qkv = torch.mm(a, Wqkv.t())                                  # (rows, 3d) bf16: q | k | v column blocks
+        qkv = _lin(ops, a, Wqkv)                                     # (rows, 3d) bf16: q | k | v column blocks
         o = torch.empty(rows, d, dtype=BF16, device=dev)
         lse = torch.empty(B, heads, L, dtype=F32, device=dev)
         kw = dict(batch=B, Lq=L, Lk=L, heads=heads, scale=scale, head_dim=head_dim, causal=True, alibi_slopes=slopes,
                   kv_len=kv_len)
         ops.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, **kw)
-        t = torch.mm(o, Wo.t())
+        t = _lin(ops, o, Wo)
         x1 = torch.empty(rows, d, dtype=F32, device=dev)
         m = torch.empty(rows, d, dtype=BF16, device=dev)
         st2 = torch.empty(rows, 2, dtype=F32, device=dev)
@@ -111,14 +137,14 @@ class _FrozenMptBlockFn(torch.autograd.Function):
             g = torch.empty_like(h)
             ops.gemm(m, Wup, g, epi=abi.EPI_GELU, out2=h)            # g = gelu(m Wup^T) from the fp32 accumulator, h = pre-activation
         else:
-            h = torch.mm(m, Wup.t())
+            h = _lin(ops, m, Wup)
             g = ops.gelu_fwd(h)
         if _MLP_FUSED_DOWN:
             from ..hip import abi
             y = torch.empty(rows, d, dtype=F32, device=dev)
             ops.gemm(g, Wdown, y, epi=abi.EPI_GATE_RESID, aux=x1)    # y = x1 + g Wdown^T (no gate: plain residual), fp32 stream
         else:
-            u = torch.mm(g, Wdown.t())
+            u = _lin(ops, g, Wdown)
             y = ops.add_bf16(x1, u)                                  # fp32 stream + bf16 branch -> fp32
         del g
         ctx.save_for_backward(x2, st1, qkv, o, lse, x1, st2, h, w1, w2, Wqkv, Wo, Wup, Wdown, slopes, kv_len)
@@ -142,20 +168,20 @@ class _FrozenMptBlockFn(torch.autograd.Function):
             dh = torch.empty(rows, Wdown.shape[1], dtype=BF16, device=dev)
             ops.gemm(_path.bf16_of(ops, dy2, ctx.scope), Wdown, dh, tb=True, epi=abi.EPI_DGELU_DOT, aux=h)     # (dY Wdown) * gelu'(h)
         else:
-            dact = _mm_dx(_path.bf16_of(ops, dy2, ctx.scope), Wdown, td)        # (rows, 4d); the bf16 copy the backward above left, or a cast
+            dact = _lin_dx(ops, _path.bf16_of(ops, dy2, ctx.scope), Wdown, td)   # (rows, 4d); the bf16 copy the backward above left, or a cast
             dh = ops.gelu_bwd(dact, h, out=dact)                     # in place: dact * gelu'(h)
             del dact
-        dm = _mm_dx(dh, Wup, tu)                                     # (rows, d)
+        dm = _lin_dx(ops, dh, Wup, tu)                               # (rows, d)
         del dh
         dx1 = torch.empty(rows, d, dtype=F32, device=dev)
         dx1b = torch.empty(rows, d, dtype=BF16, device=dev)
         ops.ln_bwd(dm, x1, st2, w2, resid=dy2, dx=dx1, dx_bf16=dx1b)  # dx1 = dy + norm_2'(dm), plus its bf16 operand copy
-        do = _mm_dx(dx1b, Wo, to)
+        do = _lin_dx(ops, dx1b, Wo, to)
         dqkv = torch.empty_like(qkv)
         delta = torch.empty(B, ctx.kw["heads"], L, dtype=F32, device=dev)
         ops.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, do, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
                      delta, **ctx.kw)
-        da = _mm_dx(dqkv, Wqkv, tq)                                  # (rows, d)
+        da = _lin_dx(ops, dqkv, Wqkv, tq)                            # (rows, d)
         dxb = torch.empty(rows, d, dtype=BF16, device=dev) if _path.TWINS else None
         ops.ln_bwd(da, x2, st1, w1, resid=dx1, dx=dx1, dx_bf16=dxb)  # in place: dx = dx1 + norm_1'(da); + its bf16 twin for the
         _path.offer_bf16_twin(dx1, dxb, ctx.scope)                   # backward of whatever produced x

@@ -686,6 +686,25 @@ def test_specialised_kernel_dot_epilogues():
 
 
 # ---- OfGemmArgs.sumsq_out (ABI v9): a weight gradient's share of the global gradient norm leaves with the GEMM that produces it -------
+@pytest.mark.parametrize("at,bt", [(0, 0), (0, 1), (1, 1)])
+def test_k_rotation_of_self_selected_big_tile_launches(at, bt):
+    """A launch of_gemm selects itself (safe = 0, >= 128 big tiles) rotates its K loop per XCD (gemm_w4m.hip: w4m_rotation -- stage
+    x * (stages / 8) first on the workgroups with block id & 7 == x, wrapping behind the last stage); the forced kernel (safe = 16) walks
+    0, 1, 2, ...  Nine stages (8 does not divide them): both are the product to fp32 summation order, and they are NOT the same bits
+    (the rotation is on; every stage is visited exactly once -- a skipped or doubled stage is off by a whole stage's products)."""
+    M, N, K = 2048, 4096, 576
+    A = _rand((K, M) if at else (M, K), 71)
+    B = _rand((K, N) if bt else (N, K), 72)
+    ref = _ref(A, B, at, bt)
+    o0, o16 = torch.zeros(M, N), torch.zeros(M, N)
+    H.gemm(A, B, a_trans=at, b_trans=bt, epi=abi.EPI_ACC_F32, C_out=o0, safe=0)
+    H.gemm(A, B, a_trans=at, b_trans=bt, epi=abi.EPI_ACC_F32, C_out=o16, safe=16)
+    scale = float(ref.abs().max())
+    assert float((o0.double() - ref).abs().max()) < 2e-6 * scale
+    assert float((o16.double() - ref).abs().max()) < 2e-6 * scale
+    assert not torch.equal(o0, o16)
+
+
 def test_weight_gradient_gemm_emits_its_sum_of_squares_per_tile():
     """TN, OF_EPI_ACC_F32, 128 big tiles (the smallest launch of_gemm gives to the 256x256 kernel): one fp32 partial per tile = the sum
     of squares of the FINAL values (alpha, tanh(gate) and beta * old applied), written not added; launches that are not a single

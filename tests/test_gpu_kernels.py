@@ -256,6 +256,33 @@ def test_gemm_pingpong_race_screen(ops, ta, tb, big):
 
 
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
+def test_gemm_k_rotation_gives_the_same_product(ops, ta, tb):
+    """Launches of_gemm selects itself (safe = 0) run the 256x256 kernel with its K loop rotated per XCD (gemm_w4m.hip: workgroups of
+    XCD x start at stage x * stages / 8 and wrap around): the same products in another order of the fp32 additions.  Against the same
+    kernel in plain stage order (safe = 16): equal up to the summation order, not bit for bit (so the rotation is really on); launch
+    after launch the same bits; 8 stages (the first K with a non-zero rotation), a K that 8 does not divide, a multi-round grid."""
+    torch.manual_seed(0)
+    differs = False
+    for (M, N, K) in [(4096, 8192, 512), (2048, 4096, 576), (8192, 2048, 8192), (8192, 8192, 2048)]:
+        A = _r((K, M) if ta else (M, K), M + K)
+        B = _r((K, N) if tb else (N, K), N + K)
+        assert ops.kernel_label(M, N, K, ta, tb, abi.EPI_ACC_F32) == "w4m256"
+        want = torch.zeros(M, N, device="cuda")
+        ops.gemm(A, B, want, ta=ta, tb=tb, epi=abi.EPI_ACC_F32, safe=16)
+        first = None
+        for it in range(4):
+            got = torch.full((M, N), float("nan"), device="cuda")
+            ops.gemm(A, B, got, ta=ta, tb=tb, epi=abi.EPI_ACC_F32)
+            if first is None:
+                first = got
+                assert _rel(got, want) < 1e-5, (M, N, K)
+                differs = differs or not torch.equal(got, want)
+            else:
+                assert torch.equal(got, first), f"{(M, N, K)} launch {it}: max diff {(got - first).abs().max().item()}"
+    assert differs
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
 def test_gemm_mid_kernel_race_screen(ops, ta, tb):
     """The 8-wave LDS-DMA 128x128 kernel (safe = 5; four-slot ring ordered by counted vmcnt + one barrier per stage): the CPU
     emulator cannot see a race.  Screen on hardware: 1..128 stages, single-tile to multi-wave grids, repeated launches, results

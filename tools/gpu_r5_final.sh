@@ -29,6 +29,10 @@ grep case gpurun_out/${TAG}_gemm_forms_probe.jsonl | cut -c1-260
 ( timeout 300 python tools/probes/w4h_family_probe.py 2>/dev/null | grep "^{" ) > gpurun_out/${TAG}_w4h_family_probe.jsonl
 ( W4H_KNOBS=0,8 W4H_CASES="NT store_bf16,NT gelu,NN dgelu" timeout 300 python tools/probes/w4h_probe.py 2>/dev/null | grep "^{" ) > gpurun_out/${TAG}_w4h_phase_probe.jsonl
 ( timeout 200 python tools/probes/helper_kernel_probe.py 2>/dev/null | grep "^{" ) > gpurun_out/${TAG}_helper_kernel_probe.jsonl
+# 4b. a launch behind a streaming pass (cold operands), and the K-rotation rules of the tools build
+( timeout 300 python tools/probes/interleaved_gemm_probe.py 2>/dev/null | grep "^{" ) > gpurun_out/${TAG}_interleaved_gemm_probe.jsonl
+cut -c1-330 gpurun_out/${TAG}_interleaved_gemm_probe.jsonl
+( IL_MAPS="0xf000,0,0x1000,0x3000,0x47000,0xf004,0xf108" IL_FILLERS="hot,200" IL_CASES="NT store K=8192,NT store,TN dW,NN dX" timeout 300 python tools/probes/interleaved_gemm_probe.py 2>/dev/null | grep "^{" ) > gpurun_out/${TAG}_k_rotation_rules.jsonl
 # 5. tile phase probe, kernel microbench (warm AND cold), vendor plain vs ours
 ( timeout 300 python tools/probes/tile_phase_probe.py 2>/dev/null | grep "^{" ) > gpurun_out/${TAG}_tile_phase_probe.jsonl
 ( timeout 500 python tools/bench_kernels.py 2>/dev/null | grep "^{" ) > gpurun_out/${TAG}_kernel_microbench.jsonl
