@@ -13,13 +13,16 @@ namespace oft {
 // the ring before its K loop and launched with 4 * ofg::RESID_LDS_BYTES of LDS behind the ring): three groups in flight -- slot 0
 // behind the ring, slots 1 / 2 behind the patches inside the idle ring (4 * PATCH_BYTES + 256 + 8 * 8 KiB = 100608 B); group g + 3
 // takes group g's slot.  vmcnt by hand as for the *_DOT epilogues: PC pieces and ST stores per group.
-template <bool ASMDMA, bool F32, class ToPatch>
+// PRE = false: nothing was requested before the K loop (the 32 KiB behind the ring hold the kernel's third image of B instead); all
+// three slots lie inside the idle ring and group 0's tile is requested here, in front of groups 1 and 2.
+template <bool ASMDMA, bool F32, bool PRE, class ToPatch>
 OF_DEV void w4_epilogue_resid_dma(const OfGemmArgs& p, ToPatch to_patch, char* smem, int ring_bytes, int m0, int n0, int wm, int wn, int wave,
                                   int lane, float gv, float sc, char* patch) {
     constexpr int PC = F32 ? 8 : 4, ST = F32 ? 8 : 4;
     float dot = 0.f;
     auto slot = [&](int g) OF_INLINE_LAMBDA -> char* {
         const int sl = g % 3;
+        if (!PRE) return smem + 4 * ofg::PATCH_BYTES + 256 + (sl * 4 + wave) * ofg::RESID_LDS_BYTES;
         return sl == 0 ? smem + ring_bytes + wave * ofg::RESID_LDS_BYTES
                        : smem + 4 * ofg::PATCH_BYTES + 256 + ((sl - 1) * 4 + wave) * ofg::RESID_LDS_BYTES;
     };
@@ -27,10 +30,12 @@ OF_DEV void w4_epilogue_resid_dma(const OfGemmArgs& p, ToPatch to_patch, char* s
         ofg::epilogue_group_resid_dma<ASMDMA>(p, m0 + wm * 128 + (g >> 1) * 32, n0 + wn * 128 + (g & 1) * 64, lane, slot(g));
     };
     of_wait_vm<0>();
+    if (!PRE) request(0);
     request(1);
     request(2);
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
+        if (g == 0 && !PRE) of_wait_vm<2 * PC>();
         if (g == 1) of_wait_vm<PC + ST + PC>();
         if (g >= 2 && g <= 5) of_wait_vm<2 * (ST + PC)>();
         if (g == 6) of_wait_vm<ST + PC + ST>();
@@ -42,7 +47,7 @@ OF_DEV void w4_epilogue_resid_dma(const OfGemmArgs& p, ToPatch to_patch, char* s
 }
 
 // dot_slot: where this tile's gate-gradient partial goes in the workspace (-1: the workgroup's id)
-template <int EPI, bool ASMDMA, class ToPatch, bool RESID_DMA = false>
+template <int EPI, bool ASMDMA, class ToPatch, bool RESID_DMA = false, bool RESID_PRE = true>
 OF_DEV void w4_epilogue_with(const OfGemmArgs& p, ToPatch to_patch, char* smem, int ring_bytes, int m0, int n0, int wm, int wn, int wave, int lane,
                              int dot_slot = -1) {
     constexpr bool AUXL = EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT;
@@ -56,8 +61,8 @@ OF_DEV void w4_epilogue_with(const OfGemmArgs& p, ToPatch to_patch, char* smem, 
     float dot = 0.f;
     char* patch = smem + wave * ofg::PATCH_BYTES;
     if constexpr (RESID_DMA && EPI == OF_EPI_GATE_RESID) {
-        if (p.io_f32) w4_epilogue_resid_dma<ASMDMA, true>(p, to_patch, smem, ring_bytes, m0, n0, wm, wn, wave, lane, gv, sc, patch);
-        else w4_epilogue_resid_dma<ASMDMA, false>(p, to_patch, smem, ring_bytes, m0, n0, wm, wn, wave, lane, gv, sc, patch);
+        if (p.io_f32) w4_epilogue_resid_dma<ASMDMA, true, RESID_PRE>(p, to_patch, smem, ring_bytes, m0, n0, wm, wn, wave, lane, gv, sc, patch);
+        else w4_epilogue_resid_dma<ASMDMA, false, RESID_PRE>(p, to_patch, smem, ring_bytes, m0, n0, wm, wn, wave, lane, gv, sc, patch);
         return;
     }
     // (Round 4 tried the aux tiles SIX groups deep -- five more 4-KiB slots per wave inside the idle ring -- on the reading that every

@@ -102,12 +102,19 @@ namespace {
 using namespace oft;
 
 constexpr int SMEM_W4M = NSLOT * STAGE_BYTES;    // 128 KiB
+// GATE_RESID: the 32 KiB behind the ring either hold the first residual tile of every wave, requested before the K loop (round 3), or the
+// third image of B -- then the epilogue requests that tile itself (gemm_w4_epi.h: PRE = false).
+#ifdef OF_W4M_RESID_PRE      // tools/ab builds only
+constexpr bool W4M_B3_RESID = false;
+#else
+constexpr bool W4M_B3_RESID = true;
+#endif
 template <int EPI>
 struct W4M_B3 {
 #ifdef OF_W4M_NO_B3          // tools/ab builds only: the other arm of the same-box A/B
     static constexpr bool value = false;
 #else
-    static constexpr bool value = EPI == OF_EPI_STORE_BF16 || EPI == OF_EPI_GELU || EPI == OF_EPI_ACC_F32;
+    static constexpr bool value = EPI == OF_EPI_STORE_BF16 || EPI == OF_EPI_GELU || EPI == OF_EPI_ACC_F32 || (EPI == OF_EPI_GATE_RESID && W4M_B3_RESID);
 #endif
 };
 
@@ -168,7 +175,7 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
     const unsigned stepB = 2u * (BT ? (unsigned)DK * (unsigned)p.ldb : (unsigned)DK);
     const unsigned smem_u = of_lds_base(smem) + (unsigned)wave * 1024u;
     constexpr bool AUXL = EPI == OF_EPI_DGELU_DOT || EPI == OF_EPI_SCALE_DOT;
-    // B3: a THIRD image of B behind the two slots (epilogues without an aux / residual tile in LDS leave 32 KiB of the CU's 160 free): B
+    // B3: a THIRD image of B behind the two slots (every epilogue but the *_DOT ones can leave 32 KiB of the CU's 160 free there): B
     // of stage d + 2 is requested in phase 0 of stage d -- six to seven phases before the barrier that needs it instead of two to three.
     // A's images stay two: requested in phase 3, three to four phases ahead.  For operands that come from HBM, not from the Infinity
     // Cache.
@@ -253,7 +260,7 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
 
         if (last_k) {      // the epilogue's first aux / residual tile travels during the K loop (gemm_w4_epi.h)
             if (AUXL) ofg::epilogue_group_aux_dma<ASMD>(p, m0 + wm * 128, n0 + wn * 128, lane, smem + SMEM_W4M + wave * ofg::AUX_LDS_BYTES);
-            if (EPI == OF_EPI_GATE_RESID) ofg::epilogue_group_resid_dma<ASMD>(p, m0 + wm * 128, n0 + wn * 128, lane, smem + SMEM_W4M + wave * ofg::RESID_LDS_BYTES);
+            if (EPI == OF_EPI_GATE_RESID && !B3) ofg::epilogue_group_resid_dma<ASMD>(p, m0 + wm * 128, n0 + wn * 128, lane, smem + SMEM_W4M + wave * ofg::RESID_LDS_BYTES);
         }
 
         s16x8 fa[2][4], fb[2][8];     // [register buffer][16-row fragment]: B of a whole k-step, A of half of the wave's rows
@@ -419,7 +426,7 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_gemm_w4m_kernel(OfGemmArgs p) {
             }
         };
         // gate-gradient partial of this TILE: slot = its position in the (m-major) tile grid, whichever workgroup finishes it
-        w4_epilogue_with<EPI, ASMD, decltype(acc_to_patch), true>(p, acc_to_patch, smem, SMEM_W4M, m0, n0, wm, wn, wave, lane, pm * tiles_n + pn);
+        w4_epilogue_with<EPI, ASMD, decltype(acc_to_patch), true, !(EPI == OF_EPI_GATE_RESID && B3)>(p, acc_to_patch, smem, SMEM_W4M, m0, n0, wm, wn, wave, lane, pm * tiles_n + pn);
         OF_STAMP(3);
     }
     OF_STAMP_FLUSH();
