@@ -121,6 +121,11 @@ typedef struct OfGemmArgs {
     float* sumsq_out;
 } OfGemmArgs;
 
+/* Reproducibility: the same call (shape, operands, workspace, cu_limit) gives the same bits launch after launch, on every kernel.  The
+ * ORDER of the fp32 additions along K belongs to the kernel of_gemm selects: launches it sends to the 256x256 kernel by itself (safe = 0)
+ * start each tile's K loop at a stage that depends on the XCD the tile runs on and wrap around (round 5: spreads the requests of
+ * operands that come from HBM over its channels) -- so two rows with the same operand values in DIFFERENT tiles agree to summation order
+ * (1e-6 relative), not bit for bit.  A kernel forced through `safe` walks K in stage order 0, 1, 2, ... like the general kernel. */
 int of_gemm(const OfGemmArgs* args, void* stream);
 /* n independent problems in ONE launch (ABI v8).  For 2..4 weight-gradient problems (a_trans = b_trans = 1, OF_EPI_ACC_F32) that
  * of_gemm would each run split along K on the 128x128 kernel -- the 512-wide projections' gradients of a gated block: to_q, to_out,

@@ -69,14 +69,17 @@ def test_layernorm_bwd_without_parameter_gradients_matches_with(on_emulator):
         assert torch.allclose(outs[0][0], xr.grad + resid, atol=1e-4, rtol=1e-4)
 
 
-@pytest.mark.parametrize("d,heads,mlp_fused", [(128, 2, False), (256, 2, False), (256, 2, True)])      # head dim 64 and 128
-def test_fused_frozen_mpt_block_matches_hf_eager(on_emulator, d, heads, mlp_fused, monkeypatch):
-    """mlp_fused: the block's MLP GEMMs (up, down, and the backward's dGELU) as of_gemm launches with fused epilogues (frozen_blocks._MLP_FUSED_*:
-    off in the product on measurement, DESIGN.md 4.9 -- the route must stay correct for the next A/B)."""
+# (d, heads, routes): head dim 64 and 128; routes = (up + GELU fused, down + residual fused, dGELU fused, plain GEMMs as of_gemm launches)
+@pytest.mark.parametrize("d,heads,routes", [(128, 2, (0, 0, 1, 0)), (256, 2, (0, 0, 1, 0)), (256, 2, (0, 0, 0, 0)), (256, 2, (1, 1, 1, 0)),
+                                            (256, 2, (0, 0, 1, 1)), (256, 2, (1, 1, 1, 1))])
+def test_fused_frozen_mpt_block_matches_hf_eager(on_emulator, d, heads, routes, monkeypatch):
+    """routes: which GEMMs of the block run as of_gemm launches (frozen_blocks._MLP_FUSED_* / _MPT_GEMMS_NATIVE).  The product's setting is
+    (0, 0, 1, 0), set from same-box A/Bs; the other routes must stay correct for the next A/B."""
     from transformers import MptConfig, MptForCausalLM
-    monkeypatch.setattr(frozen_blocks, "_MLP_FUSED_UP", mlp_fused)
-    monkeypatch.setattr(frozen_blocks, "_MLP_FUSED_DOWN", mlp_fused)
-    monkeypatch.setattr(frozen_blocks, "_MLP_FUSED_DGELU", mlp_fused)
+    monkeypatch.setattr(frozen_blocks, "_MLP_FUSED_UP", bool(routes[0]))
+    monkeypatch.setattr(frozen_blocks, "_MLP_FUSED_DOWN", bool(routes[1]))
+    monkeypatch.setattr(frozen_blocks, "_MLP_FUSED_DGELU", bool(routes[2]))
+    monkeypatch.setattr(frozen_blocks, "_MPT_GEMMS_NATIVE", bool(routes[3]))
     torch.manual_seed(0)
     lm = MptForCausalLM(MptConfig(d_model=d, n_heads=heads, n_layers=2, vocab_size=128, max_seq_len=64))
     lm.requires_grad_(False)
