@@ -255,6 +255,40 @@ def test_gemm_pingpong_race_screen(ops, ta, tb, big):
             assert torch.equal(got, want), f"{(M, N, K)} iteration {it}: max diff {(got - want).abs().max().item()}"
 
 
+def test_big_tile_epilogues_with_the_third_image_of_b_race_screen(ops):
+    """gemm_w4m.hip since round 5: every epilogue but the *_DOT ones runs its K loop with a third LDS image of B (B of stage d + 2
+    requested in phase 0 of stage d, vmcnt(8) in front of the barrier) and GATE_RESID requests its first residual tile in the epilogue,
+    into the idle ring.  The emulator executes a DMA where it is issued and cannot see a wait that is one piece short: on hardware, 1 ..
+    16 stages (every prologue / tail form of the three images), one tile and a multi-round grid, GELU with both outputs and gate + residual
+    on the fp32 and on the bf16 stream -- against fp32 torch, and six launches one bit pattern."""
+    torch.manual_seed(0)
+    gate = torch.tensor([0.43], device="cuda")
+    g = float(torch.tanh(gate))
+    for (M, N) in [(256, 256), (2048, 4096)]:
+        for K in (64, 128, 192, 256, 320, 1024):
+            A, B = _r((M, K), M + K), _r((N, K), N + K + 1, K ** -0.5)
+            acc = A.float() @ B.float().t()
+            res = torch.randn(M, N, device="cuda")
+            resb = res.to(torch.bfloat16)
+            first = None
+            for it in range(6):
+                y = torch.full((M, N), float("nan"), device="cuda")
+                ops.gemm(A, B, y, epi=abi.EPI_GATE_RESID, aux=res, gate=gate, safe=16)
+                yb = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+                ops.gemm(A, B, yb, epi=abi.EPI_GATE_RESID, aux=resb, gate=gate, safe=16)
+                b_out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+                a_out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+                ops.gemm(A, B, b_out, epi=abi.EPI_GELU, out2=a_out, safe=16)
+                got = (y, yb, b_out, a_out)
+                if first is None:
+                    first = got
+                    assert _rel(y, res + g * acc) < 1e-4, (M, N, K)
+                    assert _rel(yb, resb.float() + g * acc) < 1e-2, (M, N, K)
+                    assert _rel(a_out, acc) < 1e-2 and _rel(b_out, torch.nn.functional.gelu(acc)) < 1e-2, (M, N, K)
+                else:
+                    assert all(torch.equal(a, b) for a, b in zip(got, first)), f"{(M, N, K)} launch {it}"
+
+
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
 def test_gemm_k_rotation_gives_the_same_product(ops, ta, tb):
     """Launches of_gemm selects itself (safe = 0) run the 256x256 kernel with its K loop rotated per XCD (gemm_w4m.hip: workgroups of
