@@ -686,7 +686,7 @@ def test_specialised_kernel_dot_epilogues():
 
 
 # ---- OfGemmArgs.sumsq_out (ABI v9): a weight gradient's share of the global gradient norm leaves with the GEMM that produces it -------
-@pytest.mark.parametrize("at,bt", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("at,bt", [(0, 0), (1, 1)])      # K-contiguous and K-strided stage steps (the third layout mixes the two: hardware test)
 def test_k_rotation_of_self_selected_big_tile_launches(at, bt):
     """A launch of_gemm selects itself (safe = 0, >= 128 big tiles) rotates its K loop per XCD (gemm_w4m.hip: w4m_rotation -- stage
     x * (stages / 8) first on the workgroups with block id & 7 == x, wrapping behind the last stage); the forced kernel (safe = 16) walks
