@@ -27,7 +27,9 @@ CASES = [("NT store", 8192, 8192, 2048, 0, 0, E.EPI_STORE_BF16), ("NT store K=81
          ("NN dgelu_dot", 8192, 8192, 2048, 0, 1, E.EPI_DGELU_DOT), ("NT gate_resid K=8192", 8192, 2048, 8192, 0, 0, E.EPI_GATE_RESID),
          ("small to_q NT", 8192, 512, 2048, 0, 0, E.EPI_STORE_BF16), ("small to_out gate_resid", 8192, 2048, 512, 0, 0, E.EPI_GATE_RESID),
          ("small to_out dX scale_dot", 8192, 512, 2048, 0, 1, E.EPI_SCALE_DOT), ("small to_q dX", 8192, 2048, 512, 0, 1, E.EPI_STORE_BF16),
-         ("small to_q dW", 512, 2048, 8192, 1, 1, E.EPI_ACC_F32), ("small perceiver to_kv", 20480, 1024, 1024, 0, 0, E.EPI_STORE_BF16)]
+         ("small to_q dW", 512, 2048, 8192, 1, 1, E.EPI_ACC_F32), ("small perceiver to_kv", 20480, 1024, 1024, 0, 0, E.EPI_STORE_BF16),
+         ("small perceiver ffn up gelu", 4096, 4096, 1024, 0, 0, E.EPI_GELU), ("small perceiver ffn down", 4096, 1024, 4096, 0, 0, E.EPI_GATE_RESID),
+         ("small perceiver to_kv dX", 20480, 1024, 1024, 0, 1, E.EPI_STORE_BF16)]
 if os.environ.get("IL_CASES"):
     CASES = [c for c in CASES if any(k in c[0] for k in os.environ["IL_CASES"].split(","))]
 FILL = torch.randn(1 << 28, device="cuda").to(torch.bfloat16)          # 256 Mi elements: 512 MB in, 512 MB out at full length
@@ -66,7 +68,7 @@ for name, M, N, K, ta, tb, epi in CASES:
     for label, safe in SAFE.items():
         if label == "w4h256x128" and ta:
             continue
-        if name.startswith("small") and safe:
+        if name.startswith("small") and safe and not os.environ.get("IL_SMALL_FORCED"):
             continue
         fns[label] = (lambda safe=safe: ops.gemm(A, B, C, ta=bool(ta), tb=bool(tb), epi=epi, safe=safe, **kw))
     if MAPS:
