@@ -262,6 +262,34 @@ def test_gemm_pingpong_epilogues(big):
     assert abs(float(dot) - float(wdot)) <= 1e-3 * abs(float(wdot)) + 1e-2
 
 
+@pytest.mark.parametrize("K", [128, 320])
+def test_big_tile_residual_epilogue_behind_a_multi_stage_k_loop(K):
+    """gemm_w4m.hip, round 5: GATE_RESID runs its K loop with the third image of B in the 32 KiB that used to hold the first residual
+    tile of every wave, and requests that tile in the epilogue (gemm_w4_epi.h: PRE = false) -- two and five stages (the prologue with
+    stage 1 in flight, the steady state and both tails of the three-image rotation), fp32 and bf16 stream, in place on a strided stream."""
+    M, N = 256, 512
+    A, B = _rand((M, K), 23), _rand((N, K), 24) * 0.1
+    acc = _ref(A, B, 0, 0)
+    gate = torch.tensor([0.41])
+    g = float(torch.tanh(gate))
+    res = torch.randn(M, N)
+    out = torch.zeros(M, N)
+    H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=out, aux=res, gate=gate, io_f32=1, safe=16)
+    np.testing.assert_allclose(out.double().numpy(), (res.double() + g * acc).numpy(), rtol=1e-5, atol=1e-4)
+    resb, outb = res.to(torch.bfloat16), torch.zeros(M, N, dtype=torch.bfloat16)
+    H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=outb, aux=resb, gate=gate, io_f32=0, safe=16)
+    np.testing.assert_allclose(outb.double().numpy(), (resb.double() + g * acc).numpy(), rtol=1e-2, atol=2e-2)
+    wide = torch.randn(M, N + 64)
+    y = wide[:, 32:32 + N]
+    y0 = y.clone()
+    H.gemm(A, B, epi=abi.EPI_GATE_RESID, C_out=y, aux=y, gate=gate, io_f32=1, safe=16)
+    np.testing.assert_allclose(y.double().numpy(), (y0.double() + g * acc).numpy(), rtol=1e-5, atol=1e-4)
+    b_out, a_out = torch.zeros(M, N, dtype=torch.bfloat16), torch.zeros(M, N, dtype=torch.bfloat16)
+    H.gemm(A, B, epi=abi.EPI_GELU, C_out=b_out, C2=a_out, safe=16)
+    np.testing.assert_allclose(b_out.double().numpy(), torch.nn.functional.gelu(acc).numpy(), rtol=1e-2, atol=1e-2)
+    np.testing.assert_allclose(a_out.double().numpy(), acc.numpy(), rtol=1e-2, atol=1e-2)
+
+
 def test_fast_erf_gelu_accuracy():
     """The epilogues' erf-GELU: |gelu - exact| and |gelu' - exact| stay below bf16 resolution -- the scalar form of the general kernel
     (K = 32: Abramowitz-Stegun 7.1.26) and the packed-math forms of the tiled kernels (K = 64 -> the 128x128 LDS-DMA kernel: 7.1.28
