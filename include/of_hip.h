@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OF_ABI_VERSION 9
+#define OF_ABI_VERSION 10
 #define OF_E_ARG (-1)      /* null pointer / negative size */
 #define OF_E_SHAPE (-2)    /* shape not supported by the kernels (see each function) */
 #define OF_E_ALIGN (-3)    /* pointer or leading dimension not 16-byte aligned */
@@ -229,6 +229,47 @@ int of_attn_bwd(const OfAttnArgs* args, void* stream);
  * the per-sequence count broadcast to Lq new tokens.  media_locations: uint8 (B, Lm). */
 int of_text_time(const uint8_t* media_locations, int32_t* text_time, int B, int Lm, int Lq, int use_cached,
                  void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * The attention branch of GatedCrossAttentionBlock as ONE kernel (ABI v10; helpers.py:184-194 norm + to_q, :192-231 masked
+ * attention, :231-233 to_out, :267-276 tanh gate + residual, and the LayerNorm that opens the block's FeedForward, helpers.py:18):
+ *     xn = LN(x);  q = xn Wq^T;  o = softmax_window(q K^T * scale) V;  y = x + tanh(*gate) * (o Wout^T);  u2 = LN2(y)
+ * A workgroup owns 32 consecutive text positions of one sequence and all 8 heads.  Shapes it takes (OF_E_SHAPE otherwise -- callers
+ * then run the separate launches, of_xattn_fused_eligible() asks without launching): heads = 8, head_dim = 64, d in {256, 512,
+ * 1024, 2048}, L a multiple of 32.  x / y: (B*L) x d in the stream dtype (x_f32); k, v: (B*Lk) x 512 bf16 views (row strides ldk,
+ * ldv) of the projected media; text_time (B, L) int32 or NULL (no mask); the key window of a position is of_attn_fwd's.
+ * wq_pk / wout_pk: FRAGMENT-MAJOR copies (of_pack_frag16) of to_q.weight (512 x d) and to_out.weight (d x 512): with 32 rows per
+ * workgroup the weights are streamed from L2 once per workgroup straight into MFMA operand registers, and a wave's 16-byte-per-lane
+ * load has to be 1 KiB contiguous for that to run at the L2's rate.
+ * Optional outputs (NULL = not written): xn, stats (rows x 2: mean, rstd), q, o, lse -- exactly what of_layernorm_fwd / of_gemm /
+ * of_attn_fwd would have saved for the backward; ln2_w = NULL: no second LayerNorm (u2, stats2 unused). */
+typedef struct OfXattnFusedArgs {
+    const void* x; int x_f32; long ldx;
+    const float* ln_w; const float* ln_b;
+    const uint16_t* wq_pk;
+    const uint16_t* k; const uint16_t* v; long ldk, ldv;
+    const int32_t* text_time;
+    const uint16_t* wout_pk;
+    const float* gate;             /* device pointer to attn_gate (raw), or NULL: 1 */
+    const float* ln2_w; const float* ln2_b;
+    uint16_t* xn; long ldxn;
+    float* stats;
+    uint16_t* q; long ldq;
+    uint16_t* o; long ldo;
+    float* lse;                    /* (B, 8, L) */
+    void* y; long ldy;
+    uint16_t* u2; long ldu2;
+    float* stats2;
+    int B, L, Lk, d, heads, head_dim;
+    int n_per_media, T_img, only_immediate;
+    float scale;
+} OfXattnFusedArgs;
+int of_xattn_fused_eligible(const OfXattnFusedArgs* args);
+int of_xattn_fused_fwd(const OfXattnFusedArgs* args, void* stream);
+/* P[((nt * (K / 32) + ks) * 64 + lane) * 8 .. + 7] = W[16 nt + (lane & 15)][32 ks + 8 (lane >> 4) .. + 7]: the fragment-major copy of a
+ * row-major N x K bf16 matrix (row stride ldw) -- the 16 bytes lane `lane` of a wave feeds v_mfma_f32_16x16x32_bf16 for n-tile nt, k-step
+ * ks, one wave load = 1 KiB contiguous.  N % 16 == 0, K % 32 == 0; P holds N * K elements. */
+int of_pack_frag16(const uint16_t* W, int N, int K, long ldw, uint16_t* P, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Small element-wise helpers of the path. */

@@ -5,7 +5,7 @@ Pure declarations: nothing here loads a library.  ``open_flamingo_amd.hip.lib`` 
 """
 import ctypes as C
 
-OF_ABI_VERSION = 9
+OF_ABI_VERSION = 10
 OF_SUMSQ_PARTS = 512
 EPI_STORE_BF16, EPI_GELU, EPI_GATE_RESID, EPI_DGELU_DOT, EPI_SCALE_DOT, EPI_ACC_F32 = range(6)
 
@@ -49,6 +49,30 @@ class OfAttnArgs(C.Structure):
     ]
 
 
+class OfXattnFusedArgs(C.Structure):
+    _fields_ = [
+        ("x", vp), ("x_f32", C.c_int), ("ldx", C.c_long),
+        ("ln_w", vp), ("ln_b", vp),
+        ("wq_pk", vp),
+        ("k", vp), ("v", vp), ("ldk", C.c_long), ("ldv", C.c_long),
+        ("text_time", vp),
+        ("wout_pk", vp),
+        ("gate", vp),
+        ("ln2_w", vp), ("ln2_b", vp),
+        ("xn", vp), ("ldxn", C.c_long),
+        ("stats", vp),
+        ("q", vp), ("ldq", C.c_long),
+        ("o", vp), ("ldo", C.c_long),
+        ("lse", vp),
+        ("y", vp), ("ldy", C.c_long),
+        ("u2", vp), ("ldu2", C.c_long),
+        ("stats2", vp),
+        ("B", C.c_int), ("L", C.c_int), ("Lk", C.c_int), ("d", C.c_int), ("heads", C.c_int), ("head_dim", C.c_int),
+        ("n_per_media", C.c_int), ("T_img", C.c_int), ("only_immediate", C.c_int),
+        ("scale", C.c_float),
+    ]
+
+
 PROTOTYPES = {
     "of_abi_version": (C.c_int, []),
     "of_build_kind": (C.c_int, []),
@@ -68,6 +92,9 @@ PROTOTYPES = {
     "of_layernorm_bwd_workspace_bytes": (C.c_size_t, [C.c_long, C.c_int]),
     "of_attn_fwd": (C.c_int, [C.POINTER(OfAttnArgs), vp]),
     "of_attn_bwd": (C.c_int, [C.POINTER(OfAttnArgs), vp]),
+    "of_xattn_fused_eligible": (C.c_int, [C.POINTER(OfXattnFusedArgs)]),
+    "of_xattn_fused_fwd": (C.c_int, [C.POINTER(OfXattnFusedArgs), vp]),
+    "of_pack_frag16": (C.c_int, [vp, C.c_int, C.c_int, C.c_long, vp, vp]),
     "of_text_time": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "of_cast_f32_to_bf16": (C.c_int, [vp, vp, C.c_long, vp]),
     "of_cast_bf16_to_f32": (C.c_int, [vp, vp, C.c_long, vp]),

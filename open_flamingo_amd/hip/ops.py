@@ -297,6 +297,48 @@ class Ops:
         a.delta = delta.data_ptr()
         self._chk(self.lib.of_attn_bwd(C.byref(a), self._stream()), "of_attn_bwd")
 
+    # ------------------------------------------------------------------ fused attention branch of a gated block
+    def pack_frag16(self, W, out=None):
+        """Fragment-major copy of a row-major (N, K) bf16 matrix (of_pack_frag16): the weight operand of xattn_fused_fwd."""
+        assert W.dtype == BF16 and W.dim() == 2 and W.stride(1) == 1
+        N, K = W.shape
+        out = torch.empty(N * K, dtype=BF16, device=W.device) if out is None else out
+        assert out.dtype == BF16 and out.numel() >= N * K and out.is_contiguous()
+        self._chk(self.lib.of_pack_frag16(W.data_ptr(), N, K, W.stride(0), out.data_ptr(), self._stream()), "of_pack_frag16")
+        return out
+
+    def xattn_fused_fwd(self, x, ln_w, ln_b, wq_pk, k, v, tt, wout_pk, gate, y, *, B, L, Lk, heads, head_dim, n_per_media, T_img,
+                        only_immediate, scale, ln2_w=None, ln2_b=None, u2=None, st2=None, xn=None, st=None, q=None, o=None, lse=None,
+                        probe_only=False):
+        """The attention branch of a gated block as ONE launch (include/of_hip.h: of_xattn_fused_fwd).  Returns False -- nothing
+        launched -- when the kernel does not take these shapes (the caller then runs the separate launches)."""
+        a = abi.OfXattnFusedArgs()
+        a.x, a.x_f32, a.ldx = x.data_ptr(), _is_f32(x), x.stride(0)
+        a.ln_w, a.ln_b = ln_w.data_ptr(), ln_b.data_ptr()
+        a.wq_pk, a.wout_pk = _p(wq_pk), _p(wout_pk)
+        a.k, a.v, a.ldk, a.ldv = k.data_ptr(), v.data_ptr(), k.stride(0), v.stride(0)
+        a.text_time = _p(tt)
+        a.gate = _p(gate)
+        a.ln2_w, a.ln2_b = _p(ln2_w), _p(ln2_b)
+        a.xn, a.ldxn = _p(xn), (xn.stride(0) if xn is not None else 0)
+        a.stats = _p(st)
+        a.q, a.ldq = _p(q), (q.stride(0) if q is not None else 0)
+        a.o, a.ldo = _p(o), (o.stride(0) if o is not None else 0)
+        a.lse = _p(lse)
+        a.y, a.ldy = y.data_ptr(), y.stride(0)
+        a.u2, a.ldu2 = _p(u2), (u2.stride(0) if u2 is not None else 0)
+        a.stats2 = _p(st2)
+        a.B, a.L, a.Lk, a.d, a.heads, a.head_dim = B, L, Lk, x.shape[1], heads, head_dim
+        a.n_per_media, a.T_img, a.only_immediate = n_per_media, T_img, int(only_immediate)
+        a.scale = scale
+        if probe_only:
+            a.wq_pk = a.wout_pk = x.data_ptr()        # (any aligned non-null pointer: eligibility does not read them)
+            return bool(self.lib.of_xattn_fused_eligible(C.byref(a)))
+        if not self.lib.of_xattn_fused_eligible(C.byref(a)):
+            return False
+        self._chk(self.lib.of_xattn_fused_fwd(C.byref(a), self._stream()), "of_xattn_fused_fwd")
+        return True
+
     def text_time(self, media_locations_u8, out_i32, Lq, use_cached):
         B, Lm = media_locations_u8.shape
         self._chk(self.lib.of_text_time(media_locations_u8.data_ptr(), out_i32.data_ptr(), B, Lm, Lq, int(use_cached),

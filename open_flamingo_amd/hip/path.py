@@ -83,14 +83,18 @@ def _branch_out(ops, A, Wt, x_like, resid, gate):
     return out
 
 
-def feed_forward_fwd(ops, P, W, x, *, prefix="", gate=None, residual=False, keep=True):
-    """x (rows, d) stream dtype.  P/W keys: prefix + {0.weight, 0.bias, 1.weight, 3.weight}.  Returns (y, saved)."""
+def feed_forward_fwd(ops, P, W, x, *, prefix="", gate=None, residual=False, keep=True, pre_ln=None):
+    """x (rows, d) stream dtype.  P/W keys: prefix + {0.weight, 0.bias, 1.weight, 3.weight}.  Returns (y, saved).
+    pre_ln = (u, st): LN(x) in bf16 and its statistics, when the producer of x already computed them (the fused attention branch)."""
     dev = x.device
     rows, d = x.shape
     hid = W[prefix + "1.weight"].shape[0]
-    u = _e((rows, d), BF16, dev)
-    st = _e((rows, 2), F32, dev)
-    ops.ln_fwd(x, P[prefix + "0.weight"], P[prefix + "0.bias"], u, st)
+    if pre_ln is not None:
+        u, st = pre_ln
+    else:
+        u = _e((rows, d), BF16, dev)
+        st = _e((rows, 2), F32, dev)
+        ops.ln_fwd(x, P[prefix + "0.weight"], P[prefix + "0.bias"], u, st)
     a = _e((rows, hid), BF16, dev) if keep else None      # pre-GELU activations: only the backward reads them
     b = _e((rows, hid), BF16, dev)
     ops.gemm(u, W[prefix + "1.weight"], b, epi=EPI_GELU, out2=a)               # up-projection + erf GELU
@@ -220,24 +224,62 @@ def _softmax_scale(scale, dim_head):
     return dim_head ** -0.5 if scale is None else float(scale)
 
 
+FUSED_XATTN = True    # constant; tools/ab_fused_xattn.py clears it for the same-box A/B (the five separate launches)
+
+
+def packed_weight(ops, W, name):
+    """fragment-major copy of the bf16 weight W[name] (of_pack_frag16), made once per W dict (= per forward: the weights change with
+    every optimizer step; callers that know better -- eval mode -- put their cached copy under name + '#pk' first)"""
+    key = name + "#pk"
+    pk = W.get(key)
+    if pk is None:
+        pk = W[key] = ops.pack_frag16(W[name])
+    return pk
+
+
 def masked_cross_attention_fwd(ops, P, W, x, media_bf, tt, *, B, L, T, n, heads, only_immediate, prefix="attn.", gate=None,
-                               residual=False, safe=0, kv=None, dim_head=64, scale=None):
-    """x (B*L, d) stream dtype; media_bf (B*T*n, Dv) bf16; tt (B, L) int32 or None.  Returns (y, saved)."""
+                               residual=False, safe=0, kv=None, dim_head=64, scale=None, keep=True, next_ln=None):
+    """x (B*L, d) stream dtype; media_bf (B*T*n, Dv) bf16; tt (B, L) int32 or None.  Returns (y, saved).
+    next_ln = (weight, bias) of a LayerNorm the caller applies to y next (the block's FeedForward): when the branch runs as the ONE
+    fused launch (of_xattn_fused_fwd) that LayerNorm leaves with it and saved["next_ln"] = (LN(y) bf16, statistics)."""
     dev = x.device
     rows, d = x.shape
     inner = heads * dim_head
+    if kv is None:
+        kv = xattn_project_media(ops, W, media_bf, heads, prefix=prefix, dim_head=dim_head)   # to_kv (k | v fused)
+    sc = _softmax_scale(scale, dim_head)
+    if FUSED_XATTN and residual and safe == 0 and dim_head == 64 and ops.xattn_fused_fwd(
+            x, P[prefix + "norm.weight"], P[prefix + "norm.bias"], None, kv[:, :inner], kv[:, inner:], tt, None, gate, x, B=B, L=L,
+            Lk=T * n, heads=heads, head_dim=dim_head, n_per_media=n, T_img=T, only_immediate=only_immediate, scale=sc,
+            probe_only=True):
+        y = torch.empty_like(x)
+        xn = _e((rows, d), BF16, dev) if keep else None
+        st = _e((rows, 2), F32, dev) if keep else None
+        q = _e((rows, inner), BF16, dev) if keep else None
+        o = _e((rows, inner), BF16, dev) if keep else None
+        lse = _e((B, heads, L), F32, dev) if keep else None
+        u2 = st2 = None
+        if next_ln is not None:
+            u2, st2 = _e((rows, d), BF16, dev), _e((rows, 2), F32, dev)
+        ok = ops.xattn_fused_fwd(x, P[prefix + "norm.weight"], P[prefix + "norm.bias"], packed_weight(ops, W, prefix + "to_q.weight"),
+                                 kv[:, :inner], kv[:, inner:], tt, packed_weight(ops, W, prefix + "to_out.weight"), gate, y, B=B, L=L,
+                                 Lk=T * n, heads=heads, head_dim=dim_head, n_per_media=n, T_img=T, only_immediate=only_immediate,
+                                 scale=sc, ln2_w=next_ln[0] if next_ln else None, ln2_b=next_ln[1] if next_ln else None, u2=u2,
+                                 st2=st2, xn=xn, st=st, q=q, o=o, lse=lse)
+        assert ok
+        S = dict(x=x, xn=xn, st=st, q=q, kv=kv, o=o, lse=lse)
+        if next_ln is not None:
+            S["next_ln"] = (u2, st2)
+        return y, S
     xn = _e((rows, d), BF16, dev)
     st = _e((rows, 2), F32, dev)
     ops.ln_fwd(x, P[prefix + "norm.weight"], P[prefix + "norm.bias"], xn, st)
     q = _e((rows, inner), BF16, dev)
     ops.gemm(xn, W[prefix + "to_q.weight"], q)                                   # to_q
-    if kv is None:
-        kv = xattn_project_media(ops, W, media_bf, heads, prefix=prefix, dim_head=dim_head)   # to_kv (k | v fused)
     o = _e((rows, inner), BF16, dev)
     lse = _e((B, heads, L), F32, dev)
     ops.attn_fwd(q, kv[:, :inner], kv[:, inner:], o, lse, batch=B, Lq=L, Lk=T * n, heads=heads, text_time=tt,
-                 n_per_media=n, T_img=T, only_immediate=only_immediate, safe=safe, head_dim=dim_head,
-                 scale=_softmax_scale(scale, dim_head))
+                 n_per_media=n, T_img=T, only_immediate=only_immediate, safe=safe, head_dim=dim_head, scale=sc)
     y = _branch_out(ops, o, W[prefix + "to_out.weight"], x, x if residual else None, gate)   # to_out [, *tanh(gate), +x]
     return y, dict(x=x, xn=xn, st=st, q=q, kv=kv, o=o, lse=lse)
 
@@ -299,8 +341,8 @@ def xattn_block_fwd(ops, P, W, x, media_bf, tt, *, B, L, T, n, heads, only_immed
     backward -- the pre-GELU activations are not written -- and saved is None."""
     y1, Sa = masked_cross_attention_fwd(ops, P, W, x, media_bf, tt, B=B, L=L, T=T, n=n, heads=heads,
                                         only_immediate=only_immediate, gate=P["attn_gate"], residual=True, safe=safe,
-                                        kv=kv, dim_head=dim_head, scale=scale)
-    y2, Sf = feed_forward_fwd(ops, P, W, y1, prefix="ff.", gate=P["ff_gate"], residual=True, keep=keep)
+                                        kv=kv, dim_head=dim_head, scale=scale, keep=keep, next_ln=(P["ff.0.weight"], P["ff.0.bias"]))
+    y2, Sf = feed_forward_fwd(ops, P, W, y1, prefix="ff.", gate=P["ff_gate"], residual=True, keep=keep, pre_ln=Sa.pop("next_ln", None))
     if not keep:
         return y2, None
     return y2, dict(attn=Sa, ff=Sf)

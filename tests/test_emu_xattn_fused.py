@@ -1,0 +1,140 @@
+"""The fused attention branch of a gated block (csrc/xattn_fused.hip: LN -> to_q -> windowed attention -> to_out + gate + residual ->
+LN_ff in one launch) on the host emulator: against the five separate launches it replaces (same saved tensors, LN(x) bit for bit),
+against the oracle through the composed block (forward + the hand-written backward on what the fused forward saved), over the mask
+cases of reference helpers.py:196-229, every instantiated width, both stream dtypes, and the fragment-major weight copy."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import flamingo_oracle as O
+from open_flamingo_amd.hip import path
+from tests import path_checks as PC
+from tests.emu import harness as H
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def ops():
+    return H.emu_ops()
+
+
+def test_pack_frag16_is_the_mfma_operand_order(ops):
+    g = torch.Generator().manual_seed(3)
+    N, K = 48, 96
+    W = torch.randn(N, K + 8, generator=g).to(BF16)[:, :K]          # row stride != K
+    P = ops.pack_frag16(W).view(N // 16, K // 32, 64, 8)
+    for nt in range(N // 16):
+        for ks in range(K // 32):
+            for lane in (0, 5, 17, 38, 63):
+                want = W[16 * nt + (lane & 15), 32 * ks + 8 * (lane >> 4):32 * ks + 8 * (lane >> 4) + 8]
+                assert torch.equal(P[nt, ks, lane], want)
+
+
+def _block_inputs(B, L, T, n, d, Dv, seed, stream_dtype=F32, media_locs=None, only_immediate=True):
+    m = O.OracleGatedCrossAttentionBlock(dim=d, dim_visual=Dv, heads=8, dim_head=64, only_attend_immediate_media=only_immediate)
+    st = O.seeded_state({k: tuple(v.shape) for k, v in m.state_dict().items()}, 100 + seed)
+    st["attn_gate"], st["ff_gate"] = torch.tensor([0.6]), torch.tensor([-0.4])
+    m.load_state_dict(st)
+    g = torch.Generator().manual_seed(200 + seed)
+    x = torch.randn(B, L, d, generator=g) * 1.5 + 0.25
+    media = torch.randn(B, T, n, Dv, generator=g)
+    P = {k: v.detach().contiguous() for k, v in m.named_parameters()}
+    return m, P, x.to(stream_dtype).reshape(B * L, d).contiguous(), media, media_locs
+
+
+def _run_branch(ops, P, W, xd, media_bf, tt, fused, **kw):
+    path.FUSED_XATTN = fused
+    try:
+        return path.masked_cross_attention_fwd(ops, P, dict(W), xd, media_bf, tt, gate=P["attn_gate"], residual=True,
+                                               next_ln=(P["ff.0.weight"], P["ff.0.bias"]), **kw)
+    finally:
+        path.FUSED_XATTN = True
+
+
+def _tt(ops, media_locs, L):
+    tt = torch.empty(media_locs.shape[0], L, dtype=torch.int32)
+    ops.text_time(media_locs.to(torch.uint8).contiguous(), tt, L, False)
+    return tt
+
+
+def _compare_with_separate_launches(ops, *, B, L, T, n, d, Dv, seed, stream_dtype=F32, media_locs=None, only_immediate=True, no_mask=False):
+    m, P, xd, media, _ = _block_inputs(B, L, T, n, d, Dv, seed, stream_dtype, only_immediate=only_immediate)
+    W = PC.make_bf16_weights(ops, P)
+    media_bf = ops.to_bf16(media.reshape(B * T * n, Dv).contiguous())
+    if media_locs is None:
+        media_locs = torch.zeros(B, L, dtype=torch.bool)
+        media_locs[:, 2] = True
+        media_locs[0, L // 2] = True
+    tt = None if no_mask else _tt(ops, media_locs, L)
+    kw = dict(B=B, L=L, T=T, n=n, heads=8, only_immediate=only_immediate)
+    y, S = _run_branch(ops, P, W, xd, media_bf, tt, True, **kw)
+    assert "next_ln" in S, "the fused kernel did not take this shape"
+    y0, S0 = _run_branch(ops, P, W, xd, media_bf, tt, False, **kw)
+    assert "next_ln" not in S0
+    u0, st0 = torch.empty_like(S["next_ln"][0]), torch.empty_like(S["next_ln"][1])
+    ops.ln_fwd(y0, P["ff.0.weight"], P["ff.0.bias"], u0, st0)
+    # the LayerNorm in front is the separate kernel's arithmetic, bit for bit
+    assert torch.equal(S["xn"], S0["xn"]) and torch.equal(S["st"], S0["st"])
+    # everything behind it differs by the order of the fp32 additions along K only (packed fragments / other tile shapes)
+    def close(a, b, tol, what):
+        a, b = a.float(), b.float()
+        fin = torch.isfinite(b)
+        assert torch.equal(torch.isfinite(a), fin), what
+        err = (a[fin] - b[fin]).abs().max().item() / (b[fin].abs().max().item() + 1e-12)
+        assert err <= tol, (what, err)
+    close(S["q"], S0["q"], 1e-2, "q")                # bf16 values: one ulp where an fp32 sum rounds the other way
+    close(S["o"], S0["o"], 1.5e-2, "o")
+    close(S["lse"], S0["lse"], 2e-3, "lse")
+    close(y, y0, 1e-2 if stream_dtype == BF16 else 2e-3, "y")
+    close(S["next_ln"][0], u0, 2e-2, "LN_ff(y)")
+    close(S["next_ln"][1], st0, 2e-2 if stream_dtype == BF16 else 2e-3, "LN_ff statistics")
+    return S, S0
+
+
+@pytest.mark.parametrize("d", [256, 512, 1024, 2048])
+def test_fused_branch_equals_the_separate_launches_at_every_width(ops, d):
+    # d = 2048 is the product instantiation (OF-3B): 16 output tiles per wave, the four-unit fragment ring
+    _compare_with_separate_launches(ops, B=1, L=32 if d >= 1024 else 64, T=2, n=64, d=d, Dv=64, seed=d)
+
+
+def test_fused_branch_bf16_stream(ops):
+    _compare_with_separate_launches(ops, B=2, L=32, T=2, n=64, d=256, Dv=64, seed=5, stream_dtype=BF16)
+
+
+def test_fused_branch_mask_cases(ops):
+    """helpers.py:196-229 inside ONE 32-row tile: rows before the first <image> (zero rows), consecutive <image> tokens, a window
+    change in the middle of a 16-row MFMA tile, text_time > T (every key masked: uniform rows over all T n keys), the last position."""
+    B, L, T = 3, 64, 3
+    ml = torch.zeros(B, L, dtype=torch.bool)
+    ml[0, 5] = ml[0, 6] = ml[0, 23] = True                 # zero rows 0-4, consecutive images, third image mid-tile
+    ml[1, 0] = ml[1, 9] = ml[1, 40] = ml[1, 41] = True     # four images but T = 3: rows >= 41 are uniform rows
+    ml[2, L - 1] = True                                    # <image> at the last position
+    S, S0 = _compare_with_separate_launches(ops, B=B, L=L, T=T, n=64, d=256, Dv=64, seed=11, media_locs=ml)
+    assert float(S["o"][:5].float().abs().max()) == 0.0 and torch.isinf(S["lse"][0, :, :5]).all()
+    # the 'ge' mask (only_attend_immediate_media = False): tt = 0 rows are uniform, tt >= 1 see every image so far
+    _compare_with_separate_launches(ops, B=B, L=L, T=T, n=64, d=256, Dv=64, seed=12, media_locs=ml, only_immediate=False)
+    # T = 1 (LAION shape, train_utils.py:96), and no media_locations at all (no mask: every key)
+    _compare_with_separate_launches(ops, B=2, L=32, T=1, n=64, d=256, Dv=64, seed=13)
+    _compare_with_separate_launches(ops, B=1, L=32, T=2, n=64, d=256, Dv=64, seed=14, no_mask=True)
+    # media of another length than 64 (windows that are not key-block aligned)
+    _compare_with_separate_launches(ops, B=2, L=32, T=3, n=48, d=256, Dv=64, seed=15)
+
+
+def test_composed_block_on_the_fused_forward_against_the_oracle(ops):
+    """forward through the fused launch, backward (hand-written, on what the fused forward saved) against the rounding-point oracle"""
+    PC.check_xattn(ops, "cpu", B=2, L=64, T=2, n=64, heads=8, d=256, Dv=128, seed=7)
+    PC.check_xattn(ops, "cpu", B=2, L=32, T=2, n=64, heads=8, d=512, Dv=64, seed=8, stream_dtype=BF16)
+    PC.check_xattn(ops, "cpu", B=2, L=32, T=2, n=64, heads=8, d=256, Dv=64, seed=9, only_immediate=False, inplace=True, fresh=True)
+
+
+def test_shapes_the_fused_kernel_does_not_take_run_the_separate_launches(ops):
+    for kw in (dict(d=128), dict(L=40), dict(heads=4)):      # d not instantiated, L % 32 != 0, heads != 8
+        B, L, T, n, d, heads = 1, kw.get("L", 32), 2, 64, kw.get("d", 256), kw.get("heads", 8)
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(B * L, d, generator=g)
+        kv = torch.randn(B * T * n, 2 * heads * 64, generator=g).to(BF16)
+        ok = ops.xattn_fused_fwd(x, torch.ones(d), torch.zeros(d), None, kv[:, :heads * 64], kv[:, heads * 64:], None, None, None, x,
+                                 B=B, L=L, Lk=T * n, heads=heads, head_dim=64, n_per_media=n, T_img=T, only_immediate=True, scale=0.125,
+                                 probe_only=True)
+        assert not ok, kw

@@ -1,0 +1,104 @@
+"""The attention branch of a gated block at BASELINE config 2's shape (B 32, L 256, d 2048, T 2 x 64 media tokens): the ONE fused launch
+(csrc/xattn_fused.hip) against the five separate launches it replaces, each timed with HIP events over ROTATING buffer sets (a train
+step never finds x in the Infinity Cache), plus the two fragment-major weight copies the fused launch needs.  PROFILING TOOL."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from open_flamingo_amd.hip import path
+from open_flamingo_amd.hip.ops import Ops, BF16, F32
+
+ops = Ops.default()
+dev = "cuda"
+B, L, T, n, d, heads, Dv = int(os.environ.get("XF_B", 32)), 256, 2, 64, int(os.environ.get("XF_D", 2048)), 8, 1024
+rows, inner = B * L, 512
+NSETS, REPS = 8, 5
+g = torch.Generator(device=dev).manual_seed(1)
+P = {"attn.norm.weight": torch.rand(d, device=dev, generator=g) + 0.5, "attn.norm.bias": torch.randn(d, device=dev, generator=g) * 0.1,
+     "ff.0.weight": torch.rand(d, device=dev, generator=g) + 0.5, "ff.0.bias": torch.randn(d, device=dev, generator=g) * 0.1,
+     "attn_gate": torch.tensor([0.5], device=dev)}
+W = {"attn.to_q.weight": (torch.randn(inner, d, device=dev, generator=g) * d ** -0.5).to(BF16),
+     "attn.to_out.weight": (torch.randn(d, inner, device=dev, generator=g) * inner ** -0.5).to(BF16)}
+xs = [torch.randn(rows, d, device=dev, generator=g) for _ in range(NSETS)]
+kvs = [torch.randn(B * T * n, 2 * inner, device=dev, generator=g).to(BF16) for _ in range(NSETS)]
+ml = torch.zeros(B, L, dtype=torch.bool, device=dev)
+ml[:, 0] = True
+ml[:, L // 2] = True
+tt = torch.empty(B, L, dtype=torch.int32, device=dev)
+ops.text_time(ml.to(torch.uint8).contiguous(), tt, L, False)
+kw = dict(B=B, L=L, T=T, n=n, heads=heads, only_immediate=True)
+filler_a = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+filler_b = torch.empty_like(filler_a)
+
+
+def run(fused, i):
+    path.FUSED_XATTN = fused
+    Wd = dict(W)
+    if fused:
+        Wd["attn.to_q.weight#pk"], Wd["attn.to_out.weight#pk"] = pk_q, pk_o
+    y, S = path.masked_cross_attention_fwd(ops, P, Wd, xs[i % NSETS], None, tt, gate=P["attn_gate"], residual=True, kv=kvs[i % NSETS],
+                                           next_ln=(P["ff.0.weight"], P["ff.0.bias"]), **kw)
+    if not fused:
+        u2, st2 = torch.empty(rows, d, dtype=BF16, device=dev), torch.empty(rows, 2, device=dev)
+        ops.ln_fwd(y, P["ff.0.weight"], P["ff.0.bias"], u2, st2)
+    return y, S
+
+
+def timed(fn, cold):
+    ts = []
+    for i in range(NSETS * REPS):
+        if cold:
+            filler_b.copy_(filler_a)          # 512 MB through the caches: the next launch finds nothing of its own there
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn(i)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts = sorted(ts[NSETS:])
+    return ts[len(ts) // 2]
+
+
+pk_q, pk_o = ops.pack_frag16(W["attn.to_q.weight"]), ops.pack_frag16(W["attn.to_out.weight"])
+yf, Sf = run(True, 0)
+y0, S0 = run(False, 0)
+torch.cuda.synchronize()
+err = ((yf - y0).abs().max() / y0.abs().max()).item()
+assert "next_ln" in Sf and err < 2e-3, err
+rec = {"probe": "xattn_fused", "shape": {"B": B, "L": L, "d": d, "T": T, "n": n}, "max_rel_diff_y_fused_vs_separate": err}
+for cold in (False, True):
+    tag = "behind_a_512MB_copy" if cold else "rotating_8_sets"
+    rec["fused_us_" + tag] = round(timed(lambda i: run(True, i), cold), 1)
+    rec["separate_5_launches_us_" + tag] = round(timed(lambda i: run(False, i), cold), 1)
+rec["pack_two_weights_us"] = round(timed(lambda i: (ops.pack_frag16(W["attn.to_q.weight"], pk_q), ops.pack_frag16(W["attn.to_out.weight"], pk_o)), False), 1)
+hbm = (rows * d * 4 + rows * d * 2 + 2 * rows * inner * 2 + rows * d * 4 + rows * d * 2) / 1e6
+rec["algorithmic_MB"] = round(hbm, 1)
+rec["fused_TBps_cold"] = round(hbm / rec["fused_us_behind_a_512MB_copy"], 2)
+print(json.dumps(rec), flush=True)
+
+# ---- where the fused launch's time goes: phase stamps of the tools build (wave 0 of every workgroup, 100-MHz wall clock)
+if os.environ.get("XF_PHASES", "1") == "1":
+    import ctypes
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools_lib import tools_ops
+    tops = tools_ops()
+    tops.lib.of_tools_set_xf_stamp_buffer.argtypes = [ctypes.c_void_p]
+    ops = tops
+    nwg = rows // 32
+    for cold in (False, True):
+        for i in range(3):
+            run(True, i)
+        torch.cuda.synchronize()
+        buf = torch.zeros(nwg, 8, dtype=torch.int64, device=dev)
+        tops.lib.of_tools_set_xf_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+        if cold:
+            filler_b.copy_(filler_a)
+        run(True, 5)
+        torch.cuda.synchronize()
+        tops.lib.of_tools_set_xf_stamp_buffer(None)
+        s = buf.cpu().double()
+        t = (s[:, :7] - s[:, 0].min()) / 100.0
+        med = lambda v: round(float(v.median()), 2)
+        print(json.dumps({"probe": "xattn_fused_phases", "cold": cold, "workgroups": nwg, "entry_spread_us": med(t[:, 0]),
+                          "layernorm_us": med(t[:, 1] - t[:, 0]), "to_q_us": med(t[:, 2] - t[:, 1]), "attention_us": med(t[:, 3] - t[:, 2]),
+                          "to_out_kloop_us": med(t[:, 4] - t[:, 3]), "epilogue_issue_us": med(t[:, 5] - t[:, 4]),
+                          "store_ack_us": med(t[:, 6] - t[:, 5]), "span_us": round(float(t[:, 6].max()), 1)}), flush=True)
