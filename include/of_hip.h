@@ -270,6 +270,16 @@ int of_xattn_fused_fwd(const OfXattnFusedArgs* args, void* stream);
  * row-major N x K bf16 matrix (row stride ldw) -- the 16 bytes lane `lane` of a wave feeds v_mfma_f32_16x16x32_bf16 for n-tile nt, k-step
  * ks, one wave load = 1 KiB contiguous.  N % 16 == 0, K % 32 == 0; P holds N * K elements. */
 int of_pack_frag16(const uint16_t* W, int N, int K, long ldw, uint16_t* P, void* stream);
+/* n matrices in one launch (descs: a HOST array, copied into the kernel arguments): the step epilogue re-packs the to_q / to_out
+ * weights of every gated block once per optimizer step, behind the AdamW pass that rewrites their bf16 copies. */
+#define OF_PACK_BATCH_MAX 64
+typedef struct OfPackDesc {
+    const uint16_t* W;
+    uint16_t* P;
+    int N, K;
+    long ldw;
+} OfPackDesc;
+int of_pack_frag16_batch(const OfPackDesc* descs, int n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Small element-wise helpers of the path. */

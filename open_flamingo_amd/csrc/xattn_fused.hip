@@ -83,16 +83,32 @@ struct PackArgs {
     int N, K;
     long ldw;
 };
-OF_GLOBAL void of_pack_frag16_kernel(PackArgs a) {
-    const long idx = (long)of_bid_x() * 256 + of_tid();
-    const int KS = a.K / 32;
-    const long total = (long)(a.N / 16) * KS * 64;
-    if (idx >= total) return;
+OF_DEV void pack_piece(const bf16_t* W, bf16_t* P, int K, long ldw, long idx) {
+    const int KS = K / 32;
     const int lane = (int)(idx & 63);
     const long tile = idx >> 6;
     const int ks = (int)(tile % KS);
     const long nt = tile / KS;
-    *(u32x4*)(a.P + idx * 8) = *(const u32x4*)(a.W + (size_t)(nt * 16 + (lane & 15)) * a.ldw + ks * 32 + (lane >> 4) * 8);
+    *(u32x4*)(P + idx * 8) = *(const u32x4*)(W + (size_t)(nt * 16 + (lane & 15)) * ldw + ks * 32 + (lane >> 4) * 8);
+}
+OF_GLOBAL void of_pack_frag16_kernel(PackArgs a) {
+    const long idx = (long)of_bid_x() * 256 + of_tid();
+    if (idx >= (long)(a.N / 16) * (a.K / 32) * 64) return;
+    pack_piece(a.W, a.P, a.K, a.ldw, idx);
+}
+// several matrices in one launch (the step epilogue re-packs every gated block's to_q / to_out weight once per optimizer step)
+struct PackBatchArgs {
+    int n;
+    long end[OF_PACK_BATCH_MAX];                 // cumulative 16-byte pieces
+    OfPackDesc d[OF_PACK_BATCH_MAX];
+};
+OF_GLOBAL void of_pack_frag16_batch_kernel(PackBatchArgs a) {
+    const long idx = (long)of_bid_x() * 256 + of_tid();
+    if (idx >= a.end[a.n - 1]) return;
+    int i = 0;
+    while (idx >= a.end[i]) ++i;
+    const long first = i ? a.end[i - 1] : 0;
+    pack_piece(a.d[i].W, a.d[i].P, a.d[i].K, a.d[i].ldw, idx - first);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -117,6 +133,39 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_xattn_fused_fwd_kernel(OfXattnFusedArgs p) {
     XF_STAMP_DECL();
     XF_STAMP(0);
 
+    // ---- the key windows of this wave's 2 x 16 rows and K | V of the first key block they see (head `wave`): requested at
+    // kernel entry, they land under the LayerNorm (helpers.py:196-229: attention.hip's header)
+    Window w[2];
+    int kb_lo[2], kb_hi[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int pos = pos0 + mt * 16 + i16;
+        w[mt] = p.text_time ? media_window(p.text_time[batch * p.L + pos], p.n_per_media, p.T_img, p.only_immediate, p.Lk) : Window{0, p.Lk, 0};
+        int rlo = w[mt].hi > w[mt].lo ? w[mt].lo : 0x7fffffff, rhi = w[mt].hi > w[mt].lo ? w[mt].hi : 0;
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) {
+            const int olo = of_shfl_xor_i(rlo, m), ohi = of_shfl_xor_i(rhi, m);
+            rlo = olo < rlo ? olo : rlo;
+            rhi = ohi > rhi ? ohi : rhi;
+        }
+        kb_lo[mt] = of_uniform(rhi > rlo ? rlo / 64 : 0);
+        kb_hi[mt] = of_uniform(rhi > rlo ? (rhi + 63) / 64 : 0);
+    }
+    const int kb0 = kb_hi[0] > kb_lo[0] ? (kb_hi[1] > kb_lo[1] ? (kb_lo[0] < kb_lo[1] ? kb_lo[0] : kb_lo[1]) : kb_lo[0]) : kb_lo[1];
+    const int kb1 = kb_hi[0] > kb_hi[1] ? kb_hi[0] : kb_hi[1];
+    const bf16_t* kb_ptr = p.k + (size_t)batch * p.Lk * p.ldk + wave * 64;
+    const bf16_t* vb_ptr = p.v + (size_t)batch * p.Lk * p.ldv + wave * 64;
+    u32x4 kpre[8];                               // 64 keys x 128 B of K: 8 lanes per row (V follows at the start of the attention phase: both
+                                                 // prefetched would not fit next to the four rows of x the LayerNorm holds)
+    auto kv_load = [&](const bf16_t* base, long ld, int kb, u32x4 (&dst)[8]) OF_INLINE_LAMBDA {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int id = c * 64 + lane, row = id >> 3, cs = id & 7;
+            const long key = (long)kb * 64 + row;
+            dst[c] = u32x4{0u, 0u, 0u, 0u};
+            if (key < p.Lk) dst[c] = *(const u32x4*)(base + (size_t)key * ld + cs * 8);
+        }
+    };
     // ------------------------------------------------------------------------------------------------------ 1. LayerNorm (helpers.py:184)
     {
         float v[4][CPL][8];
@@ -126,6 +175,21 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_xattn_fused_fwd_kernel(OfXattnFusedArgs p) {
 #pragma unroll
             for (int j = 0; j < CPL; ++j)
                 if (lo + j * 512 < (unsigned)D) x_load8(xr, p.x_f32, lo + j * 512, v[i][j]);
+        }
+        // L2 warm-up: the packed weights have not been touched since the last optimizer step.  The 32 workgroups of an XCD (block b runs
+        // on XCD b % 8: placement only, any other map is merely slower) each pull 1 / 32 of the to_q matrix now, under the HBM-bound
+        // LayerNorm, so that the K loop below streams it from this XCD's L2 from its first k-step on; to_out's matrix follows under to_q
+        if (kb0 < kb1) kv_load(kb_ptr, p.ldk, kb0, kpre);
+        constexpr int NWARM = D / 256;           // 16-byte loads per lane: 1 / 32 of a 512 x D bf16 matrix per workgroup
+        const unsigned warm_soff = (((unsigned)of_bid_x() >> 3) & 31u) * (unsigned)(X_INNER * D * 2 / 32);
+        unsigned wx = 0;                         // (folded at once: in-order return puts these loads behind x's, which the statistics wait for anyway)
+        {
+            const of_buf_t bq = of_buf_make(p.wq_pk);
+#pragma unroll
+            for (int c = 0; c < NWARM; ++c) {
+                const u32x4 t = of_buf_load16(bq, (unsigned)tid * 16 + c * 8192, warm_soff);
+                wx ^= t[0] ^ t[1] ^ t[2] ^ t[3];
+            }
         }
         for (unsigned c = tid * 4; c < (unsigned)D; c += 2048) {
             *(f32x4*)(s_gamma + c) = *(const f32x4*)(p.ln_w + c);
@@ -157,7 +221,6 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_xattn_fused_fwd_kernel(OfXattnFusedArgs p) {
                 p.stats[row * 2] = mean;
                 p.stats[row * 2 + 1] = rstd;
             }
-            bf16_t* xnr = p.xn ? (bf16_t*)of_uniform_ptr(p.xn + (size_t)row * p.ldxn) : nullptr;
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
                 const unsigned eo = lo + j * 512;
@@ -170,16 +233,15 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_xattn_fused_fwd_kernel(OfXattnFusedArgs p) {
                         o[e] = (v[i][j][e] - mean) * rstd * w0[e] + b0[e];
                         o[4 + e] = (v[i][j][4 + e] - mean) * rstd * w1[e] + b1[e];
                     }
-                    const u32x4 r = {of_pack_bf16(o[0], o[1]), of_pack_bf16(o[2], o[3]), of_pack_bf16(o[4], o[5]), of_pack_bf16(o[6], o[7])};
-                    if (xnr) *(u32x4*)(xnr + eo) = r;
-                    *(u32x4*)(u_img + ximg_off(rl, (int)(eo >> 3), UROW)) = r;
+                    *(u32x4*)(u_img + ximg_off(rl, (int)(eo >> 3), UROW)) =
+                        u32x4{of_pack_bf16(o[0], o[1]), of_pack_bf16(o[2], o[3]), of_pack_bf16(o[4], o[5]), of_pack_bf16(o[6], o[7])};
                 }
             }
         }
+        if (wx == 0x9e3779b9u && p.B < 0) p.stats[0] = 0.f;            // (never true: keeps the warm-up loads alive)
     }
     of_sync();                                   // the LN(x) image is complete (and gamma / beta are dead)
     XF_STAMP(1);
-
     // ------------------------------------------------------------------------------------------------------ 2. to_q (helpers.py:186): head `wave`
     // qacc[mt][t][r] = q[row 16 mt + i16][64 wave + 16 t + 4 g + r]
     f32x4 qacc[2][4];
@@ -221,6 +283,19 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_xattn_fused_fwd_kernel(OfXattnFusedArgs p) {
             }
         }
     }
+    // LN(x) of this wave's four rows, image -> HBM (the to_q weight gradient needs it): stored HERE, behind the K loop's last load -- on
+    // gfx950 stores count into vmcnt like loads, so stores issued in front of the loop hold its first counted wait until HBM has taken
+    // them (measured: to_q 21.8 -> 31 us) -- and they drain under the attention / to_out phases, which leave HBM idle
+    if (p.xn) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rl = wave * 4 + i;
+            bf16_t* xnr = (bf16_t*)of_uniform_ptr(p.xn + (size_t)(row0 + rl) * p.ldxn);
+#pragma unroll
+            for (int j = 0; j < CPL; ++j)
+                if (lo + j * 512 < (unsigned)D) *(u32x4*)(xnr + lo + j * 512) = *(const u32x4*)(u_img + ximg_off(rl, (int)((lo + j * 512) >> 3), UROW));
+        }
+    }
     // q as the B operand of S^T = K Q^T, straight from the accumulators' lane layout: k-slot (g, j) of k-step ks' is head column
     // 32 ks' + 16 (j >> 2) + 4 g + (j & 3) -- the K fragments below are read with the same assignment
     s16x8 qf[2][2];
@@ -240,28 +315,24 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_xattn_fused_fwd_kernel(OfXattnFusedArgs p) {
 
     // ------------------------------------------------------------------------------------------------------ 3. windowed attention (helpers.py:192-231)
     {
+        // to_out's matrix into this XCD's L2 (see the LayerNorm phase): requested here, not waited for before the end of the phase
+        constexpr int NWARM = D / 256;
+        u32x4 wv[NWARM];
+        {
+            const of_buf_t bo = of_buf_make(p.wout_pk);
+            const unsigned warm_soff = (((unsigned)of_bid_x() >> 3) & 31u) * (unsigned)(X_INNER * D * 2 / 32);
+#pragma unroll
+            for (int c = 0; c < NWARM; ++c) wv[c] = of_buf_load16(bo, (unsigned)tid * 16 + c * 8192, warm_soff);
+        }
         char* k_img = smem + wave * 16384;       // normal image [64 keys][64] of head `wave`
         char* v_img = k_img + 8192;              // transpose image
         const FragOff<64> fo = make_frag_off<64>(lane);
-        Window w[2];
         RowCtx rc[2];
         TileRange tr[2];
-        int kb_lo[2], kb_hi[2];
         float m_i[2], l_i[2];
         f32x4 oacc[2][4];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            const int pos = pos0 + mt * 16 + i16;
-            w[mt] = p.text_time ? media_window(p.text_time[batch * p.L + pos], p.n_per_media, p.T_img, p.only_immediate, p.Lk) : Window{0, p.Lk, 0};
-            int rlo = w[mt].hi > w[mt].lo ? w[mt].lo : 0x7fffffff, rhi = w[mt].hi > w[mt].lo ? w[mt].hi : 0;
-#pragma unroll
-            for (int m = 8; m >= 1; m >>= 1) {
-                const int olo = of_shfl_xor_i(rlo, m), ohi = of_shfl_xor_i(rhi, m);
-                rlo = olo < rlo ? olo : rlo;
-                rhi = ohi > rhi ? ohi : rhi;
-            }
-            kb_lo[mt] = of_uniform(rhi > rlo ? rlo / 64 : 0);
-            kb_hi[mt] = of_uniform(rhi > rlo ? (rhi + 63) / 64 : 0);
             rc[mt] = make_row_ctx(w[mt].lo, w[mt].hi, w[mt].uni, 0, p.scale, 0.f);
             tr[mt] = make_tile_range(w[mt].lo, w[mt].hi);
             m_i[mt] = NEG_BIG;
@@ -269,10 +340,6 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_xattn_fused_fwd_kernel(OfXattnFusedArgs p) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) oacc[mt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        const int kb0 = kb_hi[0] > kb_lo[0] ? (kb_hi[1] > kb_lo[1] ? (kb_lo[0] < kb_lo[1] ? kb_lo[0] : kb_lo[1]) : kb_lo[0]) : kb_lo[1];
-        const int kb1 = kb_hi[0] > kb_hi[1] ? kb_hi[0] : kb_hi[1];
-        const bf16_t* kb_ptr = p.k + (size_t)batch * p.Lk * p.ldk + wave * 64;
-        const bf16_t* vb_ptr = p.v + (size_t)batch * p.Lk * p.ldv + wave * 64;
         // K fragment with the permuted k assignment: the two 8-byte halves (head columns 32 ks' + 4 g .. and 32 ks' + 16 + 4 g ..) of key row i16
         int koff[2][2];
 #pragma unroll
@@ -281,17 +348,18 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_xattn_fused_fwd_kernel(OfXattnFusedArgs p) {
             for (int hh = 0; hh < 2; ++hh) koff[ksp][hh] = img_n_off<64>(i16, 4 * ksp + 2 * hh + (g >> 1)) + 8 * (g & 1);
         for (int kb = kb0; kb < kb1; ++kb) {
             of_wave_sync();                      // the previous block's fragment reads are done
+            u32x4 vpre[8];
+            kv_load(vb_ptr, p.ldv, kb, vpre);    // lands while K goes to LDS
+            if (kb > kb0) kv_load(kb_ptr, p.ldk, kb, kpre);     // (a tile that straddles media: the first block came in under the LayerNorm)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {        // 64 keys x 128 B of K and of V: 8 lanes per row
+            for (int c = 0; c < 8; ++c) {
                 const int id = c * 64 + lane, row = id >> 3, cs = id & 7;
-                const long key = (long)kb * 64 + row;
-                u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-                if (key < p.Lk) {
-                    kv = *(const u32x4*)(kb_ptr + (size_t)key * p.ldk + cs * 8);
-                    vv = *(const u32x4*)(vb_ptr + (size_t)key * p.ldv + cs * 8);
-                }
-                *(u32x4*)(k_img + img_n_off<64>(row, cs)) = kv;
-                *(u32x4*)(v_img + img_t_off<64>(row, cs * 8)) = vv;
+                *(u32x4*)(k_img + img_n_off<64>(row, cs)) = kpre[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int id = c * 64 + lane, row = id >> 3, cs = id & 7;
+                *(u32x4*)(v_img + img_t_off<64>(row, cs * 8)) = vpre[c];
             }
             of_wave_sync();
 #pragma unroll
@@ -327,6 +395,10 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_xattn_fused_fwd_kernel(OfXattnFusedArgs p) {
             if (p.lse && g == 0)
                 p.lse[((size_t)batch * 8 + wave) * p.L + pos0 + rl] = l_i[mt] > 0.f ? (m_i[mt] + of_log2(l_i[mt])) * LN2 : __builtin_inff();
         }
+        unsigned wx = 0;
+#pragma unroll
+        for (int c = 0; c < NWARM; ++c) wx ^= wv[c][0] ^ wv[c][1] ^ wv[c][2] ^ wv[c][3];
+        if (wx == 0x9e3779b9u && p.B < 0) p.lse[0] = 0.f;              // (never true: keeps the warm-up loads alive)
     }
     of_sync();                                   // the o image is complete; the K | V images are dead
     XF_STAMP(3);
@@ -426,6 +498,7 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_xattn_fused_fwd_kernel(OfXattnFusedArgs p) {
         XF_STAMP_FLUSH();
         return;
     }
+    XF_STAMP(7);
     // row statistics: a row's D values sit in 4 lanes (g) of each of the 8 waves
     float* red = (float*)smem;                   // [2][8 waves][32 rows]
     float mean[2], rstd[2];
@@ -502,6 +575,27 @@ extern "C" int of_pack_frag16(const uint16_t* W, int N, int K, long ldw, uint16_
     PackArgs a{W, P, N, K, ldw};
     const long total = (long)(N / 16) * (K / 32) * 64;
     return of_launch(of_pack_frag16_kernel, of_dim3{(unsigned)((total + 255) / 256), 1, 1}, 256, 0, (of_stream_t)stream, a);
+}
+
+extern "C" int of_pack_frag16_batch(const OfPackDesc* descs, int n, void* stream) {
+    if (!descs || n <= 0) return OF_E_ARG;
+    for (int first = 0; first < n; first += OF_PACK_BATCH_MAX) {
+        PackBatchArgs a{};
+        a.n = n - first < OF_PACK_BATCH_MAX ? n - first : OF_PACK_BATCH_MAX;
+        long total = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const OfPackDesc& d = descs[first + i];
+            if (!d.W || !d.P || d.N <= 0 || d.K <= 0) return OF_E_ARG;
+            if ((d.N % 16) || (d.K % 32)) return OF_E_SHAPE;
+            if ((d.ldw & 7) || ((uintptr_t)d.W & 15) || ((uintptr_t)d.P & 15)) return OF_E_ALIGN;
+            total += (long)(d.N / 16) * (d.K / 32) * 64;
+            a.end[i] = total;
+            a.d[i] = d;
+        }
+        const int rc = of_launch(of_pack_frag16_batch_kernel, of_dim3{(unsigned)((total + 255) / 256), 1, 1}, 256, 0, (of_stream_t)stream, a);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 extern "C" int of_xattn_fused_eligible(const OfXattnFusedArgs* args) { return args && check(*args) == 0; }

@@ -73,6 +73,10 @@ class OfXattnFusedArgs(C.Structure):
     ]
 
 
+class OfPackDesc(C.Structure):
+    _fields_ = [("W", vp), ("P", vp), ("N", C.c_int), ("K", C.c_int), ("ldw", C.c_long)]
+
+
 PROTOTYPES = {
     "of_abi_version": (C.c_int, []),
     "of_build_kind": (C.c_int, []),
@@ -95,6 +99,7 @@ PROTOTYPES = {
     "of_xattn_fused_eligible": (C.c_int, [C.POINTER(OfXattnFusedArgs)]),
     "of_xattn_fused_fwd": (C.c_int, [C.POINTER(OfXattnFusedArgs), vp]),
     "of_pack_frag16": (C.c_int, [vp, C.c_int, C.c_int, C.c_long, vp, vp]),
+    "of_pack_frag16_batch": (C.c_int, [C.POINTER(OfPackDesc), C.c_int, vp]),
     "of_text_time": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "of_cast_f32_to_bf16": (C.c_int, [vp, vp, C.c_long, vp]),
     "of_cast_bf16_to_f32": (C.c_int, [vp, vp, C.c_long, vp]),

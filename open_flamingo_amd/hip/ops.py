@@ -307,6 +307,15 @@ class Ops:
         self._chk(self.lib.of_pack_frag16(W.data_ptr(), N, K, W.stride(0), out.data_ptr(), self._stream()), "of_pack_frag16")
         return out
 
+    def pack_frag16_batch(self, pairs):
+        """[(W (N, K) bf16 row-major, out flat bf16 of N * K elements)]: every fragment-major copy in one launch."""
+        n = len(pairs)
+        arr = (abi.OfPackDesc * n)()
+        for d, (W, out) in zip(arr, pairs):
+            assert W.dtype == BF16 and W.dim() == 2 and W.stride(1) == 1 and out.dtype == BF16 and out.is_contiguous() and out.numel() >= W.numel()
+            d.W, d.P, d.N, d.K, d.ldw = W.data_ptr(), out.data_ptr(), W.shape[0], W.shape[1], W.stride(0)
+        self._chk(self.lib.of_pack_frag16_batch(arr, n, self._stream()), "of_pack_frag16_batch")
+
     def xattn_fused_fwd(self, x, ln_w, ln_b, wq_pk, k, v, tt, wout_pk, gate, y, *, B, L, Lk, heads, head_dim, n_per_media, T_img,
                         only_immediate, scale, ln2_w=None, ln2_b=None, u2=None, st2=None, xn=None, st=None, q=None, o=None, lse=None,
                         probe_only=False):

@@ -227,13 +227,28 @@ def _softmax_scale(scale, dim_head):
 FUSED_XATTN = True    # constant; tools/ab_fused_xattn.py clears it for the same-box A/B (the five separate launches)
 
 
+class WeightDict(dict):
+    """name -> bf16 GEMM operand of a module's weights (src/helpers.py: _weights_bf16); name + '#pk' -> its fragment-major copy.
+    pk_cache: {name: (the bf16 tensor the copy was made from, copy)} kept by the owning module ACROSS forwards, or None when the
+    bf16 tensors are rewritten in place (a provider keeps them current: their identity says nothing about their content)."""
+    pk_cache = None
+
+
 def packed_weight(ops, W, name):
-    """fragment-major copy of the bf16 weight W[name] (of_pack_frag16), made once per W dict (= per forward: the weights change with
-    every optimizer step; callers that know better -- eval mode -- put their cached copy under name + '#pk' first)"""
+    """fragment-major copy of the bf16 weight W[name] (of_pack_frag16): the provider's (train/optim.py re-packs once per optimizer
+    step), else the owning module's cached one while the bf16 tensor it was made from is still the operand (eval mode), else made now"""
     key = name + "#pk"
     pk = W.get(key)
     if pk is None:
-        pk = W[key] = ops.pack_frag16(W[name])
+        src, cache = W[name], getattr(W, "pk_cache", None)
+        ent = cache.get(name) if cache is not None else None
+        if ent is not None and ent[0] is src:
+            pk = ent[1]
+        else:
+            pk = ops.pack_frag16(src)
+            if cache is not None:
+                cache[name] = (src, pk)
+        W[key] = pk
     return pk
 
 

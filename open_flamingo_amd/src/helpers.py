@@ -57,7 +57,10 @@ class _HipParamModule(nn.Module):
     def _weights_bf16(self, ops, named):
         cache = self.__dict__.setdefault("_w_bf16_cache", {})
         provider = self.__dict__.get("_w_bf16_provider")   # train/optim.py keeps bf16 copies current in its AdamW pass
-        out = {}
+        out = _path.WeightDict()
+        # fragment-major copies for the fused attention branch (hip/path.py: packed_weight): cached next to the bf16 copies they are
+        # made from -- which only holds while those are immutable tensors (no provider rewriting them in place)
+        out.pk_cache = self.__dict__.setdefault("_w_pk_cache", {}) if provider is None else None
         for name, p in named:
             if p.dim() != 2 or name.endswith("latents") or "embs" in name:
                 continue
@@ -68,6 +71,9 @@ class _HipParamModule(nn.Module):
                 view = provider.bf16_view(p)
                 if view is not None:
                     out[name] = view
+                    pk = provider.packed_view(p) if hasattr(provider, "packed_view") else None
+                    if pk is not None:
+                        out[name + "#pk"] = pk
                     continue
             ent = cache.get(name)
             if self.training or ent is None or ent[0] != p._version or ent[1] != p.data_ptr():
@@ -79,6 +85,7 @@ class _HipParamModule(nn.Module):
     def invalidate_weight_cache(self):
         """Call after mutating parameters through ``.data`` (which does not bump the version counter)."""
         self.__dict__.pop("_w_bf16_cache", None)
+        self.__dict__.pop("_w_pk_cache", None)
         self.__dict__.pop("_kv_cache", None)
         self.__dict__.pop("_decode_graph", None)
 

@@ -479,3 +479,37 @@ def test_padded_heads_do_not_add_to_gradients_the_step_epilogue_left_stale(on_em
     for k, p in blk.named_parameters():
         assert torch.allclose(p.grad, want[k], rtol=1e-5, atol=1e-6), k
         assert not getattr(p, "_of_grad_fresh", False)
+
+
+def test_fused_attention_branch_inside_a_train_step_and_its_packed_weights_follow_the_optimizer(on_emulator, monkeypatch):
+    """OF-tiny's gated blocks (d 256, 8 heads) take the fused attention branch (csrc/xattn_fused.hip) once the text length is a multiple
+    of 32.  Three optimizer steps with it and with the separate launches: the same losses to fp32 summation order -- which also proves
+    that the fragment-major weight copies the step epilogue re-packs (FlatAdamW.packed_view) are the CURRENT weights (stale copies
+    would replay step 0's projections) -- and, bit for bit, packed_view = of_pack_frag16(bf16_view) after the last step."""
+    from open_flamingo_amd.hip import path as P
+    ops = H.emu_ops()
+    calls = []
+    orig = Ops.xattn_fused_fwd
+    monkeypatch.setattr(Ops, "xattn_fused_fwd", lambda self, *a, **kw: (calls.append(kw.get("probe_only", False)), orig(self, *a, **kw))[1])
+    losses = []
+    for fused in (True, False):
+        monkeypatch.setattr(P, "FUSED_XATTN", fused)
+        model, info = _tiny()
+        red = GradReducer(model, embedding_rows=[info["media_token_id"], info["eoc_token_id"]])
+        opt = FlatAdamW(red, lr=3e-3, ops=ops)
+        batch = synthetic.make_batch(2, 2, 32, info, "cpu", seed=5, image_size=56)
+        n0 = len(calls)
+        losses.append([float(step.train_step(model, red, opt, batch, info, amp=False)) for _ in range(3)])
+        if fused:
+            assert sum(1 for c in calls[n0:] if not c) == 3 * 2, calls        # two gated blocks, three forwards, one launch each
+            for blk in model.lang_encoder.gated_cross_attn_layers:
+                if blk is None:
+                    continue
+                for lin in (blk.attn.to_q, blk.attn.to_out):
+                    pk, bf = opt.packed_view(lin.weight), opt.bf16_view(lin.weight)
+                    assert pk is not None and torch.equal(bf, lin.weight.detach().to(torch.bfloat16))
+                    assert torch.equal(pk, ops.pack_frag16(bf))
+        else:
+            assert len(calls) == n0
+    assert losses[0][0] > losses[0][2]
+    assert all(abs(a - b) <= 2e-4 * abs(b) for a, b in zip(*losses)), losses

@@ -96,9 +96,9 @@ if os.environ.get("XF_PHASES", "1") == "1":
         torch.cuda.synchronize()
         tops.lib.of_tools_set_xf_stamp_buffer(None)
         s = buf.cpu().double()
-        t = (s[:, :7] - s[:, 0].min()) / 100.0
+        t = (s[:, :8] - s[:, 0].min()) / 100.0
         med = lambda v: round(float(v.median()), 2)
         print(json.dumps({"probe": "xattn_fused_phases", "cold": cold, "workgroups": nwg, "entry_spread_us": med(t[:, 0]),
                           "layernorm_us": med(t[:, 1] - t[:, 0]), "to_q_us": med(t[:, 2] - t[:, 1]), "attention_us": med(t[:, 3] - t[:, 2]),
-                          "to_out_kloop_us": med(t[:, 4] - t[:, 3]), "epilogue_issue_us": med(t[:, 5] - t[:, 4]),
+                          "to_out_kloop_us": med(t[:, 4] - t[:, 3]), "epilogue_issue_us": med(t[:, 5] - t[:, 4]), "of_which_gate_residual_us": med(t[:, 7] - t[:, 4]),
                           "store_ack_us": med(t[:, 6] - t[:, 5]), "span_us": round(float(t[:, 6].max()), 1)}), flush=True)
