@@ -211,6 +211,12 @@ def _spawn_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+# The frozen towers' product forms: this repository's attention / LayerNorm / loss kernels inside whole-block autograd nodes.
+# The stock alternatives (torch SDPA, HF modules, eager LayerNorm / loss) are what the reference-equivalent eager leg below is built from;
+# timing them against the product forms is a profiling job: tools/ab_tower_arms.py sets this dict and calls main().
+TOWER_ARMS = dict(lm_attention="libofhip", lm_blocks="fused", vision="libofhip", tower_layernorm="libofhip", lm_loss="libofhip")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -236,19 +242,6 @@ def main():
     ap.add_argument("--frozen-fp32", action="store_true",
                     help="keep the frozen towers' Linear weights in fp32 (autocast re-casts them every forward, as the "
                          "reference does) instead of holding their bf16 copies")
-    ap.add_argument("--lm-attention", default="libofhip", choices=["libofhip", "sdpa", "eager"],
-                    help="self-attention of the frozen MPT blocks: libofhip causal+ALiBi flash kernel, torch SDPA with a "
-                         "bias, or HF's eager chain")
-    ap.add_argument("--lm-blocks", default="fused", choices=["fused", "modules"],
-                    help="frozen MPT blocks: one autograd node per block (train/frozen_blocks.py: residual adds fused into the "
-                         "LayerNorm kernels, no gradient casts / adds) or the HF modules with their pieces patched one by one")
-    ap.add_argument("--vision", default="libofhip", choices=["libofhip", "sdpa", "modules"],
-                    help="frozen CLIP tower: fused encoder forward (train/frozen_blocks.py) with this repository's attention kernel "
-                         "or torch SDPA, or the HF modules")
-    ap.add_argument("--tower-layernorm", default="libofhip", choices=["libofhip", "eager"],
-                    help="LayerNorms in front of the frozen towers' Linear layers: libofhip (bf16 operand written directly) or eager")
-    ap.add_argument("--lm-loss", default="libofhip", choices=["libofhip", "hf"],
-                    help="causal-LM loss over the LM head's logits: fused libofhip cross entropy, or transformers' eager chain")
     ap.add_argument("--torch-optimizer", action="store_true",
                     help="clip_grad_norm_ + torch.optim.AdamW(fused) instead of the libofhip step epilogue")
     ap.add_argument("--dense-embedding-rows", action="store_true",
@@ -295,6 +288,9 @@ def main():
                          "max-over-ranks timing and the overlap record are the multi-GPU ones; the wire is a socket and N replicas share "
                          "one chip, so the THROUGHPUT IS MEANINGLESS (config.one_gpu_loopback says so on the line)")
     args = ap.parse_args()
+    # how the frozen towers run is not a benchmark option: the product forms (TOWER_ARMS above; tools/ab_tower_arms.py times the others)
+    for k, v in TOWER_ARMS.items():
+        setattr(args, k, v)
     cfg_family, cfg_batch, cfg_T, cfg_L, cfg_name = CONFIGS[args.config]
     overridden = any(v is not None for v in (args.family, args.batch, args.T, args.L))
     args.family = args.family or cfg_family

@@ -73,19 +73,12 @@ typedef struct OfGemmArgs {
                           writes one partial to `workspace` (of_gemm_workspace_bytes(args) bytes, required: OF_E_WORKSPACE
                           otherwise) and a second one-workgroup launch adds the partials in a fixed order -- no fp atomics */
     int io_f32;        /* OF_EPI_GATE_RESID: 1 = fp32 stream, 0 = bf16 stream */
-    int safe;          /* DEBUG / SELF-CHECK ONLY -- production callers pass 0 (auto: M <= 16 untransposed -> weight-streaming
-                          skinny kernel; tile-aligned shapes that fill the chip -> the 4-wave 256x256 kernel on 16x16x32
-                          MFMAs; tile-aligned smaller shapes -> the 8-wave 128x128 LDS-DMA kernel; otherwise the general
-                          128x128 kernel, split along K when the output is small).  Non-zero values force one
-                          correct kernel so tests can compare kernels with each other: 1 = general kernel, slow scalar-LDS
-                          transposed-fragment path; 2 = general kernel; 3 = general kernel with 128 x 64 tiles; 4 = 8-wave ping-pong big-tile kernel;
-                          5 = 8-wave LDS-DMA 128x128 kernel; 6 / 7 = 4-wave
-                          big-tile kernel on 32x32x16 MFMAs (register-staged / LDS-DMA operands); 8..15 = general kernel with
-                          2^(safe-8) K slices; 16 = 4-wave LDS-DMA big-tile kernel on 16x16x32 MFMAs (what 0 selects for most big launches);
-                          17 = its persistent stream-K schedule; 18 = the 256x128 kernel with two workgroups per CU (what 0 selects
-                          for the *_DOT launches over >= 1024 big tiles with K <= 3072).  Every value the product library accepts gives correct results; anything else returns
-                          OF_E_ARG (timing ablations live in tools/libofhip_tools.so, built with -DOF_TOOLS_BUILD, never
-                          shipped). */
+    int safe;          /* 0 = production: of_gemm selects the kernel (M <= 16 untransposed -> weight-streaming skinny kernel; tile-aligned
+                          shapes that fill the chip -> the 4-wave 256x256 kernel on 16x16x32 MFMAs, two workgroups per CU on 256x128 tiles
+                          for the *_DOT epilogues; smaller tile-aligned shapes -> the 8-wave 128x128 LDS-DMA kernel; otherwise the general
+                          128x128 kernel, split along K when the output is small).  1 = cross-check: the general kernel on its scalar-LDS
+                          fragment path (any shape, slow) -- the one alternative the library keeps, so that a caller can check a result
+                          against an independent kernel.  Anything else: OF_E_ARG. */
     int ksplit;        /* internal: filled in by of_gemm (number of K slices of a split-K launch); callers pass 0 */
     void* workspace;   /* optional scratch for split-K partial sums (fp32 slabs): with at least
                           of_gemm_workspace_bytes(args) bytes the K slices are combined by a second pass in a fixed
@@ -125,7 +118,7 @@ typedef struct OfGemmArgs {
  * ORDER of the fp32 additions along K belongs to the kernel of_gemm selects: launches it sends to the 256x256 kernel by itself (safe = 0)
  * start each tile's K loop at a stage that depends on the XCD the tile runs on and wrap around (round 5: spreads the requests of
  * operands that come from HBM over its channels) -- so two rows with the same operand values in DIFFERENT tiles agree to summation order
- * (1e-6 relative), not bit for bit.  A kernel forced through `safe` walks K in stage order 0, 1, 2, ... like the general kernel. */
+ * (1e-6 relative), not bit for bit.  The cross-check kernel (safe = 1) walks K in stage order 0, 1, 2, ... */
 int of_gemm(const OfGemmArgs* args, void* stream);
 /* n independent problems in ONE launch (ABI v8).  For 2..4 weight-gradient problems (a_trans = b_trans = 1, OF_EPI_ACC_F32) that
  * of_gemm would each run split along K on the 128x128 kernel -- the 512-wide projections' gradients of a gated block: to_q, to_out,

@@ -18,6 +18,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 SOURCES = ["gemm.hip", "gemm_pp.hip", "gemm_w4.hip", "gemm_w4m.hip", "gemm_w4h.hip", "gemm_w4s.hip", "gemm_mid.hip", "gemm_skinny.hip", "layernorm.hip", "attention.hip", "xattn_fused.hip", "elementwise.hip", "optim.hip", "loss.hip", "api.hip"]
 HEADERS = ["of_platform.h", "gemm_common.h", "gemm_tile256.h", "gemm_w4_epi.h", "attn_core.h", os.path.join(ROOT, "include", "of_hip.h")]
+# kernels of_gemm never selects (measured, kept with their tests and records): tools / emulator builds only, not in the product library
+TOOLS_ONLY_SOURCES = ["gemm_w4.hip", "gemm_w4s.hip"]
 LIB = os.path.join(HERE, "libofhip.so")
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 EMU_LIB = os.path.join(EMU_DIR, "libofhip_emu.so")
@@ -41,7 +43,7 @@ TOOLS_LIB = os.path.join(ROOT, "tools", "libofhip_tools.so")
 
 
 def build(emu=False, verbose=False, force=False, tools=False):
-    srcs = [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
+    srcs = [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s)) and (emu or tools or s not in TOOLS_ONLY_SOURCES)]
     hdrs = [h if os.path.isabs(h) else os.path.join(HERE, h) for h in HEADERS]
     if emu:
         hdrs.append(os.path.join(EMU_DIR, "of_emu.h"))

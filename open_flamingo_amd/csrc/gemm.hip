@@ -421,6 +421,12 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
     if (!args || !args->A || !args->C) return OF_E_ARG;
     if (args->group_kind) return gemm_grouped(*args, (of_stream_t)stream);
     if (!args->B) return OF_E_ARG;
+#if !defined(OF_TOOLS_BUILD) && !defined(OF_HOST_EMU)
+    // The product library selects its kernels itself; the only alternative it keeps is the checked path (1: the general kernel with
+    // scalar-LDS transposed fragments).  The kernel-forcing selectors the test suite compares kernels with (2 ... 19) exist in
+    // tools/libofhip_tools.so (-DOF_TOOLS_BUILD) and in the host emulator build only.
+    if (args->safe != 0 && args->safe != 1) return OF_E_ARG;
+#endif
     OfGemmArgs a_own = *args;
     a_own.sk_grid = 0;                 // internal field ("callers pass 0"): only the stream-K branches below set it, a caller's value is ignored
     float* const sumsq = a_own.sumsq_out;
@@ -479,10 +485,18 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
             return dispatch(b, grid, s);
         }
     }
+#if defined(OF_TOOLS_BUILD) || defined(OF_HOST_EMU)
+    // the two big-tile kernels of rounds 3 / 5 that of_gemm never selects (gemm_w4.hip: 32x32x16 MFMAs; gemm_w4s.hip: wave-specialised):
+    // built into the tools / emulator libraries only, with their tests (records: profiles/r03*, r05*)
     if (a.safe == 6 || a.safe == 7) {              // force the 4-wave 128x128-per-wave kernel (6: register staged, 7: LDS-DMA)
         const int rc = of_gemm_w4_try(a, s);
         if (rc != OF_E_SHAPE) return rc;
     }
+    if (a.safe == 19) {                            // force the persistent wave-specialised 256x128 kernel (gemm_w4s.hip)
+        const int rc = of_gemm_w4s_try(a, s);
+        if (rc != OF_E_SHAPE) return rc;
+    }
+#endif
     if (a.safe == 16) {                            // force the 4-wave kernel on 16x16x32 MFMAs (gemm_w4m.hip)
         const int rc = of_gemm_w4m_try(a, s);
         if (rc != OF_E_SHAPE) return rc;
@@ -495,10 +509,6 @@ extern "C" int of_gemm(const OfGemmArgs* args, void* stream) {
     }
     if (a.safe == 18) {                            // force the two-workgroups-per-CU 256x128 kernel (gemm_w4h.hip)
         const int rc = of_gemm_w4h_try(a, s);
-        if (rc != OF_E_SHAPE) return rc;
-    }
-    if (a.safe == 19) {                            // force the persistent wave-specialised 256x128 kernel (gemm_w4s.hip)
-        const int rc = of_gemm_w4s_try(a, s);
         if (rc != OF_E_SHAPE) return rc;
     }
     if (a.safe >= 20) return OF_E_ARG;

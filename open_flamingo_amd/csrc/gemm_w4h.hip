@@ -21,7 +21,9 @@
 // Everything else is gemm_w4m.hip's: 16x16x32 MFMAs accumulating in place by inline asm (of_mfma_acc: guarded at the top of a stage,
 // settled in front of the epilogue, linted on the ISA by tests/test_isa_lint.py), the LDS images of gemm_tile256.h (a unit is one
 // "half" image of 128 rows), the XCD-aware tile order, the epilogue through a private LDS patch per wave (gemm_common.h).
-// Per-element summation order is the 256 x 256 kernel's (k-steps ascending), so the two kernels agree bit for bit.
+// Per-element summation order is the 256 x 256 kernel's in stage order (k-steps ascending): the two kernels agree bit for bit when that
+// kernel is forced (tools build); launches of_gemm sends to the 256 x 256 kernel itself rotate their K loop per XCD (gemm_w4m.hip) and
+// agree to summation order only.
 #include <type_traits>
 #include "gemm_tile256.h"
 

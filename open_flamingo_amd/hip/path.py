@@ -422,8 +422,11 @@ def perceiver_attention_bwd(ops, P, W, S, dout, doutb, G, *, N, Fv, n, heads, pr
     S_ = Fv + n
     dO = _e((N * n, inner), BF16, dev)
     ops.gemm(doutb, W[prefix + "to_out.weight"], dO, tb=True)
+    # the layer's three projection weight gradients (to_out, to_q, to_kv: 32 - 64 tiles of 128 x 128 each, off the critical path) leave as
+    # ONE batched launch at the end, like the gated blocks' (ops.gemm_batch_dw -> of_gemm_batch: the bits of the separate launches)
+    dw_batch = []
     t, beta = G.mat(prefix + "to_out.weight", (D, inner))
-    ops.gemm(doutb, S["o"], t, ta=True, tb=True, epi=EPI_ACC_F32, beta=beta)
+    dw_batch.append((doutb, S["o"], t, beta, None))
     dq = _e((N * n, inner), BF16, dev)
     dkv = _e((N * S_, 2 * inner), BF16, dev)
     delta = _e((N, heads, n), F32, dev)
@@ -433,11 +436,12 @@ def perceiver_attention_bwd(ops, P, W, S, dout, doutb, G, *, N, Fv, n, heads, pr
     dltn = _e((N * n, D), BF16, dev)
     ops.gemm(dq, W[prefix + "to_q.weight"], dltn, tb=True)                      # through to_q
     t, beta = G.mat(prefix + "to_q.weight", (inner, D))
-    ops.gemm(dq, S["ltn"], t, ta=True, tb=True, epi=EPI_ACC_F32, beta=beta)
+    dw_batch.append((dq, S["ltn"], t, beta, None))
     dkvin = _e((N * S_, D), BF16, dev)
     ops.gemm(dkv, W[prefix + "to_kv.weight"], dkvin, tb=True)                    # through to_kv (media + latent rows)
     t, beta = G.mat(prefix + "to_kv.weight", (2 * inner, D))
-    ops.gemm(dkv, S["kvin"], t, ta=True, tb=True, epi=EPI_ACC_F32, beta=beta)
+    dw_batch.append((dkv, S["kvin"], t, beta, None))
+    ops.gemm_batch_dw(dw_batch)
     # norm_media: parameter grads always; dx only if the vision features require grad (they do not in Flamingo,
     # flamingo.py:194-195 runs the ViT under no_grad)
     dx_new = torch.empty_like(x) if need_dx else None

@@ -592,6 +592,7 @@ class _GatedXAttnFn(torch.autograd.Function):
         for k, p in zip(_XATTN_NAMES, ctx.params):
             if k in taps:
                 p._of_sumsq_valid = bool(done.get(k, False))
+                p._of_sumsq_version = p.grad._version if p.grad is not None else None      # (step() voids the tap if the gradient is written again)
         ctx.S = None
         if dmedia is not None:
             dmedia = (dmedia if ctx.mdtype == F32 else ops.to_bf16(dmedia)).view(ctx.mshape)

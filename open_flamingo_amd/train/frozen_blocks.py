@@ -81,6 +81,15 @@ def _transposed(mod, name, w):
     return hit[1]
 
 
+def _transposed_unless_fused(mod, name, w):
+    """the MLP's second matrix: with _MLP_FUSED_DGELU its backward runs as of_gemm's NN launch on W itself, so no transposed copy is
+    made (and one cached by an earlier configuration is dropped)"""
+    if _MLP_FUSED_DGELU:
+        mod.__dict__.get("_of_wt", {}).pop(name, None)
+        return None
+    return _transposed(mod, name, w)
+
+
 def _mm_dx(dy, w, wt):
     """dX = dY W for a frozen nn.Linear weight W (out, in); wt = its cached transpose or None."""
     return torch.mm(dy, wt.t()) if wt is not None else torch.mm(dy, w)
@@ -330,8 +339,9 @@ def _mpt_block_fused_forward(self, hidden_states, position_bias, attention_mask,
         slopes, lens = _alibi_slopes_and_lens(position_bias, attention_mask, x.shape[1])
     wts = None
     if _DX_PRETRANSPOSED and torch.is_grad_enabled() and x.requires_grad:
+        # (the backward of down_proj is the fused DGELU launch on the weight as it lies: no transposed copy of it -- 0.75 GiB at MPT-1B)
         wts = (_transposed(attn, "Wqkv", attn.Wqkv.weight), _transposed(attn, "out_proj", attn.out_proj.weight),
-               _transposed(ffn, "up_proj", ffn.up_proj.weight), _transposed(ffn, "down_proj", ffn.down_proj.weight))
+               _transposed(ffn, "up_proj", ffn.up_proj.weight), _transposed_unless_fused(ffn, "down_proj", ffn.down_proj.weight))
     y = _FrozenMptBlockFn.apply(x, self.norm_1.weight, _zero_bias(self.norm_1), self.norm_2.weight, _zero_bias(self.norm_2),
                                 attn.Wqkv.weight, attn.out_proj.weight, ffn.up_proj.weight, ffn.down_proj.weight,
                                 slopes, lens, attn.n_heads, attn.head_dim, float(attn.softmax_scale), wts, _path.scope_of(self))
@@ -515,7 +525,7 @@ def _neox_layer_fused_forward(self, hidden_states, attention_mask=None, position
     if _DX_PRETRANSPOSED and torch.is_grad_enabled() and x.requires_grad:
         wts = tuple(_transposed(mod, name, lin.weight) for mod, name, lin in
                     ((at, "query_key_value", at.query_key_value), (at, "dense", at.dense),
-                     (mlp, "dense_h_to_4h", mlp.dense_h_to_4h), (mlp, "dense_4h_to_h", mlp.dense_4h_to_h)))
+                     (mlp, "dense_h_to_4h", mlp.dense_h_to_4h))) + (_transposed_unless_fused(mlp, "dense_4h_to_h", mlp.dense_4h_to_h.weight),)
     n1, n2 = self.input_layernorm, self.post_attention_layernorm
     return _FrozenNeoXBlockFn.apply(x, n1.weight, n1.bias, n2.weight, n2.bias, at.query_key_value.weight, at.query_key_value.bias,
                                     at.dense.weight, at.dense.bias, mlp.dense_h_to_4h.weight, mlp.dense_h_to_4h.bias,

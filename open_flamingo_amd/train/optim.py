@@ -100,15 +100,38 @@ class FlatAdamW(torch.optim.Optimizer):
         self._tap_groups = (total + P - 1) // P          # whole groups of P slots in FRONT of the buckets' partials
         self._parts_for(len(reducer.buckets) + 1)     # allocated here, on the construction stream, not inside a side-stream callback
         self._parts[:self._tap_groups * P].zero_()
-        for b in reducer.buckets:
-            lo = b.get("tap_lo", 0)
-            for p in b["taps"]:
-                n = (p.shape[0] // 256) * (p.shape[1] // 256)
-                p._of_sumsq_slots, p._of_sumsq_valid = self._parts[lo:lo + n], False
-                lo += n
+        self._register_taps()
         model = reducer.module
         for mod in [model.perceiver] + [b for b in model.lang_encoder.gated_cross_attn_layers if b is not None]:
             mod.__dict__["_w_bf16_provider"] = self
+
+    def _register_taps(self):
+        """Hand the tapped matrices their slots -- only while step() can use them (one rank, taps on, no early partials): the dW GEMMs
+        otherwise run their plain epilogue instead of computing sums nobody reads.  Contract of a tap: between the dW GEMM that
+        wrote `_of_sumsq_valid = True` and step() nothing else may write that gradient (a hook that rescales .grad, a second backward
+        that adds to it through AccumulateGrad): step() checks the gradient's version counter against the one the backward recorded
+        and falls back to the full pass for the bucket when they differ."""
+        on = bool(self.__dict__.get("_tap_norm", True) and self._tap_groups and self.reducer.world == 1 and self.reducer.on_bucket_final is None)
+        for b in self.reducer.buckets:
+            lo = b.get("tap_lo", 0)
+            for p in b.get("taps", ()):
+                n = (p.shape[0] // 256) * (p.shape[1] // 256)
+                if on:
+                    p._of_sumsq_slots, p._of_sumsq_valid = self._parts[lo:lo + n], False
+                else:
+                    p.__dict__.pop("_of_sumsq_slots", None)
+                    p._of_sumsq_valid = False
+                lo += n
+
+    @property
+    def tap_norm(self):
+        return self.__dict__.get("_tap_norm", True)
+
+    @tap_norm.setter
+    def tap_norm(self, on):
+        self.__dict__["_tap_norm"] = bool(on)
+        if "_tap_groups" in self.__dict__:
+            self._register_taps()
 
     # ------------------------------------------------------------------ bf16 operand copies for the modules
     def _ops(self):
@@ -163,6 +186,8 @@ class FlatAdamW(torch.optim.Optimizer):
     @early_norm.setter
     def early_norm(self, on):          # off: the reducer does not touch its side stream for this at all
         self.reducer.on_bucket_final = self._early_partial if on else None
+        if "_tap_groups" in self.__dict__:
+            self._register_taps()
 
     @torch.no_grad()
     def _early_partial(self, bi):
@@ -224,12 +249,15 @@ class FlatAdamW(torch.optim.Optimizer):
                 continue                             # this step's partial sums of the bucket are in their slots already
             b = self.reducer.buckets[i] if i < len(self.reducer.buckets) else None
             if use_taps and b is not None and b["taps"]:
-                if all(getattr(p, "_of_sumsq_valid", False) for p in b["taps"]):
+                if all(getattr(p, "_of_sumsq_valid", False) and getattr(p, "_of_sumsq_version", None) == p.grad._version for p in b["taps"]):
                     g = g[:b["tap_from"]]            # the tapped matrices' sums of squares came with their GEMMs
                     tapped += 1
                 else:
                     parts[b["tap_lo"]:b["tap_hi"]].zero_()      # (a matrix no GEMM wrote this step, or not through a tapped launch)
-            ops.sumsq_partial(g, parts[(T + i) * P:(T + i + 1) * P], nw)
+            if g.numel():
+                ops.sumsq_partial(g, parts[(T + i) * P:(T + i + 1) * P], nw)
+            else:                                    # a bucket made of tapped matrices only: nothing left for the pass
+                parts[(T + i) * P:(T + i + 1) * P].zero_()
         for b in self.reducer.buckets:
             b["early_gen"] = None
         self.early_partials_used = len(early)        # (tests, tools)

@@ -19,9 +19,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def ops():
-    from open_flamingo_amd.hip.ops import Ops
-    assert torch.cuda.is_available()
-    return Ops.default()
+    from tests.gpu_ops import routed_ops
+    return routed_ops()          # the product library; launches that FORCE a kernel (safe >= 2) go to the tools build of the same sources
 
 
 def _r(shape, seed, scale=1.0, dtype=torch.bfloat16):
@@ -807,3 +806,19 @@ def test_gemm_batch_of_weight_gradients_at_benchmark_shapes(ops):
         assert torch.equal(g_, w)
     ref = float(torch.tanh(gate)) * (dy.float().t() @ o.float()) + 1.0
     _close(got[0], ref, "to_out dW", rtol=1e-5, atol_rms=1e-4, l2=1e-5)
+
+
+def test_product_library_takes_no_kernel_forcing_selector():
+    """OfGemmArgs.safe: 0 (of_gemm selects) and 1 (the checked scalar-LDS path) are all the product library accepts -- the selectors this
+    suite forces kernels with live in the tools build of the same sources (tests/gpu_ops.py)."""
+    from open_flamingo_amd.hip.ops import Ops
+    ops = Ops.default()
+    A, B = _r((256, 64), 1), _r((256, 64), 2)
+    out = torch.empty(256, 256, dtype=torch.bfloat16, device="cuda")
+    for safe in (2, 4, 5, 7, 16, 17, 18, 19, 20, -1):
+        with pytest.raises(RuntimeError, match="OF_E_ARG"):
+            ops.gemm(A, B, out, safe=safe)
+    ops.gemm(A, B, out, safe=0)
+    want = out.clone()
+    ops.gemm(A, B, out, safe=1)
+    assert torch.equal(out, want)

@@ -11,8 +11,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def ops():
-    from open_flamingo_amd.hip.ops import Ops
-    return Ops.default()
+    from tests.gpu_ops import routed_ops
+    return routed_ops()          # the product library; launches that FORCE a kernel (safe >= 2) go to the tools build of the same sources
 
 
 @pytest.mark.parametrize("stream_dtype", [torch.float32, torch.bfloat16])

@@ -9,12 +9,15 @@ if len(sys.argv) > 1 and sys.argv[1] == "--arm":
     sys.path.insert(0, ROOT)
     from open_flamingo_amd.hip.ops import Ops
     if force:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from tools_lib import tools_ops      # the 32x32x16 kernel lives in tools/libofhip_tools.so only (round 6)
+        forced = tools_ops()
         orig = Ops.gemm
         def gemm(self, A, B, out, *, ta=False, tb=False, safe=0, **kw):
             M, K = (A.shape[1], A.shape[0]) if ta else (A.shape[0], A.shape[1])
             N = B.shape[1] if tb else B.shape[0]
             if safe == 0 and Ops.kernel_label(M, N, K, ta, tb) == "w4m256":
-                safe = 7
+                return orig(forced, A, B, out, ta=ta, tb=tb, safe=7, **kw)
             return orig(self, A, B, out, ta=ta, tb=tb, safe=safe, **kw)
         Ops.gemm = gemm
     sys.argv = ["bench.py"] + sys.argv[3:]

@@ -16,6 +16,8 @@ import torch
 
 from open_flamingo_amd.hip import abi
 from open_flamingo_amd.hip.ops import Ops
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from tools_lib import routed_ops      # product library; kernel-forcing selectors (safe >= 2) -> tools/libofhip_tools.so
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -152,10 +154,10 @@ def main():
     a = ap.parse_args()
     fam = a.family
     if a.ksweep:
-        return ksweep(Ops.default())
+        return ksweep(routed_ops())
     old = load(a.old)
     builtin = load(a.builtin) if os.path.exists(a.builtin) else None
-    new = Ops.default()
+    new = routed_ops()
     if a.ladder:
         return ladder(new)
     for name, M, N, K, ta, tb, epi in family_shapes(fam):

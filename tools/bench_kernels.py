@@ -10,6 +10,8 @@ import torch
 
 from open_flamingo_amd.hip import abi
 from open_flamingo_amd.hip.ops import Ops
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from tools_lib import routed_ops      # product library; kernel-forcing selectors (safe >= 2) -> tools/libofhip_tools.so
 
 
 def timeit(fn, iters=20, warm=3):
@@ -41,7 +43,7 @@ def timeit_cold(fn_of_set, nsets, iters=24, warm=None):
 
 
 def main():
-    ops = Ops.default()
+    ops = routed_ops()
     dev = "cuda"
     out = []
     shapes = [  # (name, M, N, K, ta, tb, epi)

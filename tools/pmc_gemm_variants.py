@@ -10,6 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from open_flamingo_amd.hip import abi
 from open_flamingo_amd.hip.ops import Ops
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from tools_lib import routed_ops      # product library; kernel-forcing selectors (safe >= 2) -> tools/libofhip_tools.so
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--lib", default="")
@@ -21,7 +23,7 @@ if a.lib:
     abi.declare(lib, require_all=False)
     ops = Ops(lib, lambda: torch.cuda.current_stream().cuda_stream)
 else:
-    ops = Ops.default()
+    ops = routed_ops()
 M, N, K = 8192, 2048, 8192
 g = torch.Generator(device="cuda").manual_seed(1)
 def r(*s): return torch.randn(*s, device="cuda", generator=g).to(torch.bfloat16)

@@ -7,9 +7,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from open_flamingo_amd.hip import abi
 from open_flamingo_amd.hip.ops import Ops
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools_lib import routed_ops      # product library; kernel-forcing selectors (safe >= 2) -> tools/libofhip_tools.so
 from bench_gemm_ab import make, timed
 
-ops = Ops.default()
+ops = routed_ops()
 E = abi
 for name, ta, tb, epi in (("NT store_bf16", 0, 0, E.EPI_STORE_BF16), ("NT gelu two outputs", 0, 0, E.EPI_GELU), ("NN dgelu_dot", 0, 1, E.EPI_DGELU_DOT),
                           ("TN acc_f32", 1, 1, E.EPI_ACC_F32)):

@@ -6,9 +6,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from open_flamingo_amd.hip import abi
 from open_flamingo_amd.hip.ops import Ops
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools_lib import routed_ops      # product library; kernel-forcing selectors (safe >= 2) -> tools/libofhip_tools.so
 from bench_gemm_ab import make, timed
 
-ops = Ops.default()
+ops = routed_ops()
 E = abi
 CASES = [("OF-3B ffn_dh", 8192, 8192, 2048), ("OF-4B ffn_dh", 8192, 10240, 2560), ("OF-9B L256 ffn_dh", 2048, 16384, 4096),
          ("OF-9B L2048 ffn_dh", 16384, 16384, 4096), ("OF-3B LAION+MMC4 rows 10240", 10240, 8192, 2048)]

@@ -8,9 +8,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from open_flamingo_amd.hip import abi
 from open_flamingo_amd.hip.ops import Ops
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools_lib import routed_ops      # product library; kernel-forcing selectors (safe >= 2) -> tools/libofhip_tools.so
 from bench_gemm_ab import make, timed
 
-ops = Ops.default()
+ops = routed_ops()
 E = abi
 CASES = [("NT store_bf16", 8192, 8192, 2048, 0, 0, E.EPI_STORE_BF16), ("NT gelu 2 outputs", 8192, 8192, 2048, 0, 0, E.EPI_GELU),
          ("NN store_bf16", 8192, 8192, 2048, 0, 1, E.EPI_STORE_BF16), ("NN dgelu_dot", 8192, 8192, 2048, 0, 1, E.EPI_DGELU_DOT),
