@@ -280,6 +280,12 @@ def main():
     ap.add_argument("--no-vision-prefetch", action="store_true",
                     help="run the frozen vision tower at the start of each step (as the reference does) instead of enqueuing the NEXT "
                          "step's tower forward on a side stream next to the step epilogue (train/step.py: next_vision_x)")
+    ap.add_argument("--sweep-comm", action="store_true",
+                    help="multi-GPU diagnostics in the SAME invocation, after the timed region (the headline numbers are untouched): a few "
+                         "extra steps for every combination of reserve_cus in {0, 8, 16, 32} and gradient wire dtype in {fp32, bf16}, each "
+                         "with its step time (max over ranks), the exposed wait for RCCL, and the latency of every bucket's all-reduce "
+                         "(HIP events on the side stream) -> 'comm_sweep' on the line: the tuning table of the first run on a real node")
+    ap.add_argument("--sweep-steps", type=int, default=4, help="timed steps per --sweep-comm combination (after one untimed step)")
     ap.add_argument("--gemm-report", default=None, help="write a per-(layout,epilogue,shape) GEMM time table (JSON lines)")
     ap.add_argument("--one-gpu-loopback", action="store_true",
                     help="REHEARSAL of the multi-rank path on a one-GPU box: every rank of --gpus N uses device 0 and the ranks talk "
@@ -394,6 +400,41 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     images = (args.batch * args.T + args.laion_batch) * world
     value = images * args.steps / elapsed
+
+    comm_sweep = None
+    if args.sweep_comm and world > 1:
+        # Everything the first run on a real node has to decide, measured in ONE call: how many CUs to leave to RCCL's kernels, and
+        # whether halving the bytes on the wire pays.  The settings are plain attributes of the reducer; the model simply trains on.
+        comm_sweep = []
+        base_wire, base_res = reducer.wire_dtype, reducer.reserve_cus
+        for wire in (torch.float32, torch.bfloat16):
+            for res in (0, 8, 16, 32):
+                reducer.wire_dtype, reducer.reserve_cus = wire, res
+                step.train_step(model, reducer, opt, batch, info, nan_check=nan_check, **step_kw)
+                sync()
+                reducer.overlap_stats(reset=True)
+                reducer.time_waits = reducer.time_collectives = True
+                t1 = time.perf_counter()
+                for _ in range(args.sweep_steps):
+                    step.train_step(model, reducer, opt, batch, info, nan_check=nan_check, **step_kw)
+                sync()
+                el = time.perf_counter() - t1
+                st = reducer.overlap_stats()
+                reducer.time_collectives = False
+                tt_ = torch.tensor([el], device=device, dtype=torch.float64)
+                dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                per = st.get("collective_ms", [])
+                n_coll = max(1, len(per) // max(1, args.sweep_steps))
+                last = per[-n_coll:]                         # the last step's collectives, in launch order
+                ms = sorted(m for _, m in per)
+                comm_sweep.append({"reserve_cus": res, "wire_dtype": str(wire).replace("torch.", ""),
+                                   "ms_per_step": round(float(tt_.item()) / args.sweep_steps * 1e3, 2),
+                                   "exposed_wait_ms_per_step": None if st["exposed_wait_ms_per_step"] is None else round(st["exposed_wait_ms_per_step"], 3),
+                                   "allreduce_ms": ({"n": len(ms), "min": round(ms[0], 3), "median": round(ms[len(ms) // 2], 3), "max": round(ms[-1], 3),
+                                                     "sum_per_step": round(sum(ms) / args.sweep_steps, 3)} if ms else None),
+                                   "last_step_buckets": [{"bytes": int(nb), "ms": round(m, 3), "GBps": round(nb / m / 1e6, 1) if m > 0 else None}
+                                                         for nb, m in last]})
+        reducer.wire_dtype, reducer.reserve_cus = base_wire, base_res
 
     roofline = None
     if survey and args.gemm_report and rank == 0:
@@ -523,6 +564,11 @@ def main():
                           "note": "one exchange per optimizer step on a side HIP stream (RCCL all-reduce per gated block + "
                                   "per Perceiver layer, launched as the backward produces them); exposed_wait = time the "
                                   "compute stream waited in GradReducer.finish(), HIP events, rank 0"}
+        if comm_sweep is not None:
+            out["comm_sweep"] = {"steps_per_setting": args.sweep_steps, "settings": comm_sweep,
+                                 "note": "measured after the timed region of this same call (value / ms_per_step above are the default setting's); "
+                                         "allreduce_ms: HIP events on the side stream around each bucket's collective -- with them on, the side "
+                                         "stream waits for every collective before the next is enqueued; GBps = wire bytes of this rank / latency"}
         if roofline is not None:
             out["roofline"] = roofline
         if world == 1 and not args.no_cpu_baseline:

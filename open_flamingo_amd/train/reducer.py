@@ -60,6 +60,9 @@ class GradReducer:
         self.generation = 0
         self.stats = dict(collectives=0, bytes=0, steps=0)
         self.time_waits, self._wait_events = False, []
+        # diagnostics (bench.py --sweep-comm): HIP events on the side stream around every collective -> per-bucket all-reduce latency.
+        # Costs one stream wait per collective (the side stream waits for each before the next is enqueued), so it is off by default.
+        self.time_collectives, self._coll_events = False, []
         lm = model.lang_encoder
         groups = []
         for blk in reversed([b for b in lm.gated_cross_attn_layers if b is not None]):
@@ -169,10 +172,28 @@ class GradReducer:
                 wire = flat.to(self.wire_dtype)
                 if side is not None:
                     wire.record_stream(compute)      # allocated on the side stream, read back on the compute stream in finish()
+                e0 = None
+                if self.time_collectives and side is not None:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record(side)
                 work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if e0 is not None:
+                    work.wait()
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record(side)
+                    self._coll_events.append((wire.numel() * wire.element_size(), e0, e1))
                 self._pending.append((work, flat, wire))
                 return None
+            e0 = None
+            if self.time_collectives and side is not None:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(side)
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if e0 is not None:
+                work.wait()                  # (a stream wait: the side stream follows the collective's end)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(side)
+                self._coll_events.append((flat.numel() * flat.element_size(), e0, e1))
             self._pending.append((work, flat, None))
             return work
 
@@ -312,9 +333,13 @@ class GradReducer:
         out = dict(collectives_per_step=self.stats["collectives"] / n, allreduce_bytes_per_step=self.stats["bytes"] / n,
                    wire_dtype=str(self.wire_dtype).replace("torch.", ""), buckets=len(self.buckets),
                    exposed_wait_ms_per_step=waited)
+        if self._coll_events:          # [(bytes on the wire, milliseconds)] in launch order over the steps since the last reset
+            torch.cuda.synchronize()
+            out["collective_ms"] = [(nb, a.elapsed_time(b)) for nb, a, b in self._coll_events]
         if reset:
             self.stats = dict(collectives=0, bytes=0, steps=0)
             self._wait_events = []
+            self._coll_events = []
         return out
 
     def zero_grad(self, flat_already_zero=False):
