@@ -318,7 +318,16 @@ template <bool ASM>
 OF_DEV void epilogue_group_aux_dma(const OfGemmArgs& p, int m_base, int n_base, int lane, char* lds_dst) {
     const bf16_t* src = (const bf16_t*)p.aux + (size_t)(m_base + (lane >> 3)) * p.ldaux + n_base + (lane & 7) * 8;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) of_glds16<ASM>(src + (size_t)it * 8 * p.ldaux, lds_dst + it * 1024);
+    // non-temporal: the saved activation is read once, by this workgroup (134 MB per 8192 x 8192 launch) -- with the default policy it
+    // pushed the B panels every workgroup of the XCD re-reads out of the 4-MB L2 (round 6, same box: the DGELU_DOT family 1090 -> 1102
+    // TFLOP/s, step -0.1 ms; profiles/r06m_ab_aux_nt_step.jsonl)
+    for (int it = 0; it < 4; ++it) {
+#ifdef OF_AUX_NOT_NT      // tools/ab builds only: the other arm of that A/B
+        of_glds16<ASM>(src + (size_t)it * 8 * p.ldaux, lds_dst + it * 1024);
+#else
+        of_glds16_nt<ASM>(src + (size_t)it * 8 * p.ldaux, lds_dst + it * 1024);
+#endif
+    }
 }
 // The residual of the GATE_RESID epilogue the same way (big-tile kernel on 16x16x32 MFMAs: three groups in flight instead of one
 // through registers).  bf16 stream: the *_DOT layout above (4 pieces).  fp32 stream: a group's residual tile = 32 rows x 256 B =
@@ -332,7 +341,13 @@ OF_DEV void epilogue_group_resid_dma(const OfGemmArgs& p, int m_base, int n_base
         const int r4 = lane >> 4, ch = (lane & 15) ^ ((r4 & 1) << 3);
         const float* src = (const float*)p.aux + (size_t)(m_base + r4) * p.ldaux + n_base + ch * 4;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) of_glds16<ASM>(src + (size_t)q * 4 * p.ldaux, lds_dst + q * 1024);
+        for (int q = 0; q < 8; ++q) {
+#ifdef OF_RESID_NT        // tools/ab builds only (round 6 A/B: the fp32 residual tile, also read once, with the non-temporal policy)
+            of_glds16_nt<ASM>(src + (size_t)q * 4 * p.ldaux, lds_dst + q * 1024);
+#else
+            of_glds16<ASM>(src + (size_t)q * 4 * p.ldaux, lds_dst + q * 1024);
+#endif
+        }
     } else {
         epilogue_group_aux_dma<ASM>(p, m_base, n_base, lane, lds_dst);
     }

@@ -225,6 +225,19 @@ OF_DEV void of_glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// The same with the non-temporal policy (nt): data that is read ONCE by one workgroup (the saved activation a *_DOT epilogue multiplies
+// with, 134 MB per launch) should not displace the operand panels every workgroup of the XCD re-reads from its L2.
+template <bool TRSAFE = true>
+OF_DEV void of_glds16_nt(const void* gsrc, void* lds_wave_base) {
+#ifndef OF_DMA_VIA_BUILTIN
+    if (TRSAFE) {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(of_lds_u32(lds_wave_base))) : "memory");
+        return;
+    }
+#endif
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
+}
 // Buffer-descriptor loads: wave-uniform 128-bit descriptor (base pointer in SGPRs) + per-lane 32-bit byte offset +
 // scalar byte offset -- no 64-bit per-lane address arithmetic.  `base` must be provably wave-uniform (kernel arguments /
 // blockIdx-derived), or hipcc wraps every load in a waterfall loop.

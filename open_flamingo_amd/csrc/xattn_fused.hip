@@ -60,8 +60,13 @@ OF_DEV int ximg_off(int row, int slot, int row_bytes) { return row * row_bytes +
 
 OF_DEV void x_load8(const void* rowp, int is_f32, unsigned eo, float (&v)[8]) {
     if (is_f32) {
+#ifdef OF_XF_X_NT         // tools/ab builds only (round 6 A/B: the LayerNorm's read of x with the non-temporal policy)
+        const f32x4 a = __builtin_nontemporal_load((const f32x4*)((const float*)rowp + eo));
+        const f32x4 b = __builtin_nontemporal_load((const f32x4*)((const float*)rowp + eo + 4));
+#else
         const f32x4 a = *(const f32x4*)((const float*)rowp + eo);
         const f32x4 b = *(const f32x4*)((const float*)rowp + eo + 4);
+#endif
         v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
         v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
     } else {

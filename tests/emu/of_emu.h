@@ -242,6 +242,8 @@ template <bool TRSAFE = true>
 OF_DEV void of_glds16(const void* gsrc, void* lds_wave_base) {
     memcpy((char*)lds_wave_base + 16 * (of_emu::g_blk->cur & 63), gsrc, 16);
 }
+template <bool TRSAFE = true>
+OF_DEV void of_glds16_nt(const void* gsrc, void* lds_wave_base) { of_glds16<TRSAFE>(gsrc, lds_wave_base); }
 template <int N>
 OF_DEV void of_wait_vm() {}
 OF_DEV void of_wait_lgkm0() {}

@@ -610,8 +610,9 @@ def test_8c_tolerance_model_family_dims(ops, d):
 
 def test_cfg2_full_batch_parity_with_nonzero_gates(ops):
     """BASELINE config 2 at its FULL per-GPU batch (B=32, T=2, L=256, OF-3B widths, gates = 0.5): these launches select
-    the kernels the benchmark times (256x256 ping-pong GEMM with the GELU / GATE_RESID / DGELU_DOT / SCALE_DOT epilogues,
-    split-K dW, CPL=4 LayerNorm).  (1) everything -- y, dx, dmedia and every parameter gradient of the whole batch --
+    the kernels the benchmark times (the fused attention branch csrc/xattn_fused.hip; the 4-wave 256x256 kernel gemm_w4m with the
+    GELU / GATE_RESID epilogues and its K rotation; the 256x128 two-workgroups-per-CU kernel gemm_w4h for DGELU_DOT; the 8-wave
+    128x128 kernel for the 512-wide projections; the batched split-K dW launch; the workgroup-per-row LayerNorm backward).  (1) everything -- y, dx, dmedia and every parameter gradient of the whole batch --
     against the oracle executed on the GPU in fp32, by the SURVEY 8c rule; (2) two sampled sequences / media items
     against the oracle on the host CPU (sequences are independent in forward and in dx)."""
     rep = PC.check_xattn_8c(ops, "cuda", B=32, L=256, T=2, n=64, heads=8, d=2048, Dv=1024, seed=21, gates=(0.5, 0.5),

@@ -19,7 +19,8 @@ if MAPS:
     ops = tools_ops()
     ops.lib.of_tools_set_w4m_map_knob.argtypes = [ctypes.c_int]
 else:
-    ops = Ops.default()
+    from tools_lib import routed_ops
+    ops = routed_ops()          # product library; the forced arms (safe >= 2) run on the tools build of the same sources
 E = abi
 CASES = [("NT store", 8192, 8192, 2048, 0, 0, E.EPI_STORE_BF16), ("NT store K=8192", 8192, 2048, 8192, 0, 0, E.EPI_STORE_BF16),
          ("NT Wqkv", 8192, 6144, 2048, 0, 0, E.EPI_STORE_BF16), ("NN dX K=8192", 8192, 2048, 8192, 0, 1, E.EPI_STORE_BF16),
