@@ -155,7 +155,11 @@ OF_DEV void epilogue_row8(const OfGemmArgs& p, const float (&a)[8], int m, int n
         for (int e = 0; e < 8; ++e) o[e] = sc * a[e];
         *(u32x4*)((bf16_t*)p.C + off) = pack8(o);
     } else if (EPI == OF_EPI_GELU) {
+#ifdef OF_SAVED_NT         // tools/ab builds only (round 6 A/B): tensors only the backward reads, stored with the non-temporal policy
+        if (p.C2) __builtin_nontemporal_store(pack8(a), (u32x4*)((bf16_t*)p.C2 + off));
+#else
         if (p.C2) *(u32x4*)((bf16_t*)p.C2 + off) = pack8(a);
+#endif
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {          // packed fp32 math, two elements per instruction (of_platform.h)
             const f32x2 g = of_gelu2(f32x2{a[e], a[e + 1]});
