@@ -271,33 +271,8 @@ typedef struct OfPackDesc {
     uint16_t* P;
     int N, K;
     long ldw;
-    int transposed;                /* 0: W is N x K row-major.  1: the N x K matrix is stored K x N (element (n, k) at W[k * ldw + n]): the
-                                      copy of W^T a dX = dY W product streams, made from the weight as it lies */
 } OfPackDesc;
 int of_pack_frag16_batch(const OfPackDesc* descs, int n, void* stream);
-/* Backward of the branch's input side in one pass over the rows (helpers.py:184-186 reversed): dxn = dq Wq stays in the accumulators and
- * goes straight into the LayerNorm backward --
- *     dx = (resid ? resid : 0) + LN_bwd(dq Wq; x, stats, ln_w),   dw += column sums of dxn * xhat,   db += column sums of dxn
- * -- replacing of_gemm(dq, Wq, b_trans) + of_layernorm_bwd (the bf16 dxn never reaches HBM).  dq: rows x 512 bf16; wqT_pk: of_pack_frag16_batch
- * copy of to_q.weight with transposed = 1 (N = d, K = 512); x / resid / dx: rows x d in the stream dtype (x_f32), dx_bf16 optional (fp32
- * stream only); partials: of_xattn_dq_ln_bwd_workspace_bytes(rows, d) bytes of scratch (one partial row of d gamma | d beta per 32-row
- * workgroup, added in a fixed order: deterministic).  rows % 32 == 0, d in {256, 512, 1024, 2048}: OF_E_SHAPE otherwise. */
-typedef struct OfXattnBwdArgs {
-    const uint16_t* dq; long lddq;
-    const uint16_t* wqT_pk;
-    const void* x; int x_f32; long ldx;
-    const float* stats;
-    const float* ln_w;
-    const void* resid;
-    void* dx; long lddx;
-    uint16_t* dx_bf16;
-    float* partials;
-    float* dw; float* db;
-    long rows; int d;
-} OfXattnBwdArgs;
-size_t of_xattn_dq_ln_bwd_workspace_bytes(long rows, int d);
-int of_xattn_dq_ln_bwd_eligible(const OfXattnBwdArgs* args);
-int of_xattn_dq_ln_bwd(const OfXattnBwdArgs* args, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Small element-wise helpers of the path. */

@@ -187,11 +187,6 @@ OF_DEV const void* of_uniform_ptr(const void* p) {
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
     return (const void*)(((unsigned long long)hi << 32) | lo);
 }
-// a pointer the optimiser knows nothing about (same value): loads through it are not merged with earlier loads of the same address
-OF_DEV const void* of_opaque_ptr(const void* p) {
-    asm volatile("" : "+s"(p));
-    return p;
-}
 // Point where the lanes of ONE wave exchange data through LDS: hardware executes a wave in lock-step and its LDS
 // operations in program order, so this is only a compiler scheduling fence (the emulator needs a real rendezvous).
 OF_DEV void of_wave_sync() { __builtin_amdgcn_wave_barrier(); }
@@ -260,12 +255,6 @@ OF_DEV u32x4 of_buf_load16(of_buf_t b, unsigned voff, unsigned soff) {
 }
 OF_DEV void of_buf_store16(of_buf_t b, unsigned voff, unsigned soff, u32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(v, b.r, (int)voff, (int)soff, 0);
-}
-OF_DEV u32x2 of_buf_load8(of_buf_t b, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(b.r, (int)voff, (int)soff, 0));
-}
-OF_DEV void of_buf_store8(of_buf_t b, unsigned voff, unsigned soff, u32x2 v) {
-    __builtin_amdgcn_raw_buffer_store_b64(v, b.r, (int)voff, (int)soff, 0);
 }
 // The same at SYSTEM scope (sc0 sc1: cache-policy bits 0 and 4 on gfx940+): the store writes through this XCD's L2, the load does
 // not take a line this XCD's L2 may hold from before -- data handed from one workgroup to another inside a launch (stream-K partial
@@ -443,14 +432,6 @@ OF_DEV unsigned of_pack_bf16(float lo, float hi) {
 // Sum over the 64 lanes, result in every lane, entirely inside the VALU: four DPP adds give every 16-lane row its total
 // (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror), two permlane swaps add the four rows.  __shfl_xor would
 // make each of the six steps a ds_bpermute round trip through the LDS pipeline (~100+ cycles of latency apiece).
-// sum over the 16 lanes of a row (lanes l with the same l >> 4), result in every lane of the row: the four DPP steps of of_wave_sum
-OF_DEV float of_row16_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));
-    return v;
-}
 OF_DEV float of_wave_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
@@ -464,35 +445,8 @@ OF_DEV float of_wave_sum(float v) {
     for (int m = 32; m >= 1; m >>= 1) v += of_shfl_xor(v, m);
     return v;
 }
-OF_DEV float of_row16_sum(float v) {
-#pragma unroll
-    for (int m = 8; m >= 1; m >>= 1) v += of_shfl_xor(v, m);
-    return v;
-}
+
 #endif
-// Sixteen values per lane, reduced over the wave: returns the total of v[lane & 15] (in every lane with that lane & 15).  A butterfly
-// inside each 16-lane row that halves the number of values a lane carries per step (15 exchanges instead of 16 x 4), then the four rows
-// (of_rows_sum) -- what sixteen of_wave_sum calls cost, and what they did to register allocation when unrolled, is in csrc/xattn_fused.hip.
-OF_DEV float of_seg16_wave_sum(const float (&v)[16], int lane) {
-    float a[8], b[4], c[2];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const bool hi = (lane & 8) != 0;
-        a[i] = (hi ? v[i + 8] : v[i]) + of_shfl_xor(hi ? v[i] : v[i + 8], 8);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const bool hi = (lane & 4) != 0;
-        b[i] = (hi ? a[i + 4] : a[i]) + of_shfl_xor(hi ? a[i] : a[i + 4], 4);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const bool hi = (lane & 2) != 0;
-        c[i] = (hi ? b[i + 2] : b[i]) + of_shfl_xor(hi ? b[i] : b[i + 2], 2);
-    }
-    const bool hi = (lane & 1) != 0;
-    return of_rows_sum((hi ? c[1] : c[0]) + of_shfl_xor(hi ? c[0] : c[1], 1));
-}
 // erf-GELU (nn.GELU() default, reference helpers.py:20) for the GEMM epilogues.  erf by Abramowitz-Stegun 7.1.26
 // (|error| <= 1.5e-7, far below the bf16 rounding of the stored result) so that one exp + one rcp + 6 fma replace
 // the ~40-instruction libm erff; the same exp(-a^2/2) also yields the Gaussian term of the derivative.

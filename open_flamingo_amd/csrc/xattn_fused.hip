@@ -88,29 +88,18 @@ struct PackArgs {
     int N, K;
     long ldw;
 };
-// transposed: the logical N x K matrix is stored K x N (row stride ldw): element (n, k) at W[k * ldw + n] -- the copy of W^T a dX product
-// streams (eight 2-byte reads per piece instead of one 16-byte read; a few MB once per optimizer step)
-OF_DEV void pack_piece(const bf16_t* W, bf16_t* P, int K, long ldw, long idx, int transposed) {
+OF_DEV void pack_piece(const bf16_t* W, bf16_t* P, int K, long ldw, long idx) {
     const int KS = K / 32;
     const int lane = (int)(idx & 63);
     const long tile = idx >> 6;
     const int ks = (int)(tile % KS);
     const long nt = tile / KS;
-    if (!transposed) {
-        *(u32x4*)(P + idx * 8) = *(const u32x4*)(W + (size_t)(nt * 16 + (lane & 15)) * ldw + ks * 32 + (lane >> 4) * 8);
-        return;
-    }
-    const bf16_t* src = W + (size_t)(ks * 32 + (lane >> 4) * 8) * ldw + nt * 16 + (lane & 15);
-    unsigned short e[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) e[j] = src[(size_t)j * ldw];
-    *(u32x4*)(P + idx * 8) = u32x4{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
-                                   (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+    *(u32x4*)(P + idx * 8) = *(const u32x4*)(W + (size_t)(nt * 16 + (lane & 15)) * ldw + ks * 32 + (lane >> 4) * 8);
 }
 OF_GLOBAL void of_pack_frag16_kernel(PackArgs a) {
     const long idx = (long)of_bid_x() * 256 + of_tid();
     if (idx >= (long)(a.N / 16) * (a.K / 32) * 64) return;
-    pack_piece(a.W, a.P, a.K, a.ldw, idx, 0);
+    pack_piece(a.W, a.P, a.K, a.ldw, idx);
 }
 // several matrices in one launch (the step epilogue re-packs every gated block's to_q / to_out weight once per optimizer step)
 struct PackBatchArgs {
@@ -124,7 +113,7 @@ OF_GLOBAL void of_pack_frag16_batch_kernel(PackBatchArgs a) {
     int i = 0;
     while (idx >= a.end[i]) ++i;
     const long first = i ? a.end[i - 1] : 0;
-    pack_piece(a.d[i].W, a.d[i].P, a.d[i].K, a.d[i].ldw, idx - first, a.d[i].transposed);
+    pack_piece(a.d[i].W, a.d[i].P, a.d[i].K, a.d[i].ldw, idx - first);
 }
 
 // acc[mt][t] (+)= P-fragments x image-fragments: the 32 rows of a [32][512] bf16 LDS image (ximg_off layout) times the d / 8 output columns
@@ -580,209 +569,6 @@ OF_GLOBAL void OF_BOUNDS(512, 2) of_xattn_fused_fwd_kernel(OfXattnFusedArgs p) {
     XF_STAMP_FLUSH();
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Backward of the branch's input side in one pass over the rows: dxn = dq Wq (the gradient through to_q, helpers.py:186) never reaches
-// HBM -- a workgroup's 32 x d tile of it stays in the accumulators of the same packed-fragment K loop and goes straight into the
-// LayerNorm backward (helpers.py:184): dx = resid + rstd (dyh - mean(dyh) - xh mean(dyh xh)), dyh = dxn gamma, xh = (x - mean) rstd,
-// plus the workgroup's column sums of dxn xh and dxn (d gamma, d beta) as one partial row each, added in a fixed order by
-// of_xattn_colsum_kernel (deterministic, no atomics).  Replaces of_gemm(dq, Wq^T) + of_layernorm_bwd: the bf16 dxn (33 MB written and
-// read back) and one launch per block.
-// The accumulators of xf_rows32_times_packed hold a wave's 16 x (d / 8) tile with a lane on ONE row and 4 columns of every 16-column
-// block: read or written like that, a wave instruction touches 16 rows x 64 bytes (measured: 25 GB/s per CU, and every block needs its
-// own gamma / residual / x loads).  xf_tile_to_rows turns the tile through a wave-private LDS slab (row pitch + 16 bytes: conflict-free
-// both ways) into v[r] = the lane's 4 CONSECUTIVE columns n0 + 4 lane .. of row r, r = 0 .. 15: a wave instruction then covers 1 KiB of
-// one row, per-column operands (gamma, beta) are loaded once, column sums stay in the lane.  Lanes >= d / 32 hold no columns (d < 2048).
-template <int NT>
-OF_DEV void xf_tile_to_rows(const f32x4 (&acc)[NT], char* slab, int lane, f32x4 (&v)[16]) {
-    constexpr int PITCH = NT * 64 + 16;
-    const int g = lane >> 4, i16 = lane & 15;
-    of_wave_sync();                              // the slab's previous readers (this wave) are done
-#pragma unroll
-    for (int t = 0; t < NT; ++t) *(f32x4*)(slab + i16 * PITCH + (16 * t + 4 * g) * 4) = acc[t];
-    of_wave_sync();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = lane < NT * 4 ? *(const f32x4*)(slab + r * PITCH + lane * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
-}
-template <int NT>
-constexpr int xf_slab_bytes() { return 16 * (NT * 64 + 16); }
-
-// (XF32 / TWIN: the stream dtype and "also write the bf16 copy of dx" as template parameters -- as run-time flags hipcc issued both forms
-// of every row load, and the branch around the second store kept the rows' loads from being issued together)
-template <int D, bool XF32, bool TWIN>
-OF_GLOBAL void OF_BOUNDS(512, 2) of_xattn_dq_ln_bwd_kernel(OfXattnBwdArgs p) {
-    constexpr int NTO = D / 128;
-    constexpr int OROW = X_INNER * 2;
-    constexpr int SLAB = xf_slab_bytes<NTO>();
-    char* smem = of_smem();
-    char* img = smem;                                        // dq tile [32][512] bf16; behind the K loop: the eight transposition slabs
-    float* red = (float*)(smem + (8 * SLAB > 32 * 1024 ? 8 * SLAB : 32 * 1024));      // [2][8 waves][16 rows] partial row sums, then [2][16 rows] their totals
-    float* s_stats = red + 320;                              // [32 rows][2]: mean, rstd of this workgroup's rows
-    const int tid = of_tid(), lane = tid & 63;
-    const int wave = of_uniform(tid >> 6);
-    const long row0 = (long)of_bid_x() * XR;
-    const int n0 = wave * (D / 8);
-    const bool act = NTO * 4 >= 64 || lane < NTO * 4;         // this lane owns columns n0 + 4 lane .. + 3 (every lane at d = 2048)
-    const int nc = n0 + 4 * lane;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int id = c * 512 + tid, row = id >> 6, slot = id & 63;
-        *(u32x4*)(img + ximg_off(row, slot, OROW)) = *(const u32x4*)(p.dq + (size_t)(row0 + row) * p.lddq + slot * 8);
-    }
-    if (tid < 64) s_stats[tid] = p.stats[row0 * 2 + tid];
-    of_sync();
-    f32x4 acc[2][NTO];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int t = 0; t < NTO; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    xf_rows32_times_packed<NTO>(p.wqT_pk, img, wave, lane, acc);
-    of_sync();                                               // every wave is done with the dq image: the slabs take its place
-
-    char* slab = smem + wave * SLAB;
-    constexpr int PITCH = NTO * 64 + 16;
-    const f32x4 w4 = act ? *(const f32x4*)(p.ln_w + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
-    // global accesses of the row passes: wave-uniform descriptor + ONE per-lane byte offset + a scalar row offset
-    const unsigned es = XF32 ? 4u : 2u;
-    const of_buf_t bx = of_buf_make(p.x), bres = of_buf_make(p.resid ? p.resid : p.x), bdx = of_buf_make(p.dx), bdxb = of_buf_make(p.dx_bf16 ? (const void*)p.dx_bf16 : p.dx);
-    const unsigned vo = (unsigned)nc * es, vob = (unsigned)nc * 2u;
-    const bool has_resid = p.resid != nullptr;
-    // the lane's four columns of a row of x / resid (raw 16 bytes: fp32 x 4, or bf16 x 4 in the low half), and xh = (x - mean) rstd from
-    // them.  Loads are issued a whole tile (x: 16 rows) or half a tile (x + resid: 8 rows each) ahead of their use: with one or four rows
-    // in flight per wave the passes ran at the latency of a row, not at the bandwidth of the chip (113 vs 86 us for the launch pair).
-    auto row_load = [&](of_buf_t b, int rl, long ld) OF_INLINE_LAMBDA {
-        const unsigned so = (unsigned)(row0 + rl) * (unsigned)ld * es;
-        u32x4 raw = {0u, 0u, 0u, 0u};
-        if (act) {
-            if (XF32) {
-                raw = of_buf_load16(b, vo, so);
-            } else {
-                const u32x2 h = of_buf_load8(b, vo, so);
-                raw[0] = h[0];
-                raw[1] = h[1];
-            }
-        }
-        return raw;
-    };
-    auto row_f32 = [&](u32x4 raw) OF_INLINE_LAMBDA {
-        if (XF32) return __builtin_bit_cast(f32x4, raw);
-        return f32x4{of_bf16_to_f32((bf16_t)(raw[0] & 0xffff)), of_bf16_to_f32((bf16_t)(raw[0] >> 16)),
-                     of_bf16_to_f32((bf16_t)(raw[1] & 0xffff)), of_bf16_to_f32((bf16_t)(raw[1] >> 16))};
-    };
-    auto xhat = [&](u32x4 raw, int rl) OF_INLINE_LAMBDA {
-        const float mean = s_stats[rl * 2], rstd = s_stats[rl * 2 + 1];
-        const f32x4 xv = row_f32(raw);
-        return act ? f32x4{(xv[0] - mean) * rstd, (xv[1] - mean) * rstd, (xv[2] - mean) * rstd, (xv[3] - mean) * rstd} : f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-    f32x4 colw = {0.f, 0.f, 0.f, 0.f}, colb = {0.f, 0.f, 0.f, 0.f};      // this lane's columns of d gamma | d beta over the 32 rows
-    const float inv_dim = 1.0f / (float)D;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        // the tile goes through the slab and STAYS there: both row passes below read dxn of a row from it (and x from global memory, the
-        // second time out of L2) instead of holding 16 rows of dyh and xh in registers across two barriers -- rolled loops, ~60 registers
-        {
-            const int g = lane >> 4, i16 = lane & 15;
-            of_wave_sync();
-#pragma unroll
-            for (int t = 0; t < NTO; ++t) *(f32x4*)(slab + i16 * PITCH + (16 * t + 4 * g) * 4) = acc[mt][t];
-            of_wave_sync();
-        }
-        // (rolled loops, eight rows per trip -- their loads go out together --: fully unrolled, hipcc spilled 80-160 registers at every width)
-        float m1 = 0.f, m2 = 0.f;                            // lane r < 16 collects row r's sums over this wave's columns
-#pragma unroll 8
-        for (int r = 0; r < 16; ++r) {
-            const f32x4 dxn = act ? *(const f32x4*)(slab + r * PITCH + lane * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
-            const f32x4 xh = xhat(row_load(bx, mt * 16 + r, p.ldx), mt * 16 + r);
-            float c1 = 0.f, c2 = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                colw[e] += dxn[e] * xh[e];
-                colb[e] += dxn[e];
-                const float dyh = dxn[e] * w4[e];
-                c1 += dyh;
-                c2 += dyh * xh[e];
-            }
-            const float s1 = of_wave_sum(c1), s2 = of_wave_sum(c2);
-            if (lane == r) {
-                m1 = s1;
-                m2 = s2;
-            }
-        }
-        if (mt == 1) of_sync();                              // everybody has read the first tile's totals
-        if (lane < 16) {
-            red[wave * 16 + lane] = m1;
-            red[128 + wave * 16 + lane] = m2;
-        }
-        of_sync();
-        if (tid < 32) {                                      // totals of row tid & 15: sum of dyh (tid < 16), of dyh xh (tid >= 16)
-            float t = 0.f;
-#pragma unroll
-            for (int wv = 0; wv < 8; ++wv) t += red[(tid >> 4) * 128 + wv * 16 + (tid & 15)];
-            red[256 + tid] = t * inv_dim;
-        }
-        of_sync();
-#pragma unroll 1
-        for (int hf = 0; hf < 2; ++hf) {                     // eight rows per trip: their sixteen loads first, then the rows (stores of one
-            u32x4 xq[8], rq[8];                              // row would otherwise hold back the loads of the next: possible aliases)
-#pragma unroll
-            for (int r8 = 0; r8 < 8; ++r8) {
-                xq[r8] = row_load(bx, mt * 16 + hf * 8 + r8, p.ldx);
-                rq[r8] = row_load(bres, mt * 16 + hf * 8 + r8, p.lddx);          // (no residual: a dummy read of x, dropped below -- no branch)
-            }
-#pragma unroll
-            for (int r8 = 0; r8 < 8; ++r8) {
-                const int r = hf * 8 + r8, rl = mt * 16 + r;
-                const float rstd = s_stats[rl * 2 + 1], a1 = red[256 + r], a2 = red[272 + r];
-                const f32x4 dxn = act ? *(const f32x4*)(slab + r * PITCH + lane * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
-                const f32x4 xh = xhat(xq[r8], rl), rv = row_f32(rq[r8]);
-                f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = rstd * (dxn[e] * w4[e] - a1 - xh[e] * a2) + (has_resid ? rv[e] : 0.f);
-                const unsigned sd = (unsigned)(row0 + rl) * (unsigned)p.lddx * es, sdb = (unsigned)(row0 + rl) * (unsigned)p.lddx * 2u;
-                if (!act) {
-                } else if (XF32) {
-                    of_buf_store16(bdx, vo, sd, __builtin_bit_cast(u32x4, o));
-                    if (TWIN) of_buf_store8(bdxb, vob, sdb, u32x2{of_pack_bf16(o[0], o[1]), of_pack_bf16(o[2], o[3])});
-                } else {
-                    of_buf_store8(bdx, vo, sd, u32x2{of_pack_bf16(o[0], o[1]), of_pack_bf16(o[2], o[3])});
-                }
-            }
-        }
-    }
-    // this workgroup's partial rows of d gamma | d beta: every lane holds its four columns' sums over the 32 rows
-    if (act) {
-        float* pr = p.partials + (size_t)of_bid_x() * 2 * D;
-        *(f32x4*)(pr + nc) = colw;
-        *(f32x4*)(pr + D + nc) = colb;
-    }
-}
-
-struct XColsumArgs {
-    const float* partials;
-    float* dw;
-    float* db;
-    int nwg, d;
-};
-// dw[c] += sum over the workgroups' partial rows, db likewise.  A workgroup takes 32 columns: thread (column c = tid & 31, row group
-// tid >> 5) adds rows rg, rg + 8, ... in ascending order, the eight groups' sums meet in LDS in a fixed order: the same bits every run.
-// (One thread per column walking all rows was a chain of nwg dependent L2 round trips on 16 workgroups: 80 us for 4 MB.)
-OF_GLOBAL void of_xattn_colsum_kernel(XColsumArgs a) {
-    float* part = (float*)of_smem();              // [8][32]
-    const int tid = of_tid(), cl = tid & 31, rg = tid >> 5;
-    const int c = of_bid_x() * 32 + cl;
-    float s = 0.f;
-    if (c < 2 * a.d)
-        for (int w = rg; w < a.nwg; w += 8) s += a.partials[(size_t)w * 2 * a.d + c];
-    part[rg * 32 + cl] = s;
-    of_sync();
-    if (rg == 0 && c < 2 * a.d) {
-        float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += part[k * 32 + cl];
-        if (c < a.d) a.dw[c] += t;
-        else a.db[c - a.d] += t;
-    }
-}
-
 int check(const OfXattnFusedArgs& a) {
     if (!a.x || !a.ln_w || !a.ln_b || !a.wq_pk || !a.k || !a.v || !a.wout_pk || !a.y) return OF_E_ARG;
     if (a.B <= 0 || a.L <= 0 || a.Lk <= 0 || a.d <= 0) return OF_E_ARG;
@@ -821,7 +607,6 @@ extern "C" int of_pack_frag16_batch(const OfPackDesc* descs, int n, void* stream
             if (!d.W || !d.P || d.N <= 0 || d.K <= 0) return OF_E_ARG;
             if ((d.N % 16) || (d.K % 32)) return OF_E_SHAPE;
             if ((d.ldw & 7) || ((uintptr_t)d.W & 15) || ((uintptr_t)d.P & 15)) return OF_E_ALIGN;
-            if (d.transposed != 0 && d.transposed != 1) return OF_E_ARG;
             total += (long)(d.N / 16) * (d.K / 32) * 64;
             a.end[i] = total;
             a.d[i] = d;
@@ -847,44 +632,4 @@ extern "C" int of_xattn_fused_fwd(const OfXattnFusedArgs* args, void* stream) {
         case 1024: return of_launch(of_xattn_fused_fwd_kernel<1024>, grid, 512, X_SMEM, s, a);
         default: return of_launch(of_xattn_fused_fwd_kernel<2048>, grid, 512, X_SMEM, s, a);
     }
-}
-
-static int check_bwd(const OfXattnBwdArgs& a) {
-    if (!a.dq || !a.wqT_pk || !a.x || !a.stats || !a.ln_w || !a.dx || !a.partials || !a.dw || !a.db) return OF_E_ARG;
-    if (a.dx_bf16 && !a.x_f32) return OF_E_ARG;          // the bf16 twin exists for the fp32 stream only
-    if (a.rows <= 0 || (a.rows % XR)) return OF_E_SHAPE;
-    if (a.d != 256 && a.d != 512 && a.d != 1024 && a.d != 2048) return OF_E_SHAPE;
-    if ((a.lddq & 7) || (a.ldx & 7) || (a.lddx & 7)) return OF_E_ALIGN;
-    const void* ptrs[] = {a.dq, a.wqT_pk, a.x, a.ln_w, a.resid, a.dx, a.dx_bf16, a.partials};
-    for (const void* q : ptrs)
-        if ((uintptr_t)q & 15) return OF_E_ALIGN;
-    return 0;
-}
-extern "C" size_t of_xattn_dq_ln_bwd_workspace_bytes(long rows, int d) { return rows > 0 && d > 0 ? (size_t)(rows / XR) * 2 * d * sizeof(float) : 0; }
-extern "C" int of_xattn_dq_ln_bwd_eligible(const OfXattnBwdArgs* args) { return args && check_bwd(*args) == 0; }
-extern "C" int of_xattn_dq_ln_bwd(const OfXattnBwdArgs* args, void* stream) {
-    if (!args) return OF_E_ARG;
-    int rc = check_bwd(*args);
-    if (rc) return rc;
-    const OfXattnBwdArgs& a = *args;
-    const int nwg = (int)(a.rows / XR);
-    of_stream_t s = (of_stream_t)stream;
-    const of_dim3 grid{(unsigned)nwg, 1, 1};
-    const int slab8 = a.d == 2048 ? 8 * xf_slab_bytes<16>() : a.d == 1024 ? 8 * xf_slab_bytes<8>() : a.d == 512 ? 8 * xf_slab_bytes<4>() : 8 * xf_slab_bytes<2>();
-    const int smem = (slab8 > 32 * 1024 ? slab8 : 32 * 1024) + 2048;      // the dq image, then the slabs; + the row-sum exchange and the rows' statistics
-    const int form = !a.x_f32 ? 0 : (a.dx_bf16 ? 2 : 1);
-#define XF_BWD_LAUNCH(DD)                                                                                                          \
-    (form == 0 ? of_launch(of_xattn_dq_ln_bwd_kernel<DD, false, false>, grid, 512, smem, s, a)                                     \
-     : form == 1 ? of_launch(of_xattn_dq_ln_bwd_kernel<DD, true, false>, grid, 512, smem, s, a)                                    \
-                 : of_launch(of_xattn_dq_ln_bwd_kernel<DD, true, true>, grid, 512, smem, s, a))
-    switch (a.d) {
-        case 256: rc = XF_BWD_LAUNCH(256); break;
-        case 512: rc = XF_BWD_LAUNCH(512); break;
-        case 1024: rc = XF_BWD_LAUNCH(1024); break;
-        default: rc = XF_BWD_LAUNCH(2048); break;
-    }
-#undef XF_BWD_LAUNCH
-    if (rc) return rc;
-    XColsumArgs c{a.partials, a.dw, a.db, nwg, a.d};
-    return of_launch(of_xattn_colsum_kernel, of_dim3{(unsigned)((2 * a.d + 31) / 32), 1, 1}, 256, 8 * 32 * sizeof(float), s, c);
 }

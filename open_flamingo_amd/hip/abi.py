@@ -74,19 +74,7 @@ class OfXattnFusedArgs(C.Structure):
 
 
 class OfPackDesc(C.Structure):
-    _fields_ = [("W", vp), ("P", vp), ("N", C.c_int), ("K", C.c_int), ("ldw", C.c_long), ("transposed", C.c_int)]
-
-
-class OfXattnBwdArgs(C.Structure):
-    _fields_ = [
-        ("dq", vp), ("lddq", C.c_long),
-        ("wqT_pk", vp),
-        ("x", vp), ("x_f32", C.c_int), ("ldx", C.c_long),
-        ("stats", vp), ("ln_w", vp), ("resid", vp),
-        ("dx", vp), ("lddx", C.c_long),
-        ("dx_bf16", vp), ("partials", vp), ("dw", vp), ("db", vp),
-        ("rows", C.c_long), ("d", C.c_int),
-    ]
+    _fields_ = [("W", vp), ("P", vp), ("N", C.c_int), ("K", C.c_int), ("ldw", C.c_long)]
 
 
 PROTOTYPES = {
@@ -112,9 +100,6 @@ PROTOTYPES = {
     "of_xattn_fused_fwd": (C.c_int, [C.POINTER(OfXattnFusedArgs), vp]),
     "of_pack_frag16": (C.c_int, [vp, C.c_int, C.c_int, C.c_long, vp, vp]),
     "of_pack_frag16_batch": (C.c_int, [C.POINTER(OfPackDesc), C.c_int, vp]),
-    "of_xattn_dq_ln_bwd_workspace_bytes": (C.c_size_t, [C.c_long, C.c_int]),
-    "of_xattn_dq_ln_bwd_eligible": (C.c_int, [C.POINTER(OfXattnBwdArgs)]),
-    "of_xattn_dq_ln_bwd": (C.c_int, [C.POINTER(OfXattnBwdArgs), vp]),
     "of_text_time": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "of_cast_f32_to_bf16": (C.c_int, [vp, vp, C.c_long, vp]),
     "of_cast_bf16_to_f32": (C.c_int, [vp, vp, C.c_long, vp]),

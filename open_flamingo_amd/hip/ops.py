@@ -307,53 +307,14 @@ class Ops:
         self._chk(self.lib.of_pack_frag16(W.data_ptr(), N, K, W.stride(0), out.data_ptr(), self._stream()), "of_pack_frag16")
         return out
 
-    def pack_frag16_batch(self, items):
-        """[(W bf16 row-major, out flat bf16 of W.numel() elements[, transposed])]: every fragment-major copy in one launch.
-        transposed: the copy is of W^T (the logical N x K matrix is W.T: N = W.shape[1], K = W.shape[0]) -- what dX = dY W streams."""
-        n = len(items)
+    def pack_frag16_batch(self, pairs):
+        """[(W (N, K) bf16 row-major, out flat bf16 of N * K elements)]: every fragment-major copy in one launch."""
+        n = len(pairs)
         arr = (abi.OfPackDesc * n)()
-        for d, it in zip(arr, items):
-            W, out, tr = it[0], it[1], bool(it[2]) if len(it) > 2 else False
+        for d, (W, out) in zip(arr, pairs):
             assert W.dtype == BF16 and W.dim() == 2 and W.stride(1) == 1 and out.dtype == BF16 and out.is_contiguous() and out.numel() >= W.numel()
-            d.W, d.P, d.ldw, d.transposed = W.data_ptr(), out.data_ptr(), W.stride(0), int(tr)
-            d.N, d.K = (W.shape[1], W.shape[0]) if tr else (W.shape[0], W.shape[1])
+            d.W, d.P, d.N, d.K, d.ldw = W.data_ptr(), out.data_ptr(), W.shape[0], W.shape[1], W.stride(0)
         self._chk(self.lib.of_pack_frag16_batch(arr, n, self._stream()), "of_pack_frag16_batch")
-
-    def pack_frag16_t(self, W, out=None):
-        """fragment-major copy of W^T (W (K, N) bf16 row-major)."""
-        out = torch.empty(W.numel(), dtype=BF16, device=W.device) if out is None else out
-        self.pack_frag16_batch([(W, out, True)])
-        return out
-
-    def xattn_dq_ln_bwd(self, dq, wqT_pk, x, stats, ln_w, resid, dx, dx_bf16, dw, db, probe_only=False):
-        """dx = (resid or 0) + LN_bwd(dq Wq; x, stats, ln_w), dw / db += the column sums, in one launch (of_xattn_dq_ln_bwd).  Returns
-        False -- nothing launched -- for shapes the kernel does not take."""
-        rows, d = x.shape
-        a = abi.OfXattnBwdArgs()
-        a.dq, a.lddq = dq.data_ptr(), dq.stride(0)
-        a.wqT_pk = _p(wqT_pk)
-        a.x, a.x_f32, a.ldx = x.data_ptr(), _is_f32(x), x.stride(0)
-        a.stats, a.ln_w = stats.data_ptr(), ln_w.data_ptr()
-        a.resid = _p(resid)
-        a.dx, a.lddx = dx.data_ptr(), dx.stride(0)
-        a.dx_bf16 = _p(dx_bf16)
-        a.dw, a.db = dw.data_ptr(), db.data_ptr()
-        a.rows, a.d = rows, d
-        assert dx.dtype == x.dtype and (resid is None or (resid.dtype == x.dtype and resid.stride(0) == dx.stride(0)))
-        assert dx_bf16 is None or dx_bf16.stride(0) == dx.stride(0)
-        need = self.lib.of_xattn_dq_ln_bwd_workspace_bytes(rows, d)
-        ws = self.__dict__.get("_xf_ws")
-        if ws is None or ws.numel() * 4 < need or ws.device != x.device:
-            ws = torch.empty(max(1, (need + 3) // 4), dtype=F32, device=x.device)
-            self._xf_ws = ws
-        a.partials = ws.data_ptr()
-        if probe_only:
-            a.wqT_pk = x.data_ptr()
-            return bool(self.lib.of_xattn_dq_ln_bwd_eligible(C.byref(a)))
-        if not self.lib.of_xattn_dq_ln_bwd_eligible(C.byref(a)):
-            return False
-        self._chk(self.lib.of_xattn_dq_ln_bwd(C.byref(a), self._stream()), "of_xattn_dq_ln_bwd")
-        return True
 
     def xattn_fused_fwd(self, x, ln_w, ln_b, wq_pk, k, v, tt, wout_pk, gate, y, *, B, L, Lk, heads, head_dim, n_per_media, T_img,
                         only_immediate, scale, ln2_w=None, ln2_b=None, u2=None, st2=None, xn=None, st=None, q=None, o=None, lse=None,

@@ -234,21 +234,20 @@ class WeightDict(dict):
     pk_cache = None
 
 
-def packed_weight(ops, W, name, transposed=False):
-    """fragment-major copy of the bf16 weight W[name] (of_pack_frag16; transposed: of W[name]^T, what a dX = dY W product streams): the
-    provider's (train/optim.py re-packs once per optimizer step), else the owning module's cached one while the bf16 tensor it was made
-    from is still the operand (eval mode), else made now"""
-    key = name + ("#pkT" if transposed else "#pk")
+def packed_weight(ops, W, name):
+    """fragment-major copy of the bf16 weight W[name] (of_pack_frag16): the provider's (train/optim.py re-packs once per optimizer
+    step), else the owning module's cached one while the bf16 tensor it was made from is still the operand (eval mode), else made now"""
+    key = name + "#pk"
     pk = W.get(key)
     if pk is None:
         src, cache = W[name], getattr(W, "pk_cache", None)
-        ent = cache.get(key) if cache is not None else None
+        ent = cache.get(name) if cache is not None else None
         if ent is not None and ent[0] is src:
             pk = ent[1]
         else:
-            pk = ops.pack_frag16_t(src) if transposed else ops.pack_frag16(src)
+            pk = ops.pack_frag16(src)
             if cache is not None:
-                cache[key] = (src, pk)
+                cache[name] = (src, pk)
         W[key] = pk
     return pk
 
@@ -327,23 +326,14 @@ def masked_cross_attention_bwd(ops, P, W, S, media_bf, tt, dy, dyb, G, *, B, L, 
     ops.attn_bwd(S["q"], kv[:, :inner], kv[:, inner:], S["o"], S["lse"], dO, dq, dkv[:, :inner], dkv[:, inner:], delta,
                  batch=B, Lq=L, Lk=T * n, heads=heads, text_time=tt, n_per_media=n, T_img=T,
                  only_immediate=only_immediate, safe=safe, head_dim=dim_head, scale=_softmax_scale(scale, dim_head))
+    dxn = _e((rows, d), BF16, dev)
+    ops.gemm(dq, W[prefix + "to_q.weight"], dxn, tb=True)
     t, beta = G.mat(prefix + "to_q.weight", (inner, d))
     dw_batch.append((dq, S["xn"], t, beta, None))
     dx = torch.empty_like(dy)
     dxb = _e((rows, d), BF16, dev) if (offer_twin and TWINS and dy.dtype == F32) else None     # for the next backward down the stream
-    dnw, dnb = G.acc(prefix + "norm.weight", (d,)), G.acc(prefix + "norm.bias", (d,))
-    # dq Wq -> LayerNorm backward as ONE launch where the kernel takes the shape (csrc/xattn_fused.hip: of_xattn_dq_ln_bwd): the gradient
-    # through to_q stays in the accumulators instead of making a round trip through HBM as a bf16 matrix
-    fused = (FUSED_XATTN and safe == 0 and inner == 512 and
-             ops.xattn_dq_ln_bwd(dq, None, S["x"], S["st"], P[prefix + "norm.weight"], dy if residual else None, dx, dxb, dnw, dnb, probe_only=True))
-    if fused:
-        ok = ops.xattn_dq_ln_bwd(dq, packed_weight(ops, W, prefix + "to_q.weight", transposed=True), S["x"], S["st"], P[prefix + "norm.weight"],
-                                 dy if residual else None, dx, dxb, dnw, dnb)
-        assert ok
-    else:
-        dxn = _e((rows, d), BF16, dev)
-        ops.gemm(dq, W[prefix + "to_q.weight"], dxn, tb=True)
-        ops.ln_bwd(dxn, S["x"], S["st"], P[prefix + "norm.weight"], resid=dy if residual else None, dx=dx, dx_bf16=dxb, dw=dnw, db=dnb)
+    ops.ln_bwd(dxn, S["x"], S["st"], P[prefix + "norm.weight"], resid=dy if residual else None, dx=dx, dx_bf16=dxb,
+               dw=G.acc(prefix + "norm.weight", (d,)), db=G.acc(prefix + "norm.bias", (d,)))
     if dxb is not None:
         offer_bf16_twin(dx, dxb, scope)
     t, beta = G.mat(prefix + "to_kv.weight", (2 * inner, Dv))

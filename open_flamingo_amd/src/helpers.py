@@ -71,11 +71,9 @@ class _HipParamModule(nn.Module):
                 view = provider.bf16_view(p)
                 if view is not None:
                     out[name] = view
-                    if hasattr(provider, "packed_view"):
-                        for key, tr in (("#pk", False), ("#pkT", True)):
-                            pk = provider.packed_view(p, transposed=tr)
-                            if pk is not None:
-                                out[name + key] = pk
+                    pk = provider.packed_view(p) if hasattr(provider, "packed_view") else None
+                    if pk is not None:
+                        out[name + "#pk"] = pk
                     continue
             ent = cache.get(name)
             if self.training or ent is None or ent[0] != p._version or ent[1] != p.data_ptr():

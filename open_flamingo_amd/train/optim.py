@@ -71,13 +71,12 @@ class FlatAdamW(torch.optim.Optimizer):
         # Fragment-major copies of the gated blocks' to_q / to_out weights (the fused attention branch streams them from L2 straight into
         # MFMA registers, csrc/xattn_fused.hip): re-packed from the fresh bf16 copies by ONE launch per step() instead of two per block
         # and forward.
-        self._pack_pairs, self._packed = [], {}      # (id(parameter), transposed) -> packed copy
+        self._pack_pairs, self._packed = [], {}
         for blk in [b for b in reducer.module.lang_encoder.gated_cross_attn_layers if b is not None]:
-            for lin, forms in ((blk.attn.to_q, (False, True)), (blk.attn.to_out, (False,))):      # to_q^T: the backward's dq Wq
+            for lin in (blk.attn.to_q, blk.attn.to_out):
                 p = lin.weight
-                if reducer._param_bucket.get(p) is not None and p.dim() == 2 and p.shape[0] % 32 == 0 and p.shape[1] % 32 == 0:
-                    for tr in forms:
-                        self._packed[(id(p), tr)] = torch.empty(p.numel(), dtype=BF16, device=p.device)
+                if reducer._param_bucket.get(p) is not None and p.dim() == 2 and p.shape[0] % 16 == 0 and p.shape[1] % 32 == 0:
+                    self._packed[id(p)] = torch.empty(p.numel(), dtype=BF16, device=p.device)
         self.refresh_bf16()
         # Norm taps (round 5; one GPU): the FFN weight gradients of a gated block are 91 % of its bucket and each leaves ONE big-tile
         # GEMM whose epilogue can emit the sum of squares of what it writes (OfGemmArgs.sumsq_out, one partial per 256x256 tile) into
@@ -149,18 +148,17 @@ class FlatAdamW(torch.optim.Optimizer):
             for p, off in zip(b["params"], b["offsets"]):
                 n = p.numel()
                 self._views[p.data_ptr()] = (b["flat_bf16"][off:off + n].view(p.shape), p._version, p.numel())
-        self._pack_pairs = [(self._views[p.data_ptr()][0], self._packed[(id(p), tr)], tr) for b in self.reducer.buckets for p in b["params"]
-                            for tr in (False, True) if (id(p), tr) in self._packed]
+        self._pack_pairs = [(self._views[p.data_ptr()][0], self._packed[id(p)]) for b in self.reducer.buckets for p in b["params"]
+                            if id(p) in self._packed]
         self._repack()
 
     def _repack(self):
         if self._pack_pairs:
             self._ops().pack_frag16_batch(self._pack_pairs)
 
-    def packed_view(self, p, transposed=False):
-        """fragment-major copy (of_pack_frag16) of parameter ``p``'s current bf16 copy -- transposed: of its transpose --, or None (not a
-        packed matrix / written behind our back)"""
-        pk = self._packed.get((id(p), bool(transposed)))
+    def packed_view(self, p):
+        """fragment-major copy (of_pack_frag16) of parameter ``p``'s current bf16 copy, or None (not a packed matrix / written behind our back)"""
+        pk = self._packed.get(id(p))
         return pk if pk is not None and self.bf16_view(p) is not None else None
 
     def bf16_view(self, p):

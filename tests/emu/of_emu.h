@@ -218,7 +218,6 @@ OF_DEV void of_sched_fence() {}
 #define OF_SCHED_GROUP(mask, n) ((void)0)
 OF_DEV int of_uniform(int v) { return v; }
 OF_DEV const void* of_uniform_ptr(const void* p) { return p; }
-OF_DEV const void* of_opaque_ptr(const void* p) { return p; }
 OF_DEV void of_wave_sync() { of_emu::wave_barrier(); }
 OF_DEV s16x4 of_lds_tr(const void* p) {
     of_emu::Block* blk = of_emu::g_blk;
@@ -254,8 +253,6 @@ struct of_buf_t {
 OF_DEV of_buf_t of_buf_make(const void* base) { return of_buf_t{(const char*)base}; }
 OF_DEV u32x4 of_buf_load16(of_buf_t b, unsigned voff, unsigned soff) { return *(const u32x4*)(b.base + voff + soff); }
 OF_DEV void of_buf_store16(of_buf_t b, unsigned voff, unsigned soff, u32x4 v) { *(u32x4*)(const_cast<char*>(b.base) + voff + soff) = v; }
-OF_DEV u32x2 of_buf_load8(of_buf_t b, unsigned voff, unsigned soff) { return *(const u32x2*)(b.base + voff + soff); }
-OF_DEV void of_buf_store8(of_buf_t b, unsigned voff, unsigned soff, u32x2 v) { *(u32x2*)(const_cast<char*>(b.base) + voff + soff) = v; }
 OF_DEV void of_buf_store16_sys(of_buf_t b, unsigned voff, unsigned soff, u32x4 v) { of_buf_store16(b, voff, soff, v); }
 OF_DEV u32x4 of_buf_load16_sys(of_buf_t b, unsigned voff, unsigned soff) { return of_buf_load16(b, voff, soff); }
 template <bool TRSAFE = true>

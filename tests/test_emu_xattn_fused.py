@@ -139,54 +139,3 @@ def test_shapes_the_fused_kernel_does_not_take_run_the_separate_launches(ops):
                                  probe_only=True)
         assert not ok, kw
 
-
-# ---- backward: dq Wq -> LayerNorm backward in one launch (of_xattn_dq_ln_bwd) ---------------------------------------------------------
-def test_pack_frag16_of_the_transpose(ops):
-    g = torch.Generator().manual_seed(4)
-    K, N = 64, 48                                            # W is (K, N): the copy is of W^T (N x K)
-    W = torch.randn(K, N + 8, generator=g).to(BF16)[:, :N]
-    P = ops.pack_frag16_t(W).view(N // 16, K // 32, 64, 8)
-    Wt = W.t().contiguous()
-    assert torch.equal(P, ops.pack_frag16(Wt).view(N // 16, K // 32, 64, 8))
-    for nt, ks, lane in ((0, 0, 0), (2, 1, 37), (1, 0, 63)):
-        assert torch.equal(P[nt, ks, lane], Wt[16 * nt + (lane & 15), 32 * ks + 8 * (lane >> 4):32 * ks + 8 * (lane >> 4) + 8])
-
-
-@pytest.mark.parametrize("d,stream_dtype,with_resid", [(256, F32, True), (512, F32, False), (1024, BF16, True), (2048, F32, True)])
-def test_dq_ln_bwd_equals_gemm_plus_layernorm_backward(ops, d, stream_dtype, with_resid):
-    g = torch.Generator().manual_seed(d)
-    rows = 64 if d < 2048 else 32
-    x = (torch.randn(rows, d, generator=g) * 1.3 + 0.2).to(stream_dtype)
-    Wq = (torch.randn(512, d, generator=g) * d ** -0.5).to(BF16)
-    dq = torch.randn(rows, 512, generator=g).to(BF16)
-    gamma = torch.rand(d, generator=g) + 0.5
-    resid = torch.randn(rows, d, generator=g).to(stream_dtype) if with_resid else None
-    xn, st = torch.empty(rows, d, dtype=BF16), torch.empty(rows, 2)
-    ops.ln_fwd(x, gamma, torch.zeros(d), xn, st)
-    # the two separate launches
-    dxn = torch.empty(rows, d, dtype=BF16)
-    ops.gemm(dq, Wq, dxn, tb=True)
-    dx0, dxb0 = torch.empty_like(x), (torch.empty(rows, d, dtype=BF16) if stream_dtype == F32 else None)
-    dw0, db0 = torch.full((d,), 0.25), torch.full((d,), -0.5)          # the kernels ADD into dw / db
-    ops.ln_bwd(dxn, x, st, gamma, resid=resid, dx=dx0, dx_bf16=dxb0, dw=dw0, db=db0)
-    # the one launch
-    dx1, dxb1 = torch.empty_like(x), (torch.empty(rows, d, dtype=BF16) if stream_dtype == F32 else None)
-    dw1, db1 = torch.full((d,), 0.25), torch.full((d,), -0.5)
-    assert ops.xattn_dq_ln_bwd(dq, ops.pack_frag16_t(Wq), x, st, gamma, resid, dx1, dxb1, dw1, db1)
-    # fp64 reference of the same mathematics on the same bf16 operands (dxn NOT rounded to bf16: what the fused launch computes)
-    xd, std = x.double(), st.double()
-    dxn_ref = dq.double() @ Wq.double()
-    xh = (xd - std[:, :1]) * std[:, 1:]
-    dyh = dxn_ref * gamma.double()
-    dx_ref = std[:, 1:] * (dyh - dyh.mean(1, keepdim=True) - xh * (dyh * xh).mean(1, keepdim=True)) + (resid.double() if with_resid else 0)
-    tol = 2e-2 if stream_dtype == BF16 else 2e-5
-    rel = lambda a, b: (a.double() - b).abs().max().item() / (b.abs().max().item() + 1e-12)
-    assert rel(dx1, dx_ref) <= tol, rel(dx1, dx_ref)
-    assert rel(dx1, dx_ref) <= rel(dx0, dx_ref) * 1.05 + 1e-6          # at least as close as the path with the bf16 round trip
-    assert rel(dw1 - 0.25, (dxn_ref * xh).sum(0)) <= 1e-4 and rel(db1 + 0.5, dxn_ref.sum(0)) <= 1e-4
-    assert rel(dw0 - 0.25, (dxn_ref * xh).sum(0)) <= 2e-2                # (the separate launches see dxn rounded to bf16)
-    if dxb1 is not None:
-        assert torch.equal(dxb1, dx1.to(BF16))
-    # shapes the kernel does not take
-    r8 = rows - 8
-    assert not ops.xattn_dq_ln_bwd(dq[:r8], None, x[:r8], st[:r8], gamma, None, dx1[:r8], None, dw1, db1, probe_only=True)
