@@ -19,6 +19,12 @@
 //      of the QK^T MFMA is permuted to match it), K / V of the head's 64-key block go through a wave-private LDS image, no barrier;
 //   4. to_out: wave w owns d / 8 output columns of all 32 rows, K = 512 from the LDS image of o, weight fragments as in 2.;
 //   5. epilogue: y1 = x + tanh(gate) * acc in the accumulator registers, row statistics across the 8 waves through LDS, u2 = LN_ff(y1).
+//
+// What it is bound by (round 6, phase stamps of the tools build, profiles/r06*_xattn_fused_probe*.jsonl; 256 workgroups = one per CU):
+// LayerNorm 19-24 us and epilogue 25 us are HBM / fabric phases (100 and 167 MB: 5-7 TB/s), to_q 22 and to_out 19 us are L2 phases
+// (every CU streams the two 2-MB weight matrices: 1 GB over the eight L2s, 17 us each at the measured ceiling), attention 7-10 us.  All
+// workgroups are in the same phase at the same time, so the phases ADD: ~105 us in the step against ~119 us for the five launches.  A
+// workgroup of more rows would halve the weight traffic but its LN(x) image does not fit the LDS (64 rows x 2048 bf16 = 256 KiB).
 #include "attn_core.h"
 
 namespace {

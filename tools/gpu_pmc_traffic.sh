@@ -12,7 +12,7 @@ import csv, glob, collections
 res = collections.OrderedDict()
 for f in sorted(glob.glob("gpurun_out/pmc_traffic_*/*/run_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if "gemm" in r["Kernel_Name"]:
+        if "gemm" in r["Kernel_Name"] or "xattn_fused" in r["Kernel_Name"]:
             res.setdefault((r["Kernel_Name"][:70], r["Grid_Size"], r["Counter_Name"]), []).append(float(r["Counter_Value"]))
 for k, v in res.items():
     print(k, [round(x) for x in v[:4]])

@@ -22,6 +22,11 @@ LAUNCHES = {
     "of_gemm_w4h_kernel<true, 3, 0>": ("0 1 3 w4h256x128 8192 8192 2048", 0,
         "ffn dX * gate * gelu'(a) + gate-gradient dot, 8192x8192x2048 (two workgroups per CU, 256x128 tiles)",
         2 * (8192 * 2048 + 2048 * 8192) + 2 * 8192 * 8192 + 2 * 8192 * 8192),
+    # the fused attention branch (not an of_gemm launch: bench.py does not quote it; here for the record): x once + once more for the residual is
+    # NOT counted twice -- algorithmic = x (fp32) + LN(x), q, o (bf16, saved) + y (fp32) + LN_ff(y) (bf16) + the two packed weights + k | v
+    "of_xattn_fused_fwd_kernel<2048>": ("xattn_fused_fwd 8192 2048", 0,
+        "LN -> to_q -> windowed attention -> to_out + gate + residual -> LN_ff, 8192 rows x 2048, 8 heads x 64, 2 x 64 media tokens per sequence",
+        4 * 8192 * 2048 + 2 * 8192 * 2048 + 2 * 2 * 8192 * 512 + 4 * 8192 * 2048 + 2 * 8192 * 2048 + 2 * 2 * 512 * 2048 + 2 * 4096 * 1024),
 }
 
 

@@ -7,6 +7,9 @@ import torch
 from open_flamingo_amd.train import sparse_rows, step, synthetic, towers
 from open_flamingo_amd.train.reducer import GradReducer
 
+if os.environ.get("STEP_REPEAT_FUSED_XATTN") == "0":          # the gated blocks' attention branch as five launches (round 6 comparison)
+    from open_flamingo_amd.hip import path as _path
+    _path.FUSED_XATTN = False
 towers.FAMILY["OF-wide-test"] = dict(lm="mpt", d=2048, layers=2, heads=16, vocab=1000, every=1)
 vkw = dict(width=64, layers=2, heads=2, patch=14, image=224)
 
