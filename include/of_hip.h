@@ -202,8 +202,9 @@ typedef struct OfAttnArgs {
     float* delta;             /* (batch,H,Lq) fp32 scratch: rowsum(dO*O), written by the dq pass */
     int safe;                 /* DEBUG / SELF-CHECK ONLY -- production callers pass 0 (auto: forward with K and V of a (batch, head)
                                  resident in LDS where that pays, else one workgroup per 64-query tile).  1 = tiled kernels with the
-                                 scalar-LDS transposed-fragment path, 2 = tiled kernels, 3 = resident-K/V forward whenever the two
-                                 images fit 160 KB: every value gives correct results, tests compare the forms with each other. */
+                                 scalar-LDS transposed-fragment path, 2 = tiled kernels (two-pass backward), 3 = resident-K/V forward whenever the
+                                 two images fit 160 KB and the single-pass backward whenever it applies (Lq, Lk <= 256, no text_time): every
+                                 value gives correct results, tests compare the forms with each other. */
     /* causal self-attention with ALiBi (the frozen MPT blocks); all zero/NULL for the two hot-path uses */
     int head_dim;             /* 0 or 64: 64;  128 */
     int causal;               /* 1: query i sees keys [0, i + 1 + Lk - Lq); text_time must be NULL */
@@ -212,8 +213,9 @@ typedef struct OfAttnArgs {
 } OfAttnArgs;
 
 int of_attn_fwd(const OfAttnArgs* args, void* stream);
-/* Backward = two passes (dq: one workgroup per query tile; dk/dv: one per key block) -- deterministic,
- * no atomics.  dq/dk/dv are bf16 (they feed the projection-weight GEMMs as operands).
+/* Backward = two passes (dq: one workgroup per query tile; dk/dv: one per key block), or -- short self-attention without
+ * text_time, Lq and Lk <= 256: the frozen MPT blocks -- one pass per (batch, head) (attn_bwd_res.hip); both deterministic,
+ * no atomics.  dq/dk/dv are bf16 (they feed the projection-weight GEMMs as operands).  `delta` is scratch of the two-pass form.
  * Alignment: q, k, v, o, dout, dq, dk, dv 16-byte aligned, every leading dimension a multiple of 8 elements (all loads and
  * stores are 16 bytes wide), else OF_E_ALIGN. */
 int of_attn_bwd(const OfAttnArgs* args, void* stream);

@@ -188,27 +188,6 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
 // tile of every wave needs key blocks <= t, block t+1 is in flight while step t computes; everything else loads all blocks
 // up front (32-80 KB: two workgroups per CU overlap each other).  Same arithmetic, masks and statistics as
 // of_attn_q_kernel<DH, false>; eligible when the two images fit the CU's 160 KB.
-template <int DH, bool TR, int NW>
-OF_DEV void dma_block(const bf16_t* __restrict__ src, long ld, long row0, long nrows, int rows_blk, int col0, int wave, int lane,
-                      char* img) {
-    constexpr int RPK = DH == 128 ? 4 : 8;          // rows per 1-KiB DMA piece
-    constexpr int LPR = 64 / RPK;                   // lanes (16-byte units) per row
-    const int r = lane / LPR, qpos = lane % LPR;
-    for (int pc = wave; pc * RPK < rows_blk; pc += NW) {
-        const int row = pc * RPK + r;               // row inside the 64-row block image
-        long arow = row0 + row;
-        if (arow >= nrows) arow = nrows - 1;        // rows past the end: finite data, their scores are masked / P = 0
-        int unit;                                    // 16-byte source unit of the row that belongs at LDS position qpos
-        if (!TR) {
-            unit = qpos ^ (DH == 128 ? (row & 15) : ((row >> 1) & 7));
-        } else {
-            const int c = (qpos >> 1) ^ (DH == 128 ? (row & 7) : ((row >> 1) & 3));
-            unit = (c << 1) | (qpos & 1);
-        }
-        of_glds16(src + (size_t)arow * ld + col0 + unit * 8, img + pc * 1024);
-    }
-}
-
 template <int DH, int NW>      // NW waves per workgroup: 8 at head dim 128 (128 KB of images -> one workgroup per CU), else 4
 OF_GLOBAL void OF_BOUNDS(NW * 64, 2) of_attn_fwd_res_kernel(OfAttnArgs p) {
     constexpr int NKS = DH / 32, NDT = DH / 16, IMG = 64 * DH * 2;
@@ -561,9 +540,19 @@ int launch_fwd(const OfAttnArgs& a, of_stream_t s) {
     if (a.safe == 1) return of_launch(of_attn_q_kernel<DH, false, true>, grid, 256, smem, s, a);
     return of_launch(of_attn_q_kernel<DH, false, false>, grid, 256, smem, s, a);
 }
+// the single-pass backward (attn_bwd_res.hip) or the two passes below
+bool bwd_single_pass(const OfAttnArgs& a) {
+    if (a.safe == 1 || a.safe == 2) return false;                // 1: scalar-LDS self-check path, 2: the two-pass kernels
+    if (!attn_bwd_res_fits(a)) return false;
+    if (a.safe == 3) return true;                                // self-check: the single pass whenever it fits
+    // one workgroup of 16 waves per (batch, head): worth it where a head has several query tiles re-reading several key blocks
+    // and the grid fills the chip (the frozen MPT blocks: 256 x 256, 512 heads per launch)
+    return a.Lq >= 128 && a.Lk >= 128 && (long)a.batch * a.heads >= 128;
+}
 template <int DH>
 int launch_bwd(const OfAttnArgs& a, of_stream_t s) {
     constexpr int IMG = 64 * DH * 2;
+    if (bwd_single_pass(a)) return attn_bwd_res_launch(a, s);
     of_dim3 gq{(unsigned)a.heads, (unsigned)((a.Lq + 63) / 64), (unsigned)a.batch};
     const size_t smem_q = 3 * IMG + 196 * sizeof(int);
     int rc = a.safe == 1 ? of_launch(of_attn_q_kernel<DH, true, true>, gq, 256, smem_q, s, a)

@@ -156,6 +156,37 @@ OF_DEV s16x8 frag_t2(const char* img, int off_dt, int kbase, int col_base, int l
     return f;
 }
 
+// LDS-DMA (global_load_lds, no VGPR staging) of rows of a row-major bf16 matrix into a block image: a 1-KiB piece = RPK whole rows.
+// The image swizzles of frag_n / frag_t are applied to the SOURCE address because the DMA destination is lane-linear.  Rows past the
+// end are clamped to the last row: finite data, their scores are masked / their probabilities 0.
+template <int DH, bool TR>
+OF_DEV void dma_piece(const bf16_t* __restrict__ src, long ld, long row0, long nrows, int col0, int pc, int lane, char* img) {
+    constexpr int RPK = DH == 128 ? 4 : 8;          // rows per 1-KiB DMA piece
+    constexpr int LPR = 64 / RPK;                   // lanes (16-byte units) per row
+    const int r = lane / LPR, qpos = lane % LPR;
+    const int row = pc * RPK + r;                   // row inside the block image
+    long arow = row0 + row;
+    if (arow >= nrows) arow = nrows - 1;
+    int unit;                                        // 16-byte source unit of the row that belongs at LDS position qpos
+    if (!TR) {
+        unit = qpos ^ (DH == 128 ? (row & 15) : ((row >> 1) & 7));
+    } else {
+        const int c = (qpos >> 1) ^ (DH == 128 ? (row & 7) : ((row >> 1) & 3));
+        unit = (c << 1) | (qpos & 1);
+    }
+    of_glds16(src + (size_t)arow * ld + col0 + unit * 8, img + pc * 1024);
+}
+template <int DH, bool TR, int NW>
+OF_DEV void dma_block(const bf16_t* __restrict__ src, long ld, long row0, long nrows, int rows_blk, int col0, int wave, int lane,
+                      char* img) {
+    constexpr int RPK = DH == 128 ? 4 : 8;
+    for (int pc = wave; pc * RPK < rows_blk; pc += NW) dma_piece<DH, TR>(src, ld, row0, nrows, col0, pc, lane, img);
+}
+
+// 16-byte slot `slot` of row `row` of a bf16 image with `row_bytes` per row (a multiple of 256): the 16 rows of a fragment read (same
+// slot) hit 16 different slots of a 256-byte bank row
+OF_DEV int ximg_off(int row, int slot, int row_bytes) { return row * row_bytes + ((slot & ~15) << 4) + (((slot & 15) ^ (row & 15)) << 4); }
+
 struct Window {
     int lo, hi, uni;
 };
@@ -314,4 +345,7 @@ OF_DEV void softmax_pv(f32x4 (&s)[4], float mb, const char* vimg, const FragOff<
     }
 }
 
+// attn_bwd_res.hip: dQ, dK, dV of one (batch, head) in one pass (short self-attention without text_time)
+bool attn_bwd_res_fits(const OfAttnArgs& a);
+int attn_bwd_res_launch(const OfAttnArgs& a, of_stream_t s);
 }  // namespace ofa

@@ -16,7 +16,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["gemm.hip", "gemm_pp.hip", "gemm_w4.hip", "gemm_w4m.hip", "gemm_w4h.hip", "gemm_w4s.hip", "gemm_mid.hip", "gemm_skinny.hip", "layernorm.hip", "attention.hip", "xattn_fused.hip", "elementwise.hip", "optim.hip", "loss.hip", "api.hip"]
+SOURCES = ["gemm.hip", "gemm_pp.hip", "gemm_w4.hip", "gemm_w4m.hip", "gemm_w4h.hip", "gemm_w4s.hip", "gemm_mid.hip", "gemm_skinny.hip", "layernorm.hip", "attention.hip", "attn_bwd_res.hip", "xattn_fused.hip", "elementwise.hip", "optim.hip", "loss.hip", "api.hip"]
 HEADERS = ["of_platform.h", "gemm_common.h", "gemm_tile256.h", "gemm_w4_epi.h", "attn_core.h", os.path.join(ROOT, "include", "of_hip.h")]
 # kernels of_gemm never selects (measured, kept with their tests and records): tools / emulator builds only, not in the product library
 TOOLS_ONLY_SOURCES = ["gemm_w4.hip", "gemm_w4s.hip"]

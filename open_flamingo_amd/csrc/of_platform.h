@@ -175,6 +175,12 @@ OF_DEV unsigned of_cycles() {
 OF_DEV void of_setprio_hi() { __builtin_amdgcn_s_setprio(1); }
 OF_DEV void of_setprio_lo() { __builtin_amdgcn_s_setprio(0); }
 // pins the instruction scheduler: nothing moves across this point
+// An integer the optimiser must treat as freshly defined here: values derived from it cannot be hoisted out of the enclosing loop (LLVM
+// hoists every loop-invariant address term and then SPILLS the lot when registers run out; re-deriving them per iteration is 1-2 VALU).
+OF_DEV int of_opaque_i(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
 OF_DEV void of_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // asks the scheduler for exactly `n` instructions of class `mask` at this point of a pinned sequence (LLVM SchedGroupMask:
 // MFMA 0x8, VMEM read 0x20, DS read 0x100, DS write 0x200); compile-time only, the emulator ignores it

@@ -60,10 +60,6 @@ constexpr int X_REGION_A = 128 * 1024;      // LN(x) image (64 * d bytes), then 
 constexpr int X_OIMG = 32 * 1024;           // first gamma / beta of the LayerNorm (8 * d bytes), then the o image [32][512] bf16
 constexpr int X_SMEM = X_REGION_A + X_OIMG; // 160 KiB: one workgroup per CU
 
-// 16-byte slot `slot` of row `row` of a bf16 image with `row_bytes` per row: the 16 rows of a fragment read (same slot) hit 16
-// different slots of a 256-byte bank row
-OF_DEV int ximg_off(int row, int slot, int row_bytes) { return row * row_bytes + ((slot & ~15) << 4) + (((slot & 15) ^ (row & 15)) << 4); }
-
 OF_DEV void x_load8(const void* rowp, int is_f32, unsigned eo, float (&v)[8]) {
     if (is_f32) {
 #ifdef OF_XF_X_NT         // tools/ab builds only (round 6 A/B: the LayerNorm's read of x with the non-temporal policy)

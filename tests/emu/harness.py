@@ -65,7 +65,7 @@ def gemm(A, B, *, a_trans=0, b_trans=0, epi=abi.EPI_STORE_BF16, C_out=None, C2=N
 
 
 def attn_args(q, k, v, o, lse, text_time=None, n_per_media=0, T_img=0, only_immediate=1, heads=None, safe=0,
-              dout=None, dq=None, dk=None, dv=None, delta=None, head_dim=64, causal=0, alibi_slopes=None):
+              dout=None, dq=None, dk=None, dv=None, delta=None, head_dim=64, causal=0, alibi_slopes=None, kv_len=None):
     """q (batch,Lq,H*64) bf16; k,v (batch,Lk,H*64) bf16 (may be views into a fused kv buffer)."""
     a = abi.OfAttnArgs()
     a.q, a.k, a.v, a.o, a.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr()
@@ -78,6 +78,7 @@ def attn_args(q, k, v, o, lse, text_time=None, n_per_media=0, T_img=0, only_imme
     a.safe = safe
     a.head_dim, a.causal = head_dim, causal
     a.alibi_slopes = alibi_slopes.data_ptr() if alibi_slopes is not None else None
+    a.kv_len = kv_len.data_ptr() if kv_len is not None else None
     if dout is not None:
         a.dout, a.lddo = dout.data_ptr(), dout.stride(1)
         a.dq, a.lddq = dq.data_ptr(), dq.stride(1)

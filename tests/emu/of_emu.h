@@ -1,6 +1,6 @@
 // TEST INFRASTRUCTURE ONLY -- host SIMT emulator behind csrc/of_platform.h (OF_HOST_EMU builds).
 //
-// One workgroup = up to 256 ucontext fibers (one per lane) scheduled round-robin on one OS thread;
+// One workgroup = up to 1024 ucontext fibers (one per lane) scheduled round-robin on one OS thread;
 // workgroups of a grid are distributed over OS threads.  Barriers and the wave-level collectives
 // (MFMA 16x16x32 bf16, ds_read_b64_tr_b16, shuffles) are implemented with the lane->element maps
 // documented in /opt/skills/guides/cdna_hip_programming.md section 2-3, so a kernel whose tile /
@@ -26,7 +26,7 @@
 typedef void* of_stream_t;
 
 namespace of_emu {
-constexpr int kMaxThreads = 512;
+constexpr int kMaxThreads = 1024;
 constexpr size_t kStack = 256 * 1024;
 struct Block {
     int nthreads = 0;
@@ -38,7 +38,7 @@ struct Block {
     bool done[kMaxThreads];
     int cur = 0;
     int blk_count = 0, blk_gen = 0;
-    int wave_count[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wave_gen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int wave_count[16] = {}, wave_gen[16] = {};
     alignas(16) char xchg[kMaxThreads][64];
     std::function<void()> body;
 };
@@ -83,7 +83,7 @@ inline void run_block(Block* b) {
         makecontext(&b->ctx[t], (void (*)())trampoline, 0);
     }
     b->blk_count = 0;
-    for (int w = 0; w < 8; ++w) b->wave_count[w] = 0;
+    for (int w = 0; w < 16; ++w) b->wave_count[w] = 0;
     int remaining = b->nthreads;
     while (remaining > 0) {
         for (int t = 0; t < b->nthreads; ++t) {
@@ -187,6 +187,22 @@ OF_DEV void of_accbank_zero(of_accbank_t& bank) {
     for (int k = 0; k < 32; ++k) bank.v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 OF_DEV f32x4 of_accbank_read(of_accbank_t& bank, int k) { return bank.v[k]; }
+// the 64-tile bank of csrc/of_accbank64.h
+struct of_accbank64_t {
+    f32x4 v[64];
+};
+OF_DEV void of_accbank64_mfma(of_accbank64_t& bank, int k, s16x8 a, s16x8 b) { bank.v[k] = of_mfma(a, b, bank.v[k]); }
+OF_DEV void of_accbank64_zero(of_accbank64_t& bank) {
+    for (int k = 0; k < 64; ++k) bank.v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+OF_DEV f32x4 of_accbank64_read(of_accbank64_t& bank, int k) { return bank.v[k]; }
+OF_DEV f32x4 of_mfma_v0(s16x8 a, s16x8 b) { return of_mfma(a, b, f32x4{0.f, 0.f, 0.f, 0.f}); }
+OF_DEV void of_mfma_v(s16x8 a, s16x8 b, f32x4& c) { c = of_mfma(a, b, c); }
+OF_DEV void of_mfma_settle4(f32x4&, f32x4&, f32x4&, f32x4&) {}
+OF_DEV void of_mfma_settle2(f32x4&, f32x4&) {}
+OF_DEV void of_mfma_operands4(s16x8&, s16x8&, s16x8&, s16x8&) {}
+OF_DEV void of_mfma_operands2(s16x8&, s16x8&) {}
+OF_DEV void of_mfma_guard_nomem() {}
 OF_DEV void of_acc_pin(f32x4&) {}
 OF_DEV void of_mfma_acc_guard() {}
 OF_DEV f32x16 of_mfma32(s16x8 a, s16x8 b, f32x16 c) {
@@ -215,6 +231,7 @@ OF_DEV unsigned of_cycles() { return 0; }
 OF_DEV void of_setprio_hi() {}
 OF_DEV void of_setprio_lo() {}
 OF_DEV void of_sched_fence() {}
+OF_DEV int of_opaque_i(int v) { return v; }
 #define OF_SCHED_GROUP(mask, n) ((void)0)
 OF_DEV int of_uniform(int v) { return v; }
 OF_DEV const void* of_uniform_ptr(const void* p) { return p; }

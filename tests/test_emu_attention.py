@@ -165,3 +165,69 @@ def test_causal_alibi_self_attention(dh, safe, Lq, Lk):
         assert torch.isfinite(got).all(), name
         err = (got - want).abs().max().item()
         assert err <= 2e-2 * (want.abs().max().item() + 1e-6), f"{name}: {err:.3e}"
+
+
+def _bwd_both_forms(q, k, v, heads, dh, **kw):
+    """forward once (tiled), then the backward as two passes (safe = 2) and as the single pass (safe = 3)"""
+    B, Lq, _ = q.shape
+    o = torch.full_like(q, float("nan"))
+    lse = torch.full((B, heads, Lq), float("nan"))
+    H.attn_fwd(H.attn_args(q, k, v, o, lse, heads=heads, safe=2, head_dim=dh, **kw))
+    dout = _r(q.shape, 77)
+    outs = []
+    for safe in (2, 3):
+        dq, dk, dv = torch.full_like(q, float("nan")), torch.full_like(k, float("nan")), torch.full_like(v, float("nan"))
+        delta = torch.zeros(B, heads, Lq)
+        H.attn_bwd(H.attn_args(q, k, v, o, lse, dout=dout, dq=dq, dk=dk, dv=dv, delta=delta, heads=heads, safe=safe, head_dim=dh, **kw))
+        outs.append((dq, dk, dv))
+    return dout, outs
+
+
+@pytest.mark.parametrize("dh,L", [(128, 256), (64, 256), (128, 200), (64, 136)])
+def test_single_pass_backward_equals_the_two_passes(dh, L):
+    """attn_bwd_res.hip (one workgroup per (batch, head): dQ, dK, dV from one recomputation of P) against the two-pass kernels at the
+    frozen MPT blocks' shape (causal, ALiBi, L = 256, head 128) and at ragged lengths: dV accumulates over the query tiles in the same
+    order with the same bf16 P (bit-equal); delta = rowsum(dO o O) is summed in another fp32 order, so a few dS round the other way
+    (dK, dQ: 1 bf16 ulp), and dQ sums dS K over the keys in another order."""
+    heads, B = 2, 1
+    q, k, v = _r((B, L, heads * dh), 81), _r((B, L, heads * dh), 82), _r((B, L, heads * dh), 83)
+    slopes = torch.tensor([0.25, 0.015625])
+    dout, (two, one) = _bwd_both_forms(q, k, v, heads, dh, causal=1, alibi_slopes=slopes)
+    for name, a, b in zip(("dq", "dk", "dv"), one, two):
+        assert torch.isfinite(a.float()).all(), name
+        err = (a.float() - b.float()).abs().max().item()
+        assert err <= 8e-3 * b.float().abs().max().item(), (name, err)
+    assert torch.equal(one[2], two[2])
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    ref = dense_attention(qd, kd, vd, heads, head_dim=dh, causal=True, alibi_slopes=slopes)
+    ref.backward(dout.double())
+    for name, got, want in (("dq", one[0], qd.grad), ("dk", one[1], kd.grad), ("dv", one[2], vd.grad)):
+        err = (got.double() - want).abs().max().item()
+        assert err <= 2e-2 * (want.abs().max().item() + 1e-6), f"{name}: {err:.3e}"
+
+
+def test_single_pass_backward_key_lengths_prefix_and_no_mask():
+    """right-padded sequences (kv_len), queries aligned to the end of a longer key sequence, and no mask at all"""
+    heads, B, dh = 2, 3, 128
+    q, k, v = _r((B, 96, heads * dh), 91), _r((B, 96, heads * dh), 92), _r((B, 96, heads * dh), 93)
+    kv_len = torch.tensor([96, 50, 17], dtype=torch.int32)
+    _, (two, one) = _bwd_both_forms(q, k, v, heads, dh, causal=1, alibi_slopes=torch.tensor([0.5, 0.0625]), kv_len=kv_len)
+    for a, b in zip(one, two):
+        assert torch.isfinite(a.float()).all()
+        assert (a.float() - b.float()).abs().max() <= 8e-3 * b.float().abs().max()
+    assert (one[1][1, 50:] == 0).all() and (one[2][2, 17:] == 0).all()       # padding keys get no gradient
+    q2 = _r((B, 72, heads * dh), 94)
+    for kw in (dict(causal=1), dict()):                                      # Lq < Lk causal (KV prefix); no mask (ViT-like)
+        _, (two, one) = _bwd_both_forms(q2, k, v, heads, dh, **kw)
+        for a, b in zip(one, two):
+            assert torch.isfinite(a.float()).all()
+            assert (a.float() - b.float()).abs().max() <= 8e-3 * b.float().abs().max()
+
+
+def test_single_pass_backward_is_not_taken_with_text_time_or_long_sequences():
+    """of_attn_bwd's selection: media windows (text_time) and L > 256 stay on the two-pass kernels even under safe = 3"""
+    heads, dh, L = 1, 64, 320
+    q, k, v = _r((1, L, dh), 95), _r((1, L, dh), 96), _r((1, L, dh), 97)
+    _, (two, one) = _bwd_both_forms(q, k, v, heads, dh, causal=1)
+    for a, b in zip(one, two):
+        assert torch.equal(a, b)
