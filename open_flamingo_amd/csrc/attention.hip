@@ -545,9 +545,16 @@ bool bwd_single_pass(const OfAttnArgs& a) {
     if (a.safe == 1 || a.safe == 2) return false;                // 1: scalar-LDS self-check path, 2: the two-pass kernels
     if (!attn_bwd_res_fits(a)) return false;
     if (a.safe == 3) return true;                                // self-check: the single pass whenever it fits
-    // one workgroup of 16 waves per (batch, head): worth it where a head has several query tiles re-reading several key blocks
-    // and the grid fills the chip (the frozen MPT blocks: 256 x 256, 512 heads per launch)
-    return a.Lq >= 128 && a.Lk >= 128 && (long)a.batch * a.heads >= 128;
+#ifdef OF_AB_ATTN_BWD_TWO_PASS                                    // tools/ab builds only (step-level A/B of the two forms)
+    return false;
+#endif
+    // One workgroup of 4 waves per (batch, head), one per CU, ~49 us each at 256 x 256 x 128; the two passes cost ~0.27 us per head
+    // of a full chip (profiles/r06z*_attn_bwd_single_pass_probe*.jsonl: 98 vs 139 us at the frozen MPT-1B blocks' 512 heads).  The
+    // single pass wins where its rounds of OF_NUM_CUS workgroups are at least ~70 % full: 512 or 256 heads yes, MPT-7B's 320
+    // (B 10 x 32 heads: two rounds for 1.25 rounds of work) no.
+    if (a.Lq < 128 || a.Lk < 128) return false;
+    const long n = (long)a.batch * a.heads, rounds = (n + OF_NUM_CUS - 1) / OF_NUM_CUS;
+    return 10 * n >= 7 * rounds * OF_NUM_CUS;
 }
 template <int DH>
 int launch_bwd(const OfAttnArgs& a, of_stream_t s) {

@@ -54,6 +54,7 @@ namespace {
 constexpr int BR_NW = 4;           // waves; each owns four 16-key tiles of Lk <= 256
 constexpr int BR_KT = 4;           // key tiles per wave: tile j of wave w = keys 16 (4 j + w) ..
 constexpr int BR_QT = 32;          // query rows per tile
+constexpr bool BR_REG_STAGE = true; // query tiles and K through registers instead of LDS-DMA (see tile_load)
 constexpr int BR_DSROW = 512;      // bytes per query row of the dS image (256 keys bf16)
 
 template <int N>
@@ -113,6 +114,32 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_attn_bwd_res_kernel(OfAttnArgs p) {
             dma_piece<DH, false>(im ? dob : qb, im ? p.lddo : p.ldq, (long)qi * BR_QT, p.Lq, hc, pc, lane, base + im * TIMG);
         }
     };
+    // the same tile through registers (BR_REG_STAGE): an LDS-DMA instruction holds its wave for ~165 ns here (one wave per SIMD: nothing
+    // else issues meanwhile), a plain global load does not; the loads of tile qi + 1 are issued at the top of tile qi and written
+    // to the other buffer at its end.  Thread t: 16-byte chunk (c 256 + t) & 15 of row (c 256 + t) >> 4 (DH 128).
+    constexpr int TCH = TIMG / 16 / 256;                           // 16-byte chunks per thread and image
+    struct TileRegs {
+        u32x4 q[TCH], d[TCH];
+    };
+    auto tile_load = [&](int qi, TileRegs& tr, int tid) OF_INLINE_LAMBDA {
+#pragma unroll
+        for (int c = 0; c < TCH; ++c) {
+            const int id = c * 256 + tid, row = id / (DH / 8), cs = id % (DH / 8);
+            long arow = (long)qi * BR_QT + row;
+            if (arow >= p.Lq) arow = p.Lq - 1;
+            tr.q[c] = *(const u32x4*)(qb + (size_t)arow * p.ldq + hc + cs * 8);
+            tr.d[c] = *(const u32x4*)(dob + (size_t)arow * p.lddo + hc + cs * 8);
+        }
+    };
+    auto tile_store = [&](int qi, const TileRegs& tr, int tid) OF_INLINE_LAMBDA {
+        char* base = qd + (qi & 1) * 2 * TIMG;
+#pragma unroll
+        for (int c = 0; c < TCH; ++c) {
+            const int id = c * 256 + tid, row = id / (DH / 8), cs = id % (DH / 8);
+            *(u32x4*)(base + img_n_off<DH>(row, cs)) = tr.q[c];
+            *(u32x4*)(base + TIMG + img_n_off<DH>(row, cs)) = tr.d[c];
+        }
+    };
     // delta / lse of tile qi: 8 threads per row, EPT elements each
     struct Stat {
         u32x4 o[EPT / 8], d[EPT / 8];
@@ -147,15 +174,40 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_attn_bwd_res_kernel(OfAttnArgs p) {
     };
 
     // prologue: tile 0, this wave's K / V fragments, the resident K image, tile 0's statistics
-    issue_tile(0, lane);
+    TileRegs tr0;
+    if (BR_REG_STAGE) tile_load(0, tr0, tid);
+    else issue_tile(0, lane);
     s16x8 vf[BR_KT][NKS];                                          // K fragments are read from the resident image tile by tile
 #pragma unroll
     for (int j = 0; j < BR_KT; ++j)
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) vf[j][ks] = gload_frag(vb_ptr, p.ldv, key0 + 64 * j, p.Lk, hc + ks * 32 + g * 8);
-    for (int kb = 0; kb * 64 < lk32; ++kb) {
-        const int rows_blk = lk32 - kb * 64 < 64 ? lk32 - kb * 64 : 64;
-        dma_block<DH, false, BR_NW>(kb_ptr, p.ldk, (long)kb * 64, p.Lk, rows_blk, hc, wave, lane, k_img + (size_t)kb * IMG);
+    if (BR_REG_STAGE) {
+        // K: 64 rows per block, thread t: chunk (c 256 + t) & 15 of row (c 256 + t) >> 4; all blocks in flight at once
+        constexpr int KCH = IMG / 16 / 256;
+        u32x4 kr[4][KCH];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) {
+                const int id = c * 256 + tid, row = id / (DH / 8), cs = id % (DH / 8);
+                long arow = (long)b * 64 + row;
+                if (arow >= p.Lk) arow = p.Lk - 1;
+                kr[b][c] = *(const u32x4*)(kb_ptr + (size_t)arow * p.ldk + hc + cs * 8);
+            }
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) {
+                const int id = c * 256 + tid, row = id / (DH / 8), cs = id % (DH / 8);
+                *(u32x4*)(k_img + (size_t)b * IMG + img_n_off<DH>(row, cs)) = kr[b][c];
+            }
+        tile_store(0, tr0, tid);
+    } else {
+        for (int kb = 0; kb * 64 < lk32; ++kb) {
+            const int rows_blk = lk32 - kb * 64 < 64 ? lk32 - kb * 64 : 64;
+            dma_block<DH, false, BR_NW>(kb_ptr, p.ldk, (long)kb * 64, p.Lk, rows_blk, hc, wave, lane, k_img + (size_t)kb * IMG);
+        }
     }
     {
         Stat st;
@@ -186,7 +238,11 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_attn_bwd_res_kernel(OfAttnArgs p) {
         const bool more = qi + 1 < nqt;
         // per-iteration copies the optimiser cannot hoist address terms out of (of_opaque_i)
         const int lane_i = of_opaque_i(lane), fo_n = of_opaque_i(fo_n0), fo_t = of_opaque_i(fo_t0);
-        if (more) issue_tile(qi + 1, lane_i);
+        TileRegs trn;
+        if (more) {
+            if (BR_REG_STAGE) tile_load(qi + 1, trn, of_opaque_i(tid));
+            else issue_tile(qi + 1, lane_i);
+        }
         BR_STAMP_ADD(2);
         const int last_row = q0 + BR_QT - 1 < p.Lq ? q0 + BR_QT - 1 : p.Lq - 1;
         const int hi_first = of_uniform(row_hi(q0)), hi_last = of_uniform(row_hi(last_row));   // row_hi grows with the row
@@ -326,7 +382,10 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_attn_bwd_res_kernel(OfAttnArgs p) {
         }
         BR_STAMP_ADD(7);
         of_wait_vm<0>();               // the next tile's images and statistics (and, long since, the previous tile's dq stores)
-        if (more) stat_finish(qi + 1, st);
+        if (more) {
+            if (BR_REG_STAGE) tile_store(qi + 1, trn, of_opaque_i(tid));
+            stat_finish(qi + 1, st);
+        }
         {
             const int row = q0 + p2_qs * 16 + i16;
             const bool live = row < p.Lq;

@@ -451,7 +451,6 @@ OF_HOSTDEV size_t of_gemm_dot_slots(const OfGemmArgs& a) { return (size_t)((a.M 
 OF_HOSTDEV size_t of_gemm_dot_bytes(const OfGemmArgs& a) {
     return of_gemm_has_dot(a) ? ((of_gemm_dot_slots(a) * sizeof(float) + 255) & ~(size_t)255) : 0;
 }
-constexpr int OF_NUM_CUS = 256;      // MI355X
 // several problems in one grid (gemm_mid.hip: of_gemm_mid_batch_kernel; gemm.hip: of_gemm_batch, of_splitk_reduce_batch_kernel)
 constexpr int OF_GEMM_BATCH_MAX = 4;
 struct OfGemmBatchArgs {

@@ -21,6 +21,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 struct of_dim3 {
     unsigned x, y, z;
 };
+constexpr int OF_NUM_CUS = 256;      // MI355X
 
 #ifndef OF_HOST_EMU
 // =============================================================================== gfx950 device build

@@ -822,3 +822,45 @@ def test_product_library_takes_no_kernel_forcing_selector():
     want = out.clone()
     ops.gemm(A, B, out, safe=1)
     assert torch.equal(out, want)
+
+
+@pytest.mark.parametrize("dh,heads,B,L,causal", [(128, 16, 32, 256, True), (64, 16, 16, 256, True), (128, 16, 16, 200, True), (128, 8, 32, 256, False)])
+def test_single_pass_backward_matches_the_two_passes_at_tower_shapes(ops, dh, heads, B, L, causal):
+    """of_attn_bwd's single-pass form (csrc/attn_bwd_res.hip: dQ, dK, dV of a (batch, head) from one recomputation of P) at the shape
+    it is selected for -- the frozen MPT blocks of OF-3B: 32 x 16 heads, 256 x 256, head 128, causal + ALiBi, q | k | v views of the
+    fused projection -- and at head 64 / a ragged length / no mask: of_attn_bwd's own choice (safe = 0) and the forced form (3) against the
+    two-pass kernels (2) and against autograd through a dense fp32 softmax."""
+    d = heads * dh
+    qkv = _r((B * L, 3 * d), 73)
+    do = _r((B * L, d), 74)
+    slopes = torch.tensor([2.0 ** (-8.0 * (i + 1) / heads) for i in range(heads)], device="cuda") if causal else None
+    kw = dict(batch=B, Lq=L, Lk=L, heads=heads, scale=dh ** -0.5, head_dim=dh, causal=causal, alibi_slopes=slopes)
+    o = torch.empty(B * L, d, device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(B, heads, L, device="cuda")
+    ops.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, **kw)
+    outs = {}
+    for safe in (0, 3, 2):
+        dqkv = torch.full_like(qkv, float("nan"))
+        delta = torch.zeros(B, heads, L, device="cuda")
+        ops.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, do, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], delta, safe=safe, **kw)
+        assert torch.isfinite(dqkv.float()).all(), safe
+        outs[safe] = dqkv
+    if 10 * B * heads >= 7 * 256 * ((B * heads + 255) // 256):
+        assert torch.equal(outs[0], outs[3]), "of_attn_bwd did not choose the single pass at a shape its rule covers"
+    assert _rel(outs[3], outs[2].double()) < 4e-3
+    # run to run: bit-reproducible (no atomics, fixed order)
+    again = torch.full_like(qkv, float("nan"))
+    ops.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, do, again[:, :d], again[:, d:2 * d], again[:, 2 * d:],
+                 torch.zeros(B, heads, L, device="cuda"), safe=3, **kw)
+    assert torch.equal(again, outs[3])
+    nb = min(B, 4)                                   # autograd reference on the first sequences
+    x = qkv[:nb * L].float().requires_grad_(True)
+    q, k, v = (x[:, i * d:(i + 1) * d].view(nb, L, heads, dh).transpose(1, 2) for i in range(3))
+    s = q @ k.transpose(-1, -2) * dh ** -0.5
+    if causal:
+        pos = torch.arange(L, device="cuda")
+        s = s + slopes.view(1, heads, 1, 1) * (pos.view(1, 1, 1, L) - pos.view(1, 1, L, 1))
+        s = s.masked_fill(pos.view(1, 1, 1, L) > pos.view(1, 1, L, 1), float("-inf"))
+    (s.softmax(-1) @ v).transpose(1, 2).reshape(nb * L, d).backward(do[:nb * L].float())
+    for i, name in enumerate(("dq", "dk", "dv")):
+        assert _rel(outs[3][:nb * L, i * d:(i + 1) * d], x.grad[:, i * d:(i + 1) * d]) < 2e-2, name
