@@ -5,14 +5,20 @@
 // dO twice (12 tensor passes); the frozen MPT blocks behind every gated block (reference flamingo_lm.py:63-65 -> HF MptAttention:
 // 16 heads x 128, L = 256, causal, ALiBi) spend 69 + 69 us per layer there.  Here (8 tensor passes):
 //   * 4 waves, one per SIMD, 512 registers each; wave w owns the 16-key MFMA tiles w, w + 4, w + 8, w + 12 (one of every 64-key
-//     block: causal work is balanced over the SIMDs): their V fragments stay in registers (K comes from the resident LDS image), dK^T / dV^T accumulate in registers
-//     over all query tiles (no atomics, fixed order: bit-reproducible);
+//     block: causal work is balanced over the SIMDs): their V fragments stay in registers, K in an LDS image that serves the plain
+//     and the transpose fragment reads; dK^T / dV^T accumulate over all query tiles in 256 FIXED accumulation registers
+//     (of_accbank64.h; no atomics, fixed order: bit-reproducible), every MFMA is inline asm (see there for why);
 //   * queries stream through LDS in tiles of 32 rows (Q and dO, one image each that serves the plain and the transpose fragment reads,
-//     LDS-DMA, double buffered: tile i + 1 lands while tile i is multiplied); every fragment read serves all key tiles of the wave;
+//     loaded through registers, double buffered: tile i + 1 lands while tile i is multiplied); every fragment read serves all key
+//     tiles of the wave; K blocks and V fragments arrive one tile before the first query tile that sees them;
 //   * phase 1 of a tile, per wave: S = Q K^T and dP = dO V^T of its visible keys x 32 queries, P = exp2(S - lse), dS = P (dP - delta);
 //     dV^T += dO^T P, dK^T += Q^T dS; dS (bf16, the operand the dK MFMA takes) also goes to an LDS image [32 queries][256 keys];
 //   * phase 2, after one barrier: four dQ^T tiles (64 d x 16 queries) per wave = K^T (transpose reads of the LDS-resident K image) x
 //     dS^T over the visible keys; scaled, stored.  delta = rowsum(dO o O) and lse of the NEXT tile are fetched under phase 2.
+// Measured (frozen MPT-1B blocks of OF-3B: 32 x 16 heads, behind a 512-MB copy; profiles/r06z*_attn_bwd_single_pass_probe*.jsonl):
+// 96-98 us against 139 us for the two passes; per workgroup 46 us = prologue 6 + S / dP + softmax 12 + dV / dK 6 + phase 2 6 + load issue
+// 4 + waits 7 + epilogue 4, two rounds of 256.  What it is bound by: instruction issue of ONE wave per SIMD (the 512-register budget the
+// 64 keys x 128 x 2 fp32 accumulators force) -- MFMA, softmax VALU and LDS waits of a wave run in series.
 // Two barriers per 32 queries.  Same arithmetic as the two-pass kernels (log2-domain scores, bf16 P / dS operands, fp32 sums): dV comes
 // out bit-identical; delta is summed in another fp32 order (a few dS round the other way: dK, dQ differ by a bf16 ulp here and there)
 // and dQ adds its products over the keys in another order.
@@ -25,8 +31,8 @@ using namespace ofa;
 #if defined(OF_TOOLS_BUILD) && !defined(OF_HOST_EMU)
 // tools/libofhip_tools.so only (tools/probes/attn_bwd_single_pass_probe.py): wave 0 of every workgroup records the 100-MHz wall clock at
 // entry [0], after the prologue [1], at the start of the epilogue [11] and at exit [10], and sums over the query tiles: issue of the next
-// tile's DMA [2], S / dP + softmax [3], dS writes + dV / dK MFMAs [4], issue of the statistics loads [5], wait at the dS barrier [6],
-// phase 2 [7], wait for the next tile's DMA + statistics + dQ store [8], wait at the tile barrier [9]
+// tile's loads [2], S / dP + softmax [3], dS writes + dV / dK MFMAs [4], issue of the statistics loads and of the next K block / V
+// fragments [5], wait at the dS barrier [6], phase 2 [7], wait for those loads + LDS writes + statistics + dQ store [8], wait at the tile barrier [9]
 __device__ unsigned long long* of_br_stamps = nullptr;
 }
 extern "C" int of_tools_set_br_stamp_buffer(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(of_br_stamps), &p, sizeof(p)); }
@@ -54,7 +60,6 @@ namespace {
 constexpr int BR_NW = 4;           // waves; each owns four 16-key tiles of Lk <= 256
 constexpr int BR_KT = 4;           // key tiles per wave: tile j of wave w = keys 16 (4 j + w) ..
 constexpr int BR_QT = 32;          // query rows per tile
-constexpr bool BR_REG_STAGE = true; // query tiles and K through registers instead of LDS-DMA (see tile_load)
 constexpr int BR_DSROW = 512;      // bytes per query row of the dS image (256 keys bf16)
 
 template <int N>
@@ -105,18 +110,10 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_attn_bwd_res_kernel(OfAttnArgs p) {
     const int nqt = (p.Lq + BR_QT - 1) / BR_QT;
     const int lk32 = (p.Lk + 31) & ~31;
 
-    // tile DMA: 2 images x (32 rows / RPK) pieces; DH 128: 16 pieces = 4 per wave, DH 64: 8 pieces = 2 per wave
-    constexpr int PPI = BR_QT / (DH == 128 ? 4 : 8);              // pieces per image
-    auto issue_tile = [&](int qi, int lane) OF_INLINE_LAMBDA {
-        char* base = qd + (qi & 1) * 2 * TIMG;
-        for (int pp = wave; pp < 2 * PPI; pp += BR_NW) {
-            const int im = pp / PPI, pc = pp % PPI;
-            dma_piece<DH, false>(im ? dob : qb, im ? p.lddo : p.ldq, (long)qi * BR_QT, p.Lq, hc, pc, lane, base + im * TIMG);
-        }
-    };
-    // the same tile through registers (BR_REG_STAGE): an LDS-DMA instruction holds its wave for ~165 ns here (one wave per SIMD: nothing
-    // else issues meanwhile), a plain global load does not; the loads of tile qi + 1 are issued at the top of tile qi and written
-    // to the other buffer at its end.  Thread t: 16-byte chunk (c 256 + t) & 15 of row (c 256 + t) >> 4 (DH 128).
+    // Query tiles travel through registers: an LDS-DMA instruction holds its wave for ~165 ns here (one wave per SIMD: nothing else
+    // issues meanwhile; measured 4.6 us per head for 4 pieces per wave and tile), a plain global load does not.  The loads of tile
+    // qi + 1 are issued at the top of tile qi and written to the other buffer at its end.  Thread t: 16-byte chunk (c 256 + t) & 15
+    // of row (c 256 + t) >> 4 (DH 128).
     constexpr int TCH = TIMG / 16 / 256;                           // 16-byte chunks per thread and image
     struct TileRegs {
         u32x4 q[TCH], d[TCH];
@@ -173,42 +170,37 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_attn_bwd_res_kernel(OfAttnArgs p) {
         }
     };
 
-    // prologue: tile 0, this wave's K / V fragments, the resident K image, tile 0's statistics
-    TileRegs tr0;
-    if (BR_REG_STAGE) tile_load(0, tr0, tid);
-    else issue_tile(0, lane);
+    // K blocks (LDS image, LDS-DMA) and this wave's V fragments (registers) arrive when the first query tile that sees them is one
+    // tile away: causal self-attention needs block j from tile 2 j on, so the prologue loads a quarter of K and V and the rest
+    // arrives under the tiles before (no mask: everything here).  blocks_for(qi) = 64-key blocks tile qi reads.
+    const int nkb = (lk32 + 63) >> 6;
+    auto blocks_for = [&](int qi) OF_INLINE_LAMBDA -> int {
+        const int last = qi * BR_QT + BR_QT - 1 < p.Lq ? qi * BR_QT + BR_QT - 1 : p.Lq - 1;
+        const int nb = (row_hi(last) + 63) >> 6;
+        return nb < nkb ? nb : nkb;
+    };
     s16x8 vf[BR_KT][NKS];                                          // K fragments are read from the resident image tile by tile
 #pragma unroll
     for (int j = 0; j < BR_KT; ++j)
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) vf[j][ks] = gload_frag(vb_ptr, p.ldv, key0 + 64 * j, p.Lk, hc + ks * 32 + g * 8);
-    if (BR_REG_STAGE) {
-        // K: 64 rows per block, thread t: chunk (c 256 + t) & 15 of row (c 256 + t) >> 4; all blocks in flight at once
-        constexpr int KCH = IMG / 16 / 256;
-        u32x4 kr[4][KCH];
+        for (int ks = 0; ks < NKS; ++ks) vf[j][ks] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    auto load_blocks = [&](int from, int to, int lane) OF_INLINE_LAMBDA {
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int j = 0; j < BR_KT; ++j)
+            if (j >= from && j < to) {                              // workgroup-uniform
+                const int rows_blk = lk32 - j * 64 < 64 ? lk32 - j * 64 : 64;
+                dma_block<DH, false, BR_NW>(kb_ptr, p.ldk, (long)j * 64, p.Lk, rows_blk, hc, wave, lane, k_img + (size_t)j * IMG);
 #pragma unroll
-            for (int c = 0; c < KCH; ++c) {
-                const int id = c * 256 + tid, row = id / (DH / 8), cs = id % (DH / 8);
-                long arow = (long)b * 64 + row;
-                if (arow >= p.Lk) arow = p.Lk - 1;
-                kr[b][c] = *(const u32x4*)(kb_ptr + (size_t)arow * p.ldk + hc + cs * 8);
+                for (int ks = 0; ks < NKS; ++ks)          // row / column from the caller's lane copy: see of_opaque_i
+                    vf[j][ks] = gload_frag(vb_ptr, p.ldv, wave * 16 + (lane & 15) + 64 * j, p.Lk, hc + ks * 32 + (lane >> 4) * 8);
             }
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int c = 0; c < KCH; ++c) {
-                const int id = c * 256 + tid, row = id / (DH / 8), cs = id % (DH / 8);
-                *(u32x4*)(k_img + (size_t)b * IMG + img_n_off<DH>(row, cs)) = kr[b][c];
-            }
-        tile_store(0, tr0, tid);
-    } else {
-        for (int kb = 0; kb * 64 < lk32; ++kb) {
-            const int rows_blk = lk32 - kb * 64 < 64 ? lk32 - kb * 64 : 64;
-            dma_block<DH, false, BR_NW>(kb_ptr, p.ldk, (long)kb * 64, p.Lk, rows_blk, hc, wave, lane, k_img + (size_t)kb * IMG);
-        }
-    }
+    };
+    // prologue: tile 0, the K blocks / V fragments it needs, its statistics
+    TileRegs tr0;
+    tile_load(0, tr0, tid);
+    int loaded = of_uniform(blocks_for(0));
+    load_blocks(0, loaded, lane);
+    tile_store(0, tr0, tid);
     {
         Stat st;
         stat_issue(0, st, tid);
@@ -238,12 +230,6 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_attn_bwd_res_kernel(OfAttnArgs p) {
         const bool more = qi + 1 < nqt;
         // per-iteration copies the optimiser cannot hoist address terms out of (of_opaque_i)
         const int lane_i = of_opaque_i(lane), fo_n = of_opaque_i(fo_n0), fo_t = of_opaque_i(fo_t0);
-        TileRegs trn;
-        if (more) {
-            if (BR_REG_STAGE) tile_load(qi + 1, trn, of_opaque_i(tid));
-            else issue_tile(qi + 1, lane_i);
-        }
-        BR_STAMP_ADD(2);
         const int last_row = q0 + BR_QT - 1 < p.Lq ? q0 + BR_QT - 1 : p.Lq - 1;
         const int hi_first = of_uniform(row_hi(q0)), hi_last = of_uniform(row_hi(last_row));   // row_hi grows with the row
         const int ks_end = (hi_last + 31) >> 5;                      // 32-key steps phase 2 reads
@@ -253,34 +239,37 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_attn_bwd_res_kernel(OfAttnArgs p) {
 #pragma unroll
         for (int j = 0; j < BR_KT; ++j) nvis += 16 * (4 * j + wave) < hi_last ? 1 : 0;
         const bool last_full = nvis > 0 && 16 * (4 * (nvis - 1) + wave) + 16 <= hi_first && q0 + BR_QT <= p.Lq;
-        auto phase1 = [&](auto nv_c) OF_INLINE_LAMBDA {
+        u32x2 pk[BR_KT][2], dk2[BR_KT][2];                            // [key tile][query sub-tile]: packed P and dS
+        auto phase1a = [&](auto nv_c) OF_INLINE_LAMBDA {              // S, dP, P, dS of the wave's NV visible key tiles
             constexpr int NV = decltype(nv_c)::value;
-            u32x2 pk[NV][2], dk2[NV][2];                             // [key tile][query sub-tile]: packed P and dS
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 f32x4 s[NV], dp[NV];
-                // fragments of k-step ks + 1 are requested before the MFMAs of k-step ks (one wave per SIMD: nothing else hides the LDS latency)
-                s16x8 qf = frag_n2<DH>(q_img, fo_n, tt * 16), dof = frag_n2<DH>(do_img, fo_n, tt * 16);
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
-                    s16x8 qf_n = qf, dof_n = dof;
-                    if (ks + 1 < NKS) {
-                        qf_n = frag_n2<DH>(q_img, fo_n ^ ((ks + 1) << 6), tt * 16);
-                        dof_n = frag_n2<DH>(do_img, fo_n ^ ((ks + 1) << 6), tt * 16);
-                    }
+                    const s16x8 qf = frag_n2<DH>(q_img, fo_n ^ (ks << 6), tt * 16), dof = frag_n2<DH>(do_img, fo_n ^ (ks << 6), tt * 16);
+                    // K fragments two key tiles at a time: one LDS latency per pair, not per tile (all four: 8 more registers than there are)
 #pragma unroll
-                    for (int j = 0; j < NV; ++j) {
-                        const s16x8 kf = *(const s16x8*)(k_img + j * IMG + wave * 16 * DH * 2 + (fo_n ^ (ks << 6)));   // key0 + 64 j, k-step ks
-                        if (ks == 0) {
-                            s[j] = of_mfma_v0(qf, kf);
-                            dp[j] = of_mfma_v0(dof, vf[j][ks]);
-                        } else {
-                            of_mfma_v(qf, kf, s[j]);
-                            of_mfma_v(dof, vf[j][ks], dp[j]);
+                    for (int j0 = 0; j0 < NV; j0 += 2) {
+                        s16x8 kf[2];
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj)
+                            if (j0 + jj < NV) kf[jj] = *(const s16x8*)(k_img + (j0 + jj) * IMG + wave * 16 * DH * 2 + (fo_n ^ (ks << 6)));   // key0 + 64 j
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int j = j0 + jj;
+                            if (j < NV) {
+                                if (ks == 0) {
+                                    dp[j] = of_mfma_v0(dof, vf[j][ks]);
+                                    s[j] = of_mfma_v0(qf, kf[jj]);
+                                } else {
+                                    of_mfma_v(dof, vf[j][ks], dp[j]);
+                                    of_mfma_v(qf, kf[jj], s[j]);
+                                }
+                            }
                         }
                     }
-                    qf = qf_n;
-                    dof = dof_n;
+                    of_accbank64_fence();
                 }
 #pragma unroll
                 for (int j = 0; j < NV; ++j) of_mfma_settle2(s[j], dp[j]);
@@ -309,9 +298,12 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_attn_bwd_res_kernel(OfAttnArgs p) {
                     }
                     pk[j][tt] = u32x2{of_pack_bf16(pm[0], pm[1]), of_pack_bf16(pm[2], pm[3])};
                     dk2[j][tt] = u32x2{of_pack_bf16(ds[0], ds[1]), of_pack_bf16(ds[2], ds[3])};
+                    of_accbank64_fence();
                 }
             }
-            BR_STAMP_ADD(3);
+        };
+        auto phase1b = [&](auto nv_c) OF_INLINE_LAMBDA {              // dS to LDS; dV^T += dO^T P, dK^T += Q^T dS
+            constexpr int NV = decltype(nv_c)::value;
             s16x8 pf[NV], dsf[NV];
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
@@ -322,41 +314,52 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_attn_bwd_res_kernel(OfAttnArgs p) {
                     *(short*)(ds_img + (ds_off[e & 3] ^ ((j & 1) << 7)) + (j >> 1) * 256 + (e >> 2) * 16 * BR_DSROW) = dsf[j][e];
                 of_mfma_operands2(pf[j], dsf[j]);
             }
-            s16x8 a_do = frag_t2<DH, false>(do_img, fo_t, 0, 0, lane), a_q = frag_t2<DH, false>(q_img, fo_t, 0, 0, lane);
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
-                s16x8 a_do_n = a_do, a_q_n = a_q;
-                if (dt + 1 < NDT) {
-                    a_do_n = frag_t2<DH, false>(do_img, fo_t ^ ((dt + 1) << 5), 0, (dt + 1) * 16, lane);
-                    a_q_n = frag_t2<DH, false>(q_img, fo_t ^ ((dt + 1) << 5), 0, (dt + 1) * 16, lane);
-                }
+                const s16x8 a_do = frag_t2<DH, false>(do_img, fo_t ^ (dt << 5), 0, dt * 16, lane), a_q = frag_t2<DH, false>(q_img, fo_t ^ (dt << 5), 0, dt * 16, lane);
                 of_mfma_guard_nomem();
 #pragma unroll
                 for (int j = 0; j < NV; ++j) {
                     of_accbank64_mfma(bank, 2 * (j * NDT + dt), a_do, pf[j]);
                     of_accbank64_mfma(bank, 2 * (j * NDT + dt) + 1, a_q, dsf[j]);
                 }
-                a_do = a_do_n;
-                a_q = a_q_n;
             }
         };
-#ifndef BR_NO_SWITCH
-        if (nvis == 4) phase1(BrInt<4>{});
-        else if (nvis == 3) phase1(BrInt<3>{});
-        else if (nvis == 2) phase1(BrInt<2>{});
-        else if (nvis == 1) phase1(BrInt<1>{});
-#else
-        if (nvis > 0) phase1(BrInt<4>{});
-#endif
+        if (nvis == 4) phase1a(BrInt<4>{});
+        else if (nvis == 3) phase1a(BrInt<3>{});
+        else if (nvis == 2) phase1a(BrInt<2>{});
+        else if (nvis == 1) phase1a(BrInt<1>{});
+        of_accbank64_fence();
+        BR_STAMP_ADD(3);
+        // the next tile's loads: issued here, in code common to every nvis (a value loaded inside the variants is merged by register
+        // copies behind them -- which wait for the load), and behind the register peak of phase 1
+        TileRegs trn;
+        if (more) tile_load(qi + 1, trn, of_opaque_i(tid));
+        BR_STAMP_ADD(2);
+        if (nvis == 4) phase1b(BrInt<4>{});
+        else if (nvis == 3) phase1b(BrInt<3>{});
+        else if (nvis == 2) phase1b(BrInt<2>{});
+        else if (nvis == 1) phase1b(BrInt<1>{});
         // a tile no row sees but inside the last k-step phase 2 reads (its other half is visible): zeros
         if (nvis < BR_KT && 16 * (4 * nvis + wave) < ks_end * 32) {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 *(short*)(ds_img + (ds_off[e & 3] ^ ((nvis & 1) << 7)) + (nvis >> 1) * 256 + (e >> 2) * 16 * BR_DSROW) = 0;
         }
+        of_accbank64_fence();
         BR_STAMP_ADD(4);
         Stat st;
-        if (more) stat_issue(qi + 1, st, of_opaque_i(tid));
+        if (more) {
+            stat_issue(qi + 1, st, of_opaque_i(tid));
+            // K blocks / V fragments the NEXT tile is the first to see: requested behind phase 1 (which reads vf: requested in front of
+            // it, hipcc would make phase 1 wait for them), arrived at the wait that closes this tile
+            const int want = of_uniform(blocks_for(qi + 1));
+            if (want > loaded) {
+                load_blocks(loaded, want, of_opaque_i(lane));
+                loaded = want;
+            }
+        }
+        of_accbank64_fence();
         BR_STAMP_ADD(5);
         of_sync();
         BR_STAMP_ADD(6);
@@ -376,15 +379,19 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_attn_bwd_res_kernel(OfAttnArgs p) {
                     if (ks == 0) acc[j] = of_mfma_v0(a, b);
                     else of_mfma_v(a, b, acc[j]);
                 }
+                of_accbank64_fence();
             }
 #pragma unroll
             for (int j = 0; j < P2T; j += 2) of_mfma_settle2(acc[j], acc[j + 1]);
         }
         BR_STAMP_ADD(7);
-        of_wait_vm<0>();               // the next tile's images and statistics (and, long since, the previous tile's dq stores)
+        of_accbank64_fence();
+        of_wait_vm0_visible();         // the next tile's images and statistics (and, long since, the previous tile's dq stores)
         if (more) {
-            if (BR_REG_STAGE) tile_store(qi + 1, trn, of_opaque_i(tid));
+            tile_store(qi + 1, trn, of_opaque_i(tid));
+            of_accbank64_fence();
             stat_finish(qi + 1, st);
+            of_accbank64_fence();
         }
         {
             const int row = q0 + p2_qs * 16 + i16;
@@ -395,6 +402,7 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_attn_bwd_res_kernel(OfAttnArgs p) {
                 o2[j] = u32x2{of_pack_bf16(acc[j][0] * p.scale, acc[j][1] * p.scale), of_pack_bf16(acc[j][2] * p.scale, acc[j][3] * p.scale)};
             store_row_blocks(p.dq + ((size_t)batch * p.Lq + (live ? row : 0)) * p.lddq + hc + p2_dt * 16, o2, g, live);
         }
+        of_accbank64_fence();
         BR_STAMP_ADD(8);
         of_sync();
         BR_STAMP_ADD(9);

@@ -307,6 +307,13 @@ OF_DEV void of_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 OF_DEV void of_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// vmcnt(0) as an instruction hipcc's wait-count pass SEES (the asm form is opaque to it): registers loaded before it count as arrived,
+// so the pass does not add its own, conservative wait (vmcnt(0) again, behind younger loads) at their first use in the next loop iteration
+OF_DEV void of_wait_vm0_visible() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) expcnt(7) lgkmcnt(15)
+    asm volatile("" ::: "memory");
+}
 // bare s_barrier (no implicit vmcnt(0) drain, unlike __syncthreads with LDS-DMA in flight) -- fenced for the COMPILER on both
 // sides: llvm.amdgcn.s.barrier is IntrNoMem, so nothing but these two empty asm statements tells hipcc that LDS reads must not
 // move across it (the kernels' loops happen to have an asm s_waitcnt in front of every barrier; their prologues and epilogues do

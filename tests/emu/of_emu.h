@@ -196,6 +196,7 @@ OF_DEV void of_accbank64_zero(of_accbank64_t& bank) {
     for (int k = 0; k < 64; ++k) bank.v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 OF_DEV f32x4 of_accbank64_read(of_accbank64_t& bank, int k) { return bank.v[k]; }
+OF_DEV void of_accbank64_fence() {}
 OF_DEV f32x4 of_mfma_v0(s16x8 a, s16x8 b) { return of_mfma(a, b, f32x4{0.f, 0.f, 0.f, 0.f}); }
 OF_DEV void of_mfma_v(s16x8 a, s16x8 b, f32x4& c) { c = of_mfma(a, b, c); }
 OF_DEV void of_mfma_settle4(f32x4&, f32x4&, f32x4&, f32x4&) {}
@@ -264,6 +265,7 @@ OF_DEV void of_glds16_nt(const void* gsrc, void* lds_wave_base) { of_glds16<TRSA
 template <int N>
 OF_DEV void of_wait_vm() {}
 OF_DEV void of_wait_lgkm0() {}
+OF_DEV void of_wait_vm0_visible() {}
 struct of_buf_t {
     const char* base;
 };

@@ -107,8 +107,8 @@ if os.environ.get("BR_PHASES", "1") == "1":
         first = s[:, 0] - t0 < 5.0            # workgroups of the first round
         print(json.dumps({"probe": "attn_bwd_single_pass_phases", "cold": cold, "workgroups": B * H, "first_round_workgroups": int(first.sum()),
                           "prologue_us": med(s[:, 1] - s[:, 0]), "prologue_first_round_us": med((s[:, 1] - s[:, 0])[first]),
-                          "prologue_second_round_us": med((s[:, 1] - s[:, 0])[~first]) if (~first).any() else None, "sum_over_tiles_us": {"dma_issue": med(s[:, 2]), "s_dp_softmax": med(s[:, 3]),
-                          "ds_writes_dv_dk": med(s[:, 4]), "stat_issue": med(s[:, 5]), "wait_dS_barrier": med(s[:, 6]), "phase2_dq": med(s[:, 7]),
-                          "wait_dma_stats_store": med(s[:, 8]), "wait_tile_barrier": med(s[:, 9])}, "epilogue_us": med(s[:, 10] - s[:, 11]),
+                          "prologue_second_round_us": med((s[:, 1] - s[:, 0])[~first]) if (~first).any() else None, "sum_over_tiles_us": {"tile_load_issue": med(s[:, 2]), "s_dp_softmax": med(s[:, 3]),
+                          "ds_writes_dv_dk": med(s[:, 4]), "stats_and_block_loads_issue": med(s[:, 5]), "wait_dS_barrier": med(s[:, 6]), "phase2_dq": med(s[:, 7]),
+                          "wait_loads_lds_writes_stats_dq_store": med(s[:, 8]), "wait_tile_barrier": med(s[:, 9])}, "epilogue_us": med(s[:, 10] - s[:, 11]),
                           "workgroup_us": med(s[:, 10] - s[:, 0]), "second_round_entry_us": med((s[:, 0] - t0)[~first]) if (~first).any() else None,
                           "span_us": round(float((s[:, 10] - t0).max()), 1)}), flush=True)
