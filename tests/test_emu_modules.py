@@ -483,7 +483,7 @@ def test_padded_heads_do_not_add_to_gradients_the_step_epilogue_left_stale(on_em
 
 def test_fused_attention_branch_inside_a_train_step_and_its_packed_weights_follow_the_optimizer(on_emulator, monkeypatch):
     """OF-tiny's gated blocks (d 256, 8 heads) take the fused attention branch (csrc/xattn_fused.hip) once the text length is a multiple
-    of 32.  Three optimizer steps with it and with the separate launches: the same losses to fp32 summation order -- which also proves
+    of 32.  Two optimizer steps with it and with the separate launches: the same losses to fp32 summation order -- which also proves
     that the fragment-major weight copies the step epilogue re-packs (FlatAdamW.packed_view) are the CURRENT weights (stale copies
     would replay step 0's projections) -- and, bit for bit, packed_view = of_pack_frag16(bf16_view) after the last step."""
     from open_flamingo_amd.hip import path as P
@@ -499,9 +499,9 @@ def test_fused_attention_branch_inside_a_train_step_and_its_packed_weights_follo
         opt = FlatAdamW(red, lr=3e-3, ops=ops)
         batch = synthetic.make_batch(2, 2, 32, info, "cpu", seed=5, image_size=56)
         n0 = len(calls)
-        losses.append([float(step.train_step(model, red, opt, batch, info, amp=False)) for _ in range(3)])
+        losses.append([float(step.train_step(model, red, opt, batch, info, amp=False)) for _ in range(2)])
         if fused:
-            assert sum(1 for c in calls[n0:] if not c) == 3 * 2, calls        # two gated blocks, three forwards, one launch each
+            assert sum(1 for c in calls[n0:] if not c) == 2 * 2, calls        # two gated blocks, two forwards, one launch each
             for blk in model.lang_encoder.gated_cross_attn_layers:
                 if blk is None:
                     continue
@@ -511,5 +511,5 @@ def test_fused_attention_branch_inside_a_train_step_and_its_packed_weights_follo
                     assert torch.equal(pk, ops.pack_frag16(bf))
         else:
             assert len(calls) == n0
-    assert losses[0][0] > losses[0][2]
+    assert losses[0][0] > losses[0][1]
     assert all(abs(a - b) <= 2e-4 * abs(b) for a, b in zip(*losses)), losses
