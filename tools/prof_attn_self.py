@@ -21,5 +21,6 @@ for _ in range(3):
     for safe in (0, 2):
         ops.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, safe=safe, **kw)
         ops.attn_fwd(qkv2[:, :1024], qkv2[:, 1024:2048], qkv2[:, 2048:], ov, lsev, batch=Nv, Lq=Sv, Lk=Sv, heads=Hv, safe=safe)
-    ops.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, do, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], delta, **kw)
+    for safe in (0, 2):       # 0: of_attn_bwd's own choice (the single pass, csrc/attn_bwd_res.hip), 2: the two-pass kernels
+        ops.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, do, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], delta, safe=safe, **kw)
 torch.cuda.synchronize()
