@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OF_ABI_VERSION 10
+#define OF_ABI_VERSION 11
 #define OF_E_ARG (-1)      /* null pointer / negative size */
 #define OF_E_SHAPE (-2)    /* shape not supported by the kernels (see each function) */
 #define OF_E_ALIGN (-3)    /* pointer or leading dimension not 16-byte aligned */
@@ -210,6 +210,11 @@ typedef struct OfAttnArgs {
     int causal;               /* 1: query i sees keys [0, i + 1 + Lk - Lq); text_time must be NULL */
     const float* alibi_slopes;/* (heads) fp32 or NULL: score += slope[h] * (j - (i + Lk - Lq)) before the softmax */
     const int32_t* kv_len;    /* (batch) or NULL, causal only: number of real (non right-padding) keys per sequence */
+    int head_valid;           /* ABI v11, compact heads: 0 or head_dim = every head owns head_dim columns.  Else a multiple of 8 with
+                                 8 <= head_valid < head_dim (OF_E_SHAPE otherwise; safe = 1: OF_E_ARG): head h owns columns [h * head_valid, (h + 1) * head_valid) of q, k, v, o,
+                                 dout, dq, dk, dv; the kernels run at head_dim with the missing columns read as zeros and never stored
+                                 (GPT-NeoX head size 80 -- RedPajama-INCITE-3B behind OF-4B -- at head_dim 128 without padded copies
+                                 in HBM).  `scale` stays the caller's (head_valid ** -0.5 for the reference's attention). */
 } OfAttnArgs;
 
 int of_attn_fwd(const OfAttnArgs* args, void* stream);

@@ -37,7 +37,9 @@ using namespace ofa;
 
 // ------------------------------------------------------------------------------------------------
 // forward (BWD=false) and dq pass (BWD=true) share the key-block loop
-template <int DH, bool BWD, bool SAFE>
+// CMP: compact heads (OfAttnArgs.head_valid = hv < DH): head h owns columns [h hv, (h + 1) hv) of every matrix; the kernel runs at DH with
+// the missing columns read as zeros and never stored (GPT-NeoX head size 80 at DH = 128 without padded copies in HBM)
+template <int DH, bool BWD, bool SAFE, bool CMP = false>
 OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
     constexpr int NKS = DH / 32, NDT = DH / 16, IMG = 64 * DH * 2;
     char* smem = of_smem();
@@ -50,7 +52,8 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
     // query tile of one (batch, head) runs on XCD h % 8 and re-reads its K / V blocks from that XCD's own L2
     const int q0 = of_bid_y() * 64, h = of_bid_x();
     const long batch = of_bid_z();
-    const int hc = h * DH;
+    const int hv = CMP ? p.head_valid : DH;
+    const int hc = h * hv;
     const float slope = p.alibi_slopes ? p.alibi_slopes[h] : 0.f;
 
     if (tid < 64) {
@@ -82,7 +85,7 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
     const bf16_t* vb_ptr = p.v + (size_t)batch * p.Lk * p.ldv;
     s16x8 qf[NKS], dof[NKS];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) qf[ks] = gload_frag(qb, p.ldq, my_row, p.Lq, hc + ks * 32 + g * 8);
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = gload_frag(qb, p.ldq, my_row, p.Lq, hc + ks * 32 + g * 8, !CMP || ks * 32 + g * 8 < hv);
     const int my_pos = my_row + (p.Lk - p.Lq);   // key index aligned with this query (ALiBi distance origin)
     const FragOff<DH> fo = make_frag_off<DH>(lane);
     const RowCtx rc = make_row_ctx(lo_i, hi_i, uni_i, my_pos, p.scale, slope);
@@ -97,8 +100,9 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
         float d = 0.f;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            dof[ks] = gload_frag(dob, p.lddo, my_row, p.Lq, hc + ks * 32 + g * 8);
-            const s16x8 o8 = gload_frag(ob, p.ldo, my_row, p.Lq, hc + ks * 32 + g * 8);
+            const bool cv = !CMP || ks * 32 + g * 8 < hv;
+            dof[ks] = gload_frag(dob, p.lddo, my_row, p.Lq, hc + ks * 32 + g * 8, cv);
+            const s16x8 o8 = gload_frag(ob, p.ldo, my_row, p.Lq, hc + ks * 32 + g * 8, cv);
 #pragma unroll
             for (int e = 0; e < 8; ++e) d += of_bf16_to_f32((bf16_t)dof[ks][e]) * of_bf16_to_f32((bf16_t)o8[e]);
         }
@@ -115,8 +119,8 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
     // block kb is multiplied (the kernel is otherwise parked on their latency: SQ_WAIT_ANY was 62 % of the wave cycles)
     u32x4 rk[DH / 32], rv[DH / 32];
     if (kb_lo < kb_hi) {
-        tile_g2r<DH>(kb_ptr, p.ldk, (long)kb_lo * 64, p.Lk, hc, tid, rk);
-        tile_g2r<DH>(vb_ptr, p.ldv, (long)kb_lo * 64, p.Lk, hc, tid, rv);
+        tile_g2r<DH>(kb_ptr, p.ldk, (long)kb_lo * 64, p.Lk, hc, tid, rk, hv);
+        tile_g2r<DH>(vb_ptr, p.ldv, (long)kb_lo * 64, p.Lk, hc, tid, rv, hv);
     }
     for (int kb = kb_lo; kb < kb_hi; ++kb) {
         const long key0 = (long)kb * 64;
@@ -129,8 +133,8 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
         }
         of_sync();
         if (kb + 1 < kb_hi) {
-            tile_g2r<DH>(kb_ptr, p.ldk, key0 + 64, p.Lk, hc, tid, rk);
-            tile_g2r<DH>(vb_ptr, p.ldv, key0 + 64, p.Lk, hc, tid, rv);
+            tile_g2r<DH>(kb_ptr, p.ldk, key0 + 64, p.Lk, hc, tid, rk, hv);
+            tile_g2r<DH>(vb_ptr, p.ldv, key0 + 64, p.Lk, hc, tid, rv, hv);
         }
         f32x4 s[4];
 #pragma unroll
@@ -174,7 +178,7 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
             o[dt] = u32x2{of_pack_bf16(acc[dt][0] * osc, acc[dt][1] * osc), of_pack_bf16(acc[dt][2] * osc, acc[dt][3] * osc)};
         const long row = live ? my_row : 0;
         bf16_t* ob = BWD ? p.dq + ((size_t)batch * p.Lq + row) * p.lddq + hc : p.o + ((size_t)batch * p.Lq + row) * p.ldo + hc;
-        store_row_blocks(ob, o, g, live);
+        store_row_blocks(ob, o, g, live, CMP ? hv : 0x40000000);
         if (!BWD && live && g == 0) p.lse[stat_idx] = l_i > 0.f ? (m_i + of_log2(l_i)) * LN2 : __builtin_inff();
     }
 }
@@ -188,14 +192,15 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
 // tile of every wave needs key blocks <= t, block t+1 is in flight while step t computes; everything else loads all blocks
 // up front (32-80 KB: two workgroups per CU overlap each other).  Same arithmetic, masks and statistics as
 // of_attn_q_kernel<DH, false>; eligible when the two images fit the CU's 160 KB.
-template <int DH, int NW>      // NW waves per workgroup: 8 at head dim 128 (128 KB of images -> one workgroup per CU), else 4
+template <int DH, int NW, bool CMP = false>      // NW waves per workgroup: 8 at head dim 128 (128 KB of images -> one workgroup per CU), else 4
 OF_GLOBAL void OF_BOUNDS(NW * 64, 2) of_attn_fwd_res_kernel(OfAttnArgs p) {
     constexpr int NKS = DH / 32, NDT = DH / 16, IMG = 64 * DH * 2;
     char* smem = of_smem();
     const int tid = of_tid(), lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
     const int h = of_bid_x();
     const long batch = of_bid_y();
-    const int hc = h * DH;
+    const int hv = CMP ? p.head_valid : DH;
+    const int hc = h * hv;
     const float slope = p.alibi_slopes ? p.alibi_slopes[h] : 0.f;
     const bool has_alibi = p.alibi_slopes != nullptr;
     const int lk32 = (p.Lk + 31) & ~31;
@@ -211,8 +216,8 @@ OF_GLOBAL void OF_BOUNDS(NW * 64, 2) of_attn_fwd_res_kernel(OfAttnArgs p) {
 
     auto issue = [&](int kb) OF_INLINE_LAMBDA {
         const int rows_blk = lk32 - kb * 64 < 64 ? lk32 - kb * 64 : 64;
-        dma_block<DH, false, NW>(kb_ptr, p.ldk, (long)kb * 64, p.Lk, rows_blk, hc, wave, lane, k_n + (size_t)kb * IMG);
-        dma_block<DH, true, NW>(vb_ptr, p.ldv, (long)kb * 64, p.Lk, rows_blk, hc, wave, lane, v_t + (size_t)kb * IMG);
+        dma_block<DH, false, NW>(kb_ptr, p.ldk, (long)kb * 64, p.Lk, rows_blk, hc, wave, lane, k_n + (size_t)kb * IMG, hv);
+        dma_block<DH, true, NW>(vb_ptr, p.ldv, (long)kb * 64, p.Lk, rows_blk, hc, wave, lane, v_t + (size_t)kb * IMG, hv);
     };
     const int first = progressive ? (BPS < nkb ? BPS : nkb) : nkb;
     for (int kb = 0; kb < first; ++kb) issue(kb);
@@ -220,7 +225,7 @@ OF_GLOBAL void OF_BOUNDS(NW * 64, 2) of_attn_fwd_res_kernel(OfAttnArgs p) {
     {
         const int row0 = wave * 16 + i16;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) qn[ks] = gload_frag(qb, p.ldq, row0, p.Lq, hc + ks * 32 + g * 8);
+        for (int ks = 0; ks < NKS; ++ks) qn[ks] = gload_frag(qb, p.ldq, row0, p.Lq, hc + ks * 32 + g * 8, !CMP || ks * 32 + g * 8 < hv);
     }
     of_wait_vm<0>();
     of_sync();
@@ -234,7 +239,7 @@ OF_GLOBAL void OF_BOUNDS(NW * 64, 2) of_attn_fwd_res_kernel(OfAttnArgs p) {
             for (int kb = (t + 1) * BPS; kb < (t + 2) * BPS && kb < nkb; ++kb) issue(kb);
         }
         if (po_live) {         // wave-uniform: set by the whole wave's tile
-            store_row_blocks(p.o + ((size_t)batch * p.Lq + (po_row >= 0 ? po_row : 0)) * p.ldo + hc, po, g, po_row >= 0);
+            store_row_blocks(p.o + ((size_t)batch * p.Lq + (po_row >= 0 ? po_row : 0)) * p.ldo + hc, po, g, po_row >= 0, CMP ? hv : 0x40000000);
             po_row = -1;
             po_live = false;
         }
@@ -245,7 +250,8 @@ OF_GLOBAL void OF_BOUNDS(NW * 64, 2) of_attn_fwd_res_kernel(OfAttnArgs p) {
             for (int ks = 0; ks < NKS; ++ks) qf[ks] = qn[ks];
             if (ti + NW < ntiles) {
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) qn[ks] = gload_frag(qb, p.ldq, my_row + NW * 16, p.Lq, hc + ks * 32 + g * 8);
+                for (int ks = 0; ks < NKS; ++ks)
+                    qn[ks] = gload_frag(qb, p.ldq, my_row + NW * 16, p.Lq, hc + ks * 32 + g * 8, !CMP || ks * 32 + g * 8 < hv);
             }
             const Window w = row_window(p, batch, my_row);
             int rlo = w.hi > w.lo ? w.lo : 0x7fffffff, rhi = w.hi > w.lo ? w.hi : 0;
@@ -303,12 +309,13 @@ OF_GLOBAL void OF_BOUNDS(NW * 64, 2) of_attn_fwd_res_kernel(OfAttnArgs p) {
             of_sync();
         }
     }
-    if (po_live) store_row_blocks(p.o + ((size_t)batch * p.Lq + (po_row >= 0 ? po_row : 0)) * p.ldo + hc, po, g, po_row >= 0);
+    if (po_live)
+        store_row_blocks(p.o + ((size_t)batch * p.Lq + (po_row >= 0 ? po_row : 0)) * p.ldo + hc, po, g, po_row >= 0, CMP ? hv : 0x40000000);
 }
 
 // ------------------------------------------------------------------------------------------------
 // dk/dv pass: one workgroup per (key block of 64, head, batch); a wave owns 16 keys.
-template <int DH, bool SAFE>
+template <int DH, bool SAFE, bool CMP = false>
 OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_dkv_kernel(OfAttnArgs p) {
     constexpr int NKS = DH / 32, NDT = DH / 16, IMG = 64 * DH * 2;
     char* smem = of_smem();
@@ -323,7 +330,8 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_dkv_kernel(OfAttnArgs p) {
     const int tid = of_tid(), lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
     const int kblk = of_bid_y(), h = of_bid_x();     // head fastest: see of_attn_q_kernel
     const long batch = of_bid_z();
-    const int hc = h * DH;
+    const int hv = CMP ? p.head_valid : DH;
+    const int hc = h * hv;
     const float slope = p.alibi_slopes ? p.alibi_slopes[h] : 0.f;
     const int key_lo = kblk * 64, key_hi = key_lo + 64;
     const int my_key = key_lo + wave * 16 + i16;
@@ -337,8 +345,9 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_dkv_kernel(OfAttnArgs p) {
     s16x8 kf[NKS], vf[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-        kf[ks] = gload_frag(kb_ptr, p.ldk, my_key, p.Lk, hc + ks * 32 + g * 8);
-        vf[ks] = gload_frag(vb_ptr, p.ldv, my_key, p.Lk, hc + ks * 32 + g * 8);
+        const bool cv = !CMP || ks * 32 + g * 8 < hv;
+        kf[ks] = gload_frag(kb_ptr, p.ldk, my_key, p.Lk, hc + ks * 32 + g * 8, cv);
+        vf[ks] = gload_frag(vb_ptr, p.ldv, my_key, p.Lk, hc + ks * 32 + g * 8, cv);
     }
     f32x4 acck[NDT], accv[NDT];
 #pragma unroll
@@ -358,8 +367,8 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_dkv_kernel(OfAttnArgs p) {
     constexpr bool PREFETCH = DH == 64 || !SAFE;
     u32x4 rq[DH / 32], rdo[DH / 32];
     if (PREFETCH && qt_lo < nqt) {
-        tile_g2r<DH>(qb, p.ldq, (long)qt_lo * 64, p.Lq, hc, tid, rq);
-        tile_g2r<DH>(dob, p.lddo, (long)qt_lo * 64, p.Lq, hc, tid, rdo);
+        tile_g2r<DH>(qb, p.ldq, (long)qt_lo * 64, p.Lq, hc, tid, rq, hv);
+        tile_g2r<DH>(dob, p.lddo, (long)qt_lo * 64, p.Lq, hc, tid, rdo, hv);
     }
     for (int qt = qt_lo; qt < nqt; ++qt) {
         const int q0 = qt * 64;
@@ -393,14 +402,14 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_dkv_kernel(OfAttnArgs p) {
                 of_sync();
             }
             if (qt + 1 < nqt) {
-                tile_g2r<DH>(qb, p.ldq, q0 + 64, p.Lq, hc, tid, rq);
-                tile_g2r<DH>(dob, p.lddo, q0 + 64, p.Lq, hc, tid, rdo);
+                tile_g2r<DH>(qb, p.ldq, q0 + 64, p.Lq, hc, tid, rq, hv);
+                tile_g2r<DH>(dob, p.lddo, q0 + 64, p.Lq, hc, tid, rdo, hv);
             }
         }
         if (hit) {
             if (!PREFETCH) {
-                load_tile64<DH>(qb, p.ldq, q0, p.Lq, hc, tid, q_n, q_t);
-                load_tile64<DH>(dob, p.lddo, q0, p.Lq, hc, tid, do_n, do_t);
+                load_tile64<DH>(qb, p.ldq, q0, p.Lq, hc, tid, q_n, q_t, hv);
+                load_tile64<DH>(dob, p.lddo, q0, p.Lq, hc, tid, do_n, do_t, hv);
                 of_sync();
             }
             // two 16-query tiles at a time (= one 32-deep k-step of the dV / dK MFMAs): keeps only 4 score fragments live
@@ -459,8 +468,8 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_dkv_kernel(OfAttnArgs p) {
             ok[dt] = u32x2{of_pack_bf16(acck[dt][0] * p.scale, acck[dt][1] * p.scale), of_pack_bf16(acck[dt][2] * p.scale, acck[dt][3] * p.scale)};
             ov[dt] = u32x2{of_pack_bf16(accv[dt][0], accv[dt][1]), of_pack_bf16(accv[dt][2], accv[dt][3])};
         }
-        store_row_blocks(p.dk + ((size_t)batch * p.Lk + row) * p.lddk + hc, ok, g, live);
-        store_row_blocks(p.dv + ((size_t)batch * p.Lk + row) * p.lddv + hc, ov, g, live);
+        store_row_blocks(p.dk + ((size_t)batch * p.Lk + row) * p.lddk + hc, ok, g, live, CMP ? hv : 0x40000000);
+        store_row_blocks(p.dv + ((size_t)batch * p.Lk + row) * p.lddv + hc, ov, g, live, CMP ? hv : 0x40000000);
     }
 }
 
@@ -502,6 +511,11 @@ int check(const OfAttnArgs& a, bool bwd) {
     if (((uintptr_t)a.q & 15) || ((uintptr_t)a.k & 15) || ((uintptr_t)a.v & 15) || ((uintptr_t)a.o & 15)) return OF_E_ALIGN;
     if (a.text_time && (a.n_per_media <= 0 || a.T_img <= 0)) return OF_E_ARG;
     if (a.head_dim != 0 && a.head_dim != 64 && a.head_dim != 128) return OF_E_SHAPE;
+    {   // compact heads: a multiple of 8 columns (every access is 16 bytes wide)
+        const int dh = a.head_dim == 128 ? 128 : 64;
+        if (a.head_valid != 0 && a.head_valid != dh && ((a.head_valid & 7) || a.head_valid < 8 || a.head_valid > dh)) return OF_E_SHAPE;
+        if (a.head_valid != 0 && a.head_valid != dh && a.safe == 1) return OF_E_ARG;     // no scalar-LDS self-check instantiation of that form
+    }
     if (a.causal && a.text_time) return OF_E_ARG;
     if (bwd) {
         if (!a.dout || !a.dq || !a.dk || !a.dv || !a.delta) return OF_E_ARG;
@@ -530,13 +544,20 @@ size_t resident_smem(const OfAttnArgs& a) {
     return need;
 }
 template <int DH>
+bool compact(const OfAttnArgs& a) {
+    return a.head_valid != 0 && a.head_valid != DH;
+}
+template <int DH>
 int launch_fwd(const OfAttnArgs& a, of_stream_t s) {
+    const bool cmp = compact<DH>(a);
     if (const size_t res = resident_smem<DH>(a)) {
         const of_dim3 grid{(unsigned)a.heads, (unsigned)a.batch, 1};
+        if (cmp) return of_launch(of_attn_fwd_res_kernel<DH, (DH == 128 ? 8 : 4), true>, grid, DH == 128 ? 512 : 256, res, s, a);
         return of_launch(of_attn_fwd_res_kernel<DH, (DH == 128 ? 8 : 4)>, grid, DH == 128 ? 512 : 256, res, s, a);
     }
     of_dim3 grid{(unsigned)a.heads, (unsigned)((a.Lq + 63) / 64), (unsigned)a.batch};
     const size_t smem = 2 * (64 * DH * 2) + 196 * sizeof(int);
+    if (cmp) return of_launch(of_attn_q_kernel<DH, false, false, true>, grid, 256, smem, s, a);
     if (a.safe == 1) return of_launch(of_attn_q_kernel<DH, false, true>, grid, 256, smem, s, a);
     return of_launch(of_attn_q_kernel<DH, false, false>, grid, 256, smem, s, a);
 }
@@ -562,11 +583,14 @@ int launch_bwd(const OfAttnArgs& a, of_stream_t s) {
     if (bwd_single_pass(a)) return attn_bwd_res_launch(a, s);
     of_dim3 gq{(unsigned)a.heads, (unsigned)((a.Lq + 63) / 64), (unsigned)a.batch};
     const size_t smem_q = 3 * IMG + 196 * sizeof(int);
-    int rc = a.safe == 1 ? of_launch(of_attn_q_kernel<DH, true, true>, gq, 256, smem_q, s, a)
-                    : of_launch(of_attn_q_kernel<DH, true, false>, gq, 256, smem_q, s, a);
+    const bool cmp = compact<DH>(a);
+    int rc = cmp           ? of_launch(of_attn_q_kernel<DH, true, false, true>, gq, 256, smem_q, s, a)
+             : a.safe == 1 ? of_launch(of_attn_q_kernel<DH, true, true>, gq, 256, smem_q, s, a)
+                           : of_launch(of_attn_q_kernel<DH, true, false>, gq, 256, smem_q, s, a);
     if (rc) return rc;
     of_dim3 gk{(unsigned)a.heads, (unsigned)((a.Lk + 63) / 64), (unsigned)a.batch};
     const size_t smem_k = 4 * IMG + 64 * 3 * sizeof(int) + 128 * sizeof(float) + 16;
+    if (cmp) return of_launch(of_attn_dkv_kernel<DH, false, true>, gk, 256, smem_k, s, a);
     return a.safe == 1 ? of_launch(of_attn_dkv_kernel<DH, true>, gk, 256, smem_k, s, a)
                   : of_launch(of_attn_dkv_kernel<DH, false>, gk, 256, smem_k, s, a);
 }

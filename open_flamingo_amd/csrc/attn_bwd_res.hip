@@ -67,9 +67,18 @@ struct BrInt {
     static constexpr int value = N;
 };
 
-template <int DH>
+// HV < DH: compact heads (OfAttnArgs.head_valid = HV, see attention.hip; a COMPILE-TIME width here -- this kernel has no register to spare
+// for a run-time one): columns HV .. DH - 1 of a head are zeros in every operand that comes through registers (Q, dO, O, V), a copy of the
+// row's first 16 bytes in the LDS-DMA'd K image (it only meets Q's zeros and dQ columns that are not stored), and are not stored.  The
+// k-steps of S / dP and the d tiles of dV / dK that hold no column < HV are skipped: head size 80 at DH = 128 runs 3 of 4 k-steps and 5 of 8
+// d tiles, and keeps 48 instead of 64 registers of V fragments.  (Phase 2 runs all its d tiles: the waves with d tiles 0 .. 3 set its time
+// whatever the others skip, and a conditional skip made hipcc copy accumulators right in front of the asm MFMAs -- tests/test_isa_lint.py.)
+template <int DH, int HV = DH>
 OF_GLOBAL void OF_BOUNDS(256, 1) of_attn_bwd_res_kernel(OfAttnArgs p) {
+    constexpr bool CMP = HV != DH;
     constexpr int NKS = DH / 32, NDT = DH / 16, IMG = 64 * DH * 2, TIMG = BR_QT * DH * 2;
+    constexpr int NKSV = (HV + 31) / 32, NDTV = (HV + 15) / 16;   // k-steps / d tiles that hold data
+    constexpr int NDTE = (NDTV + 1) & ~1;                          // ... rounded up to the pairs store_row_blocks takes
     constexpr int EPT = DH / 8;                                   // elements of a row per thread in the delta pass (8 threads per row)
     BR_STAMP_DECL();
     BR_STAMP_AT(0);
@@ -82,7 +91,8 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_attn_bwd_res_kernel(OfAttnArgs p) {
     const int tid = of_tid(), lane = tid & 63, wave = of_uniform(tid >> 6), g = lane >> 4, i16 = lane & 15;
     const int h = of_bid_x();
     const long batch = of_bid_y();
-    const int hc = h * DH;
+    constexpr int hv = HV;
+    const int hc = h * hv;
     const float slope = p.alibi_slopes ? p.alibi_slopes[h] : 0.f;
     const float scale2 = p.scale * LOG2E, slope2 = slope * LOG2E;
     const int key0 = wave * 16 + i16;                              // this lane's key of the wave's tile 0; tile j: + 64 j
@@ -124,8 +134,17 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_attn_bwd_res_kernel(OfAttnArgs p) {
             const int id = c * 256 + tid, row = id / (DH / 8), cs = id % (DH / 8);
             long arow = (long)qi * BR_QT + row;
             if (arow >= p.Lq) arow = p.Lq - 1;
-            tr.q[c] = *(const u32x4*)(qb + (size_t)arow * p.ldq + hc + cs * 8);
-            tr.d[c] = *(const u32x4*)(dob + (size_t)arow * p.lddo + hc + cs * 8);
+            // compact heads: a piece beyond the head's columns = zeros.  The load goes to the head's first piece (always there) and
+            // tile_store replaces the VALUE ("cond ? *p : 0" here made hipcc select between the global address and a zero parked in
+            // scratch; a select on the loaded value here would wait for the load at the top of the tile)
+            if (!CMP) {
+                tr.q[c] = *(const u32x4*)(qb + (size_t)arow * p.ldq + hc + cs * 8);
+                tr.d[c] = *(const u32x4*)(dob + (size_t)arow * p.lddo + hc + cs * 8);
+            } else {
+                const int co = cs * 8 < hv ? cs * 8 : 0;
+                tr.q[c] = *(const u32x4*)(qb + (size_t)arow * p.ldq + hc + co);
+                tr.d[c] = *(const u32x4*)(dob + (size_t)arow * p.lddo + hc + co);
+            }
         }
     };
     auto tile_store = [&](int qi, const TileRegs& tr, int tid) OF_INLINE_LAMBDA {
@@ -133,8 +152,20 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_attn_bwd_res_kernel(OfAttnArgs p) {
 #pragma unroll
         for (int c = 0; c < TCH; ++c) {
             const int id = c * 256 + tid, row = id / (DH / 8), cs = id % (DH / 8);
-            *(u32x4*)(base + img_n_off<DH>(row, cs)) = tr.q[c];
-            *(u32x4*)(base + TIMG + img_n_off<DH>(row, cs)) = tr.d[c];
+            if (!CMP) {
+                *(u32x4*)(base + img_n_off<DH>(row, cs)) = tr.q[c];
+                *(u32x4*)(base + TIMG + img_n_off<DH>(row, cs)) = tr.d[c];
+            } else {
+                const bool cv = cs * 8 < hv;
+                u32x4 q4, d4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    q4[e] = cv ? tr.q[c][e] : 0u;
+                    d4[e] = cv ? tr.d[c][e] : 0u;
+                }
+                *(u32x4*)(base + img_n_off<DH>(row, cs)) = q4;
+                *(u32x4*)(base + TIMG + img_n_off<DH>(row, cs)) = d4;
+            }
         }
     };
     // delta / lse of tile qi: 8 threads per row, EPT elements each
@@ -147,8 +178,15 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_attn_bwd_res_kernel(OfAttnArgs p) {
         const long r = row < p.Lq ? row : p.Lq - 1;
 #pragma unroll
         for (int e = 0; e < EPT / 8; ++e) {
-            st.o[e] = *(const u32x4*)(ob + (size_t)r * p.ldo + c + 8 * e);
-            st.d[e] = *(const u32x4*)(dob + (size_t)r * p.lddo + c + 8 * e);
+            const bool cv = !CMP || (tid & 7) * EPT + 8 * e < hv;      // see tile_load
+            if (!CMP) {
+                st.o[e] = *(const u32x4*)(ob + (size_t)r * p.ldo + c + 8 * e);
+                st.d[e] = *(const u32x4*)(dob + (size_t)r * p.lddo + c + 8 * e);
+            } else {
+                const int co = cv ? c + 8 * e : hc;                  // stat_finish drops these products
+                st.o[e] = *(const u32x4*)(ob + (size_t)r * p.ldo + co);
+                st.d[e] = *(const u32x4*)(dob + (size_t)r * p.lddo + co);
+            }
         }
         st.lse = lse_b[r];
     };
@@ -159,8 +197,9 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_attn_bwd_res_kernel(OfAttnArgs p) {
         for (int e = 0; e < EPT / 8; ++e)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                d += of_bf16_to_f32((bf16_t)(st.o[e][c] & 0xffff)) * of_bf16_to_f32((bf16_t)(st.d[e][c] & 0xffff));
-                d += of_bf16_to_f32((bf16_t)(st.o[e][c] >> 16)) * of_bf16_to_f32((bf16_t)(st.d[e][c] >> 16));
+                const unsigned o2 = !CMP || (tid & 7) * EPT + 8 * e < hv ? st.o[e][c] : 0u;      // compact heads: columns that do not exist
+                d += of_bf16_to_f32((bf16_t)(o2 & 0xffff)) * of_bf16_to_f32((bf16_t)(st.d[e][c] & 0xffff));
+                d += of_bf16_to_f32((bf16_t)(o2 >> 16)) * of_bf16_to_f32((bf16_t)(st.d[e][c] >> 16));
             }
 #pragma unroll
         for (int m = 1; m <= 4; m <<= 1) d += of_shfl_xor(d, m);
@@ -179,20 +218,21 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_attn_bwd_res_kernel(OfAttnArgs p) {
         const int nb = (row_hi(last) + 63) >> 6;
         return nb < nkb ? nb : nkb;
     };
-    s16x8 vf[BR_KT][NKS];                                          // K fragments are read from the resident image tile by tile
+    s16x8 vf[BR_KT][NKSV];                                         // K fragments are read from the resident image tile by tile
 #pragma unroll
     for (int j = 0; j < BR_KT; ++j)
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) vf[j][ks] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        for (int ks = 0; ks < NKSV; ++ks) vf[j][ks] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
     auto load_blocks = [&](int from, int to, int lane) OF_INLINE_LAMBDA {
 #pragma unroll
         for (int j = 0; j < BR_KT; ++j)
             if (j >= from && j < to) {                              // workgroup-uniform
                 const int rows_blk = lk32 - j * 64 < 64 ? lk32 - j * 64 : 64;
-                dma_block<DH, false, BR_NW>(kb_ptr, p.ldk, (long)j * 64, p.Lk, rows_blk, hc, wave, lane, k_img + (size_t)j * IMG);
+                dma_block<DH, false, BR_NW>(kb_ptr, p.ldk, (long)j * 64, p.Lk, rows_blk, hc, wave, lane, k_img + (size_t)j * IMG, hv);
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks)          // row / column from the caller's lane copy: see of_opaque_i
-                    vf[j][ks] = gload_frag(vb_ptr, p.ldv, wave * 16 + (lane & 15) + 64 * j, p.Lk, hc + ks * 32 + (lane >> 4) * 8);
+                for (int ks = 0; ks < NKSV; ++ks)         // row / column from the caller's lane copy: see of_opaque_i
+                    vf[j][ks] = gload_frag(vb_ptr, p.ldv, wave * 16 + (lane & 15) + 64 * j, p.Lk, hc + ks * 32 + (lane >> 4) * 8,
+                                           !CMP || ks * 32 + (lane >> 4) * 8 < hv);
             }
     };
     // prologue: tile 0, the K blocks / V fragments it needs, its statistics
@@ -246,7 +286,7 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_attn_bwd_res_kernel(OfAttnArgs p) {
             for (int tt = 0; tt < 2; ++tt) {
                 f32x4 s[NV], dp[NV];
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
+                for (int ks = 0; ks < NKSV; ++ks) {
                     const s16x8 qf = frag_n2<DH>(q_img, fo_n ^ (ks << 6), tt * 16), dof = frag_n2<DH>(do_img, fo_n ^ (ks << 6), tt * 16);
                     // K fragments two key tiles at a time: one LDS latency per pair, not per tile (all four: 8 more registers than there are)
 #pragma unroll
@@ -315,7 +355,7 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_attn_bwd_res_kernel(OfAttnArgs p) {
                 of_mfma_operands2(pf[j], dsf[j]);
             }
 #pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
+            for (int dt = 0; dt < NDTV; ++dt) {
                 const s16x8 a_do = frag_t2<DH, false>(do_img, fo_t ^ (dt << 5), 0, dt * 16, lane), a_q = frag_t2<DH, false>(q_img, fo_t ^ (dt << 5), 0, dt * 16, lane);
                 of_mfma_guard_nomem();
 #pragma unroll
@@ -400,7 +440,8 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_attn_bwd_res_kernel(OfAttnArgs p) {
 #pragma unroll
             for (int j = 0; j < P2T; ++j)
                 o2[j] = u32x2{of_pack_bf16(acc[j][0] * p.scale, acc[j][1] * p.scale), of_pack_bf16(acc[j][2] * p.scale, acc[j][3] * p.scale)};
-            store_row_blocks(p.dq + ((size_t)batch * p.Lq + (live ? row : 0)) * p.lddq + hc + p2_dt * 16, o2, g, live);
+            store_row_blocks(p.dq + ((size_t)batch * p.Lq + (live ? row : 0)) * p.lddq + hc + p2_dt * 16, o2, g, live,
+                             CMP ? hv - p2_dt * 16 : 0x40000000);
         }
         of_accbank64_fence();
         BR_STAMP_ADD(8);
@@ -414,15 +455,15 @@ OF_GLOBAL void OF_BOUNDS(256, 1) of_attn_bwd_res_kernel(OfAttnArgs p) {
         const int my_key = key0 + 64 * j;
         const bool live = my_key < p.Lk;
         const long row = live ? my_key : 0;
-        u32x2 ok[NDT], ov[NDT];
+        u32x2 ok[NDTE], ov[NDTE];
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
+        for (int dt = 0; dt < NDTE; ++dt) {
             const f32x4 av = of_accbank64_read(bank, 2 * (j * NDT + dt)), ak = of_accbank64_read(bank, 2 * (j * NDT + dt) + 1);
             ok[dt] = u32x2{of_pack_bf16(ak[0] * p.scale, ak[1] * p.scale), of_pack_bf16(ak[2] * p.scale, ak[3] * p.scale)};
             ov[dt] = u32x2{of_pack_bf16(av[0], av[1]), of_pack_bf16(av[2], av[3])};
         }
-        store_row_blocks(p.dk + ((size_t)batch * p.Lk + row) * p.lddk + hc, ok, g, live);
-        store_row_blocks(p.dv + ((size_t)batch * p.Lk + row) * p.lddv + hc, ov, g, live);
+        store_row_blocks(p.dk + ((size_t)batch * p.Lk + row) * p.lddk + hc, ok, g, live, CMP ? hv : 0x40000000);
+        store_row_blocks(p.dv + ((size_t)batch * p.Lk + row) * p.lddv + hc, ov, g, live, CMP ? hv : 0x40000000);
     }
     BR_STAMP_AT(10);
     BR_STAMP_FLUSH();
@@ -438,11 +479,19 @@ namespace ofa {
 bool attn_bwd_res_fits(const OfAttnArgs& a) {
     if (a.text_time || a.Lk > 256 || a.Lq > 256) return false;
     if (a.head_dim != 0 && a.head_dim != 64 && a.head_dim != 128) return false;
+    // compact heads: the widths this kernel is instantiated for (GPT-NeoX head sizes 80 -- RedPajama-INCITE-3B, Pythia-2.8B -- and 96 --
+    // GPT-NeoX-20B -- at head_dim 128); any other width takes the two passes
+    const int dh = a.head_dim == 128 ? 128 : 64;
+    if (a.head_valid != 0 && a.head_valid != dh && !(dh == 128 && (a.head_valid == 80 || a.head_valid == 96))) return false;
     return true;
 }
 int attn_bwd_res_launch(const OfAttnArgs& a, of_stream_t s) {
     const of_dim3 grid{(unsigned)a.heads, (unsigned)a.batch, 1};
-    if (a.head_dim == 128) return of_launch(of_attn_bwd_res_kernel<128>, grid, BR_NW * 64, br_smem<128>(), s, a);
+    if (a.head_dim == 128) {
+        if (a.head_valid == 80) return of_launch(of_attn_bwd_res_kernel<128, 80>, grid, BR_NW * 64, br_smem<128>(), s, a);
+        if (a.head_valid == 96) return of_launch(of_attn_bwd_res_kernel<128, 96>, grid, BR_NW * 64, br_smem<128>(), s, a);
+        return of_launch(of_attn_bwd_res_kernel<128>, grid, BR_NW * 64, br_smem<128>(), s, a);
+    }
     return of_launch(of_attn_bwd_res_kernel<64>, grid, BR_NW * 64, br_smem<64>(), s, a);
 }
 }  // namespace ofa

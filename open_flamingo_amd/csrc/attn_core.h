@@ -10,15 +10,16 @@ namespace ofa {
 // Stored as they are, one store instruction writes 32-byte pieces of 16 rows and every 128-byte line takes four instructions.
 // Blocks 2m / 2m+1 are exchanged between the lane groups g and g ^ 1 first (v_permlane16_swap), so that a lane owns 8 consecutive
 // columns: 16-byte stores, half as many, 64 contiguous bytes of a row per instruction.  All 64 lanes must call (cross-lane);
-// `live` masks the stores of rows beyond the end.
+// `live` masks the stores of rows beyond the end, `hv` the 8-column pieces at or beyond column hv (compact heads, OfAttnArgs.head_valid:
+// the kernels' columns hv .. head_dim - 1 do not exist in memory).
 template <int NB>
-OF_DEV void store_row_blocks(bf16_t* rowp, const u32x2 (&v)[NB], int g, bool live) {
+OF_DEV void store_row_blocks(bf16_t* rowp, const u32x2 (&v)[NB], int g, bool live, int hv = 0x40000000) {
 #pragma unroll
     for (int m = 0; m < NB / 2; ++m) {
         unsigned a0 = v[2 * m][0], a1 = v[2 * m][1], b0 = v[2 * m + 1][0], b1 = v[2 * m + 1][1];
         of_pair_rows16(a0, b0);
         of_pair_rows16(a1, b1);
-        if (live) *(u32x4*)(rowp + (2 * m + (g & 1)) * 16 + 4 * (g & ~1)) = u32x4{a0, a1, b0, b1};
+        if (live && (2 * m + (g & 1)) * 16 + 4 * (g & ~1) < hv) *(u32x4*)(rowp + (2 * m + (g & 1)) * 16 + 4 * (g & ~1)) = u32x4{a0, a1, b0, b1};
     }
 }
 
@@ -40,31 +41,32 @@ OF_DEV int img_t_off(int row, int col) {
 
 // cooperative load of a 64 x DH bf16 tile (rows row0.., columns col0..col0+DH-1 of a row-major matrix) into
 // the "normal" image (ds_read_b128 fragments, k = column) and/or the "transpose" image (tr-read
-// fragments, k = row).  Rows >= nrows are zero-filled.
+// fragments, k = row).  Rows >= nrows are zero-filled, and so are the columns >= hv (compact heads: OfAttnArgs.head_valid).
 template <int DH>
 OF_DEV void load_tile64(const bf16_t* __restrict__ src, long ld, long row0, long nrows, int col0, int tid,
-                        char* img_n, char* img_t) {
+                        char* img_n, char* img_t, int hv = DH) {
     constexpr int SPR = DH / 8;   // 16-byte slots per row
 #pragma unroll
     for (int c = 0; c < SPR / 4; ++c) {
         int id = c * 256 + tid;
         int row = id / SPR, cs = id % SPR;
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (row0 + row < nrows) v = *(const u32x4*)(src + (size_t)(row0 + row) * ld + col0 + cs * 8);
+        if (row0 + row < nrows && cs * 8 < hv) v = *(const u32x4*)(src + (size_t)(row0 + row) * ld + col0 + cs * 8);
         if (img_n) *(u32x4*)(img_n + img_n_off<DH>(row, cs)) = v;
         if (img_t) *(u32x4*)(img_t + img_t_off<DH>(row, cs * 8)) = v;
     }
 }
 // the same tile load in two halves so that the global loads of tile i+1 can be in flight while tile i is multiplied
 template <int DH>
-OF_DEV void tile_g2r(const bf16_t* __restrict__ src, long ld, long row0, long nrows, int col0, int tid, u32x4 (&r)[DH / 32]) {
+OF_DEV void tile_g2r(const bf16_t* __restrict__ src, long ld, long row0, long nrows, int col0, int tid, u32x4 (&r)[DH / 32],
+                     int hv = DH) {
     constexpr int SPR = DH / 8;
 #pragma unroll
     for (int c = 0; c < SPR / 4; ++c) {
         int id = c * 256 + tid;
         int row = id / SPR, cs = id % SPR;
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (row0 + row < nrows) v = *(const u32x4*)(src + (size_t)(row0 + row) * ld + col0 + cs * 8);
+        if (row0 + row < nrows && cs * 8 < hv) v = *(const u32x4*)(src + (size_t)(row0 + row) * ld + col0 + cs * 8);
         r[c] = v;
     }
 }
@@ -104,9 +106,9 @@ OF_DEV s16x8 frag_t(const char* img, int kbase, int col_base, int lane) {
     }
     return f;
 }
-OF_DEV s16x8 gload_frag(const bf16_t* __restrict__ base, long ld, long row, long nrows, int col) {
+OF_DEV s16x8 gload_frag(const bf16_t* __restrict__ base, long ld, long row, long nrows, int col, bool col_valid = true) {
     s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (row < nrows) z = *(const s16x8*)(base + (size_t)row * ld + col);
+    if (row < nrows && col_valid) z = *(const s16x8*)(base + (size_t)row * ld + col);
     return z;
 }
 // two score fragments -> one bf16 MFMA operand (v_cvt_pk_bf16_f32: round-to-nearest-even, two values per instruction)
@@ -158,9 +160,11 @@ OF_DEV s16x8 frag_t2(const char* img, int off_dt, int kbase, int col_base, int l
 
 // LDS-DMA (global_load_lds, no VGPR staging) of rows of a row-major bf16 matrix into a block image: a 1-KiB piece = RPK whole rows.
 // The image swizzles of frag_n / frag_t are applied to the SOURCE address because the DMA destination is lane-linear.  Rows past the
-// end are clamped to the last row: finite data, their scores are masked / their probabilities 0.
+// end are clamped to the last row: finite data, their scores are masked / their probabilities 0.  Compact heads (hv < DH: columns
+// hv .. DH - 1 of a head do not exist): those units of the image get the row's unit 0 again -- finite data that only ever meets the zero
+// columns of a register-loaded operand (q, dO) or lands in output columns that are not stored.
 template <int DH, bool TR>
-OF_DEV void dma_piece(const bf16_t* __restrict__ src, long ld, long row0, long nrows, int col0, int pc, int lane, char* img) {
+OF_DEV void dma_piece(const bf16_t* __restrict__ src, long ld, long row0, long nrows, int col0, int pc, int lane, char* img, int hv = DH) {
     constexpr int RPK = DH == 128 ? 4 : 8;          // rows per 1-KiB DMA piece
     constexpr int LPR = 64 / RPK;                   // lanes (16-byte units) per row
     const int r = lane / LPR, qpos = lane % LPR;
@@ -174,13 +178,14 @@ OF_DEV void dma_piece(const bf16_t* __restrict__ src, long ld, long row0, long n
         const int c = (qpos >> 1) ^ (DH == 128 ? (row & 7) : ((row >> 1) & 3));
         unit = (c << 1) | (qpos & 1);
     }
+    if (hv < DH && unit * 8 >= hv) unit = 0;
     of_glds16(src + (size_t)arow * ld + col0 + unit * 8, img + pc * 1024);
 }
 template <int DH, bool TR, int NW>
 OF_DEV void dma_block(const bf16_t* __restrict__ src, long ld, long row0, long nrows, int rows_blk, int col0, int wave, int lane,
-                      char* img) {
+                      char* img, int hv = DH) {
     constexpr int RPK = DH == 128 ? 4 : 8;
-    for (int pc = wave; pc * RPK < rows_blk; pc += NW) dma_piece<DH, TR>(src, ld, row0, nrows, col0, pc, lane, img);
+    for (int pc = wave; pc * RPK < rows_blk; pc += NW) dma_piece<DH, TR>(src, ld, row0, nrows, col0, pc, lane, img, hv);
 }
 
 // 16-byte slot `slot` of row `row` of a bf16 image with `row_bytes` per row (a multiple of 256): the 16 rows of a fragment read (same

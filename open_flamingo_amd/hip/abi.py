@@ -5,7 +5,7 @@ Pure declarations: nothing here loads a library.  ``open_flamingo_amd.hip.lib`` 
 """
 import ctypes as C
 
-OF_ABI_VERSION = 10
+OF_ABI_VERSION = 11
 OF_SUMSQ_PARTS = 512
 EPI_STORE_BF16, EPI_GELU, EPI_GATE_RESID, EPI_DGELU_DOT, EPI_SCALE_DOT, EPI_ACC_F32 = range(6)
 
@@ -46,6 +46,7 @@ class OfAttnArgs(C.Structure):
         ("delta", vp),
         ("safe", C.c_int),
         ("head_dim", C.c_int), ("causal", C.c_int), ("alibi_slopes", vp), ("kv_len", vp),
+        ("head_valid", C.c_int),
     ]
 
 

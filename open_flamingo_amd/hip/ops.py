@@ -267,7 +267,7 @@ class Ops:
 
     # ------------------------------------------------------------------ attention core
     def _attn_args(self, q, k, v, o, lse, batch, Lq, Lk, heads, text_time, n_per_media, T_img, only_immediate, scale,
-                   safe, head_dim=64, causal=False, alibi_slopes=None, kv_len=None):
+                   safe, head_dim=64, causal=False, alibi_slopes=None, kv_len=None, head_valid=0):
         a = abi.OfAttnArgs()
         a.q, a.k, a.v, a.o, a.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr()
         a.text_time = _p(text_time)
@@ -277,20 +277,22 @@ class Ops:
         a.scale = scale
         a.safe = safe
         a.head_dim, a.causal, a.alibi_slopes, a.kv_len = head_dim, int(causal), _p(alibi_slopes), _p(kv_len)
+        a.head_valid = head_valid
         return a
 
     def attn_fwd(self, q, k, v, o, lse, *, batch, Lq, Lk, heads, text_time=None, n_per_media=0, T_img=0,
-                 only_immediate=True, scale=0.125, safe=0, head_dim=64, causal=False, alibi_slopes=None, kv_len=None):
-        """q,o: (batch*Lq, >=heads*head_dim) rows; k,v: (batch*Lk, ...) rows (views into a fused kv buffer are fine)."""
+                 only_immediate=True, scale=0.125, safe=0, head_dim=64, causal=False, alibi_slopes=None, kv_len=None, head_valid=0):
+        """q,o: (batch*Lq, >=heads*head_dim) rows; k,v: (batch*Lk, ...) rows (views into a fused kv buffer are fine).
+        head_valid (compact heads, include/of_hip.h): heads of head_valid < head_dim columns each, side by side."""
         a = self._attn_args(q, k, v, o, lse, batch, Lq, Lk, heads, text_time, n_per_media, T_img, only_immediate,
-                            scale, safe, head_dim, causal, alibi_slopes, kv_len)
+                            scale, safe, head_dim, causal, alibi_slopes, kv_len, head_valid)
         self._chk(self.lib.of_attn_fwd(C.byref(a), self._stream()), "of_attn_fwd")
 
     def attn_bwd(self, q, k, v, o, lse, dout, dq, dk, dv, delta, *, batch, Lq, Lk, heads, text_time=None,
                  n_per_media=0, T_img=0, only_immediate=True, scale=0.125, safe=0, head_dim=64, causal=False,
-                 alibi_slopes=None, kv_len=None):
+                 alibi_slopes=None, kv_len=None, head_valid=0):
         a = self._attn_args(q, k, v, o, lse, batch, Lq, Lk, heads, text_time, n_per_media, T_img, only_immediate,
-                            scale, safe, head_dim, causal, alibi_slopes, kv_len)
+                            scale, safe, head_dim, causal, alibi_slopes, kv_len, head_valid)
         a.dout, a.lddo = dout.data_ptr(), dout.stride(0)
         a.dq, a.lddq = dq.data_ptr(), dq.stride(0)
         a.dk, a.dv, a.lddk, a.lddv = dk.data_ptr(), dv.data_ptr(), dk.stride(0), dv.stride(0)

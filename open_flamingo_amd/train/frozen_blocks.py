@@ -378,12 +378,17 @@ def use_fused_frozen_mpt_blocks(lm, allow_cpu=False, assume_right_padding=False)
 
 
 # ------------------------------------------------------------------------------------------------ frozen GPT-NeoX blocks (OF-4B)
-_NEOX_HEAD_PAD = {64: 64, 128: 128}
+# GPT-NeoX head sizes other than 64 / 128 (RedPajama-INCITE-3B: 80): True = compact heads (OfAttnArgs.head_valid, ABI v11: q, k, v, o and
+# their gradients stay (rows, heads x head_size) in HBM, the 128-wide kernels read the missing columns as zeros); False = zero-padded copies
+# + of_head_repack passes (rounds 2-5; kept as the other arm of tools/ab_neox_compact_heads.py).  A constant set from that same-box A/B.
+_NEOX_COMPACT_HEADS = True
 
 
 def _neox_pad(head_size):
-    """Head size the attention kernels run at: 64 / 128 as they are, anything else <= 128 zero-padded to the next of the two
-    (RedPajama-INCITE-3B: 80 -> 128)."""
+    """Head size the attention kernels run at: 64 / 128 as they are, anything else <= 128 at the next of the two with COMPACT heads
+    (OfAttnArgs.head_valid, ABI v11: RedPajama-INCITE-3B's 80 columns per head side by side in HBM, the kernels read the missing
+    columns as zeros -- round 6; before: zero-padded copies of q, k, v, o and their gradients, ~0.33 GB of extra traffic and two
+    repack launches per layer and step)."""
     return 64 if head_size <= 64 else 128
 
 
@@ -410,14 +415,16 @@ class _FrozenNeoXBlockFn(torch.autograd.Function):
         st1 = torch.empty(rows, 2, dtype=F32, device=dev)
         ops.ln_fwd(x2, w1, b1, a, st1)
         qkv = torch.addmm(bqkv, a, Wqkv.t())                             # (rows, heads * 3 * hs): [q_h | k_h | v_h] per head
-        qp = torch.empty(3, rows, heads * pad, dtype=BF16, device=dev)   # rotated + padded q, k, v
-        ops.rotary_neox(qkv, cos, sin, qp[0], qp[1], qp[2], L=L, heads=heads, head_size=hs, rot_dims=rot, head_pad=pad)
-        op = torch.empty(rows, heads * pad, dtype=BF16, device=dev)
+        hw = hs if _NEOX_COMPACT_HEADS else pad                          # columns a head owns in q, k, v, o and their gradients
+        qp = torch.empty(3, rows, heads * hw, dtype=BF16, device=dev)    # rotated q, k, v: (rows, heads x hw), heads side by side
+        ops.rotary_neox(qkv, cos, sin, qp[0], qp[1], qp[2], L=L, heads=heads, head_size=hs, rot_dims=rot, head_pad=hw)
+        op = torch.empty(rows, heads * hw, dtype=BF16, device=dev)
         lse = torch.empty(B, heads, L, dtype=F32, device=dev)
-        kw = dict(batch=B, Lq=L, Lk=L, heads=heads, scale=hs ** -0.5, head_dim=pad, causal=True, kv_len=kv_len)
+        kw = dict(batch=B, Lq=L, Lk=L, heads=heads, scale=hs ** -0.5, head_dim=pad, head_valid=0 if hw == pad else hs, causal=True,
+                  kv_len=kv_len)
         ops.attn_fwd(qp[0], qp[1], qp[2], op, lse, **kw)
-        o = op if pad == hs else ops.head_repack(op, torch.empty(rows, d, dtype=BF16, device=dev), heads=heads, src_head_size=pad,
-                                                  dst_head_size=hs)
+        o = op if hw == hs else ops.head_repack(op, torch.empty(rows, d, dtype=BF16, device=dev), heads=heads, src_head_size=hw,
+                                                 dst_head_size=hs)
         t = torch.addmm(bd, o, Wd.t())                                   # attention branch, bf16
         m = torch.empty(rows, d, dtype=BF16, device=dev)
         st2 = torch.empty(rows, 2, dtype=F32, device=dev)
@@ -434,7 +441,7 @@ class _FrozenNeoXBlockFn(torch.autograd.Function):
             ops.add_bf16(y, t, out=y)                                    # x + mlp + attn
         ctx.save_for_backward(x2, st1, qp, op, lse, x1, st2, h, w1, w2, Wqkv, Wd, Wup, Wdown, cos, sin, kv_len)
         ctx.scope = scope
-        ctx.kw, ctx.shape, ctx.wts, ctx.cfg = kw, (B, L, d), wts, (heads, hs, rot, pad, parallel)
+        ctx.kw, ctx.shape, ctx.wts, ctx.cfg = kw, (B, L, d), wts, (heads, hs, rot, hw, parallel)
         return y.view(B, L, d)
 
     @staticmethod
@@ -442,7 +449,7 @@ class _FrozenNeoXBlockFn(torch.autograd.Function):
         ops = _ops()
         x2, st1, qp, op, lse, x1, st2, h, w1, w2, Wqkv, Wd, Wup, Wdown, cos, sin, kv_len = ctx.saved_tensors
         tq, td, tu, tdn = ctx.wts if ctx.wts is not None else (None, None, None, None)
-        heads, hs, rot, pad, parallel = ctx.cfg
+        heads, hs, rot, hw, parallel = ctx.cfg
         B, L, d = ctx.shape
         rows = B * L
         dev = dy.device
@@ -468,13 +475,13 @@ class _FrozenNeoXBlockFn(torch.autograd.Function):
             dtb = torch.empty(rows, d, dtype=BF16, device=dev)
             ops.ln_bwd(dm, x1, st2, w2, resid=dy2, dx=dx1, dx_bf16=dtb)  # dx1 = dy + norm_2'(dm) reaches x AND the attention branch
         do = _mm_dx(dtb, Wd, td)                                         # (rows, d)
-        dop = do if pad == hs else ops.head_repack(do, torch.empty(rows, heads * pad, dtype=BF16, device=dev), heads=heads,
-                                                    src_head_size=hs, dst_head_size=pad)
+        dop = do if hw == hs else ops.head_repack(do, torch.empty(rows, heads * hw, dtype=BF16, device=dev), heads=heads,
+                                                   src_head_size=hs, dst_head_size=hw)
         dqp = torch.empty_like(qp)
         delta = torch.empty(B, heads, L, dtype=F32, device=dev)
         ops.attn_bwd(qp[0], qp[1], qp[2], op, lse, dop, dqp[0], dqp[1], dqp[2], delta, **ctx.kw)
         dqkv = torch.empty(rows, heads * 3 * hs, dtype=BF16, device=dev)
-        ops.rotary_neox(dqkv, cos, sin, dqp[0], dqp[1], dqp[2], L=L, heads=heads, head_size=hs, rot_dims=rot, head_pad=pad, inverse=True)
+        ops.rotary_neox(dqkv, cos, sin, dqp[0], dqp[1], dqp[2], L=L, heads=heads, head_size=hs, rot_dims=rot, head_pad=hw, inverse=True)
         da = _mm_dx(dqkv, Wqkv, tq)
         dxb = torch.empty(rows, d, dtype=BF16, device=dev) if _path.TWINS else None
         ops.ln_bwd(da, x2, st1, w1, resid=dx1, dx=dx1, dx_bf16=dxb)      # in place: dx = dx1 + norm_1'(da); + its bf16 twin

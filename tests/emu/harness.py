@@ -65,16 +65,18 @@ def gemm(A, B, *, a_trans=0, b_trans=0, epi=abi.EPI_STORE_BF16, C_out=None, C2=N
 
 
 def attn_args(q, k, v, o, lse, text_time=None, n_per_media=0, T_img=0, only_immediate=1, heads=None, safe=0,
-              dout=None, dq=None, dk=None, dv=None, delta=None, head_dim=64, causal=0, alibi_slopes=None, kv_len=None):
+              dout=None, dq=None, dk=None, dv=None, delta=None, head_dim=64, causal=0, alibi_slopes=None, kv_len=None, head_valid=0,
+              scale=None):
     """q (batch,Lq,H*64) bf16; k,v (batch,Lk,H*64) bf16 (may be views into a fused kv buffer)."""
     a = abi.OfAttnArgs()
     a.q, a.k, a.v, a.o, a.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr()
     a.text_time = text_time.data_ptr() if text_time is not None else None
     a.batch, a.Lq, a.Lk = q.shape[0], q.shape[1], k.shape[1]
-    a.heads = heads if heads is not None else q.shape[2] // head_dim
+    a.heads = heads if heads is not None else q.shape[2] // (head_valid or head_dim)
+    a.head_valid = head_valid
     a.ldq, a.ldk, a.ldv, a.ldo = q.stride(1), k.stride(1), v.stride(1), o.stride(1)
     a.n_per_media, a.T_img, a.only_immediate = n_per_media, T_img, only_immediate
-    a.scale = head_dim ** -0.5
+    a.scale = scale if scale is not None else head_dim ** -0.5
     a.safe = safe
     a.head_dim, a.causal = head_dim, causal
     a.alibi_slopes = alibi_slopes.data_ptr() if alibi_slopes is not None else None

@@ -123,12 +123,15 @@ def test_fused_frozen_mpt_block_matches_hf_eager(on_emulator, d, heads, routes, 
     assert out.past_key_values is not None
 
 
-@pytest.mark.parametrize("parallel,rotary_pct,hs", [(True, 0.25, 80), (False, 1.0, 80), (True, 1.0, 64)])
-def test_fused_frozen_neox_block_matches_hf_eager(on_emulator, parallel, rotary_pct, hs):
-    """SURVEY 8f N1 for OF-4B: whole frozen GPT-NeoX layers (RedPajama-INCITE-3B's head size 80, zero-padded to 128 for the
-    attention kernels; rotary embedding + padding in one libofhip pass; parallel and sequential residual layouts; biases in the
+@pytest.mark.parametrize("parallel,rotary_pct,hs,compact", [(True, 0.25, 80, True), (False, 1.0, 80, True), (True, 1.0, 64, True),
+                                                            (False, 1.0, 80, False)])
+def test_fused_frozen_neox_block_matches_hf_eager(on_emulator, monkeypatch, parallel, rotary_pct, hs, compact):
+    """SURVEY 8f N1 for OF-4B: whole frozen GPT-NeoX layers (RedPajama-INCITE-3B's head size 80: compact heads at the 128-wide
+    attention kernels, OfAttnArgs.head_valid -- or, compact = False, the zero-padded copies of rounds 2-5, the other arm of
+    tools/ab_neox_compact_heads.py; rotary embedding in one libofhip pass; parallel and sequential residual layouts; biases in the
     GEMMs) as one autograd node each vs the HF modules' eager forward / autograd under autocast(bf16), right padding."""
     from transformers import GPTNeoXConfig, GPTNeoXForCausalLM
+    monkeypatch.setattr(frozen_blocks, "_NEOX_COMPACT_HEADS", compact)
     torch.manual_seed(0)
     cfg = GPTNeoXConfig(hidden_size=2 * hs, num_hidden_layers=2, num_attention_heads=2, intermediate_size=8 * hs, vocab_size=128,
                         max_position_embeddings=64, rotary_pct=rotary_pct, use_parallel_residual=parallel,

@@ -864,3 +864,54 @@ def test_single_pass_backward_matches_the_two_passes_at_tower_shapes(ops, dh, he
     (s.softmax(-1) @ v).transpose(1, 2).reshape(nb * L, d).backward(do[:nb * L].float())
     for i, name in enumerate(("dq", "dk", "dv")):
         assert _rel(outs[3][:nb * L, i * d:(i + 1) * d], x.grad[:, i * d:(i + 1) * d]) < 2e-2, name
+
+
+@pytest.mark.parametrize("hv,dh,heads,B,L", [(80, 128, 32, 16, 256), (80, 128, 5, 3, 200), (40, 64, 8, 8, 256), (96, 128, 4, 2, 320)])
+def test_compact_heads_equal_the_zero_padded_launch(ops, hv, dh, heads, B, L):
+    """OfAttnArgs.head_valid (ABI v11): heads of hv < head_dim columns side by side in memory -- GPT-NeoX head size 80 at the 128-wide
+    kernels (OF-4B's frozen RedPajama-3B blocks: 16 x 32 heads, L = 256, causal, right padding) -- against the SAME kernels on zero-padded
+    copies, bit for bit (the padded columns add exact zeros to every sum): forward (tiled, resident) and backward (two passes, single
+    pass), of_attn's own choice included; and against autograd through a dense fp32 softmax."""
+    d, dp = heads * hv, heads * dh
+    q, k, v, do = (_r((B * L, d), 90 + i) for i in range(4))
+    kv_len = torch.tensor([L - 7 * (i % 5) for i in range(B)], dtype=torch.int32, device="cuda")
+
+    def pad(t):
+        p = torch.zeros(B * L, heads, dh, dtype=t.dtype, device="cuda")
+        p[..., :hv] = t.view(B * L, heads, hv)
+        return p.view(B * L, dp)
+
+    def unpad(t):
+        return t.view(B * L, heads, dh)[..., :hv].reshape(B * L, d)
+
+    def run(q, k, v, do, safe, head_valid):
+        kw = dict(batch=B, Lq=L, Lk=L, heads=heads, scale=hv ** -0.5, head_dim=dh, head_valid=head_valid, causal=True, kv_len=kv_len, safe=safe)
+        o = torch.full_like(q, float("nan"))
+        lse = torch.full((B, heads, L), float("nan"), device="cuda")
+        ops.attn_fwd(q, k, v, o, lse, **kw)
+        dq, dk, dv = (torch.full_like(q, float("nan")) for _ in range(3))
+        ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, torch.zeros(B, heads, L, device="cuda"), **kw)
+        return o, lse, dq, dk, dv
+
+    res = {}
+    single = dh == 128 and hv in (80, 96)            # the widths the single-pass backward is instantiated for; others take the two passes
+    for safe in (0, 2) + ((3,) if L <= 256 and single else ()):
+        got = run(q, k, v, do, safe, hv)
+        want = run(pad(q), pad(k), pad(v), pad(do), safe, 0)
+        assert torch.equal(got[1], want[1]), ("lse", safe)
+        for name, g, w in zip(("o", "dq", "dk", "dv"), (got[0],) + got[2:], (want[0],) + want[2:]):
+            assert torch.isfinite(g.float()).all(), (name, safe)
+            assert torch.equal(g, unpad(w)), (name, safe)
+        res[safe] = got
+    nb = min(B, 3)
+    x = [t[:nb * L].float().requires_grad_(True) for t in (q, k, v)]
+    qh, kh, vh = (t.view(nb, L, heads, hv).transpose(1, 2) for t in x)
+    s = qh @ kh.transpose(-1, -2) * hv ** -0.5
+    pos = torch.arange(L, device="cuda")
+    dead = (pos.view(1, 1, 1, L) > pos.view(1, 1, L, 1)) | (pos.view(1, 1, 1, L) >= kv_len[:nb].view(nb, 1, 1, 1))
+    out = (s.masked_fill(dead, float("-inf")).softmax(-1) @ vh).transpose(1, 2).reshape(nb * L, d)
+    out.backward(do[:nb * L].float())
+    o, _, dq, dk, dv = res[0]
+    assert _rel(o[:nb * L], out.detach()) < 1e-2
+    for name, g, t in (("dq", dq, x[0]), ("dk", dk, x[1]), ("dv", dv, x[2])):
+        assert _rel(g[:nb * L], t.grad) < 2e-2, name

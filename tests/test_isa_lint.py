@@ -53,6 +53,12 @@ def test_no_valu_write_right_in_front_of_an_asm_mfma(tmp_path, src, min_mfma):
             window = []
         elif op.startswith("v_") and args:
             window.append((op, _regs(args[0])))
+        elif op.startswith(("ds_read", "global_load", "scratch_load")) and args and _regs(args[0]):
+            # a load result replaces what a VALU wrote there (e.g. the load's own address register reused as its destination): the MFMA
+            # then reads the LOAD's data, ordered by s_waitcnt -- the earlier VALU write is dead, not a hazard
+            kind, regs = _regs(args[0])
+            window = [(wop, (wr[0], wr[1] - regs) if wr is not None and wr[0] == kind else wr) for wop, wr in window]
+            window.append((op, None))
         else:
             window.append((op, None))
         window = window[-4:]
