@@ -192,14 +192,18 @@ OF_GLOBAL void OF_BOUNDS(256, 2) of_attn_q_kernel(OfAttnArgs p) {
 // tile of every wave needs key blocks <= t, block t+1 is in flight while step t computes; everything else loads all blocks
 // up front (32-80 KB: two workgroups per CU overlap each other).  Same arithmetic, masks and statistics as
 // of_attn_q_kernel<DH, false>; eligible when the two images fit the CU's 160 KB.
-template <int DH, int NW, bool CMP = false>      // NW waves per workgroup: 8 at head dim 128 (128 KB of images -> one workgroup per CU), else 4
+// HV: DH = every head owns DH columns; 0 = compact heads of a run-time width (OfAttnArgs.head_valid); 80 / 96 (at DH 128) = compact heads
+// of that width with the k-steps of S and the d tiles of O that hold no column < HV skipped (3 of 4 k-steps, 5 of 8 d tiles at 80)
+template <int DH, int NW, int HV = DH>      // NW waves per workgroup: 8 at head dim 128 (128 KB of images -> one workgroup per CU), else 4
 OF_GLOBAL void OF_BOUNDS(NW * 64, 2) of_attn_fwd_res_kernel(OfAttnArgs p) {
-    constexpr int NKS = DH / 32, NDT = DH / 16, IMG = 64 * DH * 2;
+    constexpr bool CMP = HV != DH;
+    constexpr int NKS = HV > 0 ? (HV + 31) / 32 : DH / 32, NDT = DH / 16, IMG = 64 * DH * 2;
+    constexpr int NDTV = HV > 0 ? (HV + 15) / 16 : NDT, NDTE = (NDTV + 1) & ~1;      // d tiles with data; ... in the pairs store_row_blocks takes
     char* smem = of_smem();
     const int tid = of_tid(), lane = tid & 63, wave = tid >> 6, g = lane >> 4, i16 = lane & 15;
     const int h = of_bid_x();
     const long batch = of_bid_y();
-    const int hv = CMP ? p.head_valid : DH;
+    const int hv = HV > 0 ? HV : p.head_valid;
     const int hc = h * hv;
     const float slope = p.alibi_slopes ? p.alibi_slopes[h] : 0.f;
     const bool has_alibi = p.alibi_slopes != nullptr;
@@ -230,7 +234,7 @@ OF_GLOBAL void OF_BOUNDS(NW * 64, 2) of_attn_fwd_res_kernel(OfAttnArgs p) {
     of_wait_vm<0>();
     of_sync();
 
-    u32x2 po[NDT];                 // previous tile's packed output, stored while the next tile computes
+    u32x2 po[NDTE];                // previous tile's packed output, stored while the next tile computes
     long po_row = -1;
     bool po_live = false;          // the wave holds a finished tile (rows beyond Lq have po_row = -1 and store nothing)
     for (int t = 0; t < nsteps; ++t) {
@@ -281,7 +285,7 @@ OF_GLOBAL void OF_BOUNDS(NW * 64, 2) of_attn_fwd_res_kernel(OfAttnArgs p) {
                         for (int ks = 0; ks < NKS; ++ks) s[tt] = of_mfma(frag_n2<DH>(kimg, fo.n[ks], tt * 16), qf[ks], s[tt]);
                     }
                     const float mb = score_block_any(s, rc, tr, key0, 64, g, has_alibi);
-                    softmax_pv<DH, false, 4>(s, mb, vimg, fo, lane, acc, m_i, l_i);
+                    softmax_pv<DH, false, 4, NDTV>(s, mb, vimg, fo, lane, acc, m_i, l_i);
                 } else {                          // 32-row tail block of the images
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) s[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -290,13 +294,13 @@ OF_GLOBAL void OF_BOUNDS(NW * 64, 2) of_attn_fwd_res_kernel(OfAttnArgs p) {
 #pragma unroll
                         for (int ks = 0; ks < NKS; ++ks) s[tt] = of_mfma(frag_n2<DH>(kimg, fo.n[ks], tt * 16), qf[ks], s[tt]);
                     const float mb = score_block_any(s, rc, tr, key0, 32, g, has_alibi);
-                    softmax_pv<DH, false, 2>(s, mb, vimg, fo, lane, acc, m_i, l_i);
+                    softmax_pv<DH, false, 2, NDTV>(s, mb, vimg, fo, lane, acc, m_i, l_i);
                 }
             }
             {
                 const float inv = l_i > 0.f ? 1.0f / l_i : 0.f;
 #pragma unroll
-                for (int dt = 0; dt < NDT; ++dt)
+                for (int dt = 0; dt < NDTE; ++dt)
                     po[dt] = u32x2{of_pack_bf16(acc[dt][0] * inv, acc[dt][1] * inv), of_pack_bf16(acc[dt][2] * inv, acc[dt][3] * inv)};
                 po_live = true;
                 po_row = my_row < p.Lq ? my_row : -1;
@@ -552,7 +556,9 @@ int launch_fwd(const OfAttnArgs& a, of_stream_t s) {
     const bool cmp = compact<DH>(a);
     if (const size_t res = resident_smem<DH>(a)) {
         const of_dim3 grid{(unsigned)a.heads, (unsigned)a.batch, 1};
-        if (cmp) return of_launch(of_attn_fwd_res_kernel<DH, (DH == 128 ? 8 : 4), true>, grid, DH == 128 ? 512 : 256, res, s, a);
+        if (cmp && DH == 128 && a.head_valid == 80) return of_launch(of_attn_fwd_res_kernel<128, 8, 80>, grid, 512, res, s, a);
+        if (cmp && DH == 128 && a.head_valid == 96) return of_launch(of_attn_fwd_res_kernel<128, 8, 96>, grid, 512, res, s, a);
+        if (cmp) return of_launch(of_attn_fwd_res_kernel<DH, (DH == 128 ? 8 : 4), 0>, grid, DH == 128 ? 512 : 256, res, s, a);
         return of_launch(of_attn_fwd_res_kernel<DH, (DH == 128 ? 8 : 4)>, grid, DH == 128 ? 512 : 256, res, s, a);
     }
     of_dim3 grid{(unsigned)a.heads, (unsigned)((a.Lq + 63) / 64), (unsigned)a.batch};

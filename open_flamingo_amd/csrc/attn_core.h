@@ -312,10 +312,10 @@ OF_DEV float score_block_any(f32x4 (&s)[4], const RowCtx& rc, const TileRange& t
 // One online-softmax step of the forward: log2-domain scores of 16 queries x (16 NSUB) keys -> running max / sum,
 // O^T += V^T P^T.  vimg = transpose image of the key block; NSUB = 16-key sub-tiles the block holds (4; 2 for the tail block
 // of a resident image).
-template <int DH, bool SAFE, int NSUB>
+// NDT = d tiles of O that are computed (compact heads of a compile-time width: the tiles without a column of the head are skipped)
+template <int DH, bool SAFE, int NSUB, int NDT = DH / 16>
 OF_DEV void softmax_pv(f32x4 (&s)[4], float mb, const char* vimg, const FragOff<DH>& fo, int lane, f32x4 (&acc)[DH / 16],
                        float& m_i, float& l_i) {
-    constexpr int NDT = DH / 16;
     mb = of_rows_max(mb);
     const float m_new = of_max(mb, m_i);
     const float alpha = of_exp2(m_i - m_new);
