@@ -560,6 +560,25 @@ def use_fused_frozen_neox_blocks(lm, allow_cpu=False, assume_right_padding=False
 
 
 # ------------------------------------------------------------------------------------------------ CLIP vision tower
+# fc2 of the CLIP MLP (K = 4096) with the rows split into whole 256-row tiles + the ragged rest: 64 images x 257 tokens = 16448 rows are
+# 64.25 row tiles, every tiling of the vendor library leaves a ragged last round (tuned: 114.7 us); the first 16384 rows alone are whole
+# rounds of the 256 CUs (86.3 us) and the last 64 rows a 15.5-us launch (tools/probes/vit_rows_probe.py, profiles/r06zq_*).  The same
+# split does not pay for the tower's K = 1024 GEMMs (9-14 us gained, 13-14 us for the rest rows).  Rows are independent: same bits.
+_FC2_WHOLE_TILES = True
+
+
+def _addmm_whole_tiles(bias, a, wt):
+    """a @ wt + bias, as two launches when the rows are a ragged number of 256-row tiles (see _FC2_WHOLE_TILES)"""
+    rows = a.shape[0]
+    main = rows // 256 * 256
+    if not _FC2_WHOLE_TILES or main == rows or main < 4096:
+        return torch.addmm(bias, a, wt)
+    out = torch.empty(rows, wt.shape[1], dtype=a.dtype, device=a.device)
+    torch.addmm(bias, a[:main], wt, out=out[:main])
+    torch.addmm(bias, a[main:], wt, out=out[main:])
+    return out
+
+
 def _fused_qkv(attn):
     """(3D, D) weight and (3D,) bias of the three projections of one CLIPAttention as ONE GEMM operand (the three eager
     GEMMs read the same LayerNorm output); cached on the module, rebuilt when a source tensor is replaced or modified."""
@@ -622,7 +641,7 @@ def clip_encoder_fused(encoder, x, attention="libofhip"):
             xs = torch.empty(rows, D, dtype=F32, device=dev)
         ops.ln_fwd_add(src, t, xs, n2.weight, n2.bias, a, None)          # xs = stream + attention branch; a = LN2(xs)
         h = torch.addmm(mlp.fc1.bias, a, mlp.fc1.weight.t())
-        pending = torch.addmm(mlp.fc2.bias, ops.quick_gelu(h), mlp.fc2.weight.t())
+        pending = _addmm_whole_tiles(mlp.fc2.bias, ops.quick_gelu(h), mlp.fc2.weight.t())
     return xs, pending
 
 
