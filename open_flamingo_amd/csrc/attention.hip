@@ -583,10 +583,46 @@ bool bwd_single_pass(const OfAttnArgs& a) {
     const long n = (long)a.batch * a.heads, rounds = (n + OF_NUM_CUS - 1) / OF_NUM_CUS;
     return 10 * n >= 7 * rounds * OF_NUM_CUS;
 }
+// `a` restricted to the sequences [b0, b0 + nb) of its batch
+OfAttnArgs batch_slice(const OfAttnArgs& a, int b0, int nb) {
+    OfAttnArgs r = a;
+    r.batch = nb;
+    r.q += (size_t)b0 * a.Lq * a.ldq;
+    r.k += (size_t)b0 * a.Lk * a.ldk;
+    r.v += (size_t)b0 * a.Lk * a.ldv;
+    r.o += (size_t)b0 * a.Lq * a.ldo;
+    r.dout += (size_t)b0 * a.Lq * a.lddo;
+    r.dq += (size_t)b0 * a.Lq * a.lddq;
+    r.dk += (size_t)b0 * a.Lk * a.lddk;
+    r.dv += (size_t)b0 * a.Lk * a.lddv;
+    r.lse += (size_t)b0 * a.heads * a.Lq;
+    r.delta += (size_t)b0 * a.heads * a.Lq;
+    if (a.kv_len) r.kv_len += b0;
+    if (a.text_time) r.text_time += (size_t)b0 * a.Lq;
+    return r;
+}
 template <int DH>
 int launch_bwd(const OfAttnArgs& a, of_stream_t s) {
     constexpr int IMG = 64 * DH * 2;
     if (bwd_single_pass(a)) return attn_bwd_res_launch(a, s);
+    // A head count the single pass is not chosen for because its last round of OF_NUM_CUS workgroups would be mostly empty (OF-9B's frozen
+    // MPT-7B blocks: 10 x 32 = 320 heads): the whole rounds' worth of SEQUENCES takes the single pass (49 us per round against 69 us
+    // for the same heads on the two passes), the remaining sequences the two passes.  Every (batch, head) is computed by one form or the
+    // other exactly as a launch of that form alone would: run to run the same bits.
+#ifndef OF_AB_ATTN_BWD_TWO_PASS
+    if (a.safe == 0 && attn_bwd_res_fits(a) && a.Lq >= 128 && a.Lk >= 128) {
+        const long n = (long)a.batch * a.heads;
+        const long whole = n / OF_NUM_CUS * OF_NUM_CUS;
+        if (whole > 0 && whole % a.heads == 0 && whole < n) {
+            const int nb = (int)(whole / a.heads);
+            const int rc = attn_bwd_res_launch(batch_slice(a, 0, nb), s);
+            if (rc) return rc;
+            OfAttnArgs rest = batch_slice(a, nb, a.batch - nb);
+            rest.safe = 2;
+            return launch_bwd<DH>(rest, s);
+        }
+    }
+#endif
     of_dim3 gq{(unsigned)a.heads, (unsigned)((a.Lq + 63) / 64), (unsigned)a.batch};
     const size_t smem_q = 3 * IMG + 196 * sizeof(int);
     const bool cmp = compact<DH>(a);

@@ -915,3 +915,27 @@ def test_compact_heads_equal_the_zero_padded_launch(ops, hv, dh, heads, B, L):
     assert _rel(o[:nb * L], out.detach()) < 1e-2
     for name, g, t in (("dq", dq, x[0]), ("dk", dk, x[1]), ("dv", dv, x[2])):
         assert _rel(g[:nb * L], t.grad) < 2e-2, name
+
+
+def test_attention_backward_splits_a_ragged_head_count_between_the_two_forms(ops):
+    """of_attn_bwd at OF-9B's frozen MPT-7B blocks (BASELINE config 5: 10 sequences x 32 heads = 320 (batch, head) pairs, 256 x 256, head
+    128, causal + ALiBi): 1.25 rounds of the 256 CUs, so the single pass alone is not chosen; the first 8 sequences (one whole round)
+    take it, the last 2 the two passes -- each sequence bit for bit what a launch of that form alone gives."""
+    dh, heads, B, L = 128, 32, 10, 256
+    d = heads * dh
+    qkv, do = _r((B * L, 3 * d), 75), _r((B * L, d), 76)
+    slopes = torch.tensor([2.0 ** (-8.0 * (i + 1) / heads) for i in range(heads)], device="cuda")
+    kw = dict(batch=B, Lq=L, Lk=L, heads=heads, scale=dh ** -0.5, head_dim=dh, causal=True, alibi_slopes=slopes)
+    o = torch.empty(B * L, d, device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(B, heads, L, device="cuda")
+    ops.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, **kw)
+    outs = {}
+    for safe in (0, 3, 2):
+        dqkv = torch.full_like(qkv, float("nan"))
+        ops.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, do, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
+                     torch.zeros(B, heads, L, device="cuda"), safe=safe, **kw)
+        assert torch.isfinite(dqkv.float()).all(), safe
+        outs[safe] = dqkv
+    cut = 8 * L
+    assert torch.equal(outs[0][:cut], outs[3][:cut]) and torch.equal(outs[0][cut:], outs[2][cut:])
+    assert _rel(outs[0], outs[2].double()) < 4e-3
