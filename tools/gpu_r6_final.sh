@@ -38,3 +38,11 @@ cat gpurun_out/${TAG}_vendor_plain_vs_ours.jsonl | cut -c1-260
 # 6. HBM traffic of the dominant GEMM launches and of the fused attention branch (separate --pmc passes, --kernel-trace only)
 bash tools/gpu_pmc_traffic.sh $TAG > gpurun_out/${TAG}_gemm_hbm_traffic_pmc.log 2>&1
 cat gpurun_out/pmc_traffic_$TAG.txt gpurun_out/pmc_traffic_$TAG.sha16
+# 7. compact heads (OF-4B's head size 80 on the 128-wide attention kernels): per-layer probe + the step-level same-box A/B against the padded copies;
+#    the CLIP tower's fc2 row split and the attention backward's split of a ragged head count (config 5), same box
+( timeout 300 python tools/probes/compact_heads_probe.py 2>/dev/null | grep "^{" ) > gpurun_out/${TAG}_compact_heads_probe.jsonl
+cut -c1-420 gpurun_out/${TAG}_compact_heads_probe.jsonl
+( timeout 900 python tools/ab_neox_compact_heads.py --steps 8 --warmup 3 2>/dev/null | cut -c1-330 ) > gpurun_out/${TAG}_ab_neox_compact_heads_step.jsonl
+cut -c1-260 gpurun_out/${TAG}_ab_neox_compact_heads_step.jsonl
+( timeout 900 python tools/ab_vit_fc2_split.py --steps 12 --warmup 4 2>/dev/null | cut -c1-330 ) > gpurun_out/${TAG}_ab_vit_fc2_split_step.jsonl
+cut -c1-260 gpurun_out/${TAG}_ab_vit_fc2_split_step.jsonl
