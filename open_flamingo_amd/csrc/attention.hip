@@ -545,6 +545,15 @@ size_t resident_smem(const OfAttnArgs& a) {
     // cross-attention (128 keys) and Perceiver (64 queries) cores stay on the tiled kernel (11 vs 14 us, 13 vs 16 us).
     if (a.Lq < 256 || a.Lk < 256) return 0;
     if ((long)a.batch * a.heads < 64) return 0;                   // few heads: the tiled grid has more workgroups
+    // One workgroup per (batch, head), 160 KB / need of them per CU: a last round of those slots that is mostly empty costs a whole round
+    // (OF-9B's frozen MPT-7B blocks, 10 x 32 = 320 heads at one workgroup per CU: 48.6 us against 38.8 us for the tiled kernel; 384 heads:
+    // 49.9 against 44.0; 512 and 192 heads: a tie -- profiles/r06zw_attn_fwd_forms_probe.jsonl): resident where the rounds are >= 80 % full
+#ifndef OF_AB_ATTN_FWD_RESIDENT_ANY_ROUNDS                         // tools/ab builds only (step-level A/B of this rule)
+    {
+        const long slots = (long)OF_NUM_CUS * (long)(160 * 1024 / need), n = (long)a.batch * a.heads, rounds = (n + slots - 1) / slots;
+        if (10 * n < 8 * rounds * slots) return 0;
+    }
+#endif
     return need;
 }
 template <int DH>
