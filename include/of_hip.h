@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define OF_ABI_VERSION 12
+#define OF_ABI_VERSION 11
 #define OF_E_ARG (-1)      /* null pointer / negative size */
 #define OF_E_SHAPE (-2)    /* shape not supported by the kernels (see each function) */
 #define OF_E_ALIGN (-3)    /* pointer or leading dimension not 16-byte aligned */
@@ -354,32 +354,6 @@ int of_sumsq_partial_w(const float* g, long n, float* partials, int max_workgrou
 int of_adamw_clip_w(float* p, float* g, float* m, float* v, uint16_t* p_bf16, long n, const float* sumsq,
                     float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                     int step, int zero_grad, const int* applied_steps, int max_workgroups, void* stream);
-/* ABI v12: the step epilogue's passes over SEVERAL buffers as one launch each (per 32 segments).  With one gradient bucket per
- * gated block and per Perceiver layer (train/reducer.py) a step's epilogue was 31 of_sumsq_partial and 61 of_adamw_clip launches; a
- * bucket's norm pass reads a few MB once the weight gradients' sums of squares leave with their GEMMs (OfGemmArgs.sumsq_out), so most
- * of its 17 us was the kernel boundary.  Segment i of of_sumsq_partial_multi writes exactly what of_sumsq_partial(g, n, partials)
- * writes (the same slot -> element map); segment i of of_adamw_clip_multi is exactly of_adamw_clip on its (p, g, m, v, p_bf16, n) with
- * its own lr / weight_decay / zero_grad and the common remaining arguments: bit-identical to the separate launches. */
-typedef struct OfSumsqSeg {
-    const float* g;
-    long n;
-    float* partials;       /* OF_SUMSQ_PARTS slots of this segment */
-} OfSumsqSeg;
-typedef struct OfAdamwSeg {
-    float* p;
-    float* g;
-    float* m;
-    float* v;
-    uint16_t* p_bf16;      /* optional */
-    long n;
-    float lr;
-    float weight_decay;
-    int zero_grad;
-    int reserved;          /* 0 */
-} OfAdamwSeg;
-int of_sumsq_partial_multi(const OfSumsqSeg* segs, int nseg, void* stream);
-int of_adamw_clip_multi(const OfAdamwSeg* segs, int nseg, const float* sumsq, float max_norm, float beta1, float beta2, float eps,
-                        float grad_scale, int step, const int* applied_steps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Token-level cross entropy of the causal-LM loss (the reference's Flamingo.forward passes `labels` to the HF language

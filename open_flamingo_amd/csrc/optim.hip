@@ -31,14 +31,12 @@ constexpr int OPT_GRID_CAP = 4096;
 // The classic launch has one physical workgroup per slot; the narrow launch (of_sumsq_partial_w: a few fat workgroups, so that the
 // pass occupies only that many CUs and leaves the rest to another stream) walks the slots with 256-thread sub-blocks -- the same
 // threads' sums in the same order per slot: bit-identical partials.
-// (vbid, vgrid: the workgroup's index and count among the workgroups that work on THIS buffer -- the launch's own for the
-// single-buffer kernels, the segment's for the multi-segment launch below)
-OF_DEV void sumsq_body(const OptArgs& a, const int vbid, const int vgrid) {
+OF_GLOBAL void of_sumsq_kernel(OptArgs a) {
     float* red = (float*)of_smem();
     const long nv = a.n >> 2;
     const long stride = (long)OF_SUMSQ_PARTS * 256;
     const int nsub = of_bdim_x() >> 8, sub = of_tid() >> 8, tid = of_tid() & 255;
-    for (int base = vbid * nsub; base < OF_SUMSQ_PARTS; base += vgrid * nsub) {
+    for (int base = of_bid_x() * nsub; base < OF_SUMSQ_PARTS; base += of_gdim_x() * nsub) {
         const int part = base + sub;
         float s = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
         if (part < OF_SUMSQ_PARTS) {
@@ -70,25 +68,6 @@ OF_DEV void sumsq_body(const OptArgs& a, const int vbid, const int vgrid) {
         of_sync();          // red is reused by the next round of slots
     }
 }
-OF_GLOBAL void of_sumsq_kernel(OptArgs a) { sumsq_body(a, of_bid_x(), of_gdim_x()); }
-
-// Several buffers' partial sums in ONE launch (of_sumsq_partial_multi): workgroup b works on segment b / OF_SUMSQ_PARTS as workgroup
-// b % OF_SUMSQ_PARTS of that buffer's classic launch -- the same slot -> element map, the same bits, one kernel boundary instead of one
-// per gradient bucket (with the norm taps a bucket's pass reads a few MB: 17 us each, mostly the boundary; 31 of them per OF-3B step).
-constexpr int OPT_MULTI_MAX = 32;
-struct SumsqMultiArgs {
-    const float* g[OPT_MULTI_MAX];
-    long n[OPT_MULTI_MAX];
-    float* acc[OPT_MULTI_MAX];
-};
-OF_GLOBAL void of_sumsq_multi_kernel(SumsqMultiArgs m) {
-    const int seg = of_uniform(of_bid_x() / OF_SUMSQ_PARTS);
-    OptArgs a{};
-    a.g = const_cast<float*>(m.g[seg]);
-    a.n = m.n[seg];
-    a.acc = m.acc[seg];
-    sumsq_body(a, of_bid_x() - seg * OF_SUMSQ_PARTS, OF_SUMSQ_PARTS);
-}
 
 // one workgroup: lane t sums slots t, t+256, ... in index order, then the fixed wave/LDS tree
 OF_GLOBAL void of_sumsq_finish_kernel(OptArgs a) {
@@ -113,7 +92,7 @@ OF_DEV float adamw_one(const OptArgs& a, float coef, float step_size, float inv_
     return p;
 }
 
-OF_DEV void adamw_body(const OptArgs& a, const int vbid, const int vgrid) {
+OF_GLOBAL void of_adamw_kernel(OptArgs a) {
     // gradients arrive as SUMS over ranks: grad_scale = 1/world turns them into the average DDP would have produced;
     // *acc is the squared norm of the unscaled buffers
     const float norm = sqrtf(*a.acc) * a.grad_scale;
@@ -124,9 +103,9 @@ OF_DEV void adamw_body(const OptArgs& a, const int vbid, const int vgrid) {
     // cleared are still cleared.
     if (!(norm < 3.0e38f)) {
         if (a.zero_grad) {
-            const long nvz = a.n >> 2, strz = (long)vgrid * of_bdim_x();
-            for (long i = (long)vbid * of_bdim_x() + of_tid(); i < nvz; i += strz) *(f32x4*)(a.g + i * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (vbid == 0)
+            const long nvz = a.n >> 2, strz = (long)of_gdim_x() * of_bdim_x();
+            for (long i = (long)of_bid_x() * of_bdim_x() + of_tid(); i < nvz; i += strz) *(f32x4*)(a.g + i * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (of_bid_x() == 0)
                 for (long i = (nvz << 2) + of_tid(); i < a.n; i += of_bdim_x()) a.g[i] = 0.f;
         }
         return;
@@ -141,7 +120,7 @@ OF_DEV void adamw_body(const OptArgs& a, const int vbid, const int vgrid) {
     }
     const float step_size = a.lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2), decay = 1.0f - a.lr * a.wd;
     const long nv = a.n >> 2;
-    const long stride = (long)vgrid * of_bdim_x();      // element-wise: any grid gives the same results
+    const long stride = (long)of_gdim_x() * of_bdim_x();      // element-wise: any grid gives the same results
     auto one = [&](long i, f32x4 p, f32x4 m, f32x4 v, const f32x4 g) OF_INLINE_LAMBDA {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -155,7 +134,7 @@ OF_DEV void adamw_body(const OptArgs& a, const int vbid, const int vgrid) {
         if (a.p_bf16) *(u32x2*)(a.p_bf16 + i * 4) = u32x2{of_pack_bf16(p[0], p[1]), of_pack_bf16(p[2], p[3])};
         if (a.zero_grad) *(f32x4*)(a.g + i * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    long i = (long)vbid * of_bdim_x() + of_tid();
+    long i = (long)of_bid_x() * of_bdim_x() + of_tid();
     for (; i + stride < nv; i += 2 * stride) {       // two vectors of each stream per lane: eight 16-byte loads in flight
         const long j = i + stride;
         const f32x4 p0 = *(const f32x4*)(a.p + i * 4), m0 = *(const f32x4*)(a.m + i * 4), v0 = *(const f32x4*)(a.v + i * 4);
@@ -167,7 +146,7 @@ OF_DEV void adamw_body(const OptArgs& a, const int vbid, const int vgrid) {
     }
     for (; i < nv; i += stride)
         one(i, *(const f32x4*)(a.p + i * 4), *(const f32x4*)(a.m + i * 4), *(const f32x4*)(a.v + i * 4), *(const f32x4*)(a.g + i * 4));
-    if (vbid == 0) {
+    if (of_bid_x() == 0) {
         for (long i = (nv << 2) + of_tid(); i < a.n; i += of_bdim_x()) {
             float pe = a.p[i], me = a.m[i], ve = a.v[i];
             adamw_one(a, coef, step_size, inv_sqrt_bc2, decay, pe, a.g[i], me, ve);
@@ -176,39 +155,6 @@ OF_DEV void adamw_body(const OptArgs& a, const int vbid, const int vgrid) {
             if (a.zero_grad) a.g[i] = 0.f;
         }
     }
-}
-
-OF_GLOBAL void of_adamw_kernel(OptArgs a) { adamw_body(a, of_bid_x(), of_gdim_x()); }
-
-// Several (parameter, gradient, moments) segments in ONE launch (of_adamw_clip_multi): workgroups [wg_end[i-1], wg_end[i]) run segment i
-// exactly as its own of_adamw_clip launch would (element-wise: the same bits); learning rate, weight decay and the gradient-clear flag are
-// per segment, everything else is common to the step.
-struct AdamwSeg {
-    float* p; float* g; float* m; float* v; bf16_t* p_bf16;
-    long n;
-    float lr, wd;
-    int zero_grad, pad;
-};
-struct AdamwMultiArgs {
-    AdamwSeg seg[OPT_MULTI_MAX];
-    int wg_end[OPT_MULTI_MAX];
-    int nseg;
-    OptArgs common;        // acc, max_norm, betas, eps, bias corrections, grad_scale, applied
-};
-OF_GLOBAL void of_adamw_multi_kernel(AdamwMultiArgs m) {
-    const int bid = of_bid_x();
-    int i = 0, first = 0;
-    for (int j = 0; j + 1 < m.nseg; ++j)
-        if (bid >= m.wg_end[j]) {
-            i = j + 1;
-            first = m.wg_end[j];
-        }
-    i = of_uniform(i);
-    first = of_uniform(first);
-    OptArgs a = m.common;
-    a.p = m.seg[i].p; a.g = m.seg[i].g; a.m = m.seg[i].m; a.v = m.seg[i].v; a.p_bf16 = m.seg[i].p_bf16;
-    a.n = m.seg[i].n; a.lr = m.seg[i].lr; a.wd = m.seg[i].wd; a.zero_grad = m.seg[i].zero_grad;
-    adamw_body(a, bid - first, m.wg_end[i] - first);
 }
 
 // one thread: the device-side "optimizer step happened" counter
@@ -306,59 +252,4 @@ extern "C" int of_adamw_clip_w(float* p, float* g, float* m, float* v, uint16_t*
         return of_launch(of_adamw_kernel, of_dim3{wg, 1, 1}, OPT_FAT_BLOCK, 0, (of_stream_t)stream, a);
     }
     return of_launch(of_adamw_kernel, of_dim3{opt_grid(n), 1, 1}, 256, 0, (of_stream_t)stream, a);
-}
-
-extern "C" int of_sumsq_partial_multi(const OfSumsqSeg* segs, int nseg, void* stream) {
-    if (!segs || nseg <= 0) return OF_E_ARG;
-    for (int i = 0; i < nseg; ++i) {
-        if (!segs[i].g || !segs[i].partials || segs[i].n <= 0) return OF_E_ARG;
-        if ((uintptr_t)segs[i].g & 15) return OF_E_ALIGN;
-    }
-    for (int base = 0; base < nseg; base += OPT_MULTI_MAX) {
-        const int cnt = nseg - base < OPT_MULTI_MAX ? nseg - base : OPT_MULTI_MAX;
-        SumsqMultiArgs m{};
-        for (int i = 0; i < cnt; ++i) {
-            m.g[i] = segs[base + i].g;
-            m.n[i] = segs[base + i].n;
-            m.acc[i] = segs[base + i].partials;
-        }
-        const int rc = of_launch(of_sumsq_multi_kernel, of_dim3{(unsigned)(cnt * OF_SUMSQ_PARTS), 1, 1}, 256, 4 * sizeof(float), (of_stream_t)stream, m);
-        if (rc) return rc;
-    }
-    return 0;
-}
-
-extern "C" int of_adamw_clip_multi(const OfAdamwSeg* segs, int nseg, const float* sumsq, float max_norm, float beta1, float beta2,
-                                   float eps, float grad_scale, int step, const int* applied_steps, void* stream) {
-    if (!segs || nseg <= 0 || !sumsq || (step <= 0 && !applied_steps)) return OF_E_ARG;
-    for (int i = 0; i < nseg; ++i) {
-        const OfAdamwSeg& t = segs[i];
-        if (!t.p || !t.g || !t.m || !t.v || t.n <= 0) return OF_E_ARG;
-        if (((uintptr_t)t.p & 15) || ((uintptr_t)t.g & 15) || ((uintptr_t)t.m & 15) || ((uintptr_t)t.v & 15) || ((uintptr_t)t.p_bf16 & 7))
-            return OF_E_ALIGN;
-    }
-    OptArgs c{};
-    c.acc = const_cast<float*>(sumsq);
-    c.grad_scale = grad_scale; c.max_norm = max_norm; c.beta1 = beta1; c.beta2 = beta2; c.eps = eps;
-    c.bc1 = 1.0f - powf(beta1, (float)(step > 0 ? step : 1));
-    c.bc2 = 1.0f - powf(beta2, (float)(step > 0 ? step : 1));
-    c.applied = const_cast<int*>(applied_steps);
-    for (int base = 0; base < nseg; base += OPT_MULTI_MAX) {
-        const int cnt = nseg - base < OPT_MULTI_MAX ? nseg - base : OPT_MULTI_MAX;
-        AdamwMultiArgs m{};
-        m.common = c;
-        m.nseg = cnt;
-        long total = 0;
-        for (int i = 0; i < OPT_MULTI_MAX; ++i) {
-            if (i < cnt) {
-                const OfAdamwSeg& t = segs[base + i];
-                m.seg[i] = AdamwSeg{t.p, t.g, t.m, t.v, (bf16_t*)t.p_bf16, t.n, t.lr, t.weight_decay, t.zero_grad, 0};
-                total += opt_grid(t.n);
-            }
-            m.wg_end[i] = (int)total;
-        }
-        const int rc = of_launch(of_adamw_multi_kernel, of_dim3{(unsigned)total, 1, 1}, 256, 0, (of_stream_t)stream, m);
-        if (rc) return rc;
-    }
-    return 0;
 }

@@ -5,7 +5,7 @@ Pure declarations: nothing here loads a library.  ``open_flamingo_amd.hip.lib`` 
 """
 import ctypes as C
 
-OF_ABI_VERSION = 12
+OF_ABI_VERSION = 11
 OF_SUMSQ_PARTS = 512
 EPI_STORE_BF16, EPI_GELU, EPI_GATE_RESID, EPI_DGELU_DOT, EPI_SCALE_DOT, EPI_ACC_F32 = range(6)
 
@@ -78,15 +78,6 @@ class OfPackDesc(C.Structure):
     _fields_ = [("W", vp), ("P", vp), ("N", C.c_int), ("K", C.c_int), ("ldw", C.c_long)]
 
 
-class OfSumsqSeg(C.Structure):
-    _fields_ = [("g", vp), ("n", C.c_long), ("partials", vp)]
-
-
-class OfAdamwSeg(C.Structure):
-    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("p_bf16", vp), ("n", C.c_long), ("lr", C.c_float),
-                ("weight_decay", C.c_float), ("zero_grad", C.c_int), ("reserved", C.c_int)]
-
-
 PROTOTYPES = {
     "of_abi_version": (C.c_int, []),
     "of_build_kind": (C.c_int, []),
@@ -128,9 +119,6 @@ PROTOTYPES = {
     "of_sumsq_partial_w": (C.c_int, [vp, C.c_long, vp, C.c_int, vp]),
     "of_adamw_clip_w": (C.c_int, [vp, vp, vp, vp, vp, C.c_long, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_float, C.c_float, C.c_int, C.c_int, vp, C.c_int, vp]),
-    "of_sumsq_partial_multi": (C.c_int, [C.POINTER(OfSumsqSeg), C.c_int, vp]),
-    "of_adamw_clip_multi": (C.c_int, [C.POINTER(OfAdamwSeg), C.c_int, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
-                                     C.c_int, vp, vp]),
     "of_rotary_neox": (C.c_int, [vp, C.c_long, vp, vp, C.c_long, vp, vp, vp, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, vp]),
     "of_head_repack": (C.c_int, [vp, C.c_long, vp, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, vp]),

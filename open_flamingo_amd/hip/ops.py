@@ -404,19 +404,6 @@ class Ops:
         self._chk(self.lib.of_sumsq_partial_w(g.data_ptr(), g.numel(), partials.data_ptr(), int(max_workgroups), self._stream()),
                   "of_sumsq_partial")
 
-    def sumsq_partial_multi(self, jobs):
-        """jobs: [(g, partials)] -- every buffer's partial sums in ONE launch per 32 buffers (of_sumsq_partial_multi: the bits of
-        the separate sumsq_partial launches)."""
-        jobs = list(jobs)
-        if not jobs:
-            return
-        arr = (abi.OfSumsqSeg * len(jobs))()
-        for d, (g, partials) in zip(arr, jobs):
-            assert g.dtype == F32 and g.is_contiguous() and partials.dtype == F32 and partials.is_contiguous()
-            assert partials.numel() >= self.SUMSQ_PARTS and g.numel() > 0
-            d.g, d.n, d.partials = g.data_ptr(), g.numel(), partials.data_ptr()
-        self._chk(self.lib.of_sumsq_partial_multi(arr, len(jobs), self._stream()), "of_sumsq_partial_multi")
-
     def sumsq_finish(self, partials, acc):
         """acc[0] = sum(partials) in a fixed order."""
         assert partials.dtype == F32 and partials.is_contiguous() and acc.dtype == F32
@@ -447,21 +434,6 @@ class Ops:
                                            sumsq.data_ptr(), max_norm, lr, betas[0], betas[1], eps, weight_decay,
                                            grad_scale, step, int(zero_grad), _p(applied), int(max_workgroups), self._stream()),
                   "of_adamw_clip")
-
-    def adamw_clip_multi(self, segs, sumsq, *, step, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, grad_scale=1.0, applied=None):
-        """segs: [(p, g, m, v, p_bf16 or None, lr, weight_decay, zero_grad)] -- ONE launch per 32 segments (of_adamw_clip_multi: every
-        segment exactly as its own adamw_clip launch, the same bits)."""
-        segs = list(segs)
-        if not segs:
-            return
-        arr = (abi.OfAdamwSeg * len(segs))()
-        for d, (p, g, m, v, p_bf16, lr, wd, zero) in zip(arr, segs):
-            n = p.numel()
-            assert n > 0 and all(t.dtype == F32 and t.is_contiguous() and t.numel() == n for t in (p, g, m, v))
-            d.p, d.g, d.m, d.v, d.p_bf16, d.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(p_bf16), n
-            d.lr, d.weight_decay, d.zero_grad, d.reserved = lr, wd, int(zero), 0
-        self._chk(self.lib.of_adamw_clip_multi(arr, len(segs), sumsq.data_ptr(), max_norm, betas[0], betas[1], eps, grad_scale,
-                                               step, _p(applied), self._stream()), "of_adamw_clip_multi")
 
     # ------------------------------------------------------------------ causal-LM loss
     def ce_fwd(self, logits, labels, lse, loss_rows, ignore_index=-100):

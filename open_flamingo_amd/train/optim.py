@@ -68,10 +68,6 @@ class FlatAdamW(torch.optim.Optimizer):
         # step's end also waits for the last all-reduce is a measurement a multi-GPU node has to make: bench.py --early-norm.
         self._parts = None
         self.early_norm = False
-        # Merged launches (round 6, ABI v12): the per-bucket norm passes as ONE of_sumsq_partial_multi launch and the per-bucket AdamW
-        # segments as ONE of_adamw_clip_multi launch per 32 -- the bits of the separate launches, ~90 kernel boundaries less per step.
-        # (tools/ab_merged_epilogue.py flips this for the same-box A/B; narrow launches keep one launch per bucket.)
-        self.merged_launches = 3        # bit 0: the norm passes, bit 1: the AdamW segments
         # Fragment-major copies of the gated blocks' to_q / to_out weights (the fused attention branch streams them from L2 straight into
         # MFMA registers, csrc/xattn_fused.hip): re-packed from the fresh bf16 copies by ONE launch per step() instead of two per block
         # and forward.
@@ -248,7 +244,6 @@ class FlatAdamW(torch.optim.Optimizer):
         use_taps = bool(self.tap_norm and T and self.reducer.world == 1 and not getattr(self.reducer, "force_collectives", False)
                         and not self.early_norm and gs == 1.0)
         tapped = 0
-        norm_jobs = []
         for i, g in enumerate(bufs):
             if i in early:
                 continue                             # this step's partial sums of the bucket are in their slots already
@@ -260,16 +255,9 @@ class FlatAdamW(torch.optim.Optimizer):
                 else:
                     parts[b["tap_lo"]:b["tap_hi"]].zero_()      # (a matrix no GEMM wrote this step, or not through a tapped launch)
             if g.numel():
-                norm_jobs.append((g, parts[(T + i) * P:(T + i + 1) * P]))
+                ops.sumsq_partial(g, parts[(T + i) * P:(T + i + 1) * P], nw)
             else:                                    # a bucket made of tapped matrices only: nothing left for the pass
                 parts[(T + i) * P:(T + i + 1) * P].zero_()
-        # the buckets' passes as ONE launch (of_sumsq_partial_multi, ABI v12: the same slots, the same bits; with the norm taps a bucket's
-        # pass reads a few MB and was mostly its kernel boundary) -- narrow launches (narrow_cus) keep one launch per bucket
-        if (int(self.merged_launches) & 1) and nw == 0 and len(norm_jobs) > 1:
-            ops.sumsq_partial_multi(norm_jobs)
-        else:
-            for g, slots in norm_jobs:
-                ops.sumsq_partial(g, slots, nw)
         for b in self.reducer.buckets:
             b["early_gen"] = None
         self.early_partials_used = len(early)        # (tests, tools)
@@ -285,25 +273,19 @@ class FlatAdamW(torch.optim.Optimizer):
         if self._applied is None:
             self._applied = torch.full((1,), self.step_count - 1, dtype=torch.int32, device=dev)
         ops.step_advance(self._sumsq, self._applied)
-        merged, segs = bool((int(self.merged_launches) & 2) and nw == 0), []
         for b, lr in ((b, self.param_groups[0 if b["wd"] else 1]["lr"]) for b in self.reducer.buckets):
             # front part: small vectors whose kernels ADD into the gradient -> cleared here; back part: weight matrices
             # the next backward overwrites (their "fresh" mark makes its dW GEMM run with beta = 0): no zero pass, and no
             # read of the old value in the GEMM epilogue -- 2 x 3.5 GB of HBM traffic per step at OF-3B
             k = b.get("overwritable_from", b["flat"].numel())
             for lo, hi, zero in ((0, k, True), (k, b["flat"].numel(), False)):
-                if hi > lo and merged:
-                    segs.append((b["flat_p"][lo:hi], b["flat"][lo:hi], b["m"][lo:hi], b["v"][lo:hi], b["flat_bf16"][lo:hi], lr, b["wd"], zero))
-                elif hi > lo:
+                if hi > lo:
                     ops.adamw_clip(b["flat_p"][lo:hi], b["flat"][lo:hi], b["m"][lo:hi], b["v"][lo:hi], self._sumsq,
                                    step=self.step_count, lr=lr, betas=self.betas, eps=self.eps, weight_decay=b["wd"],
                                    max_norm=self.max_norm, p_bf16=b["flat_bf16"][lo:hi], zero_grad=zero, grad_scale=gs,
                                    applied=self._applied, max_workgroups=nw)
             for p in b.get("overwritable", ()):
                 p._of_grad_fresh = True
-        if segs:                                     # every bucket's two segments in ONE launch per 32 (of_adamw_clip_multi: the same bits)
-            ops.adamw_clip_multi(segs, self._sumsq, step=self.step_count, betas=self.betas, eps=self.eps, max_norm=self.max_norm,
-                                 grad_scale=gs, applied=self._applied)
         self._repack()
         if g_rows is not None:
             e = self._emb

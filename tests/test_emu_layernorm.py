@@ -280,50 +280,3 @@ def test_narrow_step_epilogue_launches_give_the_same_bits():
             outs.append((p, m, v, b16))
         for o in outs[1:]:
             assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
-
-
-def test_merged_step_epilogue_launches_give_the_same_bits():
-    """of_sumsq_partial_multi / of_adamw_clip_multi (ABI v12): several buffers' norm passes as one launch, several (p, g, m, v)
-    segments' AdamW as one launch per 32 -- every segment exactly as its own launch: partial slots, parameters, moments, bf16 copies
-    and the cleared / kept gradients are bit-identical.  More segments than one launch takes (33 > 32), sizes with a vector body and
-    a scalar tail, fewer elements than slots, per-segment lr / weight decay / zero_grad, a segment without a bf16 copy."""
-    ops = H.emu_ops()
-    gen = torch.Generator().manual_seed(11)
-    sizes = [1027, 300, 70001, 4, 2048] + [64 + 8 * i for i in range(28)]          # 33 segments
-    grads = [torch.randn(n, generator=gen) for n in sizes]
-    P = ops.SUMSQ_PARTS
-    one, multi = torch.full((len(sizes) * P,), -1.0), torch.full((len(sizes) * P,), -2.0)
-    for i, g in enumerate(grads):
-        ops.sumsq_partial(g, one[i * P:(i + 1) * P])
-    ops.sumsq_partial_multi([(g, multi[i * P:(i + 1) * P]) for i, g in enumerate(grads)])
-    assert torch.equal(one, multi)
-    acc = torch.zeros(1)
-    ops.sumsq_finish(one, acc)
-    applied = torch.full((1,), 3, dtype=torch.int32)
-    state = [(torch.randn(n, generator=gen), torch.rand(n, generator=gen) * 0.1, torch.rand(n, generator=gen) * 0.1) for n in sizes]
-    hyper = [(1e-2 if i % 2 else 3e-3, 0.1 if i % 3 else 0.0, bool(i % 2 == 0), i != 3) for i in range(len(sizes))]     # lr, wd, zero, bf16 copy?
-    results = []
-    for merged in (False, True):
-        segs = []
-        for (p0, m0, v0), g0, (lr, wd, zero, has16) in zip(state, grads, hyper):
-            segs.append((p0.clone(), g0.clone(), m0.clone(), v0.clone(), torch.zeros(p0.numel(), dtype=torch.bfloat16) if has16 else None, lr, wd, zero))
-        if merged:
-            ops.adamw_clip_multi(segs, acc, step=2, max_norm=1.0, grad_scale=0.5, applied=applied)
-        else:
-            for p, g, m, v, b16, lr, wd, zero in segs:
-                ops.adamw_clip(p, g, m, v, acc, step=2, lr=lr, weight_decay=wd, max_norm=1.0, p_bf16=b16, zero_grad=zero, grad_scale=0.5,
-                               applied=applied)
-        results.append(segs)
-    for a, b in zip(*results):
-        for x, y in zip(a[:5], b[:5]):
-            assert (x is None and y is None) or torch.equal(x, y)
-    for (p, g, m, v, b16, lr, wd, zero), g0, (p0, _, _) in zip(results[1], grads, state):
-        assert float(g.abs().max()) == 0.0 if zero else torch.equal(g, g0)
-        assert not torch.equal(p, p0)
-    # a non-finite norm: no segment is updated, gradients that were to be cleared are cleared
-    acc.fill_(float("nan"))
-    segs = [(p0.clone(), g0.clone(), m0.clone(), v0.clone(), None, 1e-2, 0.1, i % 2 == 0) for i, ((p0, m0, v0), g0) in enumerate(zip(state[:5], grads[:5]))]
-    ops.adamw_clip_multi(segs, acc, step=2, max_norm=1.0)
-    for i, ((p, g, m, v, _, _, _, zero), (p0, m0, v0), g0) in enumerate(zip(segs, state, grads)):
-        assert torch.equal(p, p0) and torch.equal(m, m0) and torch.equal(v, v0)
-        assert float(g.abs().max()) == 0.0 if zero else torch.equal(g, g0)
