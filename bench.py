@@ -265,10 +265,10 @@ def main():
                          "backward are then laid out stream-K for 256 - R workgroups (GradReducer.reserve_cus; default 0 = off)")
     ap.add_argument("--no-batched-dw", action="store_true",
                     help="A/B: the three 512-wide weight gradients of a gated block as separate split-K launches instead of one batched launch")
-    ap.add_argument("--optimizer-cus", type=int, default=0,
+    ap.add_argument("--optimizer-cus", type=int, default=None,
                     help="run the step epilogue's streaming passes (global norm, AdamW) as narrow launches on this many CUs (fat "
                          "workgroups, one per CU; identical results) so that the prefetched vision-tower forward on the side stream "
-                         "finds whole CUs free; 0 = launches that cover the chip")
+                         "finds whole CUs free; 0 = launches that cover the chip; default: FlatAdamW's own (192)")
     ap.add_argument("--early-norm", action="store_true",
                     help="A/B: compute every bucket's share of the global gradient norm on the reducer's side stream as soon as the bucket's "
                          "gradient is final (behind its all-reduce) instead of in the step epilogue (train/optim.py: early_norm; same bits; "
@@ -343,7 +343,7 @@ def main():
                           embedding_rows=[info["media_token_id"], info["eoc_token_id"]], reserve_cus=args.reserve_cus)
     reducer.broadcast_parameters()
     opt = step.build_optimizer(model, reducer=None if args.torch_optimizer else reducer)
-    if args.optimizer_cus and not args.torch_optimizer:
+    if args.optimizer_cus is not None and not args.torch_optimizer:
         opt.narrow_cus = args.optimizer_cus
     if args.early_norm and not args.torch_optimizer:
         opt.early_norm = True
@@ -538,7 +538,7 @@ def main():
                           "global_norm": ("torch clip_grad_norm_" if args.torch_optimizer else
                                           f"FFN weight gradients' share from their dW GEMM epilogues ({getattr(opt, 'tapped_buckets', 0)} buckets), "
                                           "the rest in one pass" if getattr(opt, "tapped_buckets", 0) else "one pass over the gradients"),
-                          "step_epilogue_launch": (f"narrow: {args.optimizer_cus} fat workgroups" if args.optimizer_cus else "covers the chip"),
+                          "step_epilogue_launch": (f"narrow: {int(getattr(opt, 'narrow_cus', 0))} fat workgroups" if int(getattr(opt, "narrow_cus", 0)) else "covers the chip"),
                           "vision_tower_schedule": ("at the start of the step" if args.no_vision_prefetch else
                                                     "next step's tower forward on a side stream next to the step epilogue"),
                           "laion_pass": (f"B={args.laion_batch} T=1 L=32, loss x0.2, same optimizer step" if args.laion_batch else "off")},

@@ -40,6 +40,7 @@ class Flamingo(nn.Module):
         _path.adopt(self)
 
     group_media_projections = True     # class-level switch (instance attribute overrides): see _encode_vision_x
+    prefetch_at_block = None           # schedule_vision_prefetch: gated block (forward order) whose backward starts the tower; None = n_blocks // 12
 
     # ------------------------------------------------------------------------------------------------ vision prefetch
     def prefetch_vision(self, vision_x: torch.Tensor, amp_dtype=None):
@@ -69,6 +70,25 @@ class Flamingo(nn.Module):
                 tokens = self.vision_encoder(vision_x.flatten(0, 2))[1]
             done = None
         self.__dict__["_of_vision_prefetch"] = (vision_x, vision_x._version, tokens, done, amp_dtype)
+
+    def schedule_vision_prefetch(self, vision_x: torch.Tensor, amp_dtype=None):
+        """``prefetch_vision(vision_x)`` from INSIDE the backward of the next grad-enabled forward, so that the tower's forward on its
+        side stream runs next to the END of the backward and the step epilogue and is done when the next step begins -- instead of
+        starting behind the backward and running on alone for ~10 ms into the next step.  Where: at the start of the backward of gated
+        block ``prefetch_at_block`` (forward order; default n_blocks // 12 -- OF-3B's 24 blocks: 2, OF-4B's 16: 1, OF-9B's 8: 0; same
+        box, round 6, profiles/r06zzd_*, r06zze_*: behind the backward 105.75 ms per step, at the Perceiver's backward 104.6, at block
+        2's 103.1; one block later / earlier +0.1...+0.6 ms, five blocks earlier +1 ms: two GEMM streams time-slice at a loss).  Without
+        grouped media projections: when the gradient of the Perceiver's output is complete.  ``fire_vision_prefetch`` runs it at once
+        if no backward did (no gradient path, a skipped step).  Same arithmetic, same bits: only the enqueue point moves."""
+        self.__dict__["_of_prefetch_pending"] = (vision_x, amp_dtype)
+
+    def fire_vision_prefetch(self):
+        hit = self.__dict__.pop("_of_prefetch_pending", None)
+        if hit is not None:
+            self.prefetch_vision(hit[0], amp_dtype=hit[1])
+
+    def cancel_vision_prefetch(self):
+        self.__dict__.pop("_of_prefetch_pending", None)
 
     def _take_prefetched_vision(self, vision_x):
         hit = self.__dict__.pop("_of_vision_prefetch", None)
@@ -100,11 +120,18 @@ class Flamingo(nn.Module):
             with torch.no_grad():
                 tokens = self.vision_encoder(vision_x.flatten(0, 2))[1]       # (b*T*F, patches, vis_dim)
         latents = self.perceiver(tokens.unflatten(0, (batch, n_media, n_frames)))
+        if self.__dict__.get("_of_prefetch_pending") is not None and torch.is_grad_enabled() and latents.requires_grad:
+            def _fire(grad, self=self):          # (tensor hook: runs in the backward, on the stream of the node that made `latents`)
+                self.fire_vision_prefetch()
+            latents.register_hook(_fire)
         # (not while media are being cached: several forwards may then run over the same latents, each with its own graph)
         if self.group_media_projections and torch.is_grad_enabled() and not self.lang_encoder._use_cached_vision_x:
             # every gated block applies its own to_kv to this one tensor: one grouped GEMM for all of them
             from . import helpers
-            helpers.group_media_projections(list(self.lang_encoder.gated_cross_attn_layers), latents)
+            grp = helpers.group_media_projections(list(self.lang_encoder.gated_cross_attn_layers), latents)
+            if grp is not None and self.__dict__.get("_of_prefetch_pending") is not None:
+                k = self.prefetch_at_block if self.prefetch_at_block is not None else len(grp.blocks) // 12
+                grp.backward_probe = (max(0, min(int(k), len(grp.blocks) - 1)), self.fire_vision_prefetch)
         for layer in self._layers():
             layer.condition_vis_x(latents)
 

@@ -470,6 +470,7 @@ class MediaKVGroup:
         self.index = {id(b): i for i, b in enumerate(self.blocks)}
         self.media = media
         self.kv_all = self.dkv_all = self.token = None
+        self.backward_probe = None      # (block index in forward order, callable): called once at the start of that block's backward
 
     def kv_of(self, block):
         i = self.index[id(block)]
@@ -580,6 +581,9 @@ class _GatedXAttnFn(torch.autograd.Function):
         ops = Ops.default()
         d = ctx.xshape[-1]
         grp = ctx.grp
+        if grp is not None and grp.backward_probe is not None and grp.index[id(ctx.mod)] == grp.backward_probe[0]:
+            probe, grp.backward_probe = grp.backward_probe[1], None
+            probe()                        # Flamingo.schedule_vision_prefetch: the next step's tower forward starts on its side stream here
         need_dmedia = ctx.needs_input_grad[2] and grp is None      # grouped: the group's node forms the media gradient
         sinks, fresh = _grad_sinks(_XATTN_NAMES, ctx.params)
         # norm taps (train/optim.py): parameters whose owner registered slots for the sum of squares of their gradient

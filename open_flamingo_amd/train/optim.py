@@ -68,6 +68,12 @@ class FlatAdamW(torch.optim.Optimizer):
         # step's end also waits for the last all-reduce is a measurement a multi-GPU node has to make: bench.py --early-norm.
         self._parts = None
         self.early_norm = False
+        # The two streaming passes of step() as NARROW launches: this many fat workgroups (one per CU) instead of grids that cover the
+        # chip -- the same bits (of_sumsq_partial_w / of_adamw_clip_w), HBM stays saturated, and the next step's frozen-tower forward on
+        # the side stream (train/step.py: next_vision_x) or a late all-reduce finds 64 whole CUs free instead of time-slicing with 4096
+        # workgroups.  Same box, alternating, round 6 (profiles/r06zzc_*): 106.27 / 106.24 ms per step wide, 105.90 / 105.81 at 192
+        # (160 and 224 the same, 128 = wide, 96 +0.4); without the prefetch a tie; config 4 -0.3 ms, config 5 -0.6 ms.  0 = wide launches.
+        self.narrow_cus = 192
         # Fragment-major copies of the gated blocks' to_q / to_out weights (the fused attention branch streams them from L2 straight into
         # MFMA registers, csrc/xattn_fused.hip): re-packed from the fresh bf16 copies by ONE launch per step() instead of two per block
         # and forward.

@@ -61,6 +61,12 @@ def mask_embedding_gradient(model, info):
     w.grad = w.grad * zero_mask
 
 
+# The next step's frozen-tower forward (train_step(next_vision_x=...)) is enqueued on its side stream from INSIDE the backward -- at the start of
+# the backward of one of the last gated blocks (Flamingo.schedule_vision_prefetch: so that the tower ends with the step epilogue) -- instead of
+# behind the whole backward: 105.75 -> 103.1 ms per step same box (profiles/r06zzd_*, r06zze_*; tools/ab_prefetch_point.py flips this).
+PREFETCH_IN_BACKWARD = True
+
+
 def train_step(model, reducer, optimizer, batch_mmc4, info, batch_laion=None, loss_multiplier_laion=1.0,
                loss_multiplier_mmc4=1.0, clip_norm=1.0, amp=True, nan_check=True, lr_scheduler=None,
                mask_embedding_rows=True, next_vision_x=None):
@@ -76,9 +82,9 @@ def train_step(model, reducer, optimizer, batch_mmc4, info, batch_laion=None, lo
     of NaN batches (use nan_check=True where that matters more than the sync); False = no check.
     next_vision_x: the ``vision_x`` tensor the NEXT step's first forward will be called with (a data loader is one batch ahead
     anyway).  Its frozen vision-tower forward -- which depends on no trainable parameter (flamingo.py:194-195) -- is enqueued on
-    a side stream between this step's backward and its step epilogue (Flamingo.prefetch_vision): MFMA-bound work next to the
-    HBM-bound clip + AdamW passes and the wait for the last all-reduce.  Same arithmetic, same bits; every step still runs
-    exactly one tower forward per forward pass."""
+    a side stream from inside this step's backward, a few gated blocks before its end (Flamingo.schedule_vision_prefetch), so that it
+    runs next to the end of the backward, the HBM-bound clip + AdamW passes and the wait for the last all-reduce, and is done when
+    the next step begins.  Same arithmetic, same bits; every step still runs exactly one tower forward per forward pass."""
     fused = hasattr(optimizer, "reducer")         # FlatAdamW: clip + AdamW + zero_grad in two device passes
     from ..hip import path as _path
     _path.scope_of(getattr(model, "module", model)).twins.clear()         # a gradient twin nobody took in the previous backward (the embedding's) is not kept alive
@@ -87,6 +93,10 @@ def train_step(model, reducer, optimizer, batch_mmc4, info, batch_laion=None, lo
         with reducer.no_sync() if reducer is not None else contextlib.nullcontext():
             loss_l = forward_loss(model, batch_laion, info, amp, kind="laion")
             (loss_l * loss_multiplier_laion).backward()
+    inner = getattr(model, "module", model)
+    in_backward = next_vision_x is not None and PREFETCH_IN_BACKWARD and hasattr(inner, "schedule_vision_prefetch")
+    if in_backward:            # fires from the backward below (Flamingo.schedule_vision_prefetch)
+        inner.schedule_vision_prefetch(next_vision_x, amp_dtype=torch.bfloat16 if amp else None)
     loss = forward_loss(model, batch_mmc4, info, amp)
     if nan_check == "device":
         assert fused, "nan_check='device' relies on the fused step epilogue (FlatAdamW)"
@@ -95,10 +105,14 @@ def train_step(model, reducer, optimizer, batch_mmc4, info, batch_laion=None, lo
             reducer.zero_grad()
         else:
             optimizer.zero_grad(set_to_none=True)
+        if in_backward:
+            inner.cancel_vision_prefetch()
         return None
     (loss * loss_multiplier_mmc4).backward()
-    if next_vision_x is not None:
-        getattr(model, "module", model).prefetch_vision(next_vision_x, amp_dtype=torch.bfloat16 if amp else None)
+    if in_backward:
+        inner.fire_vision_prefetch()           # (no-op when the backward's hook ran it)
+    elif next_vision_x is not None:
+        inner.prefetch_vision(next_vision_x, amp_dtype=torch.bfloat16 if amp else None)
     if reducer is None and mask_embedding_rows:
         mask_embedding_gradient(model, info)
     if reducer is not None:

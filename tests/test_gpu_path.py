@@ -68,6 +68,38 @@ def test_xattn_of4b_of9b_dims(ops, d, heads_lm):
     print({k: f"{v:.1e}" for k, v in errs.items()})
 
 
+def test_narrow_step_epilogue_launches_are_bit_identical_on_hardware(ops):
+    """FlatAdamW's default since round 6: the norm pass and AdamW as NARROW launches (192 fat workgroups, of_sumsq_partial_w /
+    of_adamw_clip_w) -- the partial slots and every (p, m, v, bf16 copy, cleared gradient) of the launches that cover the chip, bit
+    for bit, at a bucket's size (17 M + a scalar tail) and at sizes smaller than one fat workgroup."""
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    for n in (2048 * 8192 + 3, 70001, 300):
+        grad = torch.randn(n, device="cuda", generator=gen)
+        wide, narrow = torch.full((ops.SUMSQ_PARTS,), -1.0, device="cuda"), torch.full((ops.SUMSQ_PARTS,), -2.0, device="cuda")
+        ops.sumsq_partial(grad, wide)
+        for cus in (192, 7):
+            ops.sumsq_partial(grad, narrow, max_workgroups=cus)
+            assert torch.equal(wide, narrow), (n, cus)
+        acc = torch.zeros(1, device="cuda")
+        ops.sumsq_finish(wide, acc)
+        p0, m0, v0 = (torch.randn(n, device="cuda", generator=gen), torch.rand(n, device="cuda", generator=gen) * 0.1,
+                      torch.rand(n, device="cuda", generator=gen) * 0.1)
+        outs = []
+        for cus in (0, 192, 7):
+            p, gb, m, v, b16 = p0.clone(), grad.clone(), m0.clone(), v0.clone(), torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+            ops.adamw_clip(p, gb, m, v, acc, step=2, lr=1e-2, weight_decay=0.1, max_norm=1.0, p_bf16=b16, zero_grad=True, max_workgroups=cus)
+            assert float(gb.abs().max()) == 0.0
+            outs.append((p, m, v, b16))
+        for o in outs[1:]:
+            assert all(torch.equal(a, b) for a, b in zip(o, outs[0])), n
+        assert not torch.equal(outs[0][0], p0)
+    from open_flamingo_amd.train import step, towers
+    from open_flamingo_amd.train.reducer import GradReducer
+    model, info = towers.build_flamingo("OF-tiny", device="cuda", seed=0, gates=0.5)
+    opt = step.build_optimizer(model, lr=1e-3, reducer=GradReducer(model, embedding_rows=[info["media_token_id"], info["eoc_token_id"]]))
+    assert opt.narrow_cus == 192
+
+
 def test_fused_step_epilogue_matches_torch_optimizer():
     """train_step with the libofhip step epilogue (FlatAdamW: clip + AdamW + zero_grad + bf16 weight copies) must track
     train_step with clip_grad_norm_ + torch.optim.AdamW on the same model/batch for several steps."""
