@@ -488,6 +488,11 @@ def main():
                      "ms_per_step": round(v[1], 2), "frac": round(v[0] / v[1] / 1e9 / MFMA_PEAK_TFLOPS, 4)}
                     for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])[:4]]
         ach = fl / ms / 1e9
+        # the same family's MEDIAN launch: since round 6 the last launches of a backward run next to the prefetched tower's kernels on
+        # the side stream (Flamingo.schedule_vision_prefetch) and take longer for it -- the mean (`achieved`, `frac`) includes them
+        durs = sorted(e0.elapsed_time(e1) for k2, _, sh, e0, e1 in timing if k2 == key and sh == top_shape)
+        med_ms = durs[len(durs) // 2]
+        med_fl = next(f for k2, f, sh, _, _ in timing if k2 == key and sh == top_shape)
         traffic, traffic_note = pmc_traffic(key, top_shape)
         if traffic is None:          # a family can hold two launch shapes of equal count (dW1 / dW2): quote the one on record
             for sh in sorted(shapes, key=shapes.get, reverse=True):
@@ -503,13 +508,15 @@ def main():
                     "shapes_MNK": {"x".join(map(str, sh)): c // args.steps for sh, c in shapes.items()},
                     "launches_per_step": n // args.steps, "avg_launch_ms": round(ms / n, 4),
                     "gflop_per_launch": round(fl / n / 1e9, 2),
+                    "median_launch_ms": round(med_ms, 4), "frac_at_median": round(med_fl / med_ms / 1e9 / MFMA_PEAK_TFLOPS, 4),
                     # the four (layout, epilogue, kernel) families that take the most time in the surveyed warm-up step
                     "families": families,
                     "all_gemm_tflops": round(all_fl / all_ms / 1e9, 1),
                     # the time-weighted figure over EVERY of_gemm launch of a step: what describes the path (`frac` is the ONE family that takes the most time)
                     "all_gemm_frac": round(all_fl / all_ms / 1e9 / MFMA_PEAK_TFLOPS, 4),
                     "all_gemm_ms_per_step": round(all_ms / args.steps, 2),
-                    "note": "achieved/avg_launch_ms: HIP events around every launch of this family inside the timed region; "
+                    "note": "achieved/avg_launch_ms: HIP events around every launch of this family inside the timed region (the mean includes the launches "
+                            "that share the chip with the next step's tower forward on the side stream; median_launch_ms / frac_at_median: the family's typical launch); "
                             "all_gemm_*: every of_gemm launch of the last warm-up step"}
 
     if rank == 0:

@@ -46,3 +46,7 @@ cut -c1-420 gpurun_out/${TAG}_compact_heads_probe.jsonl
 cut -c1-260 gpurun_out/${TAG}_ab_neox_compact_heads_step.jsonl
 ( timeout 900 python tools/ab_vit_fc2_split.py --steps 12 --warmup 4 2>/dev/null | cut -c1-330 ) > gpurun_out/${TAG}_ab_vit_fc2_split_step.jsonl
 cut -c1-260 gpurun_out/${TAG}_ab_vit_fc2_split_step.jsonl
+# 8. the step schedule: where the next step's tower forward is enqueued (product rule against behind-the-backward), narrow against wide step epilogue
+( AB_ARMS=1,0 timeout 600 python tools/ab_prefetch_point.py --steps 12 --warmup 4 2>/dev/null | cut -c1-330 ) > gpurun_out/${TAG}_ab_prefetch_point_step.jsonl
+cut -c1-200 gpurun_out/${TAG}_ab_prefetch_point_step.jsonl
+for c in 192 0 192 0; do echo -n "optimizer-cus $c "; python bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-reference-eager --optimizer-cus $c 2>/dev/null | grep "^{" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['loss_last_step'])"; done | tee gpurun_out/${TAG}_ab_narrow_step_epilogue.txt
