@@ -95,6 +95,8 @@ def train_step(model, reducer, optimizer, batch_mmc4, info, batch_laion=None, lo
             (loss_l * loss_multiplier_laion).backward()
     inner = getattr(model, "module", model)
     in_backward = next_vision_x is not None and PREFETCH_IN_BACKWARD and hasattr(inner, "schedule_vision_prefetch")
+    if hasattr(inner, "cancel_vision_prefetch"):
+        inner.cancel_vision_prefetch()         # (a request an earlier, aborted step left behind)
     if in_backward:            # fires from the backward below (Flamingo.schedule_vision_prefetch)
         inner.schedule_vision_prefetch(next_vision_x, amp_dtype=torch.bfloat16 if amp else None)
     loss = forward_loss(model, batch_mmc4, info, amp)

@@ -422,8 +422,8 @@ def test_block_module_against_reference_goldens_at_dim_head_64(on_emulator, case
 
 
 def test_vision_prefetch_changes_no_bit_and_runs_the_tower_once_per_forward(on_emulator, monkeypatch):
-    """train_step(next_vision_x=...): the next step's frozen vision-tower forward is enqueued between this
-    step's backward and its step epilogue (Flamingo.prefetch_vision; on the GPU: a side stream).  Same arithmetic -> the losses of
+    """train_step(next_vision_x=...): the next step's frozen vision-tower forward is enqueued from inside this
+    step's backward (Flamingo.schedule_vision_prefetch -> prefetch_vision; on the GPU: a side stream).  Same arithmetic -> the losses of
     two steps on alternating batches (the second consumes prefetched tokens) are bit-identical with and without it; the tower runs exactly once per forward either way;
     a forward with ANOTHER tensor (or a changed one) ignores the prefetched tokens."""
     def run(prefetch):
@@ -441,9 +441,24 @@ def test_vision_prefetch_changes_no_bit_and_runs_the_tower_once_per_forward(on_e
             losses.append(float(step.train_step(model, red, opt, batches[i % 2], info, amp=False, next_vision_x=nxt)))
         return losses, len(calls), model, info, batches
 
+    # round 6: the tower forward is enqueued from INSIDE the backward (Flamingo.schedule_vision_prefetch: at the start of the backward of
+    # gated block n_blocks // 12, or where the gradient of the Perceiver's output is complete), not behind it; behind it with the switch off
+    # -- the same losses either way (the enqueue point moves, the arithmetic does not)
+    from open_flamingo_amd.src.flamingo import Flamingo
+    where = []
+    orig_prefetch = Flamingo.prefetch_vision
+    monkeypatch.setattr(Flamingo, "prefetch_vision",
+                        lambda self, v, amp_dtype=None: (where.append(torch._C._current_graph_task_id() != -1), orig_prefetch(self, v, amp_dtype=amp_dtype))[1])
     l1, n1, model, info, batches = run(True)
+    assert where == [True, True]
     l0, n0, *_ = run(False)
     assert l1 == l0, (l1, l0)
+    monkeypatch.setattr(step, "PREFETCH_IN_BACKWARD", False)
+    where.clear()
+    l3, *_ = run(True)
+    assert where == [False, False] and l3 == l0
+    monkeypatch.setattr(step, "PREFETCH_IN_BACKWARD", True)
+    monkeypatch.setattr(Flamingo, "prefetch_vision", orig_prefetch)
     assert n0 == 2 and n1 == 3            # two forwards; with prefetch one more tower run is waiting for a third step
     assert "_of_vision_prefetch" in model.__dict__
     # the waiting tokens belong to batches[1]'s tensor: a forward on another tensor must not take them ...
